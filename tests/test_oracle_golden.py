@@ -1,0 +1,168 @@
+"""CPU: pin the oracle restatement (oracle/*.py) against the golden vectors captured
+from the real reference (tests/golden/make_golden.py)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import cases
+from oracle import coreset as ocoreset
+from oracle import geometry, models, scoring
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_reference_own_test_vector():
+    proj, hm, valid, stride = cases.reference_test_input()
+    z = np.load(os.path.join(G, "triangulation_reftest.npz"))
+    r = geometry.triangulation(hm, proj, stride, valid)
+    assert r["keypoints_2d"].dtype == np.int64
+    np.testing.assert_array_equal(r["keypoints_2d"], z["keypoints_2d"])
+    np.testing.assert_array_equal(r["keypoints_2d"][0, 0], [88, 88])
+    np.testing.assert_allclose(r["keypoints_3d"], z["keypoints_3d"], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(r["keypoints_3d"][0], [-37.22307725, -125.64283665, -23.89420967], atol=1e-7)
+    assert abs(r["metric"] - float(z["metric"])) < 1e-12
+    assert r["inlier_count"] == int(z["inlier_count"]) == 3
+
+
+@pytest.mark.parametrize("name", list(cases.triangulation_cases()))
+def test_triangulation_synth(name):
+    c = cases.triangulation_cases()[name]
+    z = np.load(os.path.join(G, "triangulation_synth.npz"))
+    hm, proj, valid = cases.build_triangulation_case(c)
+    for b in range(hm.shape[0]):
+        r = geometry.triangulation(hm[b], proj[b], c["stride"], valid[b])
+        np.testing.assert_array_equal(r["keypoints_2d"], z[name + "/keypoints_2d"][b])
+        np.testing.assert_allclose(r["keypoints_3d"], z[name + "/keypoints_3d"][b], rtol=0, atol=1e-6)
+        np.testing.assert_allclose(r["metric"], z[name + "/metric"][b], rtol=1e-9)
+        assert r["inlier_count"] == z[name + "/inlier_count"][b]
+
+
+def test_nonsquare_argmax_quirk():
+    # peak at (row 10, col 7) of a 64x48 map -> (x, y) = (487 % 64, 487 // 64) * stride
+    hm = np.zeros((1, 1, 64, 48), dtype=np.float32)
+    hm[0, 0, 10, 7] = 1
+    kp = geometry.argmax_decode(hm, 4, [True])
+    np.testing.assert_array_equal(kp[0, 0], [39 * 4, 7 * 4])
+
+
+@pytest.mark.parametrize("name", list(cases.xe_cases()))
+def test_xe(name):
+    c = cases.xe_cases()[name]
+    z = np.load(os.path.join(G, "triangulation_xe.npz"))
+    hm, proj, valid = cases.build_triangulation_case(c)
+    for b in range(hm.shape[0]):
+        r = geometry.triangulation(hm[b], proj[b], c["stride"], valid[b], False, True, c["sigma"])
+        np.testing.assert_allclose(r["metric"], z[name + "/metric"][b], rtol=1e-9)
+
+
+@pytest.mark.parametrize("name", list(cases.scoring_cases()))
+def test_scoring(name):
+    c = cases.scoring_cases()[name]
+    z = np.load(os.path.join(G, "scoring.npz"))
+    hm, valid = cases.build_scoring_case(c)
+    fns = dict(HP=scoring.compute_hp, MPE=scoring.compute_mpe, BSB=scoring.compute_bsb)
+    for kind, fn in fns.items():
+        for cfg in ("AVG", "STD"):
+            want = z[f"{name}/{kind}_{cfg}"]
+            dt = str(z[f"{name}/{kind}_{cfg}_dtype"])
+            for b in range(hm.shape[0]):
+                got = torch.tensor(fn(hm[b], valid[b], cfg))
+                assert str(got.dtype) == dt
+                # HP: torch's vectorised CPU softmax sums in a different order than numpy
+                tol = 2e-6 if kind in ("HP", "BSB") else 0.0
+                assert abs(float(got) - want[b]) <= tol * max(1.0, abs(want[b])), (kind, cfg, float(got), want[b])
+
+
+def test_peak_local_max_known_answers():
+    # single interior peak -> one peak, entropy 0
+    m = np.zeros((16, 16), dtype=np.float32)
+    m[8, 8] = 1
+    np.testing.assert_array_equal(scoring.peak_local_max(m, min_distance=2), [[8, 8]])
+    assert scoring.compute_mpe(m[None, None], [True]) == 0
+    # two equal far-apart peaks -> ln 2
+    m[3, 12] = 1
+    assert abs(scoring.compute_mpe(m[None, None], [True]) - np.log(2)) < 1e-6
+    # border peaks (within min_distance of the edge) are excluded
+    b = np.zeros((16, 16), dtype=np.float32)
+    b[1, 8] = 1
+    assert len(scoring.peak_local_max(b, min_distance=2)) == 0
+    # constant image: nothing
+    assert len(scoring.peak_local_max(np.ones((8, 8), np.float32), min_distance=2)) == 0
+    # plateau of two adjacent equal maxima: the second is rejected (distance 1 < 2) ...
+    p = np.zeros((16, 16), dtype=np.float32)
+    p[8, 8] = p[8, 9] = 1
+    np.testing.assert_array_equal(scoring.peak_local_max(p, min_distance=2), [[8, 8]])
+    # ... but equal maxima exactly min_distance apart are both kept
+    q = np.zeros((16, 16), dtype=np.float32)
+    q[8, 8] = q[8, 10] = 1
+    assert len(scoring.peak_local_max(q, min_distance=2)) == 2
+    # num_peaks keeps the highest
+    r = np.zeros((16, 16), dtype=np.float32)
+    r[4, 4], r[10, 10], r[4, 10] = 1, 3, 2
+    np.testing.assert_array_equal(scoring.peak_local_max(r, min_distance=2, num_peaks=2), [[10, 10], [4, 10]])
+
+
+def test_soft_argmax_known_answers():
+    m = np.full((1, 1, 8, 12), -1e4, dtype=np.float32)
+    m[0, 0, 5, 9] = 0
+    np.testing.assert_allclose(geometry.spatial_soft_argmax2d(m)[0, 0], [9, 5], atol=1e-6)
+    u = np.zeros((1, 1, 8, 12), dtype=np.float32)
+    np.testing.assert_allclose(geometry.spatial_soft_argmax2d(u)[0, 0], [5.5, 3.5], atol=1e-5)
+
+
+@pytest.mark.parametrize("name", list(cases.coreset_cases()))
+def test_coreset(name):
+    c = cases.coreset_cases()[name]
+    z = np.load(os.path.join(G, "coreset.npz"))
+    sal, al = cases.build_coreset_case(c)
+    cs = ocoreset.CoreSet(sal, al, c["root"])
+    keys = cs.select_batch(c["select"])
+    idx = {k: i for i, k in enumerate(sal)}
+    np.testing.assert_array_equal([idx[k] for k in keys], z[name + "/picks"])
+    assert min(z[name + "/gaps"]) > 1e-6  # fixtures are not near-ties
+
+
+def test_coreset_reference_degenerate_case():
+    z = np.load(os.path.join(G, "coreset.npz"))
+    sal = {i: [[0, 1, 2] for _ in range(19)] for i in range(20)}
+    al = {i: [[0, 1, 2] for _ in range(19)] for i in range(5)}
+    picks = ocoreset.CoreSet(sal, al, 2).select_batch(5)
+    np.testing.assert_array_equal(picks, z["reftest/picks"])  # duplicates: [0]*5
+
+
+def _sd(c):
+    return {k: torch.from_numpy(v) for k, v in cases.model_state_dict(c).items()}
+
+
+@pytest.mark.parametrize("name", ["w32", "r50", "w32_small"])
+def test_models_eval(name):
+    c = cases.model_cases()[name]
+    z = np.load(os.path.join(G, "models.npz"))
+    x = torch.from_numpy(cases.model_input(c))
+    sd = _sd(c)
+    with torch.no_grad():
+        if c["arch"] == "resnet50":
+            y = models.pose_resnet_forward(sd, x)
+        else:
+            y = models.hrnet_forward(sd, x, models.HRNET_W32)
+    y = y.numpy()
+    np.testing.assert_allclose(y[0], z[name + "/heatmaps0"], rtol=0, atol=2e-5)
+    flat = y.reshape(y.shape[0], y.shape[1], -1)
+    np.testing.assert_array_equal(flat.argmax(-1), z[name + "/argmax"])
+
+
+def test_selection_order():
+    d = {"a": 1.0, "b": 3.0, "c": 3.0, "d": float("nan"), "e": 2.0}
+    assert scoring.select_top_n(d, 3) == ["b", "c", "e"]
+
+
+def test_sal_dict_fixture_is_consistent():
+    with open(os.path.join(G, "sal_dict.json")) as f:
+        z = json.load(f)
+    for name, c in cases.sal_cases().items():
+        e = z[name]
+        assert list(e["al_metric"]) == ["0-0", "1-3", "7-100", "8-103"]
+        assert scoring.select_top_n(e["al_metric"], c["select"]) == e["nlargest"]
