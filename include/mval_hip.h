@@ -1,0 +1,185 @@
+/*
+ * mval_hip.h -- C ABI of libmval_hip.so: the MI355X (gfx950) implementation of the
+ * data-parallel hot path of facebookresearch/multi_view_active_learning.
+ *
+ * The reference has NO native layer: its boundary is a Python call surface.
+ * Each entry point below therefore cites the reference *Python call site* it replaces
+ * (paths relative to the reference root), and multi_view_active_learning_amd/_lib.py is the
+ * ctypes binding a maintainer would use (INTEGRATION.md shows the stub).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer borrowed from the
+ *     caller (who keeps it alive until the stream has drained); nothing is allocated
+ *     inside a launcher except via caller-provided workspaces;
+ *   - `stream` is a hipStream_t passed as void*; all work is asynchronous on it and
+ *     graph-capturable (no synchronisation, no allocation inside);
+ *   - return 0 on success, negative on error; mval_last_error() gives the message of the
+ *     last failing call on the calling thread;
+ *   - tensors are dense row-major with the shapes given in brackets.
+ */
+#ifndef MVAL_HIP_H
+#define MVAL_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+int mval_version(void);
+const char* mval_last_error(void);
+
+/* ------------------------------------------------------------------------------------
+ * Keypoint decode
+ * ---------------------------------------------------------------------------------- */
+
+/* utils/evaluation.py:13-30 get_scaled_pred_corrdinates -- hard arg-max per (frame, view,
+ * joint) map, first index on ties (NaN counts as maximum, like torch.argmax), then
+ *   x = (idx % split_width) * stride ; y = (idx / split_width) * stride.
+ * The reference passes shape[2] (= hh) as split_width for BOTH (its non-square quirk,
+ * SURVEY A.2); pass wh for the geometrically correct split.  Invalid joints -> (0, 0).
+ *   heatmaps [B,V,J,hh,wh] f32 ; valid [B,J] u8 or NULL ; kp2d [B,V,J,2] i64 (x,y). */
+int mval_argmax_decode(const float* heatmaps, const uint8_t* valid, int64_t* kp2d,
+                       int B, int V, int J, int hh, int wh, int stride, int split_width, void* stream);
+
+/* utils/triangulation.py:191-200 (kornia.spatial_soft_argmax2d(hm, normalized_coordinates=False)
+ * * stride): softmax over hh*wh, expectation of the pixel grid; kp2d [n_maps,2] f32 (x,y)*scale. */
+int mval_soft_argmax(const float* heatmaps, float* kp2d, int64_t n_maps, int hh, int wh, float scale, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Triangulation
+ * ---------------------------------------------------------------------------------- */
+
+/* utils/triangulation.py:209-233 + :260-338 _triangulate_ransac + :341-368 _triangulate_dlt +
+ * :371-384 _calc_reprojection_error_matrix, batched over (frame, joint), float64, SVD-free
+ * (Givens QR of the 2n x 4 DLT system, then one-sided Jacobi on the 4x4 R factor).
+ * Deterministic pair order (V <= 11), first strictly larger inlier set wins, the sampled
+ * pair is always an inlier, final solve on the sorted inlier views.
+ *   kp2d [B,V,J,2] i64 (kp_is_f32 = 0) or f32 (kp_is_f32 = 1) ; proj [B,V,3,4] f64 ;
+ *   valid [B,J] u8 or NULL ;
+ *   kp3d [B,J,3] f64 (0 for invalid joints) ; joint_err [B,J] f64 mean inlier reprojection
+ *   error ; joint_inliers [B,J] i32 ; metric [B] f64 = numpy-order mean of joint_err over
+ *   valid joints (NaN if none) ; inlier_count [B] i32 = min over valid joints (-1 if none:
+ *   the reference raises ValueError there, the host wrapper does the same). */
+int mval_triangulate_ransac(const void* kp2d, int kp_is_f32, const double* proj, const uint8_t* valid,
+                            double* kp3d, double* joint_err, int32_t* joint_inliers, double* metric,
+                            int32_t* inlier_count, int B, int V, int J, double eps, void* stream);
+
+/* utils/triangulation.py:236-257 _compute_xe: sum over (view, joint) of
+ * mean_px (hm - exp(-|grid - kp|^2 / (2 sigma^2)))^2 with kp the reprojection of kp3d
+ * (input-pixel units on the heat-map grid, as the reference does).  out [B] f64 ;
+ * ws [B*V*J] f64 scratch. */
+int mval_reprojection_xe(const double* kp3d, const double* proj, const float* heatmaps, double* out, double* ws,
+                         int B, int V, int J, int hh, int wh, double sigma, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Uncertainty scorers (strategy.py:1149-1215)
+ * ---------------------------------------------------------------------------------- */
+enum { MVAL_SCORE_HP = 0, MVAL_SCORE_MPE = 1, MVAL_SCORE_BSB = 2 };
+enum { MVAL_REDUCE_AVG_F64 = 0, MVAL_REDUCE_AVG_F32 = 1, MVAL_REDUCE_STD_F64 = 2, MVAL_REDUCE_STD_F32 = 3 };
+
+/* Per-map statistic, one heat-map read:
+ *   HP  (strategy.py:1185-1187)  1 - max(row_softmax(map))           (row-wise softmax: SURVEY A.9)
+ *   MPE (strategy.py:1168-1175)  entropy of softmax over the local peaks
+ *        (skimage.feature.peak_local_max(map, min_distance=2): 5x5 maxima strictly above
+ *        map.min(), 2-px border excluded, sorted by descending value, plateau spacing)
+ *   BSB (strategy.py:1202-1208)  |p0 - p1| of the two highest local peaks of row_softmax(map)
+ *   heatmaps [n_maps,hh,wh] f32 ; stat [n_maps] f32 ; n_peaks [n_maps] i32 (MPE/BSB; 0 for HP). */
+int mval_score_maps(int kind, const float* heatmaps, float* stat, int32_t* n_peaks,
+                    int64_t n_maps, int hh, int wh, void* stream);
+
+/* AVG / STD over the valid (view, joint) maps of each frame in the reference's python /
+ * numpy evaluation order and precision (strategy.py:1151-1155,1188-1193,1210-1215;
+ * SURVEY A.8).  per_map [B,V,J] f32 ; valid [B,J] u8 or NULL ; out [B] f64. */
+int mval_score_reduce(const float* per_map, const uint8_t* valid, double* out, int B, int V, int J,
+                      int mode, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Loss / metric
+ * ---------------------------------------------------------------------------------- */
+
+/* pose_estimators/loss.py:14-20: out = sum(valid ? (h-g)^2 : 0) / denom.
+ *   h,g [lead,hw] f32 ; valid [lead] u8 or NULL ; out [1] f32 ; ws >= 2048 doubles. */
+int mval_masked_mse_fwd(const float* h, const float* g, const uint8_t* valid, float* out, double* ws,
+                        int64_t lead, int64_t hw, double denom, void* stream);
+/* d loss / d h = grad_out * 2 (h-g) valid / denom.  grad_out [1] f32 ; grad_h [lead,hw] f32. */
+int mval_masked_mse_bwd(const float* h, const float* g, const uint8_t* valid, const float* grad_out,
+                        float* grad_h, int64_t lead, int64_t hw, double denom, void* stream);
+
+/* utils/evaluation.py:198-208 compute_mkpe over S samples: pred [S,J,3] f32, gt [S,gt_rows,J]
+ * f32 (rows 0..2 used), valid [S,J] f32 ; out [1] f32 = mean_j (sum_s d_sj / sum_s valid_sj) ;
+ * per_sample [S] f32 = the same metric evaluated on each sample alone (strategy.py:1134). */
+int mval_mkpe(const float* pred, const float* gt, const float* valid, float* out, float* per_sample,
+              int64_t S, int J, int gt_rows, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Core-set selection (utils/coreset.py:35-95)
+ * ---------------------------------------------------------------------------------- */
+
+/* utils/coreset.py:35-47: pose [n,J,rows] f64 ([joint][coord], rows >= 3) ->
+ * feat [n,3J] f64 = [x_0-x_r .. , y_0-y_r .. , z_0-z_r ..]. */
+int mval_coreset_features(const double* pose, double* feat, int64_t n, int J, int rows, int root, void* stream);
+
+size_t mval_kcenter_workspace_bytes(int64_t n_obs, int D);
+
+/* utils/coreset.py:49-95 greedy k-center on feat [n_obs,D] f64 with sklearn's expanded
+ * Euclidean form  sqrt(max(0, (-2 x.c + |x|^2) + |c|^2)).
+ *   labeled [n_labeled] i64 row indices (may be NULL/0) ;
+ *   have_min_dist != 0: min_dist [n_obs] already holds the running minimum (continuation) ;
+ *   row_norms [n_obs] f64 scratch ; picks [n_select] i64 ; ws >= mval_kcenter_workspace_bytes.
+ * First maximum wins ties; nothing is masked (duplicates possible, as in the reference). */
+int mval_kcenter_select(const double* feat, int64_t n_obs, int D, const int64_t* labeled, int64_t n_labeled,
+                        int n_select, int have_min_dist, double* row_norms, double* min_dist,
+                        int64_t* picks, void* ws, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Heat-map network forward (pose_estimators/hrnet.py:468-501, pose_resnet.py:139-153)
+ * ---------------------------------------------------------------------------------- */
+
+/* One fused operator:  out = act(((bn(conv(in)) + res1) + res2))  [nearest-upsampled by 2^up].
+ * Activations are NHWC f32 (NCHW for the network input / heat-map output).  Offsets are in
+ * floats from the workspace base; -1 = absent.  Weights are in the packed fragment order
+ * written by mval_pack_conv_weights; scale/shift are the folded eval-mode BatchNorm
+ * (y = x * scale + shift, torch's batch_norm inference formula) or (1, bias). */
+enum { MVAL_OP_CONV = 0, MVAL_OP_MAXPOOL = 1, MVAL_OP_DECONV = 2 };
+enum { MVAL_ALGO_DIRECT = 0, MVAL_ALGO_MFMA = 1 };
+enum { MVAL_PACK_HWIO = 0, MVAL_PACK_MFMA16 = 1 };
+
+typedef struct mval_op {
+  int32_t kind;      /* MVAL_OP_*: conv, maxpool (k, stride, pad), transposed conv k4 s2 p1 */
+  int32_t algo;      /* MVAL_ALGO_*: which kernel family (and weight packing) the op uses */
+  int32_t k, stride, pad;
+  int32_t cin, cout;
+  int32_t hin, win, hout, wout; /* hout/wout BEFORE the fused upsample */
+  int32_t up;        /* log2 upsample factor applied on store (res1/res2/out are at hout<<up) */
+  int32_t relu;
+  int32_t in_nchw, out_nchw;
+  int64_t in_off, out_off, res1_off, res2_off;
+  int64_t w_off, scale_off, shift_off; /* floats from the params base */
+} mval_op;
+
+/* Weight packing.  MVAL_PACK_HWIO: [k*k][cin][cout] (direct kernels, deconv);
+ * MVAL_PACK_MFMA16: v_mfma_f32_16x16x4_f32 B-fragment order
+ * [k*k][cin/16][cout/16][lane 0..63][4] with lane = (cin_quad << 4) | cout_lane, cin and
+ * cout zero-padded to multiples of 16.  `transposed` != 0: w is a ConvTranspose2d weight
+ * [cin,cout,k,k], else a Conv2d weight [cout,cin,k,k]. */
+size_t mval_packed_weight_floats(int pack, int cout, int cin, int k);
+int mval_pack_conv_weights(int pack, int transposed, const float* w, float* packed, int cout, int cin, int k,
+                           void* stream);
+/* scale = gamma / sqrt(var + eps) ; shift = beta - mean * scale  (all [c] f32). */
+int mval_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var, float eps,
+                 float* scale, float* shift, int c, void* stream);
+
+int mval_op_launch(const mval_op* op, int n_images, float* workspace, const float* params,
+                   const float* net_input, float* net_output, void* stream);
+
+void* mval_net_create(const mval_op* ops, int n_ops);
+void mval_net_destroy(void* net);
+int mval_net_forward(void* net, int n_images, float* workspace, const float* params,
+                     const float* input_nchw, float* output_nchw, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MVAL_HIP_H */

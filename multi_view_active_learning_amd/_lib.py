@@ -39,7 +39,9 @@ def lib() -> C.CDLL:
                     )
                 l = C.CDLL(LIB_PATH)
                 l.mval_last_error.restype = C.c_char_p
+                l.mval_kcenter_workspace_bytes.restype = C.c_size_t
                 l.mval_net_create.restype = C.c_void_p
+                l.mval_packed_weight_floats.restype = C.c_size_t
                 _lib = l
     return _lib
 
@@ -122,10 +124,11 @@ def triangulate_ransac(kp2d, proj, valid, b, v, j, eps):
 
 def reprojection_xe(kp3d, proj, hm, b, v, j, hh, wh, sigma):
     out = torch.empty((b,), dtype=torch.float64, device=hm.device)
+    ws = torch.empty((b * v * j,), dtype=torch.float64, device=hm.device)
     _check(
         lib().mval_reprojection_xe(
             _p(_req(kp3d, torch.float64, "keypoints_3d")), _p(_req(proj, torch.float64, "proj")),
-            _p(_req(hm, torch.float32, "heatmaps")), _p(out),
+            _p(_req(hm, torch.float32, "heatmaps")), _p(out), _p(ws),
             C.c_int(b), C.c_int(v), C.c_int(j), C.c_int(hh), C.c_int(wh), C.c_double(sigma), _stream(),
         ),
         "mval_reprojection_xe",
@@ -212,8 +215,8 @@ def mkpe(pred, gt, valid, s, j, gt_rows):
 # --------------------------------------------------------------------------
 # core-set (k-center greedy)
 # --------------------------------------------------------------------------
-def kcenter_workspace_bytes(n_obs: int) -> int:
-    return int(lib().mval_kcenter_workspace_bytes(C.c_longlong(n_obs)))
+def kcenter_workspace_bytes(n_obs: int, d: int) -> int:
+    return int(lib().mval_kcenter_workspace_bytes(C.c_longlong(n_obs), C.c_int(d)))
 
 
 def kcenter_select(feat, labeled_idx, n_select, min_dist=None):
@@ -224,7 +227,7 @@ def kcenter_select(feat, labeled_idx, n_select, min_dist=None):
     picks = torch.empty((n_select,), dtype=torch.int64, device=dev)
     md = torch.empty((n_obs,), dtype=torch.float64, device=dev) if min_dist is None else min_dist
     norms = torch.empty((n_obs,), dtype=torch.float64, device=dev)
-    ws = torch.empty((lib().mval_kcenter_workspace_bytes(C.c_longlong(n_obs)) // 8 + 1,), dtype=torch.float64, device=dev)
+    ws = torch.empty((kcenter_workspace_bytes(n_obs, d) // 8 + 1,), dtype=torch.float64, device=dev)
     nl = 0 if labeled_idx is None else int(labeled_idx.numel())
     _check(
         lib().mval_kcenter_select(

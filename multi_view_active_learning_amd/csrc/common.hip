@@ -1,0 +1,13 @@
+#include "mval_common.h"
+
+static thread_local char g_err[512] = "";
+
+void mval_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" const char* mval_last_error(void) { return g_err; }
+extern "C" int mval_version(void) { return 100; }

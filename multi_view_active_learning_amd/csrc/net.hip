@@ -1,0 +1,278 @@
+// Heat-map network runner: weight packing, eval-mode BatchNorm folding, the generic
+// direct (VALU) operators, and the op-list executor behind mval_net_forward.
+//
+// The direct kernels cover the operators that are not GEMM-shaped enough for the matrix
+// cores (3-channel stems, max-pool) or not yet ported to them (transposed conv); they are
+// also the on-device cross-check for the MFMA kernels (MVAL_FORCE_DIRECT=1).
+#include <stdlib.h>
+
+#include <vector>
+
+#include "conv_common.h"
+
+// ---- weight packing ---------------------------------------------------------------------
+extern "C" size_t mval_packed_weight_floats(int pack, int cout, int cin, int k) {
+  if (pack == MVAL_PACK_HWIO) return (size_t)k * k * cin * cout;
+  size_t g = (cin + 15) / 16, ns = (cout + 15) / 16;
+  return (size_t)k * k * g * ns * 256;
+}
+
+__device__ __forceinline__ float w_at(const float* w, int transposed, int cout, int cin, int k, int co, int ci, int t) {
+  // Conv2d: [cout][cin][k][k] ; ConvTranspose2d: [cin][cout][k][k]
+  return transposed ? w[((int64_t)ci * cout + co) * k * k + t] : w[((int64_t)co * cin + ci) * k * k + t];
+}
+
+__global__ void pack_hwio_kernel(const float* __restrict__ w, float* __restrict__ p, int transposed, int cout, int cin,
+                                 int k) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t total = (int64_t)k * k * cin * cout;
+  if (i >= total) return;
+  int co = (int)(i % cout);
+  int ci = (int)((i / cout) % cin);
+  int t = (int)(i / ((int64_t)cout * cin));
+  p[i] = w_at(w, transposed, cout, cin, k, co, ci, t);
+}
+
+__global__ void pack_mfma16_kernel(const float* __restrict__ w, float* __restrict__ p, int transposed, int cout,
+                                   int cin, int k) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int G = (cin + 15) / 16, NS = (cout + 15) / 16;
+  int64_t total = (int64_t)k * k * G * NS * 256;
+  if (i >= total) return;
+  int j = (int)(i & 3);
+  int lane = (int)((i >> 2) & 63);
+  int64_t r = i >> 8;
+  int ns = (int)(r % NS);
+  int g = (int)((r / NS) % G);
+  int t = (int)(r / ((int64_t)NS * G));
+  int co = ns * 16 + (lane & 15);
+  int ci = g * 16 + (lane >> 4) * 4 + j;
+  p[i] = (co < cout && ci < cin) ? w_at(w, transposed, cout, cin, k, co, ci, t) : 0.f;
+}
+
+extern "C" int mval_pack_conv_weights(int pack, int transposed, const float* w, float* packed, int cout, int cin, int k,
+                                      void* stream) {
+  MVAL_REQUIRE(cout > 0 && cin > 0 && k > 0, "mval_pack_conv_weights: bad dims");
+  int64_t total = (int64_t)mval_packed_weight_floats(pack, cout, cin, k);
+  dim3 grid((unsigned)((total + 255) / 256));
+  if (pack == MVAL_PACK_HWIO)
+    hipLaunchKernelGGL(pack_hwio_kernel, grid, dim3(256), 0, mval_stream(stream), w, packed, transposed, cout, cin, k);
+  else if (pack == MVAL_PACK_MFMA16)
+    hipLaunchKernelGGL(pack_mfma16_kernel, grid, dim3(256), 0, mval_stream(stream), w, packed, transposed, cout, cin,
+                       k);
+  else
+    MVAL_REQUIRE(false, "mval_pack_conv_weights: unknown packing %d", pack);
+  MVAL_CHECK_LAUNCH("mval_pack_conv_weights");
+  return 0;
+}
+
+// torch's inference formula (aten batch_norm_cpu_transform_input):
+//   alpha = gamma / sqrt(var + eps) ; y = x * alpha + (beta - mean * alpha)
+__global__ void bn_fold_kernel(const float* gamma, const float* beta, const float* mean, const float* var, float eps,
+                               float* scale, float* shift, int c) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= c) return;
+  float invstd = 1.0f / sqrtf(var[i] + eps);
+  float a = gamma[i] * invstd;
+  scale[i] = a;
+  shift[i] = beta[i] - mean[i] * a;
+}
+
+extern "C" int mval_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var, float eps,
+                            float* scale, float* shift, int c, void* stream) {
+  MVAL_REQUIRE(c > 0, "mval_bn_fold: bad dims");
+  hipLaunchKernelGGL(bn_fold_kernel, dim3((c + 255) / 256), dim3(256), 0, mval_stream(stream), gamma, beta, mean, var,
+                     eps, scale, shift, c);
+  MVAL_CHECK_LAUNCH("mval_bn_fold");
+  return 0;
+}
+
+// ---- direct operators -------------------------------------------------------------------
+#define DC_CO 4  // couts per thread
+
+// thread = (output pixel, group of DC_CO couts); weights HWIO so a wave reads contiguous couts
+__global__ __launch_bounds__(256) void conv_direct_kernel(ConvArgs a) {
+  const int cog = (a.Cout + DC_CO - 1) / DC_CO;
+  int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  int64_t total = (int64_t)a.N * a.Hout * a.Wout * cog;
+  if (t >= total) return;
+  const int cg = (int)(t % cog);
+  int64_t p = t / cog;
+  const int x = (int)(p % a.Wout);
+  const int y = (int)((p / a.Wout) % a.Hout);
+  const int n = (int)(p / ((int64_t)a.Wout * a.Hout));
+  const int c0 = cg * DC_CO;
+  float acc[DC_CO];
+#pragma unroll
+  for (int q = 0; q < DC_CO; q++) acc[q] = 0.f;
+  for (int ky = 0; ky < a.k; ky++) {
+    const int iy = y * a.stride - a.pad + ky;
+    if (iy < 0 || iy >= a.Hin) continue;
+    for (int kx = 0; kx < a.k; kx++) {
+      const int ix = x * a.stride - a.pad + kx;
+      if (ix < 0 || ix >= a.Win) continue;
+      const float* wp = a.w + ((int64_t)(ky * a.k + kx) * a.Cin) * a.Cout + c0;
+      for (int ci = 0; ci < a.Cin; ci++) {
+        const float v = a.in_nchw ? a.in[(((int64_t)n * a.Cin + ci) * a.Hin + iy) * a.Win + ix]
+                                  : a.in[(((int64_t)n * a.Hin + iy) * a.Win + ix) * a.Cin + ci];
+#pragma unroll
+        for (int q = 0; q < DC_CO; q++)
+          if (c0 + q < a.Cout) acc[q] = fmaf(v, wp[(int64_t)ci * a.Cout + q], acc[q]);
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < DC_CO; q++)
+    if (c0 + q < a.Cout) conv_store(a, n, y, x, c0 + q, acc[q] * a.scale[c0 + q] + a.shift[c0 + q]);
+}
+
+// ConvTranspose2d(k, stride, pad): out[oy] gathers iy with oy = iy*stride - pad + ky
+__global__ __launch_bounds__(256) void deconv_direct_kernel(ConvArgs a) {
+  const int cog = (a.Cout + DC_CO - 1) / DC_CO;
+  int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  int64_t total = (int64_t)a.N * a.Hout * a.Wout * cog;
+  if (t >= total) return;
+  const int cg = (int)(t % cog);
+  int64_t p = t / cog;
+  const int x = (int)(p % a.Wout);
+  const int y = (int)((p / a.Wout) % a.Hout);
+  const int n = (int)(p / ((int64_t)a.Wout * a.Hout));
+  const int c0 = cg * DC_CO;
+  float acc[DC_CO];
+#pragma unroll
+  for (int q = 0; q < DC_CO; q++) acc[q] = 0.f;
+  for (int ky = 0; ky < a.k; ky++) {
+    const int ty = y + a.pad - ky;
+    if (ty < 0 || ty % a.stride) continue;
+    const int iy = ty / a.stride;
+    if (iy >= a.Hin) continue;
+    for (int kx = 0; kx < a.k; kx++) {
+      const int tx = x + a.pad - kx;
+      if (tx < 0 || tx % a.stride) continue;
+      const int ix = tx / a.stride;
+      if (ix >= a.Win) continue;
+      const float* wp = a.w + ((int64_t)(ky * a.k + kx) * a.Cin) * a.Cout + c0;
+      const float* ip = a.in + (((int64_t)n * a.Hin + iy) * a.Win + ix) * a.Cin;
+      for (int ci = 0; ci < a.Cin; ci++) {
+        const float v = ip[ci];
+#pragma unroll
+        for (int q = 0; q < DC_CO; q++)
+          if (c0 + q < a.Cout) acc[q] = fmaf(v, wp[(int64_t)ci * a.Cout + q], acc[q]);
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < DC_CO; q++)
+    if (c0 + q < a.Cout) conv_store(a, n, y, x, c0 + q, acc[q] * a.scale[c0 + q] + a.shift[c0 + q]);
+}
+
+// MaxPool2d(k, stride, pad) on NHWC (padding never wins: -inf)
+__global__ __launch_bounds__(256) void maxpool_kernel(ConvArgs a) {
+  int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  int64_t total = (int64_t)a.N * a.Hout * a.Wout * a.Cout;
+  if (t >= total) return;
+  const int c = (int)(t % a.Cout);
+  int64_t p = t / a.Cout;
+  const int x = (int)(p % a.Wout);
+  const int y = (int)((p / a.Wout) % a.Hout);
+  const int n = (int)(p / ((int64_t)a.Wout * a.Hout));
+  float m = -INFINITY;
+  for (int ky = 0; ky < a.k; ky++) {
+    const int iy = y * a.stride - a.pad + ky;
+    if (iy < 0 || iy >= a.Hin) continue;
+    for (int kx = 0; kx < a.k; kx++) {
+      const int ix = x * a.stride - a.pad + kx;
+      if (ix < 0 || ix >= a.Win) continue;
+      float v = a.in[(((int64_t)n * a.Hin + iy) * a.Win + ix) * a.Cin + c];
+      m = (v > m || v != v) ? v : m;
+    }
+  }
+  a.out[t] = m;
+}
+
+int mval_launch_conv_direct(const ConvArgs& a, int kind, hipStream_t s) {
+  if (kind == MVAL_OP_MAXPOOL) {
+    int64_t total = (int64_t)a.N * a.Hout * a.Wout * a.Cout;
+    hipLaunchKernelGGL(maxpool_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
+    return 0;
+  }
+  const int cog = (a.Cout + DC_CO - 1) / DC_CO;
+  int64_t total = (int64_t)a.N * a.Hout * a.Wout * cog;
+  dim3 grid((unsigned)((total + 255) / 256));
+  if (kind == MVAL_OP_DECONV)
+    hipLaunchKernelGGL(deconv_direct_kernel, grid, dim3(256), 0, s, a);
+  else
+    hipLaunchKernelGGL(conv_direct_kernel, grid, dim3(256), 0, s, a);
+  return 0;
+}
+
+// ---- op executor ------------------------------------------------------------------------
+static int force_direct() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("MVAL_FORCE_DIRECT");
+    v = (e && e[0] == '1') ? 1 : 0;
+  }
+  return v;
+}
+
+extern "C" int mval_op_launch(const mval_op* op, int n_images, float* workspace, const float* params,
+                              const float* net_input, float* net_output, void* stream) {
+  MVAL_REQUIRE(op && n_images > 0, "mval_op_launch: bad arguments");
+  ConvArgs a;
+  a.in = op->in_off >= 0 ? workspace + op->in_off : net_input;
+  a.out = op->out_off >= 0 ? workspace + op->out_off : net_output;
+  a.res1 = op->res1_off >= 0 ? workspace + op->res1_off : nullptr;
+  a.res2 = op->res2_off >= 0 ? workspace + op->res2_off : nullptr;
+  a.w = op->w_off >= 0 ? params + op->w_off : nullptr;
+  a.scale = op->scale_off >= 0 ? params + op->scale_off : nullptr;
+  a.shift = op->shift_off >= 0 ? params + op->shift_off : nullptr;
+  a.N = n_images;
+  a.Hin = op->hin; a.Win = op->win; a.Cin = op->cin;
+  a.Hout = op->hout; a.Wout = op->wout; a.Cout = op->cout;
+  a.k = op->k; a.stride = op->stride; a.pad = op->pad;
+  a.up = op->up; a.relu = op->relu; a.in_nchw = op->in_nchw; a.out_nchw = op->out_nchw;
+  a.th = a.tw = a.tn = a.tw_log2 = a.thw_log2 = a.tiles_x = a.tiles_y = 0;
+  a.G_total = (op->cin + 15) / 16;
+  a.NS_total = (op->cout + 15) / 16;
+  MVAL_REQUIRE(a.in && a.out, "mval_op_launch: missing input/output buffer");
+  hipStream_t s = mval_stream(stream);
+  if (op->kind == MVAL_OP_CONV && op->algo == MVAL_ALGO_MFMA) {
+    MVAL_REQUIRE(!force_direct(), "MVAL_FORCE_DIRECT=1 but the plan was packed for the MFMA kernels");
+    int rc = mval_launch_conv_mfma(a, s);
+    MVAL_REQUIRE(rc == 0, "mval_op_launch: no MFMA kernel for conv k%d s%d cin%d cout%d", op->k, op->stride, op->cin,
+                 op->cout);
+  } else {
+    MVAL_REQUIRE(op->kind == MVAL_OP_MAXPOOL || (a.w && a.scale && a.shift), "mval_op_launch: missing parameters");
+    mval_launch_conv_direct(a, op->kind, s);
+  }
+  MVAL_CHECK_LAUNCH("mval_op_launch");
+  return 0;
+}
+
+struct MvalNet {
+  std::vector<mval_op> ops;
+};
+
+extern "C" void* mval_net_create(const mval_op* ops, int n_ops) {
+  if (!ops || n_ops <= 0) {
+    mval_set_error("mval_net_create: empty op list");
+    return nullptr;
+  }
+  MvalNet* n = new MvalNet();
+  n->ops.assign(ops, ops + n_ops);
+  return n;
+}
+
+extern "C" void mval_net_destroy(void* net) { delete reinterpret_cast<MvalNet*>(net); }
+
+extern "C" int mval_net_forward(void* net, int n_images, float* workspace, const float* params,
+                                const float* input_nchw, float* output_nchw, void* stream) {
+  MVAL_REQUIRE(net, "mval_net_forward: null net");
+  MvalNet* n = reinterpret_cast<MvalNet*>(net);
+  for (size_t i = 0; i < n->ops.size(); i++) {
+    int rc = mval_op_launch(&n->ops[i], n_images, workspace, params, input_nchw, output_nchw, stream);
+    if (rc) return rc;
+  }
+  return 0;
+}

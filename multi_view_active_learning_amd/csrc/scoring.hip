@@ -1,0 +1,297 @@
+// Heat-map uncertainty statistics (K13): HP / MPE / BSB (reference strategy.py:1149-1215).
+//
+// HBM-bound by design: one workgroup per (frame, view, joint) map stages the map once into
+// LDS (coalesced float loads, row stride padded by one word so that "one thread per row"
+// reads are bank-conflict free) and derives everything from that copy; the only HBM traffic
+// is hh*wh*4 bytes in and 8 bytes out per map.
+//
+//   HP   1 - max(softmax(map, dim=1))  == 1 - max_r 1 / sum_c exp(x_rc - max_c x_rc)
+//   MPE  peaks = peak_local_max(map, min_distance=2)   (scikit-image 0.18/0.19 semantics)
+//        p = exp(peaks) / sum(exp(peaks)) ; H = sum -p * log(p)   -- float32, python left-to-right
+//   BSB  q = softmax(map, dim=1) ; |q[peak0] - q[peak1]| of its two highest local peaks
+#include "mval_common.h"
+
+#define SC_THREADS 256
+#define SC_MAX_PEAKS 2048
+
+struct ScoreSmem {
+  float red[SC_THREADS];
+  int n_cand;
+  int overflow;
+  float vmin;
+  float ssum;
+};
+
+__device__ __forceinline__ float block_reduce_min(float v, float* red) {
+  v = wave_min(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float r = fminf(fminf(red[0], red[1]), fminf(red[2], red[3]));
+  __syncthreads();
+  return r;
+}
+__device__ __forceinline__ float block_reduce_max(float v, float* red) {
+  v = wave_max(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float r = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  return r;
+}
+
+// (value desc, flat index asc) ordering for the candidate sort
+__device__ __forceinline__ bool cand_before(float va, int ia, float vb, int ib) {
+  return (va > vb) || (va == vb && ia < ib);
+}
+
+template <int KIND>
+__global__ __launch_bounds__(SC_THREADS) void score_maps_kernel(const float* __restrict__ hm, float* __restrict__ stat,
+                                                                int32_t* __restrict__ n_peaks, int hh, int wh) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const int ld = wh + 1;
+  float* tile = reinterpret_cast<float*>(smem_raw);                      // hh * ld
+  float* cval = tile + (((hh * ld) + 3) & ~3);                           // SC_MAX_PEAKS
+  int* cidx = reinterpret_cast<int*>(cval + SC_MAX_PEAKS);               // SC_MAX_PEAKS
+  ScoreSmem* sm = reinterpret_cast<ScoreSmem*>(cidx + SC_MAX_PEAKS);
+  const int tid = threadIdx.x;
+  const int64_t map = blockIdx.x;
+  const float* p = hm + map * (int64_t)hh * wh;
+  const int npix = hh * wh;
+
+  for (int i = tid; i < npix; i += SC_THREADS) {
+    int y = i / wh, x = i - y * wh;
+    tile[y * ld + x] = p[i];
+  }
+  if (tid == 0) { sm->n_cand = 0; sm->overflow = 0; }
+  __syncthreads();
+
+  // ---- row-wise softmax statistics (HP, BSB) ------------------------------------------
+  if (KIND == MVAL_SCORE_HP || KIND == MVAL_SCORE_BSB) {
+    float best = 0.f;
+    for (int r = tid; r < hh; r += SC_THREADS) {
+      float* row = tile + r * ld;
+      float m = -INFINITY;
+      for (int c = 0; c < wh; c++) m = fmaxf(m, row[c]);
+      float s = 0.f;
+      for (int c = 0; c < wh; c++) s += expf(row[c] - m);
+      if (KIND == MVAL_SCORE_BSB) {
+        for (int c = 0; c < wh; c++) row[c] = expf(row[c] - m) / s;
+      }
+      best = fmaxf(best, 1.0f / s);
+    }
+    if (KIND == MVAL_SCORE_HP) {
+      best = block_reduce_max(best, sm->red);
+      if (tid == 0) { stat[map] = 1.0f - best; n_peaks[map] = 0; }
+      return;
+    }
+    __syncthreads();
+  }
+
+  // ---- peak_local_max(min_distance=2) -------------------------------------------------
+  float vmin = INFINITY;
+  for (int i = tid; i < npix; i += SC_THREADS) {
+    int y = i / wh, x = i - y * wh;
+    vmin = fminf(vmin, tile[y * ld + x]);
+  }
+  vmin = block_reduce_min(vmin, sm->red);
+  const int ih = hh - 4, iw = wh - 4;  // interior after the 2-px border exclusion
+  if (ih > 0 && iw > 0) {
+    for (int i = tid; i < ih * iw; i += SC_THREADS) {
+      int y = i / iw + 2, x = i % iw + 2;
+      float v = tile[y * ld + x];
+      if (!(v > vmin)) continue;
+      bool is_max = true;
+#pragma unroll
+      for (int dy = -2; dy <= 2; dy++)
+#pragma unroll
+        for (int dx = -2; dx <= 2; dx++) is_max = is_max && (tile[(y + dy) * ld + x + dx] <= v);
+      if (is_max) {
+        int slot = atomicAdd(&sm->n_cand, 1);
+        if (slot < SC_MAX_PEAKS) {
+          cval[slot] = v;
+          cidx[slot] = y * wh + x;
+        } else {
+          sm->overflow = 1;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (sm->overflow) {
+    if (tid == 0) { stat[map] = NAN; n_peaks[map] = -1; }
+    return;
+  }
+  int n = sm->n_cand;
+  // bitonic sort of the candidate list (padded with -inf / INT_MAX)
+  int npow = 1;
+  while (npow < n) npow <<= 1;
+  for (int i = n + tid; i < npow; i += SC_THREADS) { cval[i] = -INFINITY; cidx[i] = 0x7fffffff; }
+  __syncthreads();
+  for (int k = 2; k <= npow; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = tid; i < npow; i += SC_THREADS) {
+        int l = i ^ j;
+        if (l > i) {
+          float va = cval[i], vb = cval[l];
+          int ia = cidx[i], ib = cidx[l];
+          bool up = (i & k) == 0;  // ascending position == "before" order
+          bool swap = up ? cand_before(vb, ib, va, ia) : cand_before(va, ia, vb, ib);
+          if (swap) { cval[i] = vb; cval[l] = va; cidx[i] = ib; cidx[l] = ia; }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  // ensure_spacing: in sorted order a kept peak rejects later peaks at Chebyshev distance < 2.
+  // Two 5x5 maxima can only be that close when their values are equal (plateaus), so the
+  // common case has nothing to do; ties are resolved sequentially by one thread.
+  if (tid == 0) {
+    int kept = 0;
+    for (int i = 0; i < n; i++) {
+      bool rej = false;
+      float v = cval[i];
+      int yi = cidx[i] / wh, xi = cidx[i] % wh;
+      for (int k = kept - 1; k >= 0 && cval[k] == v; k--) {
+        int yk = cidx[k] / wh, xk = cidx[k] % wh;
+        if (max(abs(yi - yk), abs(xi - xk)) < 2) { rej = true; break; }
+      }
+      if (!rej) {
+        cval[kept] = v;
+        cidx[kept] = cidx[i];
+        kept++;
+      }
+    }
+    sm->n_cand = kept;
+  }
+  __syncthreads();
+  n = sm->n_cand;
+
+  if (KIND == MVAL_SCORE_BSB) {
+    if (tid == 0) {
+      n_peaks[map] = n;
+      stat[map] = (n >= 2) ? fabsf(cval[0] - cval[1]) : NAN;  // reference: IndexError when < 2 peaks
+    }
+    return;
+  }
+  // ---- MPE entropy (strategy.py:1171-1175) --------------------------------------------
+  for (int i = tid; i < n; i += SC_THREADS) cval[i] = expf(cval[i]);
+  __syncthreads();
+  if (tid == 0) {
+    float s = 0.f;  // python sum(): left to right in float32
+    for (int i = 0; i < n; i++) s += cval[i];
+    sm->ssum = s;
+  }
+  __syncthreads();
+  const float s = sm->ssum;
+  for (int i = tid; i < n; i += SC_THREADS) {
+    float pr = cval[i] / s;
+    // -prob * math.log(prob): log in double, weak python float -> float32, float32 product
+    cval[i] = (-pr) * (float)log((double)pr);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    float e = 0.f;
+    for (int i = 0; i < n; i++) e += cval[i];
+    stat[map] = e;  // no peaks -> python int 0
+    n_peaks[map] = n;
+  }
+}
+
+extern "C" int mval_score_maps(int kind, const float* heatmaps, float* stat, int32_t* n_peaks, int64_t n_maps, int hh,
+                               int wh, void* stream) {
+  MVAL_REQUIRE(n_maps >= 0 && hh > 0 && wh > 0, "mval_score_maps: bad dims");
+  MVAL_REQUIRE(kind >= 0 && kind <= 2, "mval_score_maps: unknown kind %d", kind);
+  if (n_maps == 0) return 0;
+  size_t smem = (size_t)((hh * (wh + 1) + 3) & ~3) * 4 + SC_MAX_PEAKS * 8 + sizeof(ScoreSmem) + 16;
+  MVAL_REQUIRE(smem <= 160 * 1024, "mval_score_maps: heat-map %dx%d does not fit LDS", hh, wh);
+  dim3 grid((unsigned)n_maps), block(SC_THREADS);
+  hipStream_t s = mval_stream(stream);
+  if (kind == MVAL_SCORE_HP)
+    hipLaunchKernelGGL(score_maps_kernel<MVAL_SCORE_HP>, grid, block, smem, s, heatmaps, stat, n_peaks, hh, wh);
+  else if (kind == MVAL_SCORE_MPE)
+    hipLaunchKernelGGL(score_maps_kernel<MVAL_SCORE_MPE>, grid, block, smem, s, heatmaps, stat, n_peaks, hh, wh);
+  else
+    hipLaunchKernelGGL(score_maps_kernel<MVAL_SCORE_BSB>, grid, block, smem, s, heatmaps, stat, n_peaks, hh, wh);
+  MVAL_CHECK_LAUNCH("mval_score_maps");
+  return 0;
+}
+
+// ---- AVG / STD over the valid maps of a frame, in python / numpy order -----------------
+template <typename T>
+__device__ T np_pairwise_sum_t(const T* a, int n) {
+  if (n < 8) {
+    T r = 0;
+    for (int i = 0; i < n; i++) r += a[i];
+    return r;
+  }
+  if (n <= 128) {
+    T r[8];
+    for (int k = 0; k < 8; k++) r[k] = a[k];
+    int i = 8;
+    for (; i < n - (n % 8); i += 8)
+      for (int k = 0; k < 8; k++) r[k] += a[i + k];
+    T res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; i++) res += a[i];
+    return res;
+  }
+  int n2 = n / 2;
+  n2 -= n2 % 8;
+  return np_pairwise_sum_t<T>(a, n2) + np_pairwise_sum_t<T>(a + n2, n - n2);
+}
+
+#define SR_MAX 1024
+
+__global__ void score_reduce_kernel(const float* __restrict__ per_map, const uint8_t* __restrict__ valid,
+                                    double* __restrict__ out, int B, int V, int J, int mode) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const float* pm = per_map + (int64_t)b * V * J;
+  int n = 0;
+  for (int j = 0; j < J; j++) n += (!valid || valid[(int64_t)b * J + j]) ? 1 : 0;
+  n *= V;
+  if (n == 0) { out[b] = NAN; return; }  // reference: ZeroDivisionError / nan
+  if (mode == MVAL_REDUCE_AVG_F64) {  // sum(python floats) / len
+    double s = 0.0;
+    for (int v = 0; v < V; v++)
+      for (int j = 0; j < J; j++)
+        if (!valid || valid[(int64_t)b * J + j]) s += (double)pm[v * J + j];
+    out[b] = s / (double)n;
+  } else if (mode == MVAL_REDUCE_AVG_F32) {  // sum(np.float32) / len  (float32 throughout)
+    float s = 0.f;
+    for (int v = 0; v < V; v++)
+      for (int j = 0; j < J; j++)
+        if (!valid || valid[(int64_t)b * J + j]) s += pm[v * J + j];
+    out[b] = (double)(s / (float)n);
+  } else if (mode == MVAL_REDUCE_STD_F64) {  // np.std(float64 array)
+    double buf[SR_MAX];
+    int k = 0;
+    for (int v = 0; v < V; v++)
+      for (int j = 0; j < J; j++)
+        if (!valid || valid[(int64_t)b * J + j]) buf[k++] = (double)pm[v * J + j];
+    double mean = np_pairwise_sum_t<double>(buf, n) / (double)n;
+    for (int i = 0; i < n; i++) { double d = buf[i] - mean; buf[i] = d * d; }
+    out[b] = sqrt(np_pairwise_sum_t<double>(buf, n) / (double)n);
+  } else {  // np.std(float32 array): float32 intermediates
+    float buf[SR_MAX];
+    int k = 0;
+    for (int v = 0; v < V; v++)
+      for (int j = 0; j < J; j++)
+        if (!valid || valid[(int64_t)b * J + j]) buf[k++] = pm[v * J + j];
+    float mean = (float)((double)np_pairwise_sum_t<float>(buf, n) / (double)n);
+    for (int i = 0; i < n; i++) { float d = buf[i] - mean; buf[i] = d * d; }
+    out[b] = (double)sqrtf(np_pairwise_sum_t<float>(buf, n) / (float)n);
+  }
+}
+
+extern "C" int mval_score_reduce(const float* per_map, const uint8_t* valid, double* out, int B, int V, int J, int mode,
+                                 void* stream) {
+  MVAL_REQUIRE(B >= 0 && V > 0 && J > 0 && V * J <= SR_MAX, "mval_score_reduce: bad dims (V*J must be <= %d)", SR_MAX);
+  MVAL_REQUIRE(mode >= 0 && mode <= 3, "mval_score_reduce: unknown mode %d", mode);
+  if (B == 0) return 0;
+  hipLaunchKernelGGL(score_reduce_kernel, dim3((B + 63) / 64), dim3(64), 0, mval_stream(stream), per_map, valid, out, B,
+                     V, J, mode);
+  MVAL_CHECK_LAUNCH("mval_score_reduce");
+  return 0;
+}

@@ -1,2 +1,277 @@
+"""HIP execution engine for the heat-map networks.
+
+``run_network(model, x)`` is what ``PoseHighResolutionNet.forward`` / ``PoseResNet.forward``
+call.  Inference (``model.eval()``) compiles the model's layer graph
+(pose_estimators/graph.py) into a *plan* for a given (N, H, W):
+
+  * every activation gets a slot in ONE HBM arena (liveness-based reuse; NHWC fp32),
+  * every conv gets its weights re-laid-out on device into the MFMA fragment order and its
+    eval-mode BatchNorm folded to (scale, shift) in ONE parameter buffer -- re-done only when
+    a parameter's version counter changes (load_state_dict, optimizer step),
+  * the op list is handed to the C-ABI (``mval_net_create``) once; a forward is then a single
+    ``mval_net_forward`` call that enqueues ~300 fused launches on torch's current stream with
+    no host synchronisation, no allocation and no framework dispatch (graph-capturable).
+
+Training mode (``model.train()``) runs the same graph through autograd Functions with
+train-mode BatchNorm (engine_train.py).  There is no CPU path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+from . import _lib
+from .pose_estimators import params as _params
+
+OP_CONV, OP_MAXPOOL, OP_DECONV = 0, 1, 2
+ALGO_DIRECT, ALGO_MFMA = 0, 1
+PACK_HWIO, PACK_MFMA16 = 0, 1
+
+
+class MvalOp(C.Structure):
+    """include/mval_hip.h: struct mval_op."""
+
+    _fields_ = [
+        ("kind", C.c_int32), ("algo", C.c_int32),
+        ("k", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
+        ("cin", C.c_int32), ("cout", C.c_int32),
+        ("hin", C.c_int32), ("win", C.c_int32), ("hout", C.c_int32), ("wout", C.c_int32),
+        ("up", C.c_int32), ("relu", C.c_int32), ("in_nchw", C.c_int32), ("out_nchw", C.c_int32),
+        ("in_off", C.c_int64), ("out_off", C.c_int64), ("res1_off", C.c_int64), ("res2_off", C.c_int64),
+        ("w_off", C.c_int64), ("scale_off", C.c_int64), ("shift_off", C.c_int64),
+    ]
+
+
+_KIND = {"conv": OP_CONV, "maxpool": OP_MAXPOOL, "deconv": OP_DECONV}
+
+
+def _align(n, a=64):
+    return (n + a - 1) // a * a
+
+
+def _mfma_ok(op, in_nchw):
+    if os.environ.get("MVAL_FORCE_DIRECT") == "1":
+        return False
+    return (op.kind == "conv" and not in_nchw and op.cin % 16 == 0 and op.k in (1, 3)
+            and op.stride in (1, 2) and op.pad == op.k // 2)
+
+
+class InferencePlan:
+    def __init__(self, model, n, h, w, device):
+        self.model, self.n, self.h, self.w, self.device = model, n, h, w, device
+        g = model._graph
+        self.graph = g
+        # ---- activation geometry, op by op ------------------------------------------------
+        dims = {g.input: (h, w)}
+        geo = []
+        for op in g.ops:
+            hin, win = dims[op.src]
+            if op.kind == "deconv":
+                hout, wout = (hin - 1) * op.stride - 2 * op.pad + op.k, (win - 1) * op.stride - 2 * op.pad + op.k
+            else:
+                hout, wout = (hin + 2 * op.pad - op.k) // op.stride + 1, (win + 2 * op.pad - op.k) // op.stride + 1
+            full = (hout << op.up, wout << op.up)
+            for r in (op.res1, op.res2):
+                if r is not None and dims[r] != full:
+                    raise ValueError(f"input {h}x{w}: branch resolutions do not line up at {op.conv}")
+            dims[op.dst] = full
+            geo.append((hin, win, hout, wout))
+        self.out_hw = dims[g.output]
+        self.out_channels = g.acts[g.output].channels
+        # ---- arena: liveness-based slot reuse --------------------------------------------------
+        last_use = {}
+        for i, op in enumerate(g.ops):
+            for a in (op.src, op.res1, op.res2):
+                if a is not None:
+                    last_use[a] = i
+        size = {a.id: _align(n * dims[a.id][0] * dims[a.id][1] * a.channels) for a in g.acts if a.id in dims}
+        offset, free, top = {}, [], 0  # free: list of (off, size)
+        for i, op in enumerate(g.ops):
+            if op.dst != g.output:
+                need = size[op.dst]
+                best = None
+                for k, (o, s) in enumerate(free):
+                    if s >= need and (best is None or s < free[best][1]):
+                        best = k
+                if best is None:
+                    offset[op.dst] = top
+                    top += need
+                else:
+                    o, s = free.pop(best)
+                    offset[op.dst] = o
+                    if s > need:
+                        free.append((o + need, s - need))
+            for a in {op.src, op.res1, op.res2}:
+                if a is not None and a != g.input and last_use.get(a) == i:
+                    free.append((offset[a], size[a]))
+            # coalesce neighbours
+            free.sort()
+            merged = []
+            for o, s in free:
+                if merged and merged[-1][0] + merged[-1][1] == o:
+                    merged[-1] = (merged[-1][0], merged[-1][1] + s)
+                else:
+                    merged.append((o, s))
+            free = merged
+        self.arena_floats = max(top, 64)
+        # ---- parameter buffer layout -------------------------------------------------------------
+        lib = _lib.lib()
+        self.ops = (MvalOp * len(g.ops))()
+        self.param_jobs = []  # (op index, packing, w_off, scale_off, shift_off)
+        ptop = 0
+        for i, op in enumerate(g.ops):
+            hin, win, hout, wout = geo[i]
+            in_nchw = g.acts[op.src].layout == "nchw"
+            out_nchw = g.acts[op.dst].layout == "nchw"
+            m = self.ops[i]
+            m.kind = _KIND[op.kind]
+            m.algo = ALGO_MFMA if _mfma_ok(op, in_nchw) else ALGO_DIRECT
+            m.k, m.stride, m.pad, m.cin, m.cout = op.k, op.stride, op.pad, op.cin, op.cout
+            m.hin, m.win, m.hout, m.wout = hin, win, hout, wout
+            m.up, m.relu, m.in_nchw, m.out_nchw = op.up, int(op.relu), int(in_nchw), int(out_nchw)
+            m.in_off = -1 if op.src == g.input else offset[op.src]
+            m.out_off = -1 if op.dst == g.output else offset[op.dst]
+            m.res1_off = -1 if op.res1 is None else offset[op.res1]
+            m.res2_off = -1 if op.res2 is None else offset[op.res2]
+            m.w_off = m.scale_off = m.shift_off = -1
+            if op.kind in ("conv", "deconv"):
+                pack = PACK_MFMA16 if m.algo == ALGO_MFMA else PACK_HWIO
+                nw = int(lib.mval_packed_weight_floats(C.c_int(pack), C.c_int(op.cout), C.c_int(op.cin), C.c_int(op.k)))
+                m.w_off = ptop
+                ptop += _align(nw)
+                m.scale_off = ptop
+                ptop += _align(op.cout)
+                m.shift_off = ptop
+                ptop += _align(op.cout)
+                self.param_jobs.append((i, pack, m.w_off, m.scale_off, m.shift_off))
+        self.param_floats = max(ptop, 64)
+        self.arena = torch.empty(self.arena_floats, dtype=torch.float32, device=device)
+        self.params = torch.zeros(self.param_floats, dtype=torch.float32, device=device)
+        self.param_sig = None
+        self.net = lib.mval_net_create(self.ops, C.c_int(len(g.ops)))
+        if not self.net:
+            raise _lib.MvalError("mval_net_create failed: " + lib.mval_last_error().decode())
+
+    def __del__(self):
+        try:
+            if getattr(self, "net", None):
+                _lib.lib().mval_net_destroy(C.c_void_p(self.net))
+        except Exception:
+            pass
+
+    # ---- parameters ---------------------------------------------------------------------
+    def _signature(self):
+        holders = self.model._holders
+        return tuple(t._version for h in holders.values() for t in list(h.parameters()) + list(h.buffers())) + tuple(
+            t.data_ptr() for h in holders.values() for t in h.parameters()
+        )
+
+    def refresh_params(self, force=False):
+        sig = self._signature()
+        if not force and sig == self.param_sig:
+            return
+        lib = _lib.lib()
+        holders = self.model._holders
+        st = _lib._stream()
+        base = self.params.data_ptr()
+        for i, pack, w_off, s_off, b_off in self.param_jobs:
+            op = self.graph.ops[i]
+            conv = holders[op.conv]
+            w = conv.weight.detach()
+            if not w.is_cuda:
+                raise _lib.MvalError("model parameters must be on the HIP device (call .cuda())")
+            w = w.contiguous()
+            _lib._check(
+                lib.mval_pack_conv_weights(
+                    C.c_int(pack), C.c_int(1 if op.kind == "deconv" else 0), C.c_void_p(w.data_ptr()),
+                    C.c_void_p(base + 4 * w_off), C.c_int(op.cout), C.c_int(op.cin), C.c_int(op.k), st),
+                "mval_pack_conv_weights")
+            if op.bn:
+                bn = holders[op.bn]
+                _lib._check(
+                    lib.mval_bn_fold(
+                        C.c_void_p(bn.weight.data_ptr()), C.c_void_p(bn.bias.data_ptr()),
+                        C.c_void_p(bn.running_mean.data_ptr()), C.c_void_p(bn.running_var.data_ptr()),
+                        C.c_float(bn.eps), C.c_void_p(base + 4 * s_off), C.c_void_p(base + 4 * b_off),
+                        C.c_int(op.cout), st),
+                    "mval_bn_fold")
+            else:
+                self.params[s_off : s_off + op.cout] = 1.0
+                if conv.bias is not None:
+                    self.params[b_off : b_off + op.cout] = conv.bias.detach()
+                else:
+                    self.params[b_off : b_off + op.cout] = 0.0
+        self.param_sig = sig
+
+    # ---- run ---------------------------------------------------------------------------------
+    def forward(self, x):
+        self.refresh_params()
+        out = torch.empty((self.n, self.out_channels) + tuple(self.out_hw), dtype=torch.float32, device=self.device)
+        _lib._check(
+            _lib.lib().mval_net_forward(
+                C.c_void_p(self.net), C.c_int(self.n), C.c_void_p(self.arena.data_ptr()),
+                C.c_void_p(self.params.data_ptr()), C.c_void_p(x.data_ptr()), C.c_void_p(out.data_ptr()),
+                _lib._stream()),
+            "mval_net_forward")
+        return out
+
+    def run_op(self, i, x, out):
+        """Launch a single op (debug / layer-wise tests)."""
+        _lib._check(
+            _lib.lib().mval_op_launch(
+                C.byref(self.ops[i]), C.c_int(self.n), C.c_void_p(self.arena.data_ptr()),
+                C.c_void_p(self.params.data_ptr()), C.c_void_p(x.data_ptr()), C.c_void_p(out.data_ptr()),
+                _lib._stream()),
+            "mval_op_launch")
+
+
+def _plan_for(model, x):
+    n, c, h, w = x.shape
+    if c != 3:
+        raise ValueError("expected (N, 3, H, W) images")
+    cache = model.__dict__.setdefault("_plans", {})
+    key = (n, h, w, x.device.index, os.environ.get("MVAL_FORCE_DIRECT") == "1")
+    plan = cache.get(key)
+    if plan is None:
+        if len(cache) >= 4:  # keep the arena footprint bounded
+            cache.pop(next(iter(cache)))
+        plan = cache[key] = InferencePlan(model, n, h, w, x.device)
+    return plan
+
+
 def run_network(model, x):
-    raise NotImplementedError
+    if not torch.is_tensor(x) or not x.is_cuda:
+        raise _lib.MvalError("the heat-map network runs on the HIP device only (no CPU path): pass a .cuda() tensor")
+    if x.dtype != torch.float32:
+        raise TypeError("expected float32 images")
+    x = x.contiguous()
+    if model.training:
+        from .engine_train import run_network_train
+
+        return run_network_train(model, x)
+    return _plan_for(model, x).forward(x)
+
+
+def smoke(dev):
+    """Tiny HRNet-W32 forward on the device checked against the CPU oracle (used by
+    __graft_entry__.smoke())."""
+    import numpy as np
+
+    from oracle import models as omodels
+
+    from . import synth
+    from .pose_estimators import PoseHighResolutionNet
+
+    m = PoseHighResolutionNet(5)
+    sd = {k: torch.from_numpy(v) for k, v in synth.synthetic_state_dict(m._graph.param_shapes(), 1).items()}
+    m.load_state_dict(sd, strict=True)
+    m = m.to(dev).eval()
+    x = torch.from_numpy(synth.images(1, 2, 1, 64, 64).reshape(2, 3, 64, 64))
+    with torch.no_grad():
+        y = m(x.to(dev)).cpu()
+        want = omodels.hrnet_forward(sd, x, omodels.HRNET_W32)
+    err = (y - want).abs().max().item()
+    assert err < 2e-4 * max(1.0, want.abs().max().item()), err
+    print(f"smoke: HRNet-W32 forward parity OK (max abs err {err:.2e})")

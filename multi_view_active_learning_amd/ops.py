@@ -1,0 +1,93 @@
+"""Single fused operators through the C-ABI (``mval_op_launch``) -- used by layer-wise tests,
+by the training executor and for debugging; the network path uses whole-plan launches
+(engine.py)."""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+from .engine import ALGO_DIRECT, ALGO_MFMA, OP_CONV, OP_DECONV, OP_MAXPOOL, PACK_HWIO, PACK_MFMA16, MvalOp, _align
+
+
+def pack_weights(weight, algo, transposed=False):
+    """Conv2d weight (Cout,Cin,k,k) [ConvTranspose2d (Cin,Cout,k,k) if transposed] -> packed."""
+    lib = _lib.lib()
+    if transposed:
+        cin, cout, k, _ = weight.shape
+    else:
+        cout, cin, k, _ = weight.shape
+    pack = PACK_MFMA16 if algo == ALGO_MFMA else PACK_HWIO
+    n = int(lib.mval_packed_weight_floats(C.c_int(pack), C.c_int(cout), C.c_int(cin), C.c_int(k)))
+    out = torch.empty(n, dtype=torch.float32, device=weight.device)
+    w = weight.detach().contiguous()
+    _lib._check(
+        lib.mval_pack_conv_weights(C.c_int(pack), C.c_int(int(transposed)), _lib._p(w), _lib._p(out), C.c_int(cout),
+                                   C.c_int(cin), C.c_int(k), _lib._stream()),
+        "mval_pack_conv_weights")
+    return out
+
+
+def fused_conv(x, weight, scale, shift, stride=1, pad=None, relu=False, res1=None, res2=None, up=0,
+               algo=ALGO_MFMA, in_nchw=False, out_nchw=False, kind=OP_CONV):
+    """out = act(((conv(x, w) * scale + shift + res1) + res2)), nearest-upsampled by 2^up.
+    x NHWC (N,H,W,Cin) unless in_nchw; returns NHWC (N,Ho,Wo,Cout) unless out_nchw."""
+    dev = x.device
+    transposed = kind == OP_DECONV
+    if kind == OP_MAXPOOL:
+        cin = cout = x.shape[3]
+        k = weight  # kernel size passed in place of the weight
+    elif transposed:
+        cin, cout, k, _ = weight.shape
+    else:
+        cout, cin, k, _ = weight.shape
+    if pad is None:
+        pad = k // 2
+    if in_nchw:
+        n, _, hin, win = x.shape
+    else:
+        n, hin, win, _ = x.shape
+    if transposed:
+        hout, wout = (hin - 1) * stride - 2 * pad + k, (win - 1) * stride - 2 * pad + k
+    else:
+        hout, wout = (hin + 2 * pad - k) // stride + 1, (win + 2 * pad - k) // stride + 1
+    ho, wo = hout << up, wout << up
+    tensors = [x.contiguous().reshape(-1)]
+    offs = [0]
+    for t in (res1, res2):
+        if t is not None:
+            offs.append(_align(offs[-1] + tensors[-1].numel()))
+            tensors.append(t.contiguous().reshape(-1))
+    out_off = _align(offs[-1] + tensors[-1].numel())
+    arena = torch.zeros(out_off + n * ho * wo * cout, dtype=torch.float32, device=dev)
+    for o, t in zip(offs, tensors):
+        arena[o : o + t.numel()] = t
+    if kind == OP_MAXPOOL:
+        params = torch.zeros(64, dtype=torch.float32, device=dev)
+        w_off = s_off = b_off = -1
+    else:
+        pw = pack_weights(weight, algo, transposed)
+        s_off = _align(pw.numel())
+        b_off = s_off + _align(cout)
+        params = torch.zeros(b_off + _align(cout), dtype=torch.float32, device=dev)
+        params[: pw.numel()] = pw
+        params[s_off : s_off + cout] = scale
+        params[b_off : b_off + cout] = shift
+        w_off = 0
+    m = MvalOp()
+    m.kind, m.algo = kind, algo
+    m.k, m.stride, m.pad, m.cin, m.cout = k, stride, pad, cin, cout
+    m.hin, m.win, m.hout, m.wout = hin, win, hout, wout
+    m.up, m.relu, m.in_nchw, m.out_nchw = up, int(relu), int(in_nchw), int(out_nchw)
+    m.in_off, m.out_off = 0, out_off
+    it = iter(offs[1:])
+    m.res1_off = next(it) if res1 is not None else -1
+    m.res2_off = next(it) if res2 is not None else -1
+    m.w_off, m.scale_off, m.shift_off = w_off, s_off, b_off
+    _lib._check(
+        _lib.lib().mval_op_launch(C.byref(m), C.c_int(n), _lib._p(arena), _lib._p(params), C.c_void_p(0), C.c_void_p(0),
+                                  _lib._stream()),
+        "mval_op_launch")
+    out = arena[out_off:]
+    return out.reshape(n, cout, ho, wo) if out_nchw else out.reshape(n, ho, wo, cout)

@@ -1,0 +1,264 @@
+"""Hot-path entry points of the reference's ``ActiveLearningStrategy`` (strategy.py):
+
+  _compute_batch_heatmap :772-782     _compute_batch_loss :762-770
+  _compute_mpe/_compute_hp/_compute_bsb :1149-1215
+  _compute_sal_dict :1004-1147        selection part of _sal_pseudo_labeling :932-949
+  train_step (inner loop body :460-487)   _evaluate_all core :597-636
+
+Same names, arguments and result types, so that the reference's orchestration code
+(experiment dirs, checkpoints, TensorBoard -- out of scope here) can call them unchanged.
+What changes is the execution model: a batch of frames is scored by a handful of HIP
+launches with NO per-sample device->host synchronisation and NO per-sample collective;
+ranks exchange ONE packed table per scoring pass (RCCL all_gather) instead of the
+reference's 8 tiny all_gathers per sample (strategy.py:1106-1114).
+"""
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+from heapq import nlargest
+
+import numpy as np
+import torch
+
+from . import _lib
+from .pose_estimators.loss import Pose2DMeanSquaredError
+from .utils import coreset, evaluation, triangulation
+
+_KIND = {"HP": _lib.SCORE_HP, "MPE": _lib.SCORE_MPE, "BSB": _lib.SCORE_BSB}
+
+
+def _reduce_mode(kind: str, config: str) -> int:
+    """Precision/order of the reference's aggregation: HP values are python
+    floats (float64 sum), MPE/BSB values are np.float32 (float32 sum)."""
+    if config == "AVG":
+        return _lib.REDUCE_AVG_F64 if kind == "HP" else _lib.REDUCE_AVG_F32
+    if config == "STD":
+        return _lib.REDUCE_STD_F64 if kind == "HP" else _lib.REDUCE_STD_F32
+    raise NotImplementedError("AL.%s_CONFIG should be either AVG or STD." % kind)
+
+
+def score_heatmaps_batch(kind: str, config: str, heatmaps, joint_valid):
+    """heatmaps (B,V,J,Hh,Wh) f32 HIP, joint_valid (B,J) -> (B,) float64 HIP tensor holding
+    the value the reference's ``_compute_{hp,mpe,bsb}`` returns for each frame (exactly
+    representable float32 where the reference's result is float32)."""
+    b, v, j, hh, wh = heatmaps.shape
+    hm = heatmaps.to(torch.float32).contiguous()
+    per_map, n_peaks = _lib.score_maps(_KIND[kind], hm, b * v * j, hh, wh)
+    valid = (torch.as_tensor(joint_valid) != 0).to(torch.uint8).reshape(b, j).to(hm.device).contiguous()
+    out = _lib.score_reduce(per_map, valid, b, v, j, _reduce_mode(kind, config))
+    return out, per_map.reshape(b, v, j), n_peaks.reshape(b, v, j), valid
+
+
+def tables_to_sal_dict(per_rank, batch_sizes, sal_dict=None):
+    """Packed per-rank tables [pose, frame_id, al_metric, sal_metric, inlier_count, mkpe,
+    keypoints_3d(3J)] -> the reference's five dicts, inserted in its gather order
+    (for batch: for sample: for rank; strategy.py:1024,1036,1115-1145)."""
+    if sal_dict is None:
+        sal_dict = {k: OrderedDict() for k in ("al_metric", "sal_metric", "inlier_count", "pred_3d_keypoints", "mkpe")}
+    j = (per_rank[0].shape[1] - 6) // 3
+    offsets = np.concatenate([[0], np.cumsum(batch_sizes)]).astype(np.int64)
+    for bi in range(len(batch_sizes)):
+        for si in range(int(batch_sizes[bi])):
+            row = int(offsets[bi]) + si
+            for tab in per_rank:
+                if row >= tab.shape[0]:
+                    continue
+                e = tab[row]
+                guid = "%s-%s" % (int(e[0]), int(e[1]))
+                sal_dict["sal_metric"][guid] = float(e[3])
+                sal_dict["inlier_count"][guid] = float(e[4])
+                sal_dict["pred_3d_keypoints"][guid] = e[6:].reshape(j, 3).tolist()
+                sal_dict["al_metric"][guid] = float(e[2])
+                sal_dict["mkpe"][guid] = float(e[5])
+    return sal_dict
+
+
+class ActiveLearningStrategy:
+    def __init__(self, al_cfg):
+        self.al_cfg = al_cfg
+        self.num_joints = al_cfg.DATA.NUM_JOINTS
+        self.joint_root_index = 2 if al_cfg.DATA.TYPE == "panoptic" else 21  # strategy.py:34-37
+        self.loss = Pose2DMeanSquaredError()
+
+    # ---- model glue ---------------------------------------------------------------
+    @staticmethod
+    def _compute_batch_heatmap(pose_estimator, data):
+        """strategy.py:772-782: (B,V,C,H,W) -> (B*V,C,H,W), frame-major / view-minor."""
+        images = data["images"].cuda()
+        c, h, w = images.shape[2], images.shape[3], images.shape[4]
+        return pose_estimator(images.reshape([-1, c, h, w]))
+
+    @staticmethod
+    def _compute_batch_loss(gt_heatmap, heatmaps, per_view_joint_valid, loss):
+        """strategy.py:762-770."""
+        _, _, j, h, w = gt_heatmap.shape
+        return loss.pose_2d_mse(
+            heatmaps, gt_heatmap.reshape([-1, j, h, w]), per_view_joint_valid.reshape([-1, j, 1, 1])
+        )
+
+    def train_step(self, pose_estimator, optimizer, data, lr_scheduler=None):
+        """Body of the training inner loop (strategy.py:460-487): zero_grad -> heat-maps ->
+        masked MSE -> host guard (NaN / inf / > LOSS_CLIP_VALUE skips the step)
+        -> backward -> optimizer step -> scheduler step.  Returns (loss_value, stepped)."""
+        optimizer.zero_grad()
+        heatmaps = self._compute_batch_heatmap(pose_estimator, data)
+        gt = data["gt_heatmap"].cuda()
+        pv = data["per_view_joint_valid"].to(torch.uint8).cuda()
+        batch_loss = self._compute_batch_loss(gt, heatmaps, pv, self.loss)
+        value = batch_loss.data.item()
+        ok = not (math.isnan(value) or math.isinf(value) or value > self.al_cfg.TRAIN.LOSS_CLIP_VALUE)
+        if ok:
+            batch_loss.backward()
+            optimizer.step()
+        if lr_scheduler is not None:
+            lr_scheduler.step()
+        return value, ok
+
+    # ---- per-frame scorers (reference signatures) ---------------------------------------
+    def _score_one(self, kind, config, heatmaps, joint_valid):
+        out, _, n_peaks, valid = score_heatmaps_batch(kind, config, heatmaps.unsqueeze(0), torch.as_tensor(joint_valid).reshape(1, -1))
+        if kind == "BSB":
+            bad = (n_peaks[0] < 2) & (valid[0].bool()[None, :])
+            if bool(bad.any().item()):
+                raise IndexError("list index out of range")  # strategy.py:1208 with < 2 peaks
+        if bool((n_peaks < 0).any().item()):
+            raise _lib.MvalError("peak list overflow (> 2048 local maxima in one heat-map)")
+        v = out[0].item()
+        if config == "AVG":
+            return float(v)
+        return np.float64(v) if kind == "HP" else np.float32(v)
+
+    def _compute_mpe(self, heatmaps, joint_valid):
+        return self._score_one("MPE", self.al_cfg.AL.MPE_CONFIG, heatmaps, joint_valid)
+
+    def _compute_hp(self, heatmaps, joint_valid):
+        return self._score_one("HP", self.al_cfg.AL.HP_CONFIG, heatmaps, joint_valid)
+
+    def _compute_bsb(self, heatmaps, joint_valid):
+        return self._score_one("BSB", self.al_cfg.AL.BSB_CONFIG, heatmaps, joint_valid)
+
+    # ---- pool scoring ---------------------------------------------------------------
+    def score_batch(self, heatmaps, dp):
+        """Everything the reference does per sample inside _compute_sal_dict
+        (strategy.py:1036-1094,1134), for a whole batch, on device.  heatmaps (B*V,J,h,w).
+        Returns a (B, 6 + 3J) float64 HIP table:
+        [pose, frame_id, al_metric, sal_metric, inlier_count, mkpe, keypoints_3d(3J)]."""
+        cfg = self.al_cfg
+        dev = heatmaps.device
+        pose = torch.as_tensor(dp["pose"]).reshape(-1)
+        b = pose.shape[0]
+        _, j, hh, wh = heatmaps.shape
+        hm = heatmaps.reshape(b, -1, j, hh, wh)
+        joint_valid = torch.as_tensor(dp["joint_valid"]).reshape(b, j)
+        r = triangulation.triangulate_batch(
+            hm, dp["proj_matrices"], cfg.POSE_ESTIMATOR.STRIDE, joint_valid,
+            cfg.AL.USE_SOFTARGMAX, cfg.AL.USE_REPROJECTION_XE, cfg.AL.REPROJECTION_SIGMA,
+        )
+        pred32 = r["keypoints_3d"].to(torch.float32)  # torch.Tensor(results["keypoints_3d"]) (:1046)
+        sal_metric = r["metric"].to(torch.float32).to(torch.float64)  # torch.Tensor([metric]) (:1061)
+        strat = cfg.AL.STRATEGY
+        if strat == "RANDOM":
+            al = torch.cat([torch.rand(1) for _ in range(b)]).to(torch.float64).to(dev)
+        elif strat == "TRIANGULATION":
+            al = r["metric"].to(torch.float64)  # torch.tensor([np.float64]) keeps float64 (:1075)
+        elif strat in ("MPE", "HP", "BSB"):
+            conf = getattr(cfg.AL, strat + "_CONFIG")
+            al, _, n_peaks, valid = score_heatmaps_batch(strat, conf, hm, joint_valid)
+            self._pending_checks.append((strat, n_peaks, valid))
+            if conf == "AVG" or strat != "HP":
+                al = al.to(torch.float32).to(torch.float64)  # torch.tensor(python float) is float32
+        elif strat == "CORESET":
+            al = torch.zeros(b, dtype=torch.float64, device=dev)
+        else:
+            raise NotImplementedError()
+        gt = torch.as_tensor(dp["3d_keypoints"]).to(dev)
+        mk = evaluation.mkpe_per_sample(pred32, gt, joint_valid.to(dev))
+        self._pending_checks.append(("INLIER", r["inlier_count"], None))
+        table = torch.cat(
+            [
+                pose.to(dev, torch.float64)[:, None],
+                torch.as_tensor(dp["frame_id"]).reshape(b).to(dev, torch.float64)[:, None],
+                al[:, None],
+                sal_metric[:, None],
+                r["inlier_count"].to(torch.float64)[:, None],
+                mk.to(torch.float64)[:, None],
+                pred32.to(torch.float64).reshape(b, 3 * j),
+            ],
+            dim=1,
+        )
+        return table
+
+    def _compute_sal_dict(self, data_loader, pose_estimator):
+        """strategy.py:1004-1147.  Same five OrderedDicts keyed "<pose>-<frame_id>", filled in
+        the reference's gather order (batch -> sample -> rank), but with one device->host
+        copy and (when torch.distributed is initialised) one all_gather for the whole pass."""
+        sal_dict = {
+            "al_metric": OrderedDict(),
+            "sal_metric": OrderedDict(),
+            "inlier_count": OrderedDict(),
+            "pred_3d_keypoints": OrderedDict(),
+            "mkpe": OrderedDict(),
+        }
+        self._pending_checks = []
+        tables, sizes = [], []
+        with torch.no_grad():
+            for dp in data_loader:
+                heatmaps = self._compute_batch_heatmap(pose_estimator, dp)
+                t = self.score_batch(heatmaps, dp)
+                tables.append(t)
+                sizes.append(t.shape[0])
+        if not tables:
+            return sal_dict
+        self._raise_deferred_errors()
+        local = torch.cat(tables, dim=0)
+        from .parallel import gather_tables
+
+        per_rank = gather_tables(local)  # list over ranks of (n_r, 6+3J) host arrays
+        return tables_to_sal_dict(per_rank, sizes, sal_dict)
+
+    def _raise_deferred_errors(self):
+        """Error behaviour of the reference's per-sample loop, checked once per pass."""
+        for kind, t, valid in self._pending_checks:
+            if kind == "INLIER":
+                if bool((t < 0).any().item()):
+                    raise ValueError("zero-size array to reduction operation minimum which has no identity")
+            else:
+                if bool((t < 0).any().item()):
+                    raise _lib.MvalError("peak list overflow (> 2048 local maxima in one heat-map)")
+                if kind == "BSB" and bool(((t < 2) & valid.bool()[:, None, :]).any().item()):
+                    raise IndexError("list index out of range")
+        self._pending_checks = []
+
+    def select_al_guids(self, sal_dict, al_num_frames, labeled_dict=None):
+        """Selection part of _sal_pseudo_labeling (strategy.py:932-949): NaN filter, then
+        CORESET -> CoreSet(pred_3d_keypoints, labeled, root).select_batch(N), else
+        heapq.nlargest(N, ...) (stable: ties keep gather order)."""
+        al_metric_dict = {g: m for g, m in sal_dict["al_metric"].items() if not math.isnan(m)}
+        if self.al_cfg.AL.STRATEGY == "CORESET":
+            cs = coreset.CoreSet(sal_dict["pred_3d_keypoints"], labeled_dict, self.joint_root_index)
+            return cs.select_batch(al_num_frames)
+        return nlargest(al_num_frames, al_metric_dict, key=al_metric_dict.get)
+
+    # ---- evaluation core (strategy.py:597-636) ----------------------------------------
+    def evaluate_mkpe(self, data_loader, pose_estimator):
+        """_evaluate_all's MKPE path: heat-maps -> hard arg-max triangulation -> MPJPE over the
+        whole loader (one packed gather instead of 3 all_gathers per sample)."""
+        preds, gts, valids = [], [], []
+        with torch.no_grad():
+            for dp in data_loader:
+                hm = self._compute_batch_heatmap(pose_estimator, dp)
+                b = torch.as_tensor(dp["pose"]).reshape(-1).shape[0] if "pose" in dp else dp["images"].shape[0]
+                _, j, hh, wh = hm.shape
+                jv = torch.as_tensor(dp["joint_valid"]).reshape(b, j)
+                r = triangulation.triangulate_batch(hm.reshape(b, -1, j, hh, wh), dp["proj_matrices"],
+                                                    self.al_cfg.POSE_ESTIMATOR.STRIDE, jv)
+                preds.append(r["keypoints_3d"].to(torch.float32))
+                gts.append(torch.as_tensor(dp["3d_keypoints"]).to(hm.device, torch.float32))
+                valids.append(jv.to(hm.device, torch.float32))
+        pred, gt, valid = torch.cat(preds), torch.cat(gts), torch.cat(valids)
+        from .parallel import all_gather_cat
+
+        pred, gt, valid = all_gather_cat(pred), all_gather_cat(gt), all_gather_cat(valid)
+        out, _ = _lib.mkpe(pred.contiguous(), gt.contiguous(), valid.contiguous(), pred.shape[0], pred.shape[1], gt.shape[1])
+        return out

@@ -1,0 +1,277 @@
+"""GPU parity tests (run with ``-m gpu`` on an MI355X): the HIP path, called through the
+C-ABI via ctypes, against (a) the golden vectors captured from the real reference and
+(b) the CPU oracle restatement on the same seeded inputs."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import cases
+from oracle import coreset as ocoreset
+from oracle import geometry, models, scoring
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    from multi_view_active_learning_amd import _lib
+
+    _lib.lib()  # fail loudly when the extension is missing
+    return torch.device("cuda:0")
+
+
+# ---------------------------------------------------------------------------------
+def test_reference_own_test_vector(dev):
+    from multi_view_active_learning_amd.utils.triangulation import triangulation
+
+    proj, hm, valid, stride = cases.reference_test_input()
+    z = np.load(os.path.join(G, "triangulation_reftest.npz"))
+    r = triangulation(torch.from_numpy(hm).to(dev), torch.from_numpy(proj), stride, torch.from_numpy(valid))
+    assert r["keypoints_2d"].dtype == np.int64 and r["keypoints_3d"].dtype == np.float64
+    np.testing.assert_array_equal(r["keypoints_2d"], z["keypoints_2d"])
+    # tolerance: 1e-6 mm vs the reference's LAPACK SVD (budget 1e-3 mm end to end)
+    np.testing.assert_allclose(r["keypoints_3d"], z["keypoints_3d"], rtol=0, atol=1e-6)
+    assert abs(r["metric"] - float(z["metric"])) < 1e-9 * float(z["metric"])
+    assert r["inlier_count"] == 3 and isinstance(r["inlier_count"], int) and isinstance(r["metric"], float)
+
+
+@pytest.mark.parametrize("name", list(cases.triangulation_cases()))
+def test_triangulation_vs_reference_golden(dev, name):
+    from multi_view_active_learning_amd.utils.triangulation import triangulate_batch
+
+    c = cases.triangulation_cases()[name]
+    z = np.load(os.path.join(G, "triangulation_synth.npz"))
+    hm, proj, valid = cases.build_triangulation_case(c)
+    r = triangulate_batch(torch.from_numpy(hm).to(dev), torch.from_numpy(proj), c["stride"], torch.from_numpy(valid))
+    np.testing.assert_array_equal(r["keypoints_2d"].cpu().numpy(), z[name + "/keypoints_2d"])
+    np.testing.assert_array_equal(r["inlier_count"].cpu().numpy(), z[name + "/inlier_count"])
+    np.testing.assert_allclose(r["keypoints_3d"].cpu().numpy(), z[name + "/keypoints_3d"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(r["metric"].cpu().numpy(), z[name + "/metric"], rtol=1e-9)
+
+
+def test_triangulation_noise_free_known_answer(dev):
+    """Analytic KAT: exact projections of known 3-D points triangulate back to them."""
+    from multi_view_active_learning_amd import synth
+    from multi_view_active_learning_amd import _lib
+
+    v, j, b = 4, 19, 5
+    proj = np.stack([synth.ring_cameras(v, 256, 256, seed=s) for s in range(b)])
+    x = synth.joints_3d(3, b, j).astype(np.float64)  # (b,3,j)
+    kp2 = np.stack([synth.project(proj[i], x[i].T) for i in range(b)]).astype(np.float32)  # (b,v,j,2)
+    k3, _, inl, metric, cnt = _lib.triangulate_ransac(
+        torch.from_numpy(kp2).to(dev), torch.from_numpy(proj).to(dev), None, b, v, j, 5.0)
+    np.testing.assert_allclose(k3.cpu().numpy(), x.transpose(0, 2, 1), rtol=0, atol=5e-2)  # f32 pixel rounding
+    assert int(cnt.min()) == v and float(metric.max()) < 1e-2
+
+
+@pytest.mark.parametrize("name", list(cases.xe_cases()))
+def test_xe_vs_reference_golden(dev, name):
+    from multi_view_active_learning_amd.utils.triangulation import triangulate_batch
+
+    c = cases.xe_cases()[name]
+    z = np.load(os.path.join(G, "triangulation_xe.npz"))
+    hm, proj, valid = cases.build_triangulation_case(c)
+    r = triangulate_batch(torch.from_numpy(hm).to(dev), torch.from_numpy(proj), c["stride"], torch.from_numpy(valid),
+                          False, True, c["sigma"])
+    np.testing.assert_allclose(r["metric"].cpu().numpy(), z[name + "/metric"], rtol=1e-9)
+
+
+def test_argmax_ties_nan_nonsquare_invalid(dev):
+    from multi_view_active_learning_amd.utils.evaluation import get_scaled_pred_corrdinates
+
+    hm = np.zeros((2, 3, 64, 48), dtype=np.float32)
+    hm[0, 0, 10, 7] = 1.0  # non-square quirk: (487 % 64, 487 // 64)
+    hm[0, 1, 5, 5] = hm[0, 1, 30, 2] = 2.0  # tie -> lowest flat index
+    hm[1, 0, 20, 20] = np.nan  # NaN is the maximum, like torch.argmax
+    hm[1, 0, 40, 1] = 9.0
+    hm[1, 2, 63, 47] = 1.0
+    got = get_scaled_pred_corrdinates(torch.from_numpy(hm).to(dev), 4, 3, torch.tensor([1, 1, 1]))
+    want = geometry.argmax_decode(hm, 4, [True] * 3)
+    np.testing.assert_array_equal(got, want)
+    np.testing.assert_array_equal(got[0, 0], [39 * 4, 7 * 4])
+    got = get_scaled_pred_corrdinates(torch.from_numpy(hm).to(dev), 4, 3, torch.tensor([1, 0, 1]))
+    np.testing.assert_array_equal(got[:, 1], 0)
+    # all -inf and constant maps -> index 0
+    flat = np.full((1, 2, 8, 8), -np.inf, dtype=np.float32)
+    flat[0, 1] = 3.0
+    got = get_scaled_pred_corrdinates(torch.from_numpy(flat).to(dev), 4, 2, torch.ones(2))
+    np.testing.assert_array_equal(got, 0)
+
+
+def test_soft_argmax_vs_oracle(dev):
+    from multi_view_active_learning_amd import _lib
+
+    rng = np.random.default_rng(5)
+    hm = (rng.standard_normal((3, 4, 5, 32, 24)) * 3).astype(np.float32)
+    got = _lib.soft_argmax(torch.from_numpy(hm).to(dev), 60, 32, 24, 4.0).cpu().numpy().reshape(3, 4, 5, 2)
+    want = geometry.spatial_soft_argmax2d(hm) * np.float32(4)
+    np.testing.assert_allclose(got, want, rtol=2e-5, atol=2e-4)  # fp32 sums in a different order
+
+
+# ---------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", list(cases.scoring_cases()))
+def test_scoring_vs_reference_golden(dev, name):
+    from multi_view_active_learning_amd.strategy import score_heatmaps_batch
+
+    c = cases.scoring_cases()[name]
+    z = np.load(os.path.join(G, "scoring.npz"))
+    hm, valid = cases.build_scoring_case(c)
+    t = torch.from_numpy(hm).to(dev)
+    for kind in ("HP", "MPE", "BSB"):
+        for cfg in ("AVG", "STD"):
+            out, per_map, n_peaks, _ = score_heatmaps_batch(kind, cfg, t, torch.from_numpy(valid))
+            got = out.cpu().numpy()
+            want = z[f"{name}/{kind}_{cfg}"]
+            # fp32 exp / sum order differ between torch-CPU, numpy and the device: few ulp
+            np.testing.assert_allclose(got, want, rtol=3e-6, atol=1e-7, err_msg=f"{kind}_{cfg}")
+
+
+def test_scoring_per_map_vs_oracle(dev):
+    from multi_view_active_learning_amd import _lib
+
+    c = cases.scoring_cases()["noise_nonsq"]
+    hm, valid = cases.build_scoring_case(c)
+    b, v, j, hh, wh = hm.shape
+    t = torch.from_numpy(hm).to(dev)
+    allv = np.ones(j, bool)
+    for kind, fn in ((_lib.SCORE_HP, scoring.compute_hps), (_lib.SCORE_MPE, scoring.compute_mpes), (_lib.SCORE_BSB, scoring.compute_bsbs)):
+        per, cnt = _lib.score_maps(kind, t, b * v * j, hh, wh)
+        per = per.cpu().numpy().reshape(b, v * j)
+        for bi in range(b):
+            want = np.asarray(fn(hm[bi], allv), dtype=np.float64)
+            np.testing.assert_allclose(per[bi], want, rtol=3e-6, atol=1e-7)
+        if kind == _lib.SCORE_MPE:
+            cnt = cnt.cpu().numpy().reshape(b, v, j)
+            want_n = [[len(scoring.peak_local_max(hm[0, vi, ji], min_distance=2)) for ji in range(j)] for vi in range(v)]
+            np.testing.assert_array_equal(cnt[0], want_n)
+
+
+def test_peak_known_answers_on_device(dev):
+    from multi_view_active_learning_amd import _lib
+
+    maps = np.zeros((5, 16, 16), dtype=np.float32)
+    maps[0, 8, 8] = 1  # single peak -> H = 0
+    maps[1, 8, 8] = maps[1, 3, 12] = 1  # two equal peaks -> ln 2
+    maps[2, 1, 8] = 1  # border peak excluded -> no peaks -> 0
+    maps[3, 8, 8] = maps[3, 8, 9] = 1  # adjacent plateau -> one peak
+    maps[4, 8, 8] = maps[4, 8, 10] = 1  # plateau at distance 2 -> both kept
+    per, cnt = _lib.score_maps(_lib.SCORE_MPE, torch.from_numpy(maps).to(dev), 5, 16, 16)
+    np.testing.assert_array_equal(cnt.cpu().numpy(), [1, 2, 0, 1, 2])
+    np.testing.assert_allclose(per.cpu().numpy(), [0, np.log(2), 0, 0, np.log(2)], atol=1e-6)
+    hp, _ = _lib.score_maps(_lib.SCORE_HP, torch.zeros((1, 64, 64), device=dev), 1, 64, 64)
+    assert abs(float(hp[0]) - (1 - 1 / 64)) < 1e-7  # row-wise softmax
+
+
+# ---------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", list(cases.coreset_cases()))
+def test_coreset_vs_reference_golden(dev, name):
+    from multi_view_active_learning_amd.utils.coreset import CoreSet
+
+    c = cases.coreset_cases()[name]
+    z = np.load(os.path.join(G, "coreset.npz"))
+    sal, al = cases.build_coreset_case(c)
+    cs = CoreSet(sal, al, c["root"])
+    keys = cs.select_batch(c["select"])
+    np.testing.assert_array_equal(cs.last_picks, z[name + "/picks"])  # bit-exact selected indices
+    assert keys == [list(sal)[i] for i in z[name + "/picks"]]
+    md = cs.min_distances.cpu().numpy()
+    np.testing.assert_allclose(md[:: max(1, cs.n_obs // 64)], z[name + "/final_min_distances"], rtol=1e-12, atol=1e-9)
+
+
+def test_coreset_degenerate_duplicates_and_tensor_path(dev):
+    from multi_view_active_learning_amd.utils.coreset import CoreSet
+
+    sal = {i: [[0, 1, 2] for _ in range(19)] for i in range(20)}
+    al = {i: [[0, 1, 2] for _ in range(19)] for i in range(5)}
+    assert CoreSet(sal, al, 2).select_batch(5) == [0, 0, 0, 0, 0]  # reference tests/test_coreset.py
+    with pytest.raises(IndexError):
+        CoreSet(sal, {}, 2)
+    c = cases.coreset_cases()["n1000_l200_j42"]
+    pool, lab = cases.coreset_arrays(c)
+    z = np.load(os.path.join(G, "coreset.npz"))
+    cs = CoreSet.from_tensors(torch.from_numpy(pool).to(dev), torch.from_numpy(lab).to(dev), c["root"])
+    np.testing.assert_array_equal(cs.select_batch(c["select"]), z["n1000_l200_j42/picks"])
+    # continuation: a second call keeps the running minimum (coreset.py:59-62)
+    more = cs.select_batch(3)
+    o = ocoreset.kcenter_greedy(cs.features.cpu().numpy(), cs.al_indices, c["select"] + 3)[0]
+    assert more == o[-3:]
+
+
+# ---------------------------------------------------------------------------------
+def test_masked_mse_and_mkpe_vs_oracle(dev):
+    from multi_view_active_learning_amd.pose_estimators.loss import Pose2DMeanSquaredError
+    from multi_view_active_learning_amd.utils.evaluation import compute_mkpe, mkpe_per_sample
+
+    rng = np.random.default_rng(7)
+    h = rng.standard_normal((6, 19, 64, 48)).astype(np.float32)
+    g = rng.standard_normal((6, 19, 64, 48)).astype(np.float32)
+    valid = rng.uniform(size=(6, 19, 1, 1)) > 0.3
+    ht = torch.from_numpy(h).to(dev).requires_grad_(True)
+    loss = Pose2DMeanSquaredError().pose_2d_mse(ht, torch.from_numpy(g).to(dev), torch.from_numpy(valid).to(dev))
+    loss.backward()
+    hc = torch.from_numpy(h).requires_grad_(True)
+    want = models.pose_2d_mse(hc, torch.from_numpy(g), torch.from_numpy(valid))
+    want.backward()
+    assert abs(loss.item() - want.item()) <= 2e-6 * abs(want.item())
+    np.testing.assert_allclose(ht.grad.cpu().numpy(), hc.grad.numpy(), rtol=1e-6, atol=1e-12)
+    l1 = Pose2DMeanSquaredError().pose_2d_mse_single_batch(torch.from_numpy(h[0, :1]).to(dev), torch.from_numpy(g[0, :1]).to(dev))
+    assert abs(l1.item() - float(((h[0, :1] - g[0, :1]) ** 2).sum() / (64 * 48))) < 1e-4
+    # MKPE
+    s, j = 7, 19
+    pred = rng.standard_normal((s, j, 3)).astype(np.float32) * 100
+    gt = rng.standard_normal((s, 4, j)).astype(np.float32) * 100
+    vj = (rng.uniform(size=(s, j)) > 0.2).astype(np.float32)
+    vj[:, 0] = 1
+    got = compute_mkpe([torch.from_numpy(p).to(dev) for p in pred], [torch.from_numpy(x).to(dev) for x in gt],
+                       [torch.from_numpy(x).to(dev) for x in vj])
+    want = models.compute_mkpe([torch.from_numpy(p) for p in pred], [torch.from_numpy(x) for x in gt], [torch.from_numpy(x) for x in vj])
+    assert abs(got.item() - want.item()) <= 2e-6 * abs(want.item()) or (np.isnan(got.item()) and np.isnan(want.item()))
+    per = mkpe_per_sample(torch.from_numpy(pred).to(dev), torch.from_numpy(gt).to(dev), torch.from_numpy(vj).to(dev)).cpu().numpy()
+    for i in range(s):
+        w = models.compute_mkpe([torch.from_numpy(pred[i])], [torch.from_numpy(gt[i])], [torch.from_numpy(vj[i])]).item()
+        assert (np.isnan(per[i]) and np.isnan(w)) or abs(per[i] - w) <= 2e-6 * abs(w)
+
+
+# ---------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", list(cases.sal_cases()))
+def test_sal_dict_vs_reference_golden(dev, name):
+    """_compute_sal_dict + selection: same five dicts, same key order, same picks as the
+    reference run captured in tests/golden/sal_dict.json."""
+    from multi_view_active_learning_amd.config import get_default_configs
+    from multi_view_active_learning_amd.strategy import ActiveLearningStrategy
+
+    with open(os.path.join(G, "sal_dict.json")) as f:
+        want = json.load(f)[name]
+    c = cases.sal_cases()[name]
+    cfg = get_default_configs()
+    cfg.AL.STRATEGY = c["strategy"]
+    cfg.POSE_ESTIMATOR.STRIDE = c["stride"]
+    cfg.AL.USE_REPROJECTION_XE = c.get("xe", False)
+    cfg.AL.REPROJECTION_SIGMA = c.get("sigma", 1.0)
+    loader, heatmaps = cases.build_sal_loader(c)
+    it = iter(heatmaps)
+
+    def fake_model(images):
+        return torch.from_numpy(next(it)).to(dev)
+
+    tl = [{k: torch.from_numpy(v) for k, v in dp.items()} for dp in loader]
+    sal = ActiveLearningStrategy(cfg)._compute_sal_dict(tl, fake_model)
+    for field in ("al_metric", "sal_metric", "inlier_count", "mkpe", "pred_3d_keypoints"):
+        assert list(sal[field]) == list(want[field]), field  # key order = gather order
+    for g in want["al_metric"]:
+        tol = 0 if c["strategy"] == "CORESET" else 3e-6
+        assert abs(sal["al_metric"][g] - want["al_metric"][g]) <= tol * abs(want["al_metric"][g]) + 1e-12, (g, sal["al_metric"][g], want["al_metric"][g])
+        assert abs(sal["sal_metric"][g] - want["sal_metric"][g]) <= 1e-6 * abs(want["sal_metric"][g])
+        assert sal["inlier_count"][g] == want["inlier_count"][g]
+        a, b_ = sal["mkpe"][g], want["mkpe"][g]
+        assert (np.isnan(a) and np.isnan(b_)) or abs(a - b_) <= 1e-5 * abs(b_)
+        # fp32-rounded keypoints: 1e-3 mm budget, typically identical
+        np.testing.assert_allclose(sal["pred_3d_keypoints"][g], want["pred_3d_keypoints"][g], rtol=0, atol=1e-3)
+    st = ActiveLearningStrategy(cfg)
+    if c["strategy"] != "CORESET":
+        assert st.select_al_guids(sal, c["select"]) == want["nlargest"]
