@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path on MI355X: frames x views / s, heat-map -> triangulated 3-D.
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+
+Workload (BASELINE.json configs[1], "c2"): HRNet-W32, 4 views, 256x256, batch 32 frames
+(128 images per step and per GPU), forward-only heat-maps + hard arg-max decode + pairwise
+RANSAC-DLT triangulation + reprojection metric.  Random synthetic weights / frames / cameras
+(multi_view_active_learning_amd/synth.py); inputs are resident in HBM before the timed region.
+
+One step = one pass of the hot path over one batch.  Frames are independent, so ranks shard
+frames with NO data-path collective (weak scaling: per-GPU work is fixed).
+
+Prints ONE JSON line on rank 0 with the driver's contract fields plus
+  roofline     dominant kernel family = fused conv on the fp32 matrix cores: algorithmic conv
+               FLOPs of one step / time spent in those launches (hipEvents around every launch
+               on the launch stream, mval_net_forward_timed), against the 157.3 TFLOP/s dense
+               fp32-MFMA peak;
+  cpu_baseline the CPU oracle (stock torch fp32 HRNet-W32 + numpy RANSAC-DLT restatement,
+               oracle/) timed on the host on a bounded sample of the same workload.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_FP32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, dense fp32-input MFMA
+FLOP_PER_IMAGE = {"hrnet_w32_256": 20.387e9}  # conv FLOPs (2*MAC) per frame x view
+
+WORKLOADS = {
+    # name: (arch, views, H, W, frames per step, joints, train?)
+    "c2": dict(arch="hrnet_w32", v=4, h=256, w=256, frames=32, j=19,
+               desc="HRNet-W32 4-view 256x256 batch-32 forward heat-maps + arg-max + RANSAC-DLT triangulation"),
+}
+
+
+def build_model(arch, j, dev, seed=0):
+    from multi_view_active_learning_amd import synth
+    from multi_view_active_learning_amd.pose_estimators import PoseHighResolutionNet, PoseResNet, hrnet_w48
+
+    if arch == "hrnet_w32":
+        m = PoseHighResolutionNet(j)
+    elif arch == "hrnet_w48":
+        m = PoseHighResolutionNet(j, hrnet_cfg=hrnet_w48())
+    else:
+        m = PoseResNet(j)
+    sd = synth.synthetic_state_dict(m._graph.param_shapes(), seed)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    return m.to(dev).eval(), sd
+
+
+def cpu_baseline(wl, sd_np, seconds_target=20.0):
+    """CPU oracle on a bounded sample: frames of the same shape until ~seconds_target."""
+    from multi_view_active_learning_amd import synth
+    from oracle import geometry, models
+
+    sd = {k: torch.from_numpy(v) for k, v in sd_np.items()}
+    v, h, w, j = wl["v"], wl["h"], wl["w"], wl["j"]
+    frames_per_call = 2
+    imgs = torch.from_numpy(synth.images(123, frames_per_call, v, h, w)).reshape(-1, 3, h, w)
+    proj = np.stack([synth.ring_cameras(v, h, w, seed=s) for s in range(frames_per_call)])
+    valid = np.ones(j, dtype=bool)
+    done, t0 = 0, time.perf_counter()
+    with torch.no_grad():
+        models.hrnet_forward(sd, imgs[:v], models.HRNET_W32)  # warm-up (page-in, thread pool)
+        t0 = time.perf_counter()
+        while True:
+            hm = models.hrnet_forward(sd, imgs, models.HRNET_W32).numpy().reshape(frames_per_call, v, j, h // 4, w // 4)
+            for b in range(frames_per_call):
+                geometry.triangulation(hm[b], proj[b], 4, valid)
+            done += frames_per_call
+            el = time.perf_counter() - t0
+            if el > seconds_target or done >= 64:
+                break
+    return dict(
+        value=done * v / el, unit="frames*views/s", cores=torch.get_num_threads(), kind="port",
+        sample=f"{done} frames x {v} views ({done * v} images) of the same workload, {el:.1f} s, "
+               f"stock torch fp32 HRNet-W32 + numpy RANSAC-DLT (oracle/), {torch.get_num_threads()} threads",
+    )
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    if world != args.gpus and rank == 0:
+        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; reporting n_gpus={world}", file=sys.stderr)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from multi_view_active_learning_amd import _lib, synth
+    from multi_view_active_learning_amd.engine import ALGO_MFMA, _plan_for
+    from multi_view_active_learning_amd.utils.triangulation import triangulate_batch
+
+    _lib.lib()  # fail loudly if the HIP extension is missing
+    wl = WORKLOADS[args.workload]
+    v, h, w, j, frames = wl["v"], wl["h"], wl["w"], wl["j"], wl["frames"]
+    model, sd_np = build_model(wl["arch"], j, dev)
+    images = torch.from_numpy(synth.images(1000 + rank, frames, v, h, w)).to(dev).reshape(frames * v, 3, h, w)
+    proj = torch.from_numpy(np.stack([synth.ring_cameras(v, h, w, seed=rank * 1000 + s) for s in range(frames)])).to(dev)
+    valid = torch.ones(frames, j, dtype=torch.uint8, device=dev)
+
+    def step():
+        hm = model(images)
+        return triangulate_batch(hm.reshape(frames, v, j, h // 4, w // 4), proj, 4, valid)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for _ in range(max(args.warmup, 1)):
+            r = step()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            r = step()
+        sync()
+        el = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([el], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    assert torch.isfinite(r["keypoints_3d"]).all()
+
+    # ---- roofline of the dominant kernel family (outside the timed region) ------------------------
+    roof = None
+    if rank == 0:
+        plan = _plan_for(model, images)
+        with torch.no_grad():
+            ms_acc, reps = None, 3
+            for _ in range(reps):
+                _, ms, flops = plan.forward_timed(images)
+                ms_acc = ms if ms_acc is None else ms_acc + ms
+        ms = ms_acc / reps
+        is_mfma = np.asarray([o.algo == ALGO_MFMA and o.kind == 0 for o in plan.ops])
+        t_mfma = float(ms[is_mfma].sum()) * 1e-3
+        f_mfma = float(flops[is_mfma].sum())
+        achieved = f_mfma / t_mfma / 1e12
+        k3 = np.asarray([o.algo == ALGO_MFMA and o.k == 3 and o.stride == 1 for o in plan.ops])
+        roof = dict(
+            bound="mfma", achieved=round(achieved, 2), peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s",
+            frac=round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), traffic=None,
+            kernel="conv_mfma_kernel (fused conv+BN+residual+ReLU, v_mfma_f32_16x16x4_f32), all template instances",
+            launches_per_step=int(is_mfma.sum()), avg_launch_us=round(t_mfma / is_mfma.sum() * 1e6, 2),
+            flops_per_step=f_mfma, seconds_in_kernel_per_step=round(t_mfma, 6),
+            conv3x3s1_tflops=round(float(flops[k3].sum()) / (float(ms[k3].sum()) * 1e-3) / 1e12, 2),
+            whole_forward_ms=round(float(ms.sum()), 3),
+            non_mfma_ms=round(float(ms[~is_mfma].sum()), 3),
+        )
+
+    if rank == 0:
+        total_units = world * frames * v * args.steps
+        out = {
+            "metric": "frames*views/sec (heatmap->triangulated 3D) HRNet-W32 4-view 256x256",
+            "value": round(total_units / el, 2),
+            "unit": "frames*views/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(el / args.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic (random variance-preserving weights, N(0,1) frames, ring cameras)",
+            "config": {"workload": wl["desc"], "frames_per_step_per_gpu": frames, "views": v,
+                       "images_per_step_per_gpu": frames * v, "parallelism": f"frame-sharded x{world}, no collective"},
+            "roofline": roof,
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(wl, sd_np, args.cpu_seconds)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

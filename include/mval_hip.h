@@ -178,6 +178,13 @@ void* mval_net_create(const mval_op* ops, int n_ops);
 void mval_net_destroy(void* net);
 int mval_net_forward(void* net, int n_images, float* workspace, const float* params,
                      const float* input_nchw, float* output_nchw, void* stream);
+/* Same, with a hipEvent recorded on `stream` around every op; blocks until the stream has
+ * drained and writes the elapsed milliseconds of each op to ms_per_op [n_ops] (HOST pointer).
+ * Measurement only (not graph-capturable). */
+int mval_net_forward_timed(void* net, int n_images, float* workspace, const float* params,
+                           const float* input_nchw, float* output_nchw, void* stream, float* ms_per_op);
+/* Algorithmic FLOPs (2*MAC) of one op for n_images. */
+double mval_op_flops(const mval_op* op, int n_images);
 
 #ifdef __cplusplus
 }

@@ -42,6 +42,7 @@ def lib() -> C.CDLL:
                 l.mval_kcenter_workspace_bytes.restype = C.c_size_t
                 l.mval_net_create.restype = C.c_void_p
                 l.mval_packed_weight_floats.restype = C.c_size_t
+                l.mval_op_flops.restype = C.c_double
                 _lib = l
     return _lib
 

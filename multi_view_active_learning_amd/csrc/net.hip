@@ -276,3 +276,38 @@ extern "C" int mval_net_forward(void* net, int n_images, float* workspace, const
   }
   return 0;
 }
+
+extern "C" double mval_op_flops(const mval_op* op, int n_images) {
+  if (!op || op->kind == MVAL_OP_MAXPOOL) return 0.0;
+  if (op->kind == MVAL_OP_DECONV)  // every input pixel meets every tap once
+    return 2.0 * n_images * op->hin * op->win * (double)op->cin * op->cout * op->k * op->k;
+  return 2.0 * n_images * op->hout * op->wout * (double)op->cin * op->cout * op->k * op->k;
+}
+
+extern "C" int mval_net_forward_timed(void* net, int n_images, float* workspace, const float* params,
+                                      const float* input_nchw, float* output_nchw, void* stream, float* ms_per_op) {
+  MVAL_REQUIRE(net && ms_per_op, "mval_net_forward_timed: null argument");
+  MvalNet* n = reinterpret_cast<MvalNet*>(net);
+  hipStream_t s = mval_stream(stream);
+  std::vector<hipEvent_t> ev(n->ops.size() + 1);
+  for (auto& e : ev) {
+    if (hipEventCreate(&e) != hipSuccess) {
+      mval_set_error("mval_net_forward_timed: hipEventCreate failed");
+      return -3;
+    }
+  }
+  int rc = 0;
+  (void)hipEventRecord(ev[0], s);
+  for (size_t i = 0; i < n->ops.size() && !rc; i++) {
+    rc = mval_op_launch(&n->ops[i], n_images, workspace, params, input_nchw, output_nchw, stream);
+    (void)hipEventRecord(ev[i + 1], s);
+  }
+  (void)hipEventSynchronize(ev.back());
+  for (size_t i = 0; i < n->ops.size(); i++) {
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, ev[i], ev[i + 1]);
+    ms_per_op[i] = ms;
+  }
+  for (auto& e : ev) (void)hipEventDestroy(e);
+  return rc;
+}

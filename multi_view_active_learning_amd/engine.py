@@ -217,6 +217,22 @@ class InferencePlan:
             "mval_net_forward")
         return out
 
+    def forward_timed(self, x):
+        """Forward with a hipEvent around every op: returns (out, per-op ms list, per-op FLOPs)."""
+        import numpy as np
+
+        self.refresh_params()
+        out = torch.empty((self.n, self.out_channels) + tuple(self.out_hw), dtype=torch.float32, device=self.device)
+        ms = (C.c_float * len(self.ops))()
+        _lib._check(
+            _lib.lib().mval_net_forward_timed(
+                C.c_void_p(self.net), C.c_int(self.n), C.c_void_p(self.arena.data_ptr()),
+                C.c_void_p(self.params.data_ptr()), C.c_void_p(x.data_ptr()), C.c_void_p(out.data_ptr()),
+                _lib._stream(), ms),
+            "mval_net_forward_timed")
+        flops = [float(_lib.lib().mval_op_flops(C.byref(self.ops[i]), C.c_int(self.n))) for i in range(len(self.ops))]
+        return out, np.asarray(list(ms), dtype=np.float64), np.asarray(flops)
+
     def run_op(self, i, x, out):
         """Launch a single op (debug / layer-wise tests)."""
         _lib._check(
