@@ -171,6 +171,10 @@ int mval_pack_conv_weights(int pack, int transposed, const float* w, float* pack
 int mval_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var, float eps,
                  float* scale, float* shift, int c, void* stream);
 
+/* 1 when the MFMA kernel family has a configuration for this op geometry (the plan builder
+ * asks before choosing MVAL_ALGO_MFMA / MVAL_PACK_MFMA16), else 0. */
+int mval_op_mfma_supported(const mval_op* op, int n_images);
+
 int mval_op_launch(const mval_op* op, int n_images, float* workspace, const float* params,
                    const float* net_input, float* net_output, void* stream);
 

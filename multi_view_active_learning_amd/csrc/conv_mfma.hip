@@ -5,36 +5,46 @@
 // reference's HRNet / PoseResNet forward (pose_estimators/hrnet.py:36-52,75-95,199-287).
 //
 // Implicit GEMM, M = output pixels, N = couts, K = taps x cin:
-//   * a workgroup (4 waves) owns a tile of tn x th x tw output pixels x (16*NT*WN) couts of
-//     one image group; the INPUT PATCH of that tile (with its halo) for a chunk of KC input
-//     channels is staged once in LDS ([pixel][KC+8] floats: the +8 pad makes the per-tap
-//     ds_read_b128 fragment reads bank-conflict free) and re-used by all k*k taps, so global
-//     ->LDS traffic is ~1.3x the activations instead of 9x (im2col);
-//   * A fragments (pixels x 4 consecutive cin) come from LDS with one ds_read_b128 per
-//     16-pixel sub-tile per 16 cin; a tap is just a constant LDS offset;
+//   * a workgroup (4 waves) owns a tile of tn x th x tw output pixels x (16*NT*WN) couts; the
+//     INPUT PATCH of that tile (with its halo) for a chunk of KC input channels is staged once
+//     in LDS ([pixel][KC+8] floats; the +8 pad spreads a ds_read_b128 lane group over all 64
+//     banks) and re-used by all k*k taps, so global->LDS traffic is ~1.3x the activations
+//     instead of 9x (im2col); a tap is a constant LDS offset;
+//   * chunks are double-buffered: the global loads of chunk c+1 are issued into registers
+//     before the MFMAs of chunk c and written to the other LDS buffer after them (one
+//     barrier per chunk, "issue early / write late");
+//   * A fragments: one ds_read_b128 per 16-pixel sub-tile per 16 cin;
 //   * B fragments (weights) are pre-packed on device in fragment order
-//     [tap][cin/16][cout/16][lane][4] (mval_pack_conv_weights) so each wave fetches its
-//     16 cin x 16 cout block with ONE fully coalesced 1 KiB global_load_dwordx4, straight
-//     to VGPRs (weights are shared by every workgroup -> L2 hits), prefetched one step ahead;
-//   * waves split N first (each cout block is fetched by one wave only) and M second;
-//   * epilogue in registers: y = acc*scale + shift (+res1) (+res2), ReLU, optional 2^up
-//     nearest replication, NHWC or NCHW store.
+//     [tap][cin/16][cout/16][lane][4] (mval_pack_conv_weights): ONE fully coalesced 1 KiB
+//     global_load_dwordx4 per wave per (tap, 16 cin), straight to VGPRs (weights are shared by
+//     every workgroup -> L2 hits), prefetched one step ahead; waves split N first so each
+//     weight block is fetched once per workgroup;
+//   * epilogue: y = acc*scale + shift goes through LDS so that the residual loads and the
+//     stores are float4 along channels (full 128-B lines) -- (+res1) (+res2), ReLU, optional
+//     2^up nearest replication, NHWC or NCHW store.
 // fp32 MFMA runs at the fp32 vector rate (157 TFLOP/s peak); the kernel is MFMA-bound.
+#include <stdlib.h>
+
 #include "conv_common.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define KPAD 8
+#define OPAD 4
 
-template <int KS, int S, int KC, int WN, int WM, int NT, int MS>
+template <int KS, int S, int KC, int WN, int WM, int NT, int MS, int NE>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int KCP = KC + KPAD;
-  constexpr int GC = KC / 16;  // 16-cin groups per chunk
+  constexpr int GC = KC / 16;       // 16-cin groups per chunk
+  constexpr int C4 = KC / 4;        // float4 per pixel per chunk
+  constexpr int MT = 16 * MS * WM;  // pixels per tile
+  constexpr int NTILE = 16 * NT * WN;
+  constexpr int LDW = NTILE + OPAD;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wn = wave % WN, wm = wave / WN;
   const int PH = (a.th - 1) * S + KS, PW = (a.tw - 1) * S + KS;
-  const int pad = (KS - 1) / 2;
+  constexpr int pad = (KS - 1) / 2;
 
   // tile origin
   int t = blockIdx.x;
@@ -45,8 +55,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
   const int oy0 = tyi * a.th, ox0 = txi * a.tw;
   const int iy0 = oy0 * S - pad, ix0 = ox0 * S - pad;
 
-  // cout blocks of this wave
-  const int ns0 = (blockIdx.y * WN + wn) * NT;
+  const int ns0 = (blockIdx.y * WN + wn) * NT;  // first 16-cout block of this wave
   const bool wave_active = ns0 < a.NS_total;
 
   // per-lane LDS base of each 16-pixel sub-tile (pixel = lane & 15, cin quad = lane >> 4)
@@ -60,6 +69,26 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
     abase[ms] = ((tni * PH + ty * S) * PW + tx * S) * KCP + (lane >> 4) * 4;
   }
 
+  // staging descriptors: element e = tid + 256*i -> patch pixel e / C4, float4 e % C4
+  const int patch_px = a.tn * PH * PW;
+  const int patch_e = patch_px * C4;
+  const int patch_floats = patch_px * KCP;
+  constexpr int NEA = NE > 0 ? NE : 1;
+  int goff[NEA];  // float offset of the element in the input for chunk 0, -1 outside the image
+#pragma unroll
+  for (int i = 0; i < NE; i++) {
+    const int e = tid + 256 * i;
+    const int px = e / C4, q = e % C4;
+    int r = px;
+    const int pxx = r % PW;
+    r /= PW;
+    const int pyy = r % PH;
+    const int tni = r / PH;
+    const int iy = iy0 + pyy, ix = ix0 + pxx, n = n0 + tni;
+    const bool ok = e < patch_e && n < a.N && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
+    goff[i] = ok ? ((n * a.Hin + iy) * a.Win + ix) * a.Cin + q * 4 : -1;
+  }
+
   f32x4 acc[MS][NT];
 #pragma unroll
   for (int ms = 0; ms < MS; ms++)
@@ -67,14 +96,14 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
     for (int nt = 0; nt < NT; nt++) acc[ms][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const f32x4* wq = reinterpret_cast<const f32x4*>(a.w) + lane;
-  const int patch_px = a.tn * PH * PW;
-  constexpr int C4 = KC / 4;  // float4 per pixel per chunk
+  const int nchunks = a.Cin / KC;
+  f32x4 stage[NEA];
 
-  for (int c0 = 0; c0 < a.Cin; c0 += KC) {
-    if (c0) __syncthreads();
-    // ---- stage the input patch chunk: coalesced float4 loads (NHWC), zero outside ----
-    for (int e = tid; e < patch_px * C4; e += 256) {
-      const int px = e / C4, q = e - px * C4;
+  // generic (NE == 0) staging for rare tile shapes whose patch exceeds the register budget:
+  // plain load -> LDS store loop, single buffer, two barriers per chunk
+  auto stage_generic = [&](int c0) {
+    for (int e = tid; e < patch_e; e += 256) {
+      const int px = e / C4, q = e % C4;
       int r = px;
       const int pxx = r % PW;
       r /= PW;
@@ -86,65 +115,153 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
         v = *reinterpret_cast<const f32x4*>(a.in + (((int64_t)n * a.Hin + iy) * a.Win + ix) * a.Cin + c0 + q * 4);
       *reinterpret_cast<f32x4*>(smem + px * KCP + q * 4) = v;
     }
-    __syncthreads();
-    if (!wave_active) continue;
+  };
 
-    const int g0 = c0 / 16;
-    // weight fragment stream for this chunk: index ((tap*G + g)*NS + ns) * 64 (+lane)
-    f32x4 bcur[NT], bnxt[NT];
+  // prologue: chunk 0 -> LDS buffer 0
+  if constexpr (NE > 0) {
+#pragma unroll
+    for (int i = 0; i < NE; i++)
+      stage[i] = goff[i] >= 0 ? *reinterpret_cast<const f32x4*>(a.in + goff[i]) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < NE; i++) {
+      const int e = tid + 256 * i;
+      if (e < patch_e) *reinterpret_cast<f32x4*>(smem + (e / C4) * KCP + (e % C4) * 4) = stage[i];
+    }
+  } else {
+    stage_generic(0);
+  }
+  __syncthreads();
+
+  for (int ch = 0; ch < nchunks; ch++) {
+    const float* cur = NE > 0 ? smem + (ch & 1) * patch_floats : smem;
+    const bool more = ch + 1 < nchunks;
+    if (NE > 0 && more) {  // issue the next chunk's global loads before the MFMAs
+      const int c1 = (ch + 1) * KC;
+#pragma unroll
+      for (int i = 0; i < NE; i++)
+        stage[i] = goff[i] >= 0 ? *reinterpret_cast<const f32x4*>(a.in + goff[i] + c1) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    if (wave_active) {
+      const int g0 = ch * GC;
+      f32x4 bcur[NT], bnxt[NT];
+#pragma unroll
+      for (int nt = 0; nt < NT; nt++) {
+        const int ns = min(ns0 + nt, a.NS_total - 1);
+        bcur[nt] = wq[((int64_t)g0 * a.NS_total + ns) * 64];
+      }
+#pragma unroll
+      for (int it = 0; it < KS * KS * GC; it++) {
+        const int tap = it / GC, gg = it % GC;
+        if (it + 1 < KS * KS * GC) {
+          const int tap2 = (it + 1) / GC, gg2 = (it + 1) % GC;
+#pragma unroll
+          for (int nt = 0; nt < NT; nt++) {
+            const int ns = min(ns0 + nt, a.NS_total - 1);
+            bnxt[nt] = wq[((int64_t)(tap2 * a.G_total + g0 + gg2) * a.NS_total + ns) * 64];
+          }
+        }
+        const int toff = ((tap / KS) * PW + (tap % KS)) * KCP + gg * 16;
+        f32x4 af[MS];
+#pragma unroll
+        for (int ms = 0; ms < MS; ms++) af[ms] = *reinterpret_cast<const f32x4*>(cur + abase[ms] + toff);
+#pragma unroll
+        for (int jj = 0; jj < 4; jj++)
+#pragma unroll
+          for (int ms = 0; ms < MS; ms++)
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++)
+              acc[ms][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[ms][jj], bcur[nt][jj], acc[ms][nt], 0, 0, 0);
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++) bcur[nt] = bnxt[nt];
+      }
+    }
+    if (NE == 0 && more) {
+      __syncthreads();
+      stage_generic((ch + 1) * KC);
+    }
+    if (NE > 0 && more) {  // write the staged chunk into the other buffer (last read two barriers ago)
+      float* nxt = smem + ((ch + 1) & 1) * patch_floats;
+#pragma unroll
+      for (int i = 0; i < NE; i++) {
+        const int e = tid + 256 * i;
+        if (e < patch_e) *reinterpret_cast<f32x4*>(nxt + (e / C4) * KCP + (e % C4) * 4) = stage[i];
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue ---------------------------------------------------------------------------
+  // C layout: col(cout) = lane & 15, row(pixel) = (lane >> 4) * 4 + reg.  BN in registers,
+  // then through LDS ([pixel][NTILE+4]) so that global accesses run along channels.
+  if (wave_active) {
 #pragma unroll
     for (int nt = 0; nt < NT; nt++) {
-      const int ns = min(ns0 + nt, a.NS_total - 1);
-      bcur[nt] = wq[((int64_t)(0 * a.G_total + g0) * a.NS_total + ns) * 64];
-    }
+      const int cl = (wn * NT + nt) * 16 + (lane & 15);
+      const int c = blockIdx.y * NTILE + cl;
+      const float sc = c < a.Cout ? a.scale[c] : 0.f, sh = c < a.Cout ? a.shift[c] : 0.f;
 #pragma unroll
-    for (int it = 0; it < KS * KS * GC; it++) {
-      const int tap = it / GC, gg = it % GC;
-      if (it + 1 < KS * KS * GC) {
-        const int tap2 = (it + 1) / GC, gg2 = (it + 1) % GC;
+      for (int ms = 0; ms < MS; ms++)
 #pragma unroll
-        for (int nt = 0; nt < NT; nt++) {
-          const int ns = min(ns0 + nt, a.NS_total - 1);
-          bnxt[nt] = wq[((int64_t)(tap2 * a.G_total + g0 + gg2) * a.NS_total + ns) * 64];
+        for (int r = 0; r < 4; r++) {
+          const int p = (wm * MS + ms) * 16 + (lane >> 4) * 4 + r;
+          smem[p * LDW + cl] = acc[ms][nt][r] * sc + sh;
         }
-      }
-      const int toff = ((tap / KS) * PW + (tap % KS)) * KCP + gg * 16;
-      f32x4 af[MS];
+    }
+  } else {
 #pragma unroll
-      for (int ms = 0; ms < MS; ms++) af[ms] = *reinterpret_cast<const f32x4*>(smem + abase[ms] + toff);
+    for (int nt = 0; nt < NT; nt++) {
+      const int cl = (wn * NT + nt) * 16 + (lane & 15);
 #pragma unroll
-      for (int jj = 0; jj < 4; jj++)
+      for (int ms = 0; ms < MS; ms++)
 #pragma unroll
-        for (int ms = 0; ms < MS; ms++)
-#pragma unroll
-          for (int nt = 0; nt < NT; nt++)
-            acc[ms][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[ms][jj], bcur[nt][jj], acc[ms][nt], 0, 0, 0);
-#pragma unroll
-      for (int nt = 0; nt < NT; nt++) bcur[nt] = bnxt[nt];
+        for (int r = 0; r < 4; r++) smem[((wm * MS + ms) * 16 + (lane >> 4) * 4 + r) * LDW + cl] = 0.f;
     }
   }
-  if (!wave_active) return;
-
-  // ---- epilogue: C layout col(cout) = lane & 15, row(pixel) = (lane >> 4) * 4 + reg ----
-#pragma unroll
-  for (int nt = 0; nt < NT; nt++) {
-    const int c = (ns0 + nt) * 16 + (lane & 15);
-    if (c >= a.Cout) continue;
-    const float sc = a.scale[c], sh = a.shift[c];
-#pragma unroll
-    for (int ms = 0; ms < MS; ms++) {
-#pragma unroll
-      for (int r = 0; r < 4; r++) {
-        const int p = (wm * MS + ms) * 16 + (lane >> 4) * 4 + r;
-        const int tni = p >> a.thw_log2;
-        const int rem = p & ((1 << a.thw_log2) - 1);
-        const int y = oy0 + (rem >> a.tw_log2), x = ox0 + (rem & ((1 << a.tw_log2) - 1));
-        const int n = n0 + tni;
-        if (n < a.N && y < a.Hout && x < a.Wout) conv_store(a, n, y, x, c, acc[ms][nt][r] * sc + sh);
-      }
+  __syncthreads();
+  const int cbase = blockIdx.y * NTILE;
+  const int Ho = a.Hout << a.up, Wo = a.Wout << a.up, rep = 1 << a.up;
+  if (!a.out_nchw && (a.Cout & 3) == 0) {
+    constexpr int Q = NTILE / 4;
+    for (int e = tid; e < MT * Q; e += 256) {
+      const int p = e / Q, c4 = e % Q;
+      const int c = cbase + c4 * 4;
+      if (c >= a.Cout) continue;
+      const int tni = p >> a.thw_log2;
+      const int rem = p & ((1 << a.thw_log2) - 1);
+      const int y = oy0 + (rem >> a.tw_log2), x = ox0 + (rem & ((1 << a.tw_log2) - 1));
+      const int n = n0 + tni;
+      if (n >= a.N || y >= a.Hout || x >= a.Wout) continue;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(smem + p * LDW + c4 * 4);
+      for (int dy = 0; dy < rep; dy++)
+        for (int dx = 0; dx < rep; dx++) {
+          const int64_t o = (((int64_t)n * Ho + (y << a.up) + dy) * Wo + (x << a.up) + dx) * a.Cout + c;
+          f32x4 r = v;
+          if (a.res1) r += *reinterpret_cast<const f32x4*>(a.res1 + o);
+          if (a.res2) r += *reinterpret_cast<const f32x4*>(a.res2 + o);
+          if (a.relu) {
+            r.x = fmaxf(r.x, 0.f); r.y = fmaxf(r.y, 0.f); r.z = fmaxf(r.z, 0.f); r.w = fmaxf(r.w, 0.f);
+          }
+          *reinterpret_cast<f32x4*>(a.out + o) = r;
+        }
+    }
+  } else {
+    // scalar path (NCHW heat-map output, odd channel counts): pixel-fastest so that NCHW rows
+    // are written in contiguous runs
+    for (int e = tid; e < MT * NTILE; e += 256) {
+      const int cl = e / MT, p = e % MT;
+      const int c = cbase + cl;
+      if (c >= a.Cout) continue;
+      const int tni = p >> a.thw_log2;
+      const int rem = p & ((1 << a.thw_log2) - 1);
+      const int y = oy0 + (rem >> a.tw_log2), x = ox0 + (rem & ((1 << a.tw_log2) - 1));
+      const int n = n0 + tni;
+      if (n >= a.N || y >= a.Hout || x >= a.Wout) continue;
+      conv_store(a, n, y, x, c, smem[p * LDW + cl]);
     }
   }
 }
+
+static thread_local int g_dry_run = 0;  // feasibility query: run the selection logic, launch nothing
 
 template <int KS, int S, int KC, int WN, int WM, int NT, int MS>
 static int launch_cfg(ConvArgs a, int th, int tw, int tn, hipStream_t s) {
@@ -155,9 +272,25 @@ static int launch_cfg(ConvArgs a, int th, int tw, int tn, hipStream_t s) {
   a.tiles_y = (a.Hout + th - 1) / th;
   const int ngroups = (a.N + tn - 1) / tn;
   const int PH = (th - 1) * S + KS, PW = (tw - 1) * S + KS;
-  size_t smem = (size_t)tn * PH * PW * (KC + KPAD) * sizeof(float);
+  constexpr int MT = 16 * MS * WM, NTILE = 16 * NT * WN;
+  const int patch_floats = tn * PH * PW * (KC + KPAD);
+  const int ne = (tn * PH * PW * (KC / 4) + 255) / 256;
+  const int nbuf = (a.Cin / KC > 1 && ne <= 10) ? 2 : 1;  // the generic staging path is single-buffered
+  size_t smem = (size_t)patch_floats * nbuf * sizeof(float);
+  const size_t otile = (size_t)MT * (NTILE + OPAD) * sizeof(float);
+  if (otile > smem) smem = otile;
+  if (smem > 128 * 1024) return 1;  // LDS is 160 KiB per CU on gfx950
+  if (g_dry_run) return 0;
   dim3 grid((unsigned)(a.tiles_x * a.tiles_y * ngroups), (unsigned)((a.NS_total + WN * NT - 1) / (WN * NT)));
-  hipLaunchKernelGGL((conv_mfma_kernel<KS, S, KC, WN, WM, NT, MS>), grid, dim3(256), smem, s, a);
+  // staging registers are sized at compile time (runtime-indexed arrays would go to scratch)
+  if (ne <= 4)
+    hipLaunchKernelGGL((conv_mfma_kernel<KS, S, KC, WN, WM, NT, MS, 4>), grid, dim3(256), smem, s, a);
+  else if (ne <= 6)
+    hipLaunchKernelGGL((conv_mfma_kernel<KS, S, KC, WN, WM, NT, MS, 6>), grid, dim3(256), smem, s, a);
+  else if (ne <= 10)
+    hipLaunchKernelGGL((conv_mfma_kernel<KS, S, KC, WN, WM, NT, MS, 10>), grid, dim3(256), smem, s, a);
+  else
+    hipLaunchKernelGGL((conv_mfma_kernel<KS, S, KC, WN, WM, NT, MS, 0>), grid, dim3(256), smem, s, a);
   return 0;
 }
 
@@ -176,7 +309,9 @@ static void pick_tile(int H, int W, int mt, int* th, int* tw, int* tn) {
 
 template <int KS, int S>
 static int dispatch(const ConvArgs& a, hipStream_t s) {
-  const int kc32 = (a.Cin % 32 == 0);
+  // stride-2 3x3 patches are ~4x larger per output pixel: 16-channel chunks keep two LDS
+  // buffers under 64 KB so that two workgroups still fit on a CU
+  const int kc32 = (a.Cin % 32 == 0) && !(S == 2 && KS == 3);
   int th, tw, tn;
   const int64_t px = (int64_t)a.N * a.Hout * a.Wout;
   const bool n48 = (a.NS_total % 3 == 0) && (a.NS_total % 4 != 0);  // HRNet-W48 widths
@@ -199,9 +334,18 @@ static int dispatch(const ConvArgs& a, hipStream_t s) {
 
 int mval_launch_conv_mfma(const ConvArgs& a, hipStream_t s) {
   if (a.in_nchw || a.Cin % 16 != 0 || a.pad != (a.k - 1) / 2) return 1;
+  // 32-bit element offsets inside the staging loop
+  if ((int64_t)a.N * a.Hin * a.Win * a.Cin >= (int64_t)1 << 31) return 1;  // TODO(next round): 64-bit path
   if (a.k == 3 && a.stride == 1) return dispatch<3, 1>(a, s);
   if (a.k == 3 && a.stride == 2) return dispatch<3, 2>(a, s);
   if (a.k == 1 && a.stride == 1) return dispatch<1, 1>(a, s);
   if (a.k == 1 && a.stride == 2) return dispatch<1, 2>(a, s);
   return 1;
+}
+
+int mval_conv_mfma_supported(const ConvArgs& a) {
+  g_dry_run = 1;
+  int rc = mval_launch_conv_mfma(a, nullptr);
+  g_dry_run = 0;
+  return rc == 0;
 }

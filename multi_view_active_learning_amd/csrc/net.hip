@@ -216,6 +216,26 @@ static int force_direct() {
   return v;
 }
 
+static void fill_geometry(ConvArgs& a, const mval_op* op, int n_images) {
+  a.N = n_images;
+  a.Hin = op->hin; a.Win = op->win; a.Cin = op->cin;
+  a.Hout = op->hout; a.Wout = op->wout; a.Cout = op->cout;
+  a.k = op->k; a.stride = op->stride; a.pad = op->pad;
+  a.up = op->up; a.relu = op->relu; a.in_nchw = op->in_nchw; a.out_nchw = op->out_nchw;
+  a.th = a.tw = a.tn = a.tw_log2 = a.thw_log2 = a.tiles_x = a.tiles_y = 0;
+  a.G_total = (op->cin + 15) / 16;
+  a.NS_total = (op->cout + 15) / 16;
+}
+
+extern "C" int mval_op_mfma_supported(const mval_op* op, int n_images) {
+  if (!op || op->kind != MVAL_OP_CONV || n_images <= 0) return 0;
+  ConvArgs a;
+  a.in = a.w = a.scale = a.shift = a.res1 = a.res2 = nullptr;
+  a.out = nullptr;
+  fill_geometry(a, op, n_images);
+  return mval_conv_mfma_supported(a);
+}
+
 extern "C" int mval_op_launch(const mval_op* op, int n_images, float* workspace, const float* params,
                               const float* net_input, float* net_output, void* stream) {
   MVAL_REQUIRE(op && n_images > 0, "mval_op_launch: bad arguments");
@@ -227,14 +247,7 @@ extern "C" int mval_op_launch(const mval_op* op, int n_images, float* workspace,
   a.w = op->w_off >= 0 ? params + op->w_off : nullptr;
   a.scale = op->scale_off >= 0 ? params + op->scale_off : nullptr;
   a.shift = op->shift_off >= 0 ? params + op->shift_off : nullptr;
-  a.N = n_images;
-  a.Hin = op->hin; a.Win = op->win; a.Cin = op->cin;
-  a.Hout = op->hout; a.Wout = op->wout; a.Cout = op->cout;
-  a.k = op->k; a.stride = op->stride; a.pad = op->pad;
-  a.up = op->up; a.relu = op->relu; a.in_nchw = op->in_nchw; a.out_nchw = op->out_nchw;
-  a.th = a.tw = a.tn = a.tw_log2 = a.thw_log2 = a.tiles_x = a.tiles_y = 0;
-  a.G_total = (op->cin + 15) / 16;
-  a.NS_total = (op->cout + 15) / 16;
+  fill_geometry(a, op, n_images);
   MVAL_REQUIRE(a.in && a.out, "mval_op_launch: missing input/output buffer");
   hipStream_t s = mval_stream(stream);
   if (op->kind == MVAL_OP_CONV && op->algo == MVAL_ALGO_MFMA) {
@@ -244,7 +257,9 @@ extern "C" int mval_op_launch(const mval_op* op, int n_images, float* workspace,
                  op->cout);
   } else {
     MVAL_REQUIRE(op->kind == MVAL_OP_MAXPOOL || (a.w && a.scale && a.shift), "mval_op_launch: missing parameters");
-    mval_launch_conv_direct(a, op->kind, s);
+    // 3-channel NCHW stems have their own store-shaped kernel; everything else is generic
+    if (op->kind != MVAL_OP_CONV || force_direct() || mval_launch_conv_stem(a, s))
+      mval_launch_conv_direct(a, op->kind, s);
   }
   MVAL_CHECK_LAUNCH("mval_op_launch");
   return 0;

@@ -127,10 +127,12 @@ class InferencePlan:
             out_nchw = g.acts[op.dst].layout == "nchw"
             m = self.ops[i]
             m.kind = _KIND[op.kind]
-            m.algo = ALGO_MFMA if _mfma_ok(op, in_nchw) else ALGO_DIRECT
             m.k, m.stride, m.pad, m.cin, m.cout = op.k, op.stride, op.pad, op.cin, op.cout
             m.hin, m.win, m.hout, m.wout = hin, win, hout, wout
             m.up, m.relu, m.in_nchw, m.out_nchw = op.up, int(op.relu), int(in_nchw), int(out_nchw)
+            m.algo = ALGO_DIRECT
+            if _mfma_ok(op, in_nchw) and lib.mval_op_mfma_supported(C.byref(m), C.c_int(n)):
+                m.algo = ALGO_MFMA
             m.in_off = -1 if op.src == g.input else offset[op.src]
             m.out_off = -1 if op.dst == g.output else offset[op.dst]
             m.res1_off = -1 if op.res1 is None else offset[op.res1]
