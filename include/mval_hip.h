@@ -190,6 +190,68 @@ int mval_net_forward_timed(void* net, int n_images, float* workspace, const floa
 /* Algorithmic FLOPs (2*MAC) of one op for n_images. */
 double mval_op_flops(const mval_op* op, int n_images);
 
+/* ------------------------------------------------------------------------------------
+ * Training step of the heat-map network (strategy.py:460-487: forward in train mode,
+ * ``batch_loss.backward()``); the optimizer stays in PyTorch (Adam, strategy.py:405).
+ * ---------------------------------------------------------------------------------- */
+
+/* Train-mode BatchNorm statistics of z [M, C] (NHWC rows): mean, invstd = 1/sqrt(biased var +
+ * eps); running stats updated in place with `momentum` and the unbiased variance (torch).
+ * ws >= 512 * C * 2 doubles. */
+int mval_bn_batch_stats(const float* z, int64_t M, int C, float eps, float momentum, float* mean, float* invstd,
+                        float* running_mean, float* running_var, double* ws, void* stream);
+/* out = act(((z*alpha + (beta - mean*alpha)) nearest-upsampled 2^up) + res1 + res2), alpha = invstd*gamma. */
+int mval_bn_apply_fwd(const float* z, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                      const float* res1, const float* res2, float* out, int N, int H, int W, int C, int up, int relu,
+                      void* stream);
+/* Backward of the above: masks gout by (out > 0) when relu, adds it into gres1/gres2, window-sums
+ * it to the conv resolution, then (has_bn) dgamma/dbeta and dz = gamma*invstd*(g - dbeta/M -
+ * xhat*dgamma/M) written to gz; without BN gz is the masked/window-summed gradient and dbeta its
+ * per-channel sum (bias gradient).  ws >= 512*C*2 doubles, sums >= 2*C floats. */
+int mval_bn_bwd(const float* gout, const float* out, const float* z, const float* mean, const float* invstd,
+                const float* gamma, float* gres1, float* gres2, float* gz, float* dgamma, float* dbeta, double* ws,
+                float* sums, int N, int H, int W, int C, int up, int relu, int has_bn, void* stream);
+/* Weight gradient dw [cout][cin][k][k] of a conv: x NHWC (NCHW when x_nchw), dz NHWC.
+ * ws >= mval_conv_wgrad_workspace_floats(cin, cout, k) floats. */
+size_t mval_conv_wgrad_workspace_floats(int cin, int cout, int k);
+int mval_conv_wgrad(const float* x, const float* dz, float* dw, float* ws, int N, int Hin, int Win, int Cin,
+                    int Hout, int Wout, int Cout, int k, int stride, int pad, int x_nchw, void* stream);
+int mval_slab_reduce(const float* slabs, int S, int64_t n, float* out, int accumulate, void* stream);
+/* Data gradient of a conv (geometry given in FORWARD terms: x [N,hin,win,cin] -> z
+ * [N,hout,wout,cout], k/stride/pad): dx (+)= conv(dz zero-dilated by the stride, flipped W^T).
+ * w_packed: mval_pack_conv_weights(pack, transposed = 2, w, ..., cout' = cin, cin' = cout, k);
+ * ones / zeros: >= cin floats of 1.0 / 0.0; algo = MVAL_ALGO_MFMA needs cout % 16 == 0. */
+int mval_conv_dgrad(const float* dz, const float* w_packed, const float* ones, const float* zeros, float* dx,
+                    int accumulate, int N, int hin, int win, int cin, int hout, int wout, int cout, int k,
+                    int stride, int pad, int algo, void* stream);
+
+/* One operator of the training graph: the forward geometry / arena offsets (`op`, as in
+ * inference, weights packed for the forward kernel at op.w_off; op.shift_off = bias for a conv
+ * without BatchNorm) plus what backward needs.  Offsets are floats into `arena` (activations,
+ * no reuse), `garena` (activation gradients, zero-filled by the caller) and `params`. */
+typedef struct mval_train_op {
+  mval_op op;
+  int64_t z_off;      /* raw conv output at conv resolution (arena); unused when has_bn == 0 */
+  int64_t gin_off, gout_off, gres1_off, gres2_off; /* garena; -1 = no gradient needed */
+  int64_t wd_off;     /* params: weights packed for the data-gradient conv (-1: none) */
+  int32_t has_bn, dgrad_algo, reserved0, reserved1;
+  float* gamma; float* beta; float* running_mean; float* running_var; /* device pointers */
+  float* mean; float* invstd;            /* saved batch statistics [cout] */
+  float* dweight; float* dgamma; float* dbeta; /* gradient outputs (dbeta = bias grad w/o BN) */
+} mval_train_op;
+
+/* ones_off / zeros_off: params offsets of >= max(cout) floats of 1.0 / 0.0.
+ * ws: >= 512*maxC*2 doubles. */
+int mval_train_forward(const mval_train_op* ops, int n_ops, int n_images, float* arena, const float* params,
+                       int64_t ones_off, int64_t zeros_off, const float* input_nchw, float* output_nchw,
+                       double* ws, float momentum, float eps, void* stream);
+/* gz: scratch >= max over ops of N*hout*wout*cout floats; wsf: >= max wgrad workspace;
+ * sums: >= 2*maxC floats.  The gradient w.r.t. the network output must already be in garena at
+ * the last op's gout_off (NHWC). */
+int mval_train_backward(const mval_train_op* ops, int n_ops, int n_images, float* arena, float* garena,
+                        const float* params, int64_t ones_off, int64_t zeros_off, const float* input_nchw,
+                        float* gz, float* wsf, double* ws, float* sums, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -13,6 +13,7 @@ struct ConvArgs {
   int N, Hin, Win, Cin, Hout, Wout, Cout;  // Hout/Wout before the fused upsample
   int k, stride, pad;
   int up, relu, in_nchw, out_nchw;
+  int dil;  // 1, or 2: the input is read as if zero-dilated by 2 (data gradient of a stride-2 conv)
   // MFMA tiling (filled by the launcher)
   int th, tw, tn, tw_log2, thw_log2;
   int tiles_x, tiles_y;

@@ -85,8 +85,11 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
     const int pyy = r % PH;
     const int tni = r / PH;
     const int iy = iy0 + pyy, ix = ix0 + pxx, n = n0 + tni;
-    const bool ok = e < patch_e && n < a.N && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
-    goff[i] = ok ? ((n * a.Hin + iy) * a.Win + ix) * a.Cin + q * 4 : -1;
+    // dil == 2: (iy, ix) index the zero-dilated input; only even positions carry data
+    const int dsh = a.dil - 1;
+    const int sy = iy >> dsh, sx = ix >> dsh;
+    const bool ok = e < patch_e && n < a.N && iy >= 0 && ix >= 0 && ((iy | ix) & dsh) == 0 && sy < a.Hin && sx < a.Win;
+    goff[i] = ok ? ((n * a.Hin + sy) * a.Win + sx) * a.Cin + q * 4 : -1;
   }
 
   f32x4 acc[MS][NT];
@@ -110,9 +113,11 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
       const int pyy = r % PH;
       const int tni = r / PH;
       const int iy = iy0 + pyy, ix = ix0 + pxx, n = n0 + tni;
+      const int dsh = a.dil - 1;
+      const int sy = iy >> dsh, sx = ix >> dsh;
       f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (n < a.N && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win)
-        v = *reinterpret_cast<const f32x4*>(a.in + (((int64_t)n * a.Hin + iy) * a.Win + ix) * a.Cin + c0 + q * 4);
+      if (n < a.N && iy >= 0 && ix >= 0 && ((iy | ix) & dsh) == 0 && sy < a.Hin && sx < a.Win)
+        v = *reinterpret_cast<const f32x4*>(a.in + (((int64_t)n * a.Hin + sy) * a.Win + sx) * a.Cin + c0 + q * 4);
       *reinterpret_cast<f32x4*>(smem + px * KCP + q * 4) = v;
     }
   };

@@ -1,0 +1,257 @@
+// Weight gradients of the fused conv operators (the wgrad half of K7; autograd of the
+// reference's nn.Conv2d under strategy.py:478 ``batch_loss.backward()``).
+//
+//   dW[co][ci][tap] = sum over (n, oy, ox) of  x[n, oy*s - p + ty, ox*s - p + tx, ci] * dz[n, oy, ox, co]
+//
+// GEMM with M = cin, N = cout, K = output pixels (hundreds of thousands) on
+// v_mfma_f32_16x16x4_f32 (exact fp32):
+//   * a workgroup owns a (32 cin x 32 cout) block for ALL k*k taps -- 4 waves = 2 cin tiles x
+//     2 cout tiles, each wave keeps k*k accumulator tiles in registers -- and walks a strided
+//     share of the pixel tiles (split-K over workgroups);
+//   * per pixel tile the x patch (with halo, 32 cin) and the dz tile (32 cout) are staged in LDS
+//     with row stride 48 floats (== 16 mod 32 banks, so the 4 pixel-quads of a ds_read_b32 do
+//     not collide); a tap is a constant LDS offset into the patch, so each 4-pixel step costs
+//     one B read + k*k A reads for k*k MFMAs;
+//   * partial sums go to per-split slabs [split][tap][cin][cout]; a second kernel reduces the
+//     slabs in float64 and writes torch's [cout][cin][kh][kw] layout (deterministic, no atomics).
+// Tiny operators (3-channel stem, 19-joint final layer) use a direct VALU kernel.
+#include "conv_common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define WG_CB 32   // cin / cout block
+#define WG_LD 48   // LDS row stride (floats)
+
+struct WgradArgs {
+  const float* x;    // NHWC (N, Hin, Win, Cin)
+  const float* dz;   // NHWC (N, Hout, Wout, Cout)
+  float* slabs;      // [PS][T][Cin][Cout]
+  int N, Hin, Win, Cin, Hout, Wout, Cout;
+  int pad;
+  int th, tw, tn, tw_log2, thw_log2, tiles_x, tiles_y, ntiles, PS;
+};
+
+template <int KS, int S, int MT>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int T = KS * KS;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ci_t = wave & 1, co_t = wave >> 1;
+  const int ci0 = blockIdx.y * WG_CB, co0 = blockIdx.z * WG_CB;
+  const int PH = (a.th - 1) * S + KS, PW = (a.tw - 1) * S + KS;
+  const int patch_px = a.tn * PH * PW;
+  float* patch = smem;                    // [patch_px][WG_LD]
+  float* dzt = smem + patch_px * WG_LD;   // [MT][WG_LD]
+
+  f32x4 acc[T];
+#pragma unroll
+  for (int t = 0; t < T; t++) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  for (int tile = blockIdx.x; tile < a.ntiles; tile += a.PS) {
+    int t = tile;
+    const int txi = t % a.tiles_x;
+    t /= a.tiles_x;
+    const int tyi = t % a.tiles_y;
+    const int n0 = (t / a.tiles_y) * a.tn;
+    const int oy0 = tyi * a.th, ox0 = txi * a.tw;
+    const int iy0 = oy0 * S - a.pad, ix0 = ox0 * S - a.pad;
+    __syncthreads();
+    // x patch: 32 cin of this block, zero outside the image / channel range
+    for (int e = tid; e < patch_px * (WG_CB / 4); e += 256) {
+      const int px = e >> 3, q = e & 7;
+      int r = px;
+      const int pxx = r % PW;
+      r /= PW;
+      const int pyy = r % PH;
+      const int tni = r / PH;
+      const int iy = iy0 + pyy, ix = ix0 + pxx, n = n0 + tni;
+      const int c = ci0 + q * 4;
+      f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (n < a.N && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win && c < a.Cin)
+        v = *reinterpret_cast<const f32x4*>(a.x + (((int64_t)n * a.Hin + iy) * a.Win + ix) * a.Cin + c);
+      *reinterpret_cast<f32x4*>(patch + px * WG_LD + q * 4) = v;
+    }
+    // dz tile: 32 cout of this block
+    for (int e = tid; e < MT * (WG_CB / 4); e += 256) {
+      const int p = e >> 3, q = e & 7;
+      const int tni = p >> a.thw_log2;
+      const int rem = p & ((1 << a.thw_log2) - 1);
+      const int y = oy0 + (rem >> a.tw_log2), x = ox0 + (rem & ((1 << a.tw_log2) - 1));
+      const int n = n0 + tni;
+      const int c = co0 + q * 4;
+      f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (n < a.N && y < a.Hout && x < a.Wout && c < a.Cout)
+        v = *reinterpret_cast<const f32x4*>(a.dz + (((int64_t)n * a.Hout + y) * a.Wout + x) * a.Cout + c);
+      *reinterpret_cast<f32x4*>(dzt + p * WG_LD + q * 4) = v;
+    }
+    __syncthreads();
+    // K loop over the tile's pixels, 4 per MFMA (pixel = 4*step + (lane >> 4))
+    for (int st = 0; st < MT / 4; st++) {
+      const int p = st * 4 + (lane >> 4);
+      const int tni = p >> a.thw_log2;
+      const int rem = p & ((1 << a.thw_log2) - 1);
+      const int ty = rem >> a.tw_log2, tx = rem & ((1 << a.tw_log2) - 1);
+      const float b = dzt[p * WG_LD + co_t * 16 + (lane & 15)];
+      const float* ap = patch + ((tni * PH + ty * S) * PW + tx * S) * WG_LD + ci_t * 16 + (lane & 15);
+#pragma unroll
+      for (int t2 = 0; t2 < T; t2++) {
+        const float av = ap[((t2 / KS) * PW + (t2 % KS)) * WG_LD];
+        acc[t2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b, acc[t2], 0, 0, 0);
+      }
+    }
+  }
+  // slab[ps][t][ci][co]; C layout: row (cin) = (lane >> 4) * 4 + r, col (cout) = lane & 15
+  const int co = co0 + co_t * 16 + (lane & 15);
+#pragma unroll
+  for (int t2 = 0; t2 < T; t2++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int ci = ci0 + ci_t * 16 + (lane >> 4) * 4 + r;
+      if (ci < a.Cin && co < a.Cout)
+        a.slabs[(((int64_t)blockIdx.x * T + t2) * a.Cin + ci) * a.Cout + co] = acc[t2][r];
+    }
+}
+
+// dW[co][ci][t] = sum_ps slab[ps][t][ci][co]
+__global__ void wgrad_reduce_kernel(const float* __restrict__ slabs, int PS, int T, int Cin, int Cout,
+                                    float* __restrict__ dw) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t n = (int64_t)T * Cin * Cout;
+  if (i >= n) return;
+  const int co = (int)(i % Cout);
+  const int ci = (int)((i / Cout) % Cin);
+  const int t = (int)(i / ((int64_t)Cout * Cin));
+  double s = 0;
+  for (int p = 0; p < PS; p++) s += (double)slabs[(int64_t)p * n + i];
+  dw[((int64_t)co * Cin + ci) * T + t] = (float)s;
+}
+
+// ---- direct wgrad for tiny operators (cin = 3 NCHW stem, odd cout) -----------------------
+struct WgradDirectArgs {
+  const float* x;
+  const float* dz;
+  float* slabs;  // [PS][T*Cin*Cout] in [t][ci][co] order
+  int N, Hin, Win, Cin, Hout, Wout, Cout, k, stride, pad, x_nchw, PS;
+};
+
+#define WD_EPT 8
+
+__global__ __launch_bounds__(256) void conv_wgrad_direct_kernel(WgradDirectArgs a) {
+  const int E = a.k * a.k * a.Cin * a.Cout;
+  const int64_t M = (int64_t)a.N * a.Hout * a.Wout;
+  float acc[WD_EPT];
+  int xo[WD_EPT], co[WD_EPT], dy[WD_EPT], dx[WD_EPT], ci[WD_EPT];
+#pragma unroll
+  for (int i = 0; i < WD_EPT; i++) {
+    const int e = threadIdx.x + 256 * i;
+    acc[i] = 0.f;
+    co[i] = e % a.Cout;
+    ci[i] = (e / a.Cout) % a.Cin;
+    const int t = e / (a.Cout * a.Cin);
+    dy[i] = t / a.k - a.pad;
+    dx[i] = t % a.k - a.pad;
+    xo[i] = e < E;
+  }
+  const int64_t per = (M + a.PS - 1) / a.PS;
+  const int64_t p0 = blockIdx.x * per, p1 = min(M, p0 + per);
+  for (int64_t p = p0; p < p1; p++) {
+    const int x = (int)(p % a.Wout);
+    const int y = (int)((p / a.Wout) % a.Hout);
+    const int n = (int)(p / ((int64_t)a.Wout * a.Hout));
+#pragma unroll
+    for (int i = 0; i < WD_EPT; i++) {
+      if (!xo[i]) continue;
+      const int iy = y * a.stride + dy[i], ix = x * a.stride + dx[i];
+      if (iy < 0 || iy >= a.Hin || ix < 0 || ix >= a.Win) continue;
+      const float xv = a.x_nchw ? a.x[(((int64_t)n * a.Cin + ci[i]) * a.Hin + iy) * a.Win + ix]
+                                : a.x[(((int64_t)n * a.Hin + iy) * a.Win + ix) * a.Cin + ci[i]];
+      acc[i] = fmaf(xv, a.dz[p * a.Cout + co[i]], acc[i]);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < WD_EPT; i++) {
+    const int e = threadIdx.x + 256 * i;
+    if (e < E) a.slabs[(int64_t)blockIdx.x * E + e] = acc[i];
+  }
+}
+
+static void wg_pick_tile(int H, int W, int mt, int* th, int* tw, int* tn) {
+  int w = (W > 8) ? 16 : 8;
+  int h = mt / w, n = 1;
+  int hh = 1;
+  while (hh < H) hh <<= 1;
+  if (hh < h) {
+    n = h / hh;
+    h = hh;
+  }
+  *th = h; *tw = w; *tn = n;
+}
+
+static int wg_splits(int cin, int cout) {
+  const int cb = ((cin + WG_CB - 1) / WG_CB) * ((cout + WG_CB - 1) / WG_CB);
+  int ps = 1024 / cb;  // ~1024 workgroups in flight
+  if (ps < 1) ps = 1;
+  if (ps > 512) ps = 512;
+  return ps;
+}
+
+extern "C" size_t mval_conv_wgrad_workspace_floats(int cin, int cout, int k) {
+  return (size_t)wg_splits(cin, cout) * k * k * cin * cout;  // PS slabs of [tap][cin][cout]
+}
+
+// x NHWC (or NCHW when x_nchw), dz NHWC, dw [cout][cin][k][k]; ws >= mval_conv_wgrad_workspace_floats
+extern "C" int mval_conv_wgrad(const float* x, const float* dz, float* dw, float* ws, int N, int Hin, int Win, int Cin,
+                               int Hout, int Wout, int Cout, int k, int stride, int pad, int x_nchw, void* stream) {
+  MVAL_REQUIRE(N > 0 && Cin > 0 && Cout > 0 && k > 0 && stride > 0, "mval_conv_wgrad: bad dims");
+  hipStream_t s = mval_stream(stream);
+  const int T = k * k;
+  const int64_t n_out = (int64_t)T * Cin * Cout;
+  const bool mfma = !x_nchw && (Cin & 3) == 0 && (Cout & 3) == 0 && (k == 1 || k == 3) && (stride == 1 || stride == 2) &&
+                    pad == k / 2 && Cin >= 16;
+  int PS;
+  if (mfma) {
+    WgradArgs a;
+    a.x = x; a.dz = dz; a.slabs = ws;
+    a.N = N; a.Hin = Hin; a.Win = Win; a.Cin = Cin; a.Hout = Hout; a.Wout = Wout; a.Cout = Cout; a.pad = pad;
+    const int mt = (stride == 2 || (int64_t)N * Hout * Wout < 65536) ? 64 : 128;
+    wg_pick_tile(Hout, Wout, mt, &a.th, &a.tw, &a.tn);
+    a.tw_log2 = __builtin_ctz(a.tw);
+    a.thw_log2 = __builtin_ctz(a.th * a.tw);
+    a.tiles_x = (Wout + a.tw - 1) / a.tw;
+    a.tiles_y = (Hout + a.th - 1) / a.th;
+    a.ntiles = a.tiles_x * a.tiles_y * ((N + a.tn - 1) / a.tn);
+    PS = wg_splits(Cin, Cout);
+    if (PS > a.ntiles) PS = a.ntiles;
+    a.PS = PS;
+    const int PH = (a.th - 1) * stride + k, PW = (a.tw - 1) * stride + k;
+    size_t smem = (size_t)(a.tn * PH * PW + mt) * WG_LD * sizeof(float);
+    MVAL_REQUIRE(smem <= 128 * 1024, "mval_conv_wgrad: tile does not fit LDS");
+    dim3 grid(PS, (Cin + WG_CB - 1) / WG_CB, (Cout + WG_CB - 1) / WG_CB);
+#define WG_LAUNCH(KS_, S_, MT_) \
+  hipLaunchKernelGGL((conv_wgrad_kernel<KS_, S_, MT_>), grid, dim3(256), smem, s, a)
+    if (k == 3 && stride == 1 && mt == 128) WG_LAUNCH(3, 1, 128);
+    else if (k == 3 && stride == 1) WG_LAUNCH(3, 1, 64);
+    else if (k == 3 && stride == 2) WG_LAUNCH(3, 2, 64);
+    else if (k == 1 && stride == 1 && mt == 128) WG_LAUNCH(1, 1, 128);
+    else if (k == 1 && stride == 1) WG_LAUNCH(1, 1, 64);
+    else WG_LAUNCH(1, 2, 64);
+#undef WG_LAUNCH
+    MVAL_CHECK_LAUNCH("mval_conv_wgrad/mfma");
+  } else {
+    MVAL_REQUIRE(n_out <= 256 * WD_EPT, "mval_conv_wgrad: operator too large for the direct kernel (%lld outputs)",
+                 (long long)n_out);
+    WgradDirectArgs a;
+    a.x = x; a.dz = dz; a.slabs = ws;
+    a.N = N; a.Hin = Hin; a.Win = Win; a.Cin = Cin; a.Hout = Hout; a.Wout = Wout; a.Cout = Cout;
+    a.k = k; a.stride = stride; a.pad = pad; a.x_nchw = x_nchw;
+    int64_t M = (int64_t)N * Hout * Wout;
+    PS = (int)(M < 512 ? M : 512);
+    a.PS = PS;
+    hipLaunchKernelGGL(conv_wgrad_direct_kernel, dim3(PS), dim3(256), 0, s, a);
+    MVAL_CHECK_LAUNCH("mval_conv_wgrad/direct");
+  }
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, s, ws, PS, T, Cin, Cout,
+                     dw);
+  MVAL_CHECK_LAUNCH("mval_conv_wgrad/reduce");
+  return 0;
+}

@@ -18,7 +18,10 @@ extern "C" size_t mval_packed_weight_floats(int pack, int cout, int cin, int k) 
 }
 
 __device__ __forceinline__ float w_at(const float* w, int transposed, int cout, int cin, int k, int co, int ci, int t) {
-  // Conv2d: [cout][cin][k][k] ; ConvTranspose2d: [cin][cout][k][k]
+  // 0: Conv2d [cout][cin][k][k] ; 1: ConvTranspose2d [cin][cout][k][k] ;
+  // 2: data-gradient form of a Conv2d whose weight is [cin'=cout][cout'=cin][k][k]: swap the
+  //    channel roles and flip the taps (dx = conv(dz, W^T flipped))
+  if (transposed == 2) return w[((int64_t)ci * cout + co) * k * k + (k * k - 1 - t)];
   return transposed ? w[((int64_t)ci * cout + co) * k * k + t] : w[((int64_t)co * cin + ci) * k * k + t];
 }
 
@@ -222,6 +225,7 @@ static void fill_geometry(ConvArgs& a, const mval_op* op, int n_images) {
   a.Hout = op->hout; a.Wout = op->wout; a.Cout = op->cout;
   a.k = op->k; a.stride = op->stride; a.pad = op->pad;
   a.up = op->up; a.relu = op->relu; a.in_nchw = op->in_nchw; a.out_nchw = op->out_nchw;
+  a.dil = 1;
   a.th = a.tw = a.tn = a.tw_log2 = a.thw_log2 = a.tiles_x = a.tiles_y = 0;
   a.G_total = (op->cin + 15) / 16;
   a.NS_total = (op->cout + 15) / 16;

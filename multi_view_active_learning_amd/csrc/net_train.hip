@@ -1,0 +1,153 @@
+// Training-step executor: forward in train mode (batch-statistics BatchNorm) and the full
+// backward pass of the heat-map network, as ONE C call each (reference: strategy.py:460-487;
+// forward pose_estimators/hrnet.py:468-501 in train mode, backward = autograd).
+//
+// Per operator  out = act(((bn(conv(x, w)) up) + res1) + res2):
+//   forward   conv on the matrix cores (raw z) -> batch statistics -> fused normalise + residual
+//             + ReLU (+ nearest upsample) stream;
+//   backward  mask / residual-gradient scatter / window-sum + dgamma, dbeta (two-stage float64
+//             reduction) -> dz in place -> weight gradient (MFMA split-K, conv_wgrad.hip) ->
+//             data gradient = the SAME forward MFMA kernel on tap-flipped, channel-swapped
+//             weights (stride-2 convs read dz as a zero-dilated input), accumulated in place
+//             into the producer's gradient buffer.
+// Activation gradients accumulate into a zero-filled arena, so fan-out (residual skips, HRNet
+// fuse layers, transitions) needs no special casing.
+#include "conv_common.h"
+
+extern "C" int mval_bn_batch_stats(const float*, int64_t, int, float, float, float*, float*, float*, float*, double*,
+                                   void*);
+extern "C" int mval_bn_apply_fwd(const float*, const float*, const float*, const float*, const float*, const float*,
+                                 const float*, float*, int, int, int, int, int, int, void*);
+
+static void geometry(ConvArgs& a, const mval_op& op, int n_images) {
+  a.N = n_images;
+  a.Hin = op.hin; a.Win = op.win; a.Cin = op.cin;
+  a.Hout = op.hout; a.Wout = op.wout; a.Cout = op.cout;
+  a.k = op.k; a.stride = op.stride; a.pad = op.pad;
+  a.up = 0; a.relu = 0; a.in_nchw = op.in_nchw; a.out_nchw = 0;
+  a.dil = 1;
+  a.th = a.tw = a.tn = a.tw_log2 = a.thw_log2 = a.tiles_x = a.tiles_y = 0;
+  a.G_total = (op.cin + 15) / 16;
+  a.NS_total = (op.cout + 15) / 16;
+  a.res1 = a.res2 = nullptr;
+}
+
+static int run_conv(const ConvArgs& a, int algo, hipStream_t s, const char* what) {
+  if (algo == MVAL_ALGO_MFMA) {
+    if (mval_launch_conv_mfma(a, s)) {
+      mval_set_error("%s: no MFMA configuration (k%d cin%d cout%d dil%d)", what, a.k, a.Cin, a.Cout, a.dil);
+      return -1;
+    }
+  } else if (mval_launch_conv_stem(a, s)) {
+    mval_launch_conv_direct(a, MVAL_OP_CONV, s);
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    mval_set_error("%s: launch failed: %s", what, hipGetErrorString(e));
+    return -2;
+  }
+  return 0;
+}
+
+extern "C" int mval_train_forward(const mval_train_op* ops, int n_ops, int n_images, float* arena, const float* params,
+                                  int64_t ones_off, int64_t zeros_off, const float* input_nchw, float* output_nchw,
+                                  double* ws, float momentum, float eps, void* stream) {
+  MVAL_REQUIRE(ops && n_ops > 0 && n_images > 0, "mval_train_forward: bad arguments");
+  hipStream_t s = mval_stream(stream);
+  for (int i = 0; i < n_ops; i++) {
+    const mval_train_op& t = ops[i];
+    const mval_op& op = t.op;
+    MVAL_REQUIRE(op.kind == MVAL_OP_CONV, "mval_train_forward: op %d: only conv operators are trainable here", i);
+    ConvArgs a;
+    geometry(a, op, n_images);
+    a.in = op.in_off >= 0 ? arena + op.in_off : input_nchw;
+    a.w = params + op.w_off;
+    float* out = op.out_off >= 0 ? arena + op.out_off : output_nchw;
+    if (t.has_bn) {
+      a.out = arena + t.z_off;
+      a.scale = params + ones_off;
+      a.shift = params + zeros_off;
+      int rc = run_conv(a, op.algo, s, "mval_train_forward/conv");
+      if (rc) return rc;
+      const int64_t M = (int64_t)n_images * op.hout * op.wout;
+      rc = mval_bn_batch_stats(a.out, M, op.cout, eps, momentum, t.mean, t.invstd, t.running_mean, t.running_var, ws,
+                               stream);
+      if (rc) return rc;
+      rc = mval_bn_apply_fwd(a.out, t.mean, t.invstd, t.gamma, t.beta, op.res1_off >= 0 ? arena + op.res1_off : nullptr,
+                             op.res2_off >= 0 ? arena + op.res2_off : nullptr, out, n_images, op.hout, op.wout, op.cout,
+                             op.up, op.relu, stream);
+      if (rc) return rc;
+    } else {
+      MVAL_REQUIRE(op.up == 0, "mval_train_forward: op %d: upsample without BatchNorm is not part of any graph", i);
+      a.out = out;
+      a.out_nchw = op.out_nchw;
+      a.relu = op.relu;
+      a.scale = params + op.scale_off;
+      a.shift = params + op.shift_off;
+      a.res1 = op.res1_off >= 0 ? arena + op.res1_off : nullptr;
+      a.res2 = op.res2_off >= 0 ? arena + op.res2_off : nullptr;
+      int rc = run_conv(a, op.algo, s, "mval_train_forward/conv");
+      if (rc) return rc;
+    }
+  }
+  return 0;
+}
+
+extern "C" int mval_train_backward(const mval_train_op* ops, int n_ops, int n_images, float* arena, float* garena,
+                                   const float* params, int64_t ones_off, int64_t zeros_off, const float* input_nchw,
+                                   float* gz, float* wsf, double* ws, float* sums, void* stream) {
+  MVAL_REQUIRE(ops && n_ops > 0 && n_images > 0 && garena && gz && wsf && ws && sums,
+               "mval_train_backward: bad arguments");
+  hipStream_t s = mval_stream(stream);
+  for (int i = n_ops - 1; i >= 0; i--) {
+    const mval_train_op& t = ops[i];
+    const mval_op& op = t.op;
+    MVAL_REQUIRE(t.gout_off >= 0, "mval_train_backward: op %d has no output gradient slot", i);
+    // the output activation is only needed for the ReLU mask; NCHW outputs (final layer) have none
+    const float* outp = op.out_off >= 0 ? arena + op.out_off : nullptr;
+    MVAL_REQUIRE(!(op.relu && !outp), "mval_train_backward: op %d: ReLU on an external output", i);
+    int rc = mval_bn_bwd(garena + t.gout_off, outp, t.has_bn ? arena + t.z_off : nullptr, t.mean, t.invstd, t.gamma,
+                         t.gres1_off >= 0 ? garena + t.gres1_off : nullptr,
+                         t.gres2_off >= 0 ? garena + t.gres2_off : nullptr, gz, t.dgamma, t.dbeta, ws, sums, n_images,
+                         op.hout, op.wout, op.cout, op.up, op.relu, t.has_bn, stream);
+    if (rc) return rc;
+    const float* x = op.in_off >= 0 ? arena + op.in_off : input_nchw;
+    rc = mval_conv_wgrad(x, gz, t.dweight, wsf, n_images, op.hin, op.win, op.cin, op.hout, op.wout, op.cout, op.k,
+                         op.stride, op.pad, op.in_nchw, stream);
+    if (rc) return rc;
+    if (t.gin_off >= 0) {
+      rc = mval_conv_dgrad(gz, params + t.wd_off, params + ones_off, params + zeros_off, garena + t.gin_off, 1, n_images,
+                           op.hin, op.win, op.cin, op.hout, op.wout, op.cout, op.k, op.stride, op.pad, t.dgrad_algo,
+                           stream);
+      if (rc) return rc;
+    }
+  }
+  return 0;
+}
+
+// dx (+)= conv(dz [zero-dilated by the stride], flip(W)^T), stride 1, pad k-1-p: the forward
+// kernels on weights packed with mode 2 (mval_pack_conv_weights), cin' = cout, cout' = cin.
+extern "C" int mval_conv_dgrad(const float* dz, const float* w_packed, const float* ones, const float* zeros, float* dx,
+                               int accumulate, int N, int hin, int win, int cin, int hout, int wout, int cout, int k,
+                               int stride, int pad, int algo, void* stream) {
+  MVAL_REQUIRE(dz && w_packed && ones && zeros && dx && N > 0, "mval_conv_dgrad: bad arguments");
+  MVAL_REQUIRE(algo == MVAL_ALGO_MFMA || stride == 1, "mval_conv_dgrad: strided data gradient needs the MFMA kernel");
+  ConvArgs a;
+  a.N = N;
+  a.Hin = hout; a.Win = wout; a.Cin = cout;
+  a.Hout = hin; a.Wout = win; a.Cout = cin;
+  a.k = k; a.stride = 1; a.pad = k - 1 - pad;
+  a.up = 0; a.relu = 0; a.in_nchw = 0; a.out_nchw = 0;
+  a.dil = stride;
+  a.th = a.tw = a.tn = a.tw_log2 = a.thw_log2 = a.tiles_x = a.tiles_y = 0;
+  a.G_total = (cout + 15) / 16;
+  a.NS_total = (cin + 15) / 16;
+  a.in = dz;
+  a.w = w_packed;
+  a.scale = ones;
+  a.shift = zeros;
+  a.out = dx;
+  a.res1 = accumulate ? dx : nullptr;  // in place: each element is read and written by one thread
+  a.res2 = nullptr;
+  return run_conv(a, algo, mval_stream(stream), "mval_conv_dgrad");
+}

@@ -1,0 +1,345 @@
+// Train-mode BatchNorm and the elementwise forward/backward pieces of a fused operator
+//   out = act(((bn(z) [nearest-upsampled 2^up]) + res1) + res2),   z = conv(x, w)
+// (reference: nn.BatchNorm2d in training mode + ReLU + residual adds inside
+// pose_estimators/hrnet.py:36-52,75-95,269-287, differentiated by strategy.py:478
+// ``batch_loss.backward()``).  All tensors NHWC fp32; every kernel is an HBM-bound stream with
+// float4 lanes along channels; per-channel reductions accumulate in float64 and are
+// two-stage (per-workgroup partials -> finalize) so results are deterministic.
+#include "mval_common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define TR_BLOCKS 512
+
+// ---- batch statistics -----------------------------------------------------------------
+// partial[block][c][2] = (sum, sum of squares) over the block's pixel slice
+__global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __restrict__ z, double* __restrict__ part,
+                                                               int64_t M, int C) {
+  extern __shared__ double sh[];  // [rows_per_block][C][2] folded below
+  const int c4n = C >> 2;
+  const int lanes = min(c4n, 256);            // float4 columns handled per pass
+  const int rows = 256 / lanes;               // pixel rows in flight per block
+  const int col = threadIdx.x % lanes, row = threadIdx.x / lanes;
+  for (int cb = 0; cb < c4n; cb += lanes) {
+    const int q = cb + col;
+    double s[4] = {0, 0, 0, 0}, ss[4] = {0, 0, 0, 0};
+    if (q < c4n && row < rows) {
+      for (int64_t p = (int64_t)blockIdx.x * rows + row; p < M; p += (int64_t)gridDim.x * rows) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(z + p * C + q * 4);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          s[k] += (double)v[k];
+          ss[k] += (double)v[k] * (double)v[k];
+        }
+      }
+    }
+    // fold the rows of this block through LDS
+    __syncthreads();
+    if (q < c4n && row < rows)
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        sh[((row * lanes + col) * 4 + k) * 2] = s[k];
+        sh[((row * lanes + col) * 4 + k) * 2 + 1] = ss[k];
+      }
+    __syncthreads();
+    if (row == 0 && q < c4n) {
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        double a = 0, b = 0;
+        for (int r = 0; r < rows; r++) {
+          a += sh[((r * lanes + col) * 4 + k) * 2];
+          b += sh[((r * lanes + col) * 4 + k) * 2 + 1];
+        }
+        part[((int64_t)blockIdx.x * C + q * 4 + k) * 2] = a;
+        part[((int64_t)blockIdx.x * C + q * 4 + k) * 2 + 1] = b;
+      }
+    }
+  }
+}
+
+// mean / invstd (biased variance, as normalisation uses) + running-stat update with the
+// unbiased variance (torch: running = (1 - m) * running + m * stat)
+__global__ void bn_stats_finalize_kernel(const double* __restrict__ part, int nblocks, int64_t M, int C, float eps,
+                                         float momentum, float* __restrict__ mean, float* __restrict__ invstd,
+                                         float* __restrict__ running_mean, float* __restrict__ running_var) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0, ss = 0;
+  for (int b = 0; b < nblocks; b++) {
+    s += part[((int64_t)b * C + c) * 2];
+    ss += part[((int64_t)b * C + c) * 2 + 1];
+  }
+  const double mu = s / (double)M;
+  double var = ss / (double)M - mu * mu;
+  if (var < 0) var = 0;
+  mean[c] = (float)mu;
+  invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+  if (running_mean) {
+    const double unbiased = M > 1 ? var * (double)M / (double)(M - 1) : var;
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mu;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+  }
+}
+
+extern "C" int mval_bn_batch_stats(const float* z, int64_t M, int C, float eps, float momentum, float* mean,
+                                   float* invstd, float* running_mean, float* running_var, double* ws, void* stream) {
+  MVAL_REQUIRE(M > 0 && C > 0 && (C & 3) == 0, "mval_bn_batch_stats: bad dims (C must be a multiple of 4)");
+  const int c4n = C >> 2;
+  const int lanes = c4n < 256 ? c4n : 256;
+  const int rows = 256 / lanes;
+  int nb = (int)((M + rows - 1) / rows);
+  if (nb > TR_BLOCKS) nb = TR_BLOCKS;
+  size_t sh = (size_t)rows * lanes * 4 * 2 * sizeof(double);
+  hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(nb), dim3(256), sh, mval_stream(stream), z, ws, M, C);
+  MVAL_CHECK_LAUNCH("mval_bn_batch_stats/partial");
+  hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, mval_stream(stream), ws, nb, M, C, eps,
+                     momentum, mean, invstd, running_mean, running_var);
+  MVAL_CHECK_LAUNCH("mval_bn_batch_stats/finalize");
+  return 0;
+}
+
+// ---- forward apply: out = act(((z*alpha + beta') up) + res1 + res2) ------------------------
+__global__ __launch_bounds__(256) void bn_apply_fwd_kernel(const float* __restrict__ z, const float* __restrict__ mean,
+                                                           const float* __restrict__ invstd,
+                                                           const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta,
+                                                           const float* __restrict__ res1,
+                                                           const float* __restrict__ res2, float* __restrict__ out,
+                                                           int N, int H, int W, int C, int up, int relu) {
+  const int c4n = C >> 2;
+  const int Ho = H << up, Wo = W << up;
+  const int64_t total = (int64_t)N * Ho * Wo * c4n;
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+    const int q = (int)(t % c4n);
+    int64_t p = t / c4n;
+    const int X = (int)(p % Wo);
+    const int Y = (int)((p / Wo) % Ho);
+    const int n = (int)(p / ((int64_t)Wo * Ho));
+    const int64_t zi = (((int64_t)n * H + (Y >> up)) * W + (X >> up)) * C + q * 4;
+    const f32x4 zv = *reinterpret_cast<const f32x4*>(z + zi);
+    const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + q * 4);
+    const f32x4 is = *reinterpret_cast<const f32x4*>(invstd + q * 4);
+    const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + q * 4);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(beta + q * 4);
+    const f32x4 alpha = is * g;  // torch: alpha = invstd * weight ; beta' = bias - mean * alpha
+    f32x4 r = zv * alpha + (b - mu * alpha);
+    const int64_t o = p * C + q * 4;
+    if (res1) r += *reinterpret_cast<const f32x4*>(res1 + o);
+    if (res2) r += *reinterpret_cast<const f32x4*>(res2 + o);
+    if (relu) {
+      r.x = fmaxf(r.x, 0.f); r.y = fmaxf(r.y, 0.f); r.z = fmaxf(r.z, 0.f); r.w = fmaxf(r.w, 0.f);
+    }
+    *reinterpret_cast<f32x4*>(out + o) = r;
+  }
+}
+
+extern "C" int mval_bn_apply_fwd(const float* z, const float* mean, const float* invstd, const float* gamma,
+                                 const float* beta, const float* res1, const float* res2, float* out, int N, int H,
+                                 int W, int C, int up, int relu, void* stream) {
+  MVAL_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && (C & 3) == 0 && up >= 0, "mval_bn_apply_fwd: bad dims");
+  int64_t total = (int64_t)N * (H << up) * (W << up) * (C >> 2);
+  int nb = (int)((total + 255) / 256);
+  if (nb > 8192) nb = 8192;
+  hipLaunchKernelGGL(bn_apply_fwd_kernel, dim3(nb), dim3(256), 0, mval_stream(stream), z, mean, invstd, gamma, beta,
+                     res1, res2, out, N, H, W, C, up, relu);
+  MVAL_CHECK_LAUNCH("mval_bn_apply_fwd");
+  return 0;
+}
+
+// ---- backward, stage 1 ------------------------------------------------------------------
+// g_hi = gout * (out > 0 if relu) ; gres1 += g_hi ; gres2 += g_hi ; gz = window-sum(g_hi) at the
+// conv resolution ; per-channel partial sums of gz and gz * xhat (xhat = (z - mean) * invstd).
+// has_bn == 0: only the masking / residual / window-sum part (gz is then dz itself) and the
+// per-channel sum of gz (bias gradient).
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ gout,
+                                                            const float* __restrict__ out,
+                                                            const float* __restrict__ z, const float* __restrict__ mean,
+                                                            const float* __restrict__ invstd, float* __restrict__ gres1,
+                                                            float* __restrict__ gres2, float* __restrict__ gz,
+                                                            double* __restrict__ part, int N, int H, int W, int C, int up,
+                                                            int relu, int has_bn) {
+  extern __shared__ double sh[];
+  const int c4n = C >> 2;
+  const int lanes = min(c4n, 256);
+  const int rows = 256 / lanes;
+  const int col = threadIdx.x % lanes, row = threadIdx.x / lanes;
+  const int64_t M = (int64_t)N * H * W;
+  const int rep = 1 << up;
+  const int Ho = H << up, Wo = W << up;
+  for (int cb = 0; cb < c4n; cb += lanes) {
+    const int q = cb + col;
+    double sb[4] = {0, 0, 0, 0}, sg[4] = {0, 0, 0, 0};
+    if (q < c4n && row < rows) {
+      f32x4 mu = (f32x4){0, 0, 0, 0}, is = (f32x4){0, 0, 0, 0};
+      if (has_bn) {
+        mu = *reinterpret_cast<const f32x4*>(mean + q * 4);
+        is = *reinterpret_cast<const f32x4*>(invstd + q * 4);
+      }
+      for (int64_t p = (int64_t)blockIdx.x * rows + row; p < M; p += (int64_t)gridDim.x * rows) {
+        const int x = (int)(p % W);
+        const int y = (int)((p / W) % H);
+        const int n = (int)(p / ((int64_t)W * H));
+        f32x4 acc = (f32x4){0, 0, 0, 0};
+        for (int dy = 0; dy < rep; dy++)
+          for (int dx = 0; dx < rep; dx++) {
+            const int64_t o = (((int64_t)n * Ho + (y << up) + dy) * Wo + (x << up) + dx) * C + q * 4;
+            f32x4 g = *reinterpret_cast<const f32x4*>(gout + o);
+            if (relu) {
+              const f32x4 ov = *reinterpret_cast<const f32x4*>(out + o);
+              g.x = ov.x > 0.f ? g.x : 0.f; g.y = ov.y > 0.f ? g.y : 0.f;
+              g.z = ov.z > 0.f ? g.z : 0.f; g.w = ov.w > 0.f ? g.w : 0.f;
+            }
+            if (gres1) *reinterpret_cast<f32x4*>(gres1 + o) += g;
+            if (gres2) *reinterpret_cast<f32x4*>(gres2 + o) += g;
+            acc += g;
+          }
+        *reinterpret_cast<f32x4*>(gz + p * C + q * 4) = acc;
+        f32x4 xh = (f32x4){0, 0, 0, 0};
+        if (has_bn) xh = (*reinterpret_cast<const f32x4*>(z + p * C + q * 4) - mu) * is;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          sb[k] += (double)acc[k];
+          sg[k] += (double)acc[k] * (double)xh[k];
+        }
+      }
+    }
+    __syncthreads();
+    if (q < c4n && row < rows)
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        sh[((row * lanes + col) * 4 + k) * 2] = sb[k];
+        sh[((row * lanes + col) * 4 + k) * 2 + 1] = sg[k];
+      }
+    __syncthreads();
+    if (row == 0 && q < c4n) {
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        double a = 0, b = 0;
+        for (int r = 0; r < rows; r++) {
+          a += sh[((r * lanes + col) * 4 + k) * 2];
+          b += sh[((r * lanes + col) * 4 + k) * 2 + 1];
+        }
+        part[((int64_t)blockIdx.x * C + q * 4 + k) * 2] = a;
+        part[((int64_t)blockIdx.x * C + q * 4 + k) * 2 + 1] = b;
+      }
+    }
+  }
+}
+
+// dbeta / dgamma (float, also kept in `sums` for stage 2)
+__global__ void bn_bwd_finalize_kernel(const double* __restrict__ part, int nblocks, int C, float* __restrict__ dbeta,
+                                       float* __restrict__ dgamma, float* __restrict__ sums) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double a = 0, b = 0;
+  for (int k = 0; k < nblocks; k++) {
+    a += part[((int64_t)k * C + c) * 2];
+    b += part[((int64_t)k * C + c) * 2 + 1];
+  }
+  if (dbeta) dbeta[c] = (float)a;
+  if (dgamma) dgamma[c] = (float)b;
+  if (sums) {
+    sums[c] = (float)a;
+    sums[C + c] = (float)b;
+  }
+}
+
+// stage 2 (in place on gz): dz = gamma * invstd * (gz - dbeta / M - xhat * dgamma / M)
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(float* __restrict__ gz, const float* __restrict__ z,
+                                                           const float* __restrict__ mean,
+                                                           const float* __restrict__ invstd,
+                                                           const float* __restrict__ gamma,
+                                                           const float* __restrict__ sums, int64_t M, int C) {
+  const int c4n = C >> 2;
+  const int64_t total = M * c4n;
+  const float invM = 1.0f / (float)M;
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+    const int q = (int)(t % c4n);
+    const int64_t i = (t / c4n) * C + q * 4;
+    const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + q * 4);
+    const f32x4 is = *reinterpret_cast<const f32x4*>(invstd + q * 4);
+    const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + q * 4);
+    const f32x4 db = *reinterpret_cast<const f32x4*>(sums + q * 4);
+    const f32x4 dg = *reinterpret_cast<const f32x4*>(sums + C + q * 4);
+    const f32x4 xh = (*reinterpret_cast<const f32x4*>(z + i) - mu) * is;
+    const f32x4 gv = *reinterpret_cast<const f32x4*>(gz + i);
+    *reinterpret_cast<f32x4*>(gz + i) = (g * is) * (gv - db * invM - xh * (dg * invM));
+  }
+}
+
+// channel counts that are not a multiple of 4 (the 19-joint heat-map layer): plain conv with
+// bias, no BN / residual / upsample -- copy the (masked) gradient and sum it per channel
+__global__ __launch_bounds__(256) void bias_bwd_scalar_kernel(const float* __restrict__ gout,
+                                                              const float* __restrict__ out, float* __restrict__ gz,
+                                                              float* __restrict__ dbias, int64_t M, int C, int relu) {
+  __shared__ double red[256];
+  const int c = blockIdx.x;
+  double acc = 0;
+  for (int64_t p = threadIdx.x; p < M; p += 256) {
+    float g = gout[p * C + c];
+    if (relu && !(out[p * C + c] > 0.f)) g = 0.f;
+    gz[p * C + c] = g;
+    acc += (double)g;
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0 && dbias) dbias[c] = (float)red[0];
+}
+
+extern "C" int mval_bn_bwd(const float* gout, const float* out, const float* z, const float* mean, const float* invstd,
+                           const float* gamma, float* gres1, float* gres2, float* gz, float* dgamma, float* dbeta,
+                           double* ws, float* sums, int N, int H, int W, int C, int up, int relu, int has_bn,
+                           void* stream) {
+  MVAL_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && up >= 0, "mval_bn_bwd: bad dims");
+  if (C & 3) {
+    MVAL_REQUIRE(!has_bn && up == 0 && !gres1 && !gres2, "mval_bn_bwd: odd channel count only for plain conv+bias");
+    hipLaunchKernelGGL(bias_bwd_scalar_kernel, dim3(C), dim3(256), 0, mval_stream(stream), gout, out, gz, dbeta,
+                       (int64_t)N * H * W, C, relu);
+    MVAL_CHECK_LAUNCH("mval_bn_bwd/scalar");
+    return 0;
+  }
+  const int64_t M = (int64_t)N * H * W;
+  const int c4n = C >> 2;
+  const int lanes = c4n < 256 ? c4n : 256;
+  const int rows = 256 / lanes;
+  int nb = (int)((M + rows - 1) / rows);
+  if (nb > TR_BLOCKS) nb = TR_BLOCKS;
+  size_t sh = (size_t)rows * lanes * 4 * 2 * sizeof(double);
+  hipStream_t s = mval_stream(stream);
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nb), dim3(256), sh, s, gout, out, z, mean, invstd, gres1, gres2, gz, ws,
+                     N, H, W, C, up, relu, has_bn);
+  MVAL_CHECK_LAUNCH("mval_bn_bwd/reduce");
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, s, ws, nb, C, dbeta,
+                     has_bn ? dgamma : nullptr, sums);
+  MVAL_CHECK_LAUNCH("mval_bn_bwd/finalize");
+  if (has_bn) {
+    int64_t total = M * c4n;
+    int nb2 = (int)((total + 255) / 256);
+    if (nb2 > 8192) nb2 = 8192;
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(nb2), dim3(256), 0, s, gz, z, mean, invstd, gamma, sums, M, C);
+    MVAL_CHECK_LAUNCH("mval_bn_bwd/apply");
+  }
+  return 0;
+}
+
+// sum of S slabs of n floats (float64 accumulation), deterministic split-K reduction
+__global__ void slab_reduce_kernel(const float* __restrict__ slabs, int S, int64_t n, float* __restrict__ out,
+                                   int accumulate) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double a = 0;
+  for (int s = 0; s < S; s++) a += (double)slabs[(int64_t)s * n + i];
+  out[i] = accumulate ? out[i] + (float)a : (float)a;
+}
+
+extern "C" int mval_slab_reduce(const float* slabs, int S, int64_t n, float* out, int accumulate, void* stream) {
+  MVAL_REQUIRE(S > 0 && n > 0, "mval_slab_reduce: bad dims");
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, mval_stream(stream), slabs, S,
+                     n, out, accumulate);
+  MVAL_CHECK_LAUNCH("mval_slab_reduce");
+  return 0;
+}

@@ -1,7 +1,282 @@
-"""Training-mode executor (train-mode BatchNorm + autograd over the HIP operators)."""
+"""Training-mode executor: train-mode BatchNorm forward + full backward of the heat-map
+network on the HIP kernels, exposed to PyTorch as ONE autograd node.
+
+Reference behaviour reproduced (strategy.py:460-487): batch statistics per GPU (no
+SyncBN), biased variance for normalisation, running stats updated with momentum 0.1 and the
+unbiased variance, ``num_batches_tracked`` incremented; gradients for every conv weight, BN
+gamma/beta and the final-layer bias.  The optimizer (Adam) and LR schedule stay in PyTorch, and
+so does DistributedDataParallel's gradient all-reduce (RCCL): parameters enter the autograd
+node as inputs, so DDP's hooks fire as usual.
+
+The plan keeps every operator's raw conv output z and activation (no arena reuse: backward needs
+them) and a mirror arena for activation gradients; forward and backward are one C call each
+(``mval_train_forward`` / ``mval_train_backward``), with weights (re)packed on device only when a
+parameter version changes.  PoseResNet (max-pool / transposed conv) training is not wired yet.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+from .engine import ALGO_DIRECT, ALGO_MFMA, PACK_HWIO, PACK_MFMA16, MvalOp, _align, _mfma_ok
+
+BN_MOMENTUM = 0.1
+BN_EPS = 1e-5
+_F = C.POINTER(C.c_float)
+
+
+class MvalTrainOp(C.Structure):
+    """include/mval_hip.h: struct mval_train_op."""
+
+    _fields_ = [
+        ("op", MvalOp),
+        ("z_off", C.c_int64),
+        ("gin_off", C.c_int64), ("gout_off", C.c_int64), ("gres1_off", C.c_int64), ("gres2_off", C.c_int64),
+        ("wd_off", C.c_int64),
+        ("has_bn", C.c_int32), ("dgrad_algo", C.c_int32), ("reserved0", C.c_int32), ("reserved1", C.c_int32),
+        ("gamma", C.c_void_p), ("beta", C.c_void_p), ("running_mean", C.c_void_p), ("running_var", C.c_void_p),
+        ("mean", C.c_void_p), ("invstd", C.c_void_p),
+        ("dweight", C.c_void_p), ("dgamma", C.c_void_p), ("dbeta", C.c_void_p),
+    ]
+
+
+class TrainPlan:
+    def __init__(self, model, n, h, w, device):
+        g = model._graph
+        if any(op.kind != "conv" for op in g.ops):
+            raise NotImplementedError("training on the HIP engine covers conv/BN graphs (HRNet); PoseResNet's max-pool / "
+                                      "transposed-conv backward is not wired yet")
+        self.model, self.graph, self.n, self.device = model, g, n, device
+        lib = _lib.lib()
+        dims = {g.input: (h, w)}
+        geo = []
+        for op in g.ops:
+            hin, win = dims[op.src]
+            hout, wout = (hin + 2 * op.pad - op.k) // op.stride + 1, (win + 2 * op.pad - op.k) // op.stride + 1
+            full = (hout << op.up, wout << op.up)
+            for r in (op.res1, op.res2):
+                if r is not None and dims[r] != full:
+                    raise ValueError(f"input {h}x{w}: branch resolutions do not line up at {op.conv}")
+            dims[op.dst] = full
+            geo.append((hin, win, hout, wout))
+        self.out_hw = dims[g.output]
+        self.out_channels = g.acts[g.output].channels
+        # ---- arenas: every activation and every raw conv output is kept --------------------------
+        top = 0
+        act_off = {}
+        for a in g.acts:
+            if a.id in (g.input,) or a.id not in dims:
+                continue
+            # the graph output also gets a slot: its NHWC gradient lives at the same offset of garena
+            act_off[a.id] = top
+            top += _align(n * dims[a.id][0] * dims[a.id][1] * a.channels)
+        z_off = []
+        for i, op in enumerate(g.ops):
+            if op.bn:
+                z_off.append(top)
+                top += _align(n * geo[i][2] * geo[i][3] * op.cout)
+            else:
+                z_off.append(-1)
+        self.arena_floats = top
+        # ---- parameters: forward packing, dgrad packing, ones / zeros ---------------------------
+        maxc = max(op.cout for op in g.ops)
+        self.maxc = maxc
+        ptop = 0
+        self.ops = (MvalTrainOp * len(g.ops))()
+        self.jobs = []
+        stat_top = 0
+        self.stat_off = []
+        gz_max, wsf_max = 0, 0
+        for i, op in enumerate(g.ops):
+            hin, win, hout, wout = geo[i]
+            in_nchw = g.acts[op.src].layout == "nchw"
+            out_nchw = g.acts[op.dst].layout == "nchw"
+            t = self.ops[i]
+            m = t.op
+            m.kind = 0
+            m.k, m.stride, m.pad, m.cin, m.cout = op.k, op.stride, op.pad, op.cin, op.cout
+            m.hin, m.win, m.hout, m.wout = hin, win, hout, wout
+            m.up, m.relu, m.in_nchw, m.out_nchw = op.up, int(op.relu), int(in_nchw), int(out_nchw)
+            m.algo = ALGO_DIRECT
+            if _mfma_ok(op, in_nchw) and lib.mval_op_mfma_supported(C.byref(m), C.c_int(n)):
+                m.algo = ALGO_MFMA
+            m.in_off = -1 if op.src == g.input else act_off[op.src]
+            m.out_off = -1 if op.dst == g.output else act_off[op.dst]
+            m.res1_off = -1 if op.res1 is None else act_off[op.res1]
+            m.res2_off = -1 if op.res2 is None else act_off[op.res2]
+            fpack = PACK_MFMA16 if m.algo == ALGO_MFMA else PACK_HWIO
+            nw = int(lib.mval_packed_weight_floats(C.c_int(fpack), C.c_int(op.cout), C.c_int(op.cin), C.c_int(op.k)))
+            m.w_off = ptop
+            ptop += _align(nw)
+            m.scale_off = -1
+            m.shift_off = -1
+            if not op.bn:  # conv + bias
+                m.shift_off = ptop
+                ptop += _align(op.cout)
+            t.z_off = z_off[i]
+            t.has_bn = int(bool(op.bn))
+            t.gout_off = act_off[op.dst]
+            t.gin_off = -1 if op.src == g.input else act_off[op.src]
+            t.gres1_off = -1 if op.res1 is None else act_off[op.res1]
+            t.gres2_off = -1 if op.res2 is None else act_off[op.res2]
+            t.wd_off = -1
+            t.dgrad_algo = ALGO_DIRECT
+            dpack = None
+            if t.gin_off >= 0:
+                ok = op.cout % 16 == 0 and op.k in (1, 3) and op.stride in (1, 2) and op.pad == op.k // 2
+                t.dgrad_algo = ALGO_MFMA if ok else ALGO_DIRECT
+                dpack = PACK_MFMA16 if ok else PACK_HWIO
+                # the data-gradient conv has cin' = cout, cout' = cin
+                nd = int(lib.mval_packed_weight_floats(C.c_int(dpack), C.c_int(op.cin), C.c_int(op.cout), C.c_int(op.k)))
+                t.wd_off = ptop
+                ptop += _align(nd)
+            self.jobs.append((i, fpack, dpack))
+            self.stat_off.append(stat_top)
+            stat_top += 2 * _align(op.cout)
+            gz_max = max(gz_max, n * hout * wout * op.cout)
+            wsf_max = max(wsf_max, int(lib.mval_conv_wgrad_workspace_floats(C.c_int(op.cin), C.c_int(op.cout), C.c_int(op.k))))
+        self.ones_off = ptop
+        ptop += _align(maxc)
+        self.zeros_off = ptop
+        ptop += _align(maxc)
+        for t in self.ops:
+            if not t.has_bn:
+                t.op.scale_off = self.ones_off
+        self.param_floats = ptop
+        f32 = dict(dtype=torch.float32, device=device)
+        self.arena = torch.empty(self.arena_floats, **f32)
+        self.garena = torch.empty(self.arena_floats, **f32)
+        self.params = torch.zeros(self.param_floats, **f32)
+        self.params[self.ones_off : self.ones_off + maxc] = 1.0
+        self.stats = torch.zeros(max(stat_top, 64), **f32)
+        self.gz = torch.empty(max(gz_max, 64), **f32)
+        self.wsf = torch.empty(max(wsf_max, 64), **f32)
+        self.ws = torch.empty(512 * maxc * 2 + 64, dtype=torch.float64, device=device)
+        self.sums = torch.empty(2 * maxc + 64, **f32)
+        self.param_sig = None
+        # parameter order of the autograd node: conv.weight [, conv.bias] [, bn.weight, bn.bias] per op
+        holders = model._holders
+        self.param_list, self.grad_slots = [], []
+        gtop = 0
+        for op in g.ops:
+            conv = holders[op.conv]
+            slots = {"w": gtop}
+            self.param_list.append(conv.weight)
+            gtop += _align(conv.weight.numel(), 4)
+            if conv.bias is not None:
+                slots["b"] = gtop
+                self.param_list.append(conv.bias)
+                gtop += _align(op.cout, 4)
+            if op.bn:
+                bn = holders[op.bn]
+                slots["g"], slots["be"] = gtop, gtop + _align(op.cout, 4)
+                self.param_list += [bn.weight, bn.bias]
+                gtop += 2 * _align(op.cout, 4)
+            self.grad_slots.append(slots)
+        self.grad_floats = gtop
+        self.bn_counters = [holders[op.bn].num_batches_tracked for op in g.ops if op.bn]
+
+    # ---- parameters ---------------------------------------------------------------------------
+    def _refresh(self):
+        holders = self.model._holders
+        lib = _lib.lib()
+        st = _lib._stream()
+        sig = tuple(p._version for p in self.param_list) + tuple(p.data_ptr() for p in self.param_list)
+        repack = sig != self.param_sig
+        base = self.params.data_ptr()
+        sbase = self.stats.data_ptr()
+        for (i, fpack, dpack), op in zip(self.jobs, self.graph.ops):
+            t = self.ops[i]
+            conv = holders[op.conv]
+            w = conv.weight
+            if not w.is_cuda:
+                raise _lib.MvalError("model parameters must be on the HIP device (call .cuda())")
+            if repack:
+                wp = C.c_void_p(w.detach().contiguous().data_ptr())
+                _lib._check(lib.mval_pack_conv_weights(C.c_int(fpack), C.c_int(0), wp, C.c_void_p(base + 4 * t.op.w_off),
+                                                       C.c_int(op.cout), C.c_int(op.cin), C.c_int(op.k), st), "pack fwd")
+                if dpack is not None:
+                    _lib._check(lib.mval_pack_conv_weights(C.c_int(dpack), C.c_int(2), wp, C.c_void_p(base + 4 * t.wd_off),
+                                                           C.c_int(op.cin), C.c_int(op.cout), C.c_int(op.k), st), "pack dgrad")
+                if conv.bias is not None:
+                    self.params[t.op.shift_off : t.op.shift_off + op.cout] = conv.bias.detach()
+            if op.bn:
+                bn = holders[op.bn]
+                t.gamma, t.beta = bn.weight.data_ptr(), bn.bias.data_ptr()
+                t.running_mean, t.running_var = bn.running_mean.data_ptr(), bn.running_var.data_ptr()
+                t.mean = sbase + 4 * self.stat_off[i]
+                t.invstd = sbase + 4 * (self.stat_off[i] + _align(op.cout))
+        self.param_sig = sig
+
+    def forward(self, x):
+        self._refresh()
+        out = torch.empty((self.n, self.out_channels) + tuple(self.out_hw), dtype=torch.float32, device=self.device)
+        _lib._check(
+            _lib.lib().mval_train_forward(
+                self.ops, C.c_int(len(self.ops)), C.c_int(self.n), C.c_void_p(self.arena.data_ptr()),
+                C.c_void_p(self.params.data_ptr()), C.c_int64(self.ones_off), C.c_int64(self.zeros_off),
+                C.c_void_p(x.data_ptr()), C.c_void_p(out.data_ptr()), C.c_void_p(self.ws.data_ptr()),
+                C.c_float(BN_MOMENTUM), C.c_float(BN_EPS), _lib._stream()),
+            "mval_train_forward")
+        if self.bn_counters:
+            torch._foreach_add_(self.bn_counters, 1)
+        return out
+
+    def backward(self, x, gout_nchw):
+        g = self.graph
+        grads = torch.empty(self.grad_floats, dtype=torch.float32, device=self.device)
+        gb = grads.data_ptr()
+        for t, slots, op in zip(self.ops, self.grad_slots, g.ops):
+            t.dweight = gb + 4 * slots["w"]
+            t.dgamma = gb + 4 * slots["g"] if "g" in slots else None
+            t.dbeta = gb + 4 * (slots["be"] if "be" in slots else slots["b"]) if ("be" in slots or "b" in slots) else None
+        self.garena.zero_()
+        last = self.ops[len(self.ops) - 1]
+        gn = gout_nchw.to(torch.float32).permute(0, 2, 3, 1).contiguous()
+        self.garena[last.gout_off : last.gout_off + gn.numel()] = gn.reshape(-1)
+        _lib._check(
+            _lib.lib().mval_train_backward(
+                self.ops, C.c_int(len(self.ops)), C.c_int(self.n), C.c_void_p(self.arena.data_ptr()),
+                C.c_void_p(self.garena.data_ptr()), C.c_void_p(self.params.data_ptr()), C.c_int64(self.ones_off),
+                C.c_int64(self.zeros_off), C.c_void_p(x.data_ptr()), C.c_void_p(self.gz.data_ptr()),
+                C.c_void_p(self.wsf.data_ptr()), C.c_void_p(self.ws.data_ptr()), C.c_void_p(self.sums.data_ptr()),
+                _lib._stream()),
+            "mval_train_backward")
+        out = []
+        holders = self.model._holders
+        for slots, op in zip(self.grad_slots, g.ops):
+            conv = holders[op.conv]
+            out.append(grads[slots["w"] : slots["w"] + conv.weight.numel()].view_as(conv.weight))
+            if "b" in slots:
+                out.append(grads[slots["b"] : slots["b"] + op.cout])
+            if op.bn:
+                out.append(grads[slots["g"] : slots["g"] + op.cout])
+                out.append(grads[slots["be"] : slots["be"] + op.cout])
+        return out
+
+
+class _NetTrainFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, plan, *params):
+        ctx.plan = plan
+        ctx.save_for_backward(x)
+        return plan.forward(x)
+
+    @staticmethod
+    def backward(ctx, gout):
+        (x,) = ctx.saved_tensors
+        grads = ctx.plan.backward(x, gout.contiguous())
+        return (None, None, *grads)
 
 
 def run_network_train(model, x):
-    raise NotImplementedError(
-        "training-mode forward/backward on the HIP engine is not wired yet; call model.eval() for inference"
-    )
+    n, c, h, w = x.shape
+    cache = model.__dict__.setdefault("_train_plans", {})
+    key = (n, h, w, x.device.index)
+    plan = cache.get(key)
+    if plan is None:
+        cache.clear()  # one training geometry at a time: the arenas are large
+        plan = cache[key] = TrainPlan(model, n, h, w, x.device)
+    return _NetTrainFn.apply(x, plan, *plan.param_list)

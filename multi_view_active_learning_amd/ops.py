@@ -91,3 +91,29 @@ def fused_conv(x, weight, scale, shift, stride=1, pad=None, relu=False, res1=Non
         "mval_op_launch")
     out = arena[out_off:]
     return out.reshape(n, cout, ho, wo) if out_nchw else out.reshape(n, ho, wo, cout)
+
+
+def conv_dgrad(dz, weight, in_hw, stride=1, algo=ALGO_MFMA, accumulate_into=None):
+    """Data gradient of ``F.conv2d(x, weight, stride=stride, padding=k//2)``: dz NHWC
+    (N,Ho,Wo,Cout), weight (Cout,Cin,k,k) -> dx NHWC (N,H,W,Cin) via the forward kernels on
+    flipped / channel-swapped weights (mval_conv_dgrad)."""
+    lib = _lib.lib()
+    cout, cin, k, _ = weight.shape
+    n, ho, wo, _ = dz.shape
+    h, w = in_hw
+    pack = PACK_MFMA16 if algo == ALGO_MFMA else PACK_HWIO
+    nw = int(lib.mval_packed_weight_floats(C.c_int(pack), C.c_int(cin), C.c_int(cout), C.c_int(k)))
+    wp = torch.empty(nw, dtype=torch.float32, device=dz.device)
+    wt = weight.detach().contiguous()
+    _lib._check(lib.mval_pack_conv_weights(C.c_int(pack), C.c_int(2), _lib._p(wt), _lib._p(wp), C.c_int(cin), C.c_int(cout),
+                                           C.c_int(k), _lib._stream()), "mval_pack_conv_weights")
+    ones = torch.ones(max(cin, cout), dtype=torch.float32, device=dz.device)
+    zeros = torch.zeros_like(ones)
+    dx = accumulate_into if accumulate_into is not None else torch.empty((n, h, w, cin), dtype=torch.float32, device=dz.device)
+    _lib._check(
+        lib.mval_conv_dgrad(_lib._p(dz.contiguous()), _lib._p(wp), _lib._p(ones), _lib._p(zeros), _lib._p(dx),
+                            C.c_int(int(accumulate_into is not None)), C.c_int(n), C.c_int(h), C.c_int(w), C.c_int(cin),
+                            C.c_int(ho), C.c_int(wo), C.c_int(cout), C.c_int(k), C.c_int(stride), C.c_int(k // 2),
+                            C.c_int(algo), _lib._stream()),
+        "mval_conv_dgrad")
+    return dx

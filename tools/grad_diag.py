@@ -1,0 +1,24 @@
+import sys, os
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..")); sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tests", "golden")); sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tests"))
+import numpy as np, torch, cases
+from oracle import models
+import test_gpu_train as T
+dev = torch.device("cuda:0")
+c = dict(arch="hrnet_w32", seed=5, n=3, h=64, w=64, j=7)
+m, _, hm, loss, sd = T._train_once(c, dev)
+x, gt, valid = cases.train_input(c)
+def cpu(dt):
+    sdc = {k: (v.clone().to(dt) if v.dtype.is_floating_point else v.clone()) for k, v in sd.items()}
+    for k, v in sdc.items():
+        if v.dtype.is_floating_point and "running" not in k: v.requires_grad_(True)
+    h = models.hrnet_forward(sdc, torch.from_numpy(x).to(dt), models.HRNET_W32, training=True)
+    l = models.pose_2d_mse(h, torch.from_numpy(gt).to(dt), torch.from_numpy(valid).reshape(h.shape[0], -1, 1, 1)); l.backward()
+    return sdc
+s64, s32 = cpu(torch.float64), cpu(torch.float32)
+rows = []
+for k, p in m.named_parameters():
+    t = s64[k].grad.numpy()
+    rows.append((T._rel(p.grad.cpu().numpy(), t) / (T._rel(s32[k].grad.numpy(), t) + 1e-4), T._rel(p.grad.cpu().numpy(), t), T._rel(s32[k].grad.numpy(), t), k))
+rows.sort(reverse=True)
+for r in rows[:25]: print("%.1f %.2e %.2e %s" % r)
+print("median gpu", np.median([r[1] for r in rows]), "median cpu", np.median([r[2] for r in rows]))
