@@ -35,6 +35,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, dense fp32-input MFMA
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # same guide: dense bf16 MFMA (the 5 PF headline includes 2:1 sparsity)
 FLOP_PER_IMAGE = {"hrnet_w32_256": 20.387e9}  # conv FLOPs (2*MAC) per frame x view
 
 WORKLOADS = {
@@ -45,7 +46,12 @@ WORKLOADS = {
     # backward, Adam) -- selectable for measurement; the driver's default line stays c2
     "c3": dict(arch="hrnet_w32", v=4, h=256, w=256, frames=32, j=19, train=True,
                desc="HRNet-W32 4-view 256x256 batch-32 training step (masked-MSE backward + Adam)"),
+    # BASELINE.json configs[3]/[4] per-GPU slice: HRNet-W48, 8 views, 384x288; one step = 8 frames
+    # (64 images) of the unlabeled pool: heat-maps + arg-max + RANSAC-DLT + MPE entropy scoring
+    "c4": dict(arch="hrnet_w48", v=8, h=384, w=288, frames=8, j=19, train=False, score="MPE",
+               desc="HRNet-W48 8-view 384x288 pool scoring: heat-maps + triangulation + MPE entropy, 8 frames/step"),
 }
+FLOP_PER_IMAGE["hrnet_w48_384x288"] = 70.615e9
 
 
 def build_model(arch, j, dev, seed=0):
@@ -115,7 +121,7 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     from multi_view_active_learning_amd import _lib, synth
-    from multi_view_active_learning_amd.engine import ALGO_MFMA, _plan_for
+    from multi_view_active_learning_amd.engine import ALGO_MFMA, ALGO_MFMA_BF3, _conv_mode, _plan_for
     from multi_view_active_learning_amd.utils.triangulation import triangulate_batch
 
     _lib.lib()  # fail loudly if the HIP extension is missing
@@ -146,8 +152,13 @@ def main():
             loss.backward()
             opt.step()
             return {"keypoints_3d": loss.detach().reshape(1)}
-        hm = model(images)
-        return triangulate_batch(hm.reshape(frames, v, j, h // 4, w // 4), proj, 4, valid)
+        hm = model(images).reshape(frames, v, j, h // 4, w // 4)
+        r = triangulate_batch(hm, proj, 4, valid)
+        if wl.get("score"):
+            from multi_view_active_learning_amd.strategy import score_heatmaps_batch
+
+            r["al_metric"] = score_heatmaps_batch(wl["score"], "AVG", hm, valid)[0]
+        return r
 
     def sync():
         torch.cuda.synchronize()
@@ -187,26 +198,42 @@ def main():
                 _, ms, flops = plan.forward_timed(images)
                 ms_acc = ms if ms_acc is None else ms_acc + ms
         ms = ms_acc / reps
-        is_mfma = np.asarray([o.algo == ALGO_MFMA and o.kind == 0 for o in plan.ops])
-        t_mfma = float(ms[is_mfma].sum()) * 1e-3
-        f_mfma = float(flops[is_mfma].sum())
-        achieved = f_mfma / t_mfma / 1e12
-        k3 = np.asarray([o.algo == ALGO_MFMA and o.k == 3 and o.stride == 1 for o in plan.ops])
-        roof = dict(
-            bound="mfma", achieved=round(achieved, 2), peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s",
-            frac=round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), traffic=None,
-            kernel="conv_mfma_kernel (fused conv+BN+residual+ReLU, v_mfma_f32_16x16x4_f32), all template instances",
-            launches_per_step=int(is_mfma.sum()), avg_launch_us=round(t_mfma / is_mfma.sum() * 1e6, 2),
-            flops_per_step=f_mfma, seconds_in_kernel_per_step=round(t_mfma, 6),
-            conv3x3s1_tflops=round(float(flops[k3].sum()) / (float(ms[k3].sum()) * 1e-3) / 1e12, 2),
-            whole_forward_ms=round(float(ms.sum()), 3),
-            non_mfma_ms=round(float(ms[~is_mfma].sum()), 3),
-        )
+
+        def family(mask, name, peak, peak_note):
+            n = int(mask.sum())
+            if n == 0:
+                return None
+            t = float(ms[mask].sum()) * 1e-3
+            f = float(flops[mask].sum())
+            return dict(bound="mfma", achieved=round(f / t / 1e12, 2), peak=peak, unit="TFLOP/s",
+                        frac=round(f / t / 1e12 / peak, 4), traffic=None, kernel=name, peak_note=peak_note,
+                        launches_per_step=n, avg_launch_us=round(t / n * 1e6, 2), flops_per_step=f,
+                        seconds_in_kernel_per_step=round(t, 6))
+
+        conv = np.asarray([o.kind == 0 for o in plan.ops])
+        bf3 = np.asarray([o.algo == ALGO_MFMA_BF3 for o in plan.ops]) & conv
+        f32 = np.asarray([o.algo == ALGO_MFMA for o in plan.ops]) & conv
+        fams = [
+            family(bf3, "conv_bf3_kernel (fused 3x3 conv+BN+residual+ReLU; fp32 values as exact 3-way bf16 splits, "
+                        "6 x v_mfma_f32_16x16x32_bf16 per 32-deep step, fp32 accumulate)", PEAK_BF16_MFMA_TFLOPS / 6.0,
+                   "dense bf16 MFMA peak 2500 TFLOP/s / 6 MFMA products per algorithmic product"),
+            family(f32, "conv_mfma_kernel (fused 1x1 / strided conv+BN+residual+ReLU, v_mfma_f32_16x16x4_f32)",
+                   PEAK_FP32_MFMA_TFLOPS, "dense fp32-input MFMA peak"),
+        ]
+        fams = sorted([f for f in fams if f], key=lambda f: -f["seconds_in_kernel_per_step"])
+        roof = fams[0]
+        roof["other_kernels"] = fams[1:]
+        allc = bf3 | f32
+        roof["all_conv_tflops"] = round(float(flops[allc].sum()) / (float(ms[allc].sum()) * 1e-3) / 1e12, 2)
+        roof["all_conv_frac_of_fp32_mfma_peak"] = round(roof["all_conv_tflops"] / PEAK_FP32_MFMA_TFLOPS, 4)
+        roof["whole_forward_ms"] = round(float(ms.sum()), 3)
+        roof["non_mfma_ms"] = round(float(ms[~allc].sum()), 3)
 
     if rank == 0:
         total_units = world * frames * v * args.steps
         out = {
             "metric": ("frames*views/sec (training step) HRNet-W32 4-view 256x256" if train else
+                       "frames*views/sec (pool scoring) HRNet-W48 8-view 384x288" if wl.get("score") else
                        "frames*views/sec (heatmap->triangulated 3D) HRNet-W32 4-view 256x256"),
             "value": round(total_units / el, 2),
             "unit": "frames*views/s",
@@ -217,7 +244,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f32" if _conv_mode() == "fp32" else "f32 (3x3 convs: exact 3-way bf16 split on bf16 MFMA, fp32 accumulate)",
             "data": "synthetic (random variance-preserving weights, N(0,1) frames, ring cameras)",
             "config": {"workload": wl["desc"], "frames_per_step_per_gpu": frames, "views": v,
                        "images_per_step_per_gpu": frames * v, "parallelism": f"frame-sharded x{world}, no collective"},

@@ -143,8 +143,8 @@ int mval_kcenter_select(const double* feat, int64_t n_obs, int D, const int64_t*
  * written by mval_pack_conv_weights; scale/shift are the folded eval-mode BatchNorm
  * (y = x * scale + shift, torch's batch_norm inference formula) or (1, bias). */
 enum { MVAL_OP_CONV = 0, MVAL_OP_MAXPOOL = 1, MVAL_OP_DECONV = 2 };
-enum { MVAL_ALGO_DIRECT = 0, MVAL_ALGO_MFMA = 1 };
-enum { MVAL_PACK_HWIO = 0, MVAL_PACK_MFMA16 = 1 };
+enum { MVAL_ALGO_DIRECT = 0, MVAL_ALGO_MFMA = 1, MVAL_ALGO_MFMA_BF3 = 2 };
+enum { MVAL_PACK_HWIO = 0, MVAL_PACK_MFMA16 = 1, MVAL_PACK_MFMA16_BF3 = 2 };
 
 typedef struct mval_op {
   int32_t kind;      /* MVAL_OP_*: conv, maxpool (k, stride, pad), transposed conv k4 s2 p1 */
@@ -162,8 +162,12 @@ typedef struct mval_op {
 /* Weight packing.  MVAL_PACK_HWIO: [k*k][cin][cout] (direct kernels, deconv);
  * MVAL_PACK_MFMA16: v_mfma_f32_16x16x4_f32 B-fragment order
  * [k*k][cin/16][cout/16][lane 0..63][4] with lane = (cin_quad << 4) | cout_lane, cin and
- * cout zero-padded to multiples of 16.  `transposed` != 0: w is a ConvTranspose2d weight
- * [cin,cout,k,k], else a Conv2d weight [cout,cin,k,k]. */
+ * cout zero-padded to multiples of 16;
+ * MVAL_PACK_MFMA16_BF3: the exact three-way bf16 split of every weight in
+ * v_mfma_f32_16x16x32_bf16 B-fragment order [k*k][cin/32][cout/16][plane h,m,l][lane][8 bf16]
+ * (conv_mfma_bf3.hip).  `transposed`: 0 = Conv2d weight [cout,cin,k,k]; 1 = ConvTranspose2d
+ * weight [cin,cout,k,k]; 2 = data-gradient form of a Conv2d weight (channel roles swapped, taps
+ * flipped; pass cout' = cin, cin' = cout). */
 size_t mval_packed_weight_floats(int pack, int cout, int cin, int k);
 int mval_pack_conv_weights(int pack, int transposed, const float* w, float* packed, int cout, int cin, int k,
                            void* stream);
@@ -174,6 +178,8 @@ int mval_bn_fold(const float* gamma, const float* beta, const float* mean, const
 /* 1 when the MFMA kernel family has a configuration for this op geometry (the plan builder
  * asks before choosing MVAL_ALGO_MFMA / MVAL_PACK_MFMA16), else 0. */
 int mval_op_mfma_supported(const mval_op* op, int n_images);
+/* Same question for a given MVAL_ALGO_* (MFMA or MFMA_BF3). */
+int mval_op_algo_supported(const mval_op* op, int n_images, int algo);
 
 int mval_op_launch(const mval_op* op, int n_images, float* workspace, const float* params,
                    const float* net_input, float* net_output, void* stream);

@@ -42,5 +42,8 @@ __device__ __forceinline__ void conv_store(const ConvArgs& a, int n, int y, int 
 
 int mval_launch_conv_mfma(const ConvArgs& a, hipStream_t s);  // conv_mfma.hip; returns 1 if unsupported
 int mval_conv_mfma_supported(const ConvArgs& a);            // same selection logic, no launch
+int mval_launch_conv_bf3(const ConvArgs& a, hipStream_t s);   // conv_mfma_bf3.hip; returns 1 if unsupported
+int mval_conv_bf3_supported(const ConvArgs& a);
+int mval_pack_bf3(int mode, const float* w, float* packed, int cout, int cin, int k, hipStream_t s);
 int mval_launch_conv_direct(const ConvArgs& a, int kind, hipStream_t s);
 int mval_launch_conv_stem(const ConvArgs& a, hipStream_t s);  // conv_stem.hip; returns 1 if unsupported

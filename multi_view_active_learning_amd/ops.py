@@ -8,7 +8,8 @@ import ctypes as C
 import torch
 
 from . import _lib
-from .engine import ALGO_DIRECT, ALGO_MFMA, OP_CONV, OP_DECONV, OP_MAXPOOL, PACK_HWIO, PACK_MFMA16, MvalOp, _align
+from .engine import (ALGO_DIRECT, ALGO_MFMA, ALGO_MFMA_BF3, OP_CONV, OP_DECONV, OP_MAXPOOL, PACK_HWIO, PACK_MFMA16,
+                     PACK_MFMA16_BF3, _PACK_OF, MvalOp, _align)
 
 
 def pack_weights(weight, algo, transposed=False):
@@ -18,7 +19,7 @@ def pack_weights(weight, algo, transposed=False):
         cin, cout, k, _ = weight.shape
     else:
         cout, cin, k, _ = weight.shape
-    pack = PACK_MFMA16 if algo == ALGO_MFMA else PACK_HWIO
+    pack = _PACK_OF[algo]
     n = int(lib.mval_packed_weight_floats(C.c_int(pack), C.c_int(cout), C.c_int(cin), C.c_int(k)))
     out = torch.empty(n, dtype=torch.float32, device=weight.device)
     w = weight.detach().contiguous()
