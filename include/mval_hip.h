@@ -157,6 +157,9 @@ typedef struct mval_op {
   int32_t in_nchw, out_nchw;
   int64_t in_off, out_off, res1_off, res2_off;
   int64_t w_off, scale_off, shift_off; /* floats from the params base */
+  int32_t phase, lane; /* scheduling hints: ops of one phase on different lanes are independent
+                          (HRNet branches / fuse outputs) and run on separate HIP streams; all
+                          lanes join at a phase change.  0/0 = plain in-order execution. */
 } mval_op;
 
 /* Weight packing.  MVAL_PACK_HWIO: [k*k][cin][cout] (direct kernels, deconv);

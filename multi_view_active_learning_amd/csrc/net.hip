@@ -289,9 +289,27 @@ extern "C" int mval_op_launch(const mval_op* op, int n_images, float* workspace,
   return 0;
 }
 
+// Lanes > 0 run on private non-blocking streams that fork from / join into the caller's stream
+// at every phase change (events, no host synchronisation), so the short tail of one branch's
+// kernel overlaps the head of another's instead of leaving CUs idle at ~300 kernel boundaries.
+#define MVAL_MAX_LANES 4
+
 struct MvalNet {
   std::vector<mval_op> ops;
+  hipStream_t side[MVAL_MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t fork_ev = nullptr;
+  hipEvent_t join_ev[MVAL_MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};
+  int n_lanes = 1;
 };
+
+static int multi_stream_enabled() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("MVAL_STREAMS");
+    v = (e && e[0] == '1' && e[1] == 0) ? 0 : 1;  // MVAL_STREAMS=1 forces single-stream execution
+  }
+  return v;
+}
 
 extern "C" void* mval_net_create(const mval_op* ops, int n_ops) {
   if (!ops || n_ops <= 0) {
@@ -300,19 +318,77 @@ extern "C" void* mval_net_create(const mval_op* ops, int n_ops) {
   }
   MvalNet* n = new MvalNet();
   n->ops.assign(ops, ops + n_ops);
+  for (const auto& o : n->ops)
+    if (o.lane + 1 > n->n_lanes) n->n_lanes = o.lane + 1;
+  if (n->n_lanes > MVAL_MAX_LANES) n->n_lanes = MVAL_MAX_LANES;
   return n;
 }
 
-extern "C" void mval_net_destroy(void* net) { delete reinterpret_cast<MvalNet*>(net); }
+extern "C" void mval_net_destroy(void* net) {
+  MvalNet* n = reinterpret_cast<MvalNet*>(net);
+  if (!n) return;
+  for (int l = 1; l < MVAL_MAX_LANES; l++) {
+    if (n->side[l]) (void)hipStreamDestroy(n->side[l]);
+    if (n->join_ev[l]) (void)hipEventDestroy(n->join_ev[l]);
+  }
+  if (n->fork_ev) (void)hipEventDestroy(n->fork_ev);
+  delete n;
+}
+
+static int ensure_streams(MvalNet* n) {
+  if (n->fork_ev) return 0;
+  if (hipEventCreateWithFlags(&n->fork_ev, hipEventDisableTiming) != hipSuccess) return -1;
+  for (int l = 1; l < n->n_lanes; l++) {
+    if (hipStreamCreateWithFlags(&n->side[l], hipStreamNonBlocking) != hipSuccess) return -1;
+    if (hipEventCreateWithFlags(&n->join_ev[l], hipEventDisableTiming) != hipSuccess) return -1;
+  }
+  return 0;
+}
 
 extern "C" int mval_net_forward(void* net, int n_images, float* workspace, const float* params,
                                 const float* input_nchw, float* output_nchw, void* stream) {
   MVAL_REQUIRE(net, "mval_net_forward: null net");
   MvalNet* n = reinterpret_cast<MvalNet*>(net);
+  hipStream_t main_s = mval_stream(stream);
+  const bool multi = n->n_lanes > 1 && multi_stream_enabled();
+  if (multi) MVAL_REQUIRE(ensure_streams(n) == 0, "mval_net_forward: could not create side streams");
+  bool used[MVAL_MAX_LANES] = {false, false, false, false};
+  int phase = n->ops.empty() ? 0 : n->ops[0].phase;
+  auto join = [&]() {  // side streams -> main
+    for (int l = 1; l < n->n_lanes; l++)
+      if (used[l]) {
+        (void)hipEventRecord(n->join_ev[l], n->side[l]);
+        (void)hipStreamWaitEvent(main_s, n->join_ev[l], 0);
+        used[l] = false;
+      }
+  };
+  bool forked = false;
   for (size_t i = 0; i < n->ops.size(); i++) {
-    int rc = mval_op_launch(&n->ops[i], n_images, workspace, params, input_nchw, output_nchw, stream);
+    const mval_op& op = n->ops[i];
+    hipStream_t s = main_s;
+    if (multi) {
+      if (op.phase != phase) {
+        join();
+        phase = op.phase;
+        forked = false;
+      }
+      int lane = op.lane < n->n_lanes ? op.lane : 0;
+      if (lane > 0) {
+        if (!forked) {  // everything enqueued on main so far precedes this phase's side work
+          (void)hipEventRecord(n->fork_ev, main_s);
+          forked = true;
+        }
+        if (!used[lane]) {
+          (void)hipStreamWaitEvent(n->side[lane], n->fork_ev, 0);
+          used[lane] = true;
+        }
+        s = n->side[lane];
+      }
+    }
+    int rc = mval_op_launch(&n->ops[i], n_images, workspace, params, input_nchw, output_nchw, s);
     if (rc) return rc;
   }
+  if (multi) join();
   return 0;
 }
 

@@ -42,6 +42,7 @@ class MvalOp(C.Structure):
         ("up", C.c_int32), ("relu", C.c_int32), ("in_nchw", C.c_int32), ("out_nchw", C.c_int32),
         ("in_off", C.c_int64), ("out_off", C.c_int64), ("res1_off", C.c_int64), ("res2_off", C.c_int64),
         ("w_off", C.c_int64), ("scale_off", C.c_int64), ("shift_off", C.c_int64),
+        ("phase", C.c_int32), ("lane", C.c_int32),
     ]
 
 
@@ -97,7 +98,13 @@ class InferencePlan:
                     last_use[a] = i
         size = {a.id: _align(n * dims[a.id][0] * dims[a.id][1] * a.channels) for a in g.acts if a.id in dims}
         offset, free, top = {}, [], 0  # free: list of (off, size)
+        pending, cur_phase = [], g.ops[0].phase if g.ops else 0
         for i, op in enumerate(g.ops):
+            if op.phase != cur_phase:
+                # lanes of a phase run concurrently on separate streams: a slot released inside
+                # the phase may only be re-used after the join at the phase change
+                free += pending
+                pending, cur_phase = [], op.phase
             if op.dst != g.output:
                 need = size[op.dst]
                 best = None
@@ -114,7 +121,7 @@ class InferencePlan:
                         free.append((o + need, s - need))
             for a in {op.src, op.res1, op.res2}:
                 if a is not None and a != g.input and last_use.get(a) == i:
-                    free.append((offset[a], size[a]))
+                    pending.append((offset[a], size[a]))
             # coalesce neighbours
             free.sort()
             merged = []
@@ -151,6 +158,7 @@ class InferencePlan:
             m.res1_off = -1 if op.res1 is None else offset[op.res1]
             m.res2_off = -1 if op.res2 is None else offset[op.res2]
             m.w_off = m.scale_off = m.shift_off = -1
+            m.phase, m.lane = op.phase, op.lane
             if op.kind in ("conv", "deconv"):
                 pack = _PACK_OF[m.algo]
                 nw = int(lib.mval_packed_weight_floats(C.c_int(pack), C.c_int(op.cout), C.c_int(op.cin), C.c_int(op.k)))

@@ -48,7 +48,10 @@ class Op:
     res1: Optional[int] = None  # out = act(((bn(conv) + res1) + res2)), left to right
     res2: Optional[int] = None
     up: int = 0  # log2 of the nearest-neighbour upsample fused into the store
-    bn_momentum_named: bool = True  # informational: BN built with momentum=BN_MOMENTUM
+    # scheduling hints: ops of one phase that sit on different lanes are independent (HRNet
+    # branches / fuse outputs) and may run concurrently on separate HIP streams; phases join
+    phase: int = 0
+    lane: int = 0
 
 
 @dataclass
@@ -57,6 +60,12 @@ class Graph:
     ops: List[Op] = field(default_factory=list)
     input: int = 0
     output: int = 0
+    cur_phase: int = 0
+    cur_lane: int = 0
+
+    def new_phase(self, lane: int = 0):
+        self.cur_phase += 1
+        self.cur_lane = lane
 
     def act(self, channels: int, down: int, layout: str = "nhwc") -> int:
         self.acts.append(Act(len(self.acts), channels, down, layout))
@@ -69,7 +78,8 @@ class Graph:
             down //= 1 << up
         dst = self.act(cout, down, layout)
         self.ops.append(
-            Op("conv", src, dst, a.channels, cout, k, stride, k // 2, conv, bn, bias, relu, res1, res2, up)
+            Op("conv", src, dst, a.channels, cout, k, stride, k // 2, conv, bn, bias, relu, res1, res2, up,
+               self.cur_phase, self.cur_lane)
         )
         return dst
 
@@ -120,13 +130,17 @@ def _hr_module(g: Graph, xs: List[int], prefix: str, blocks: int, n_out: int) ->
     stand-alone add/ReLU kernel exists."""
     nb = len(xs)
     xs = list(xs)
+    g.new_phase()
     for b in range(nb):
+        g.cur_lane = b  # branches are independent until the fuse
         for k in range(blocks):
             xs[b] = _basic_block(g, xs[b], f"{prefix}.branches.{b}.{k}")
     if nb == 1:
         return xs
     outs = []
+    g.new_phase()
     for i in range(n_out):
+        g.cur_lane = i  # each fused output is its own chain
         ci = g.acts[xs[i]].channels
         acc = None  # activation holding the partial sum so far
         j = 0
@@ -178,7 +192,9 @@ def build_hrnet(num_joints: int, hrnet_cfg) -> Graph:
         nb = st.NUM_BRANCHES
         t = f"transition{s + 1}"
         xs = []
+        g.new_phase()
         for i in range(nb):  # hrnet.py:370-413
+            g.cur_lane = i
             if i < len(ys):
                 if g.acts[ys[i]].channels != chans[i]:
                     xs.append(g.conv(ys[i], chans[i], 3, 1, f"{t}.{i}.0", f"{t}.{i}.1", relu=True))
@@ -199,6 +215,7 @@ def build_hrnet(num_joints: int, hrnet_cfg) -> Graph:
             xs = _hr_module(g, xs, f"stage{s + 2}.{m}", nblk[0], 1 if last else nb)
         ys = xs
     k = hrnet_cfg.FINAL_CONV_KERNEL
+    g.new_phase()
     g.output = g.conv(ys[0], num_joints, k, 1, "final_layer", None, bias=True, layout="nchw")
     return g
 
