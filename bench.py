@@ -223,6 +223,18 @@ def main():
         fams = sorted([f for f in fams if f], key=lambda f: -f["seconds_in_kernel_per_step"])
         roof = fams[0]
         roof["other_kernels"] = fams[1:]
+        # HBM bytes per launch of the dominant kernel: PMC counters cannot be read from inside
+        # the process, so this is the committed rocprofv3 measurement of THIS command (separate
+        # --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE x2 gfx950 correction; tools/pmc_summary.py)
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01", "bench_c2_v3_summary.json")) as f:
+                pmc = {r["kernel"]: r for r in json.load(f)["hbm_traffic_per_launch"]}
+            key = "conv_bf3_kernel" if "conv_bf3" in roof["kernel"] else "conv_mfma_kernel"
+            if args.workload == "c2" and key in pmc:
+                roof["traffic"] = pmc[key]["total_bytes"]
+                roof["traffic_source"] = "profiles/r01/bench_c2_v3_summary.json (rocprofv3 --pmc, per launch)"
+        except (OSError, KeyError, ValueError):
+            pass
         allc = bf3 | f32
         roof["all_conv_tflops"] = round(float(flops[allc].sum()) / (float(ms[allc].sum()) * 1e-3) / 1e12, 2)
         roof["all_conv_frac_of_fp32_mfma_peak"] = round(roof["all_conv_tflops"] / PEAK_FP32_MFMA_TFLOPS, 4)
