@@ -19,6 +19,8 @@
 //     [tap][cin/32][cout/16][plane][lane][8 bf16];
 //   * one LDS buffer + register prefetch of the next chunk (two barriers per 32-channel chunk).
 // Used for 3x3 convs with cin % 32 == 0 when the plan selects MVAL_ALGO_MFMA_BF3.
+#include <stdlib.h>
+
 #include "conv_common.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -289,6 +291,23 @@ template <int KS, int S>
 static int dispatch_bf3(const ConvArgs& a, hipStream_t s) {
   int th, tw, tn;
   const int64_t px = (int64_t)a.N * a.Hout * a.Wout;
+  static int cfg = -1;  // MVAL_BF3_CFG: tile-shape experiments (tools/op_profile.py)
+  if (cfg < 0) {
+    const char* e = getenv("MVAL_BF3_CFG");
+    cfg = e ? atoi(e) : 0;
+  }
+  if (cfg == 1 || cfg == 2) {
+    if (a.NS_total <= 2) {  // 128 px x 32 couts, every wave both cout blocks
+      bf3_pick_tile(a.Hout, a.Wout, 128, &th, &tw, &tn);
+      return launch_bf3<KS, S, 1, 4, 2, 2>(a, th, tw, tn, s);
+    }
+    if (cfg == 1) {  // 128 px x 64 couts, 2 cout blocks per wave
+      bf3_pick_tile(a.Hout, a.Wout, 128, &th, &tw, &tn);
+      return launch_bf3<KS, S, 2, 2, 2, 4>(a, th, tw, tn, s);
+    }
+    bf3_pick_tile(a.Hout, a.Wout, 64, &th, &tw, &tn);  // 64 px x 64 couts, 2 cout blocks per wave
+    return launch_bf3<KS, S, 2, 2, 2, 2>(a, th, tw, tn, s);
+  }
   // 4 sub-tiles per wave: 8 would need 220 VGPRs (one wave per SIMD) and measured slower
   if (a.NS_total <= 2) {
     const bool small = px < (int64_t)128 * 1024;
@@ -303,9 +322,21 @@ static int dispatch_bf3(const ConvArgs& a, hipStream_t s) {
 int mval_launch_conv_bf3(const ConvArgs& a, hipStream_t s) {
   if (a.in_nchw || a.Cin % BF_KC != 0 || a.k != 3 || a.pad != 1) return 1;
   if ((int64_t)a.N * a.Hin * a.Win * a.Cin >= (int64_t)1 << 31) return 1;
-  // stride 1 only: the 4x larger stride-2 patches push this kernel to 196 VGPRs / 87 KB LDS and it
-  // measured slower than the exact-fp32 kernel there
   if (a.stride == 1 && a.dil == 1) return dispatch_bf3<3, 1>(a, s);
+  // stride 2: the patch is ~4x larger per output pixel, so 32-pixel tiles (44 KB of LDS planes);
+  // 64-pixel tiles (87 KB, 196 VGPRs) measured slower than the exact-fp32 kernel
+  if (a.stride == 2 && a.dil == 1) {
+    static int s2 = -1;
+    if (s2 < 0) {
+      const char* e = getenv("MVAL_BF3_S2");
+      s2 = e ? atoi(e) : 1;
+    }
+    if (!s2) return 1;
+    int th, tw, tn;
+    bf3_pick_tile(a.Hout, a.Wout, 32, &th, &tw, &tn);
+    if (a.NS_total <= 2) return launch_bf3<3, 2, 2, 2, 1, 1>(a, th, tw, tn, s);
+    return launch_bf3<3, 2, 4, 1, 1, 2>(a, th, tw, tn, s);
+  }
   return 1;
 }
 
