@@ -112,18 +112,26 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     }
 }
 
-// dW[co][ci][t] = sum_ps slab[ps][t][ci][co]
-__global__ void wgrad_reduce_kernel(const float* __restrict__ slabs, int PS, int T, int Cin, int Cout,
-                                    float* __restrict__ dw) {
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+// dW[co][ci][t] = sum_ps slab[ps][t][ci][co]; 64 outputs x 4 split-lanes per workgroup so that the
+// (up to 512) slabs are walked by 4 lanes per output instead of one long dependent chain
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slabs, int PS, int T, int Cin,
+                                                           int Cout, float* __restrict__ dw) {
+  __shared__ double red[256];
   const int64_t n = (int64_t)T * Cin * Cout;
-  if (i >= n) return;
-  const int co = (int)(i % Cout);
-  const int ci = (int)((i / Cout) % Cin);
-  const int t = (int)(i / ((int64_t)Cout * Cin));
+  const int64_t i = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63);
+  const int part = threadIdx.x >> 6;
   double s = 0;
-  for (int p = 0; p < PS; p++) s += (double)slabs[(int64_t)p * n + i];
-  dw[((int64_t)co * Cin + ci) * T + t] = (float)s;
+  if (i < n)
+    for (int p = part; p < PS; p += 4) s += (double)slabs[(int64_t)p * n + i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (part == 0 && i < n) {
+    s = (red[threadIdx.x] + red[threadIdx.x + 64]) + (red[threadIdx.x + 128] + red[threadIdx.x + 192]);
+    const int co = (int)(i % Cout);
+    const int ci = (int)((i / Cout) % Cin);
+    const int t = (int)(i / ((int64_t)Cout * Cin));
+    dw[((int64_t)co * Cin + ci) * T + t] = (float)s;
+  }
 }
 
 // ---- direct wgrad for tiny operators (cin = 3 NCHW stem, odd cout) -----------------------
@@ -250,7 +258,7 @@ extern "C" int mval_conv_wgrad(const float* x, const float* dz, float* dw, float
     hipLaunchKernelGGL(conv_wgrad_direct_kernel, dim3(PS), dim3(256), 0, s, a);
     MVAL_CHECK_LAUNCH("mval_conv_wgrad/direct");
   }
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, s, ws, PS, T, Cin, Cout,
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n_out + 63) / 64)), dim3(256), 0, s, ws, PS, T, Cin, Cout,
                      dw);
   MVAL_CHECK_LAUNCH("mval_conv_wgrad/reduce");
   return 0;

@@ -33,7 +33,12 @@ static void geometry(ConvArgs& a, const mval_op& op, int n_images) {
 }
 
 static int run_conv(const ConvArgs& a, int algo, hipStream_t s, const char* what) {
-  if (algo == MVAL_ALGO_MFMA) {
+  if (algo == MVAL_ALGO_MFMA_BF3) {
+    if (mval_launch_conv_bf3(a, s)) {
+      mval_set_error("%s: no bf16x3 MFMA configuration (k%d cin%d cout%d dil%d)", what, a.k, a.Cin, a.Cout, a.dil);
+      return -1;
+    }
+  } else if (algo == MVAL_ALGO_MFMA) {
     if (mval_launch_conv_mfma(a, s)) {
       mval_set_error("%s: no MFMA configuration (k%d cin%d cout%d dil%d)", what, a.k, a.Cin, a.Cout, a.dil);
       return -1;

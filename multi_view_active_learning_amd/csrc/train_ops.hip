@@ -59,16 +59,21 @@ __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __re
 
 // mean / invstd (biased variance, as normalisation uses) + running-stat update with the
 // unbiased variance (torch: running = (1 - m) * running + m * stat)
-__global__ void bn_stats_finalize_kernel(const double* __restrict__ part, int nblocks, int64_t M, int C, float eps,
-                                         float momentum, float* __restrict__ mean, float* __restrict__ invstd,
-                                         float* __restrict__ running_mean, float* __restrict__ running_var) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+// one 64-lane wave per channel: lanes stride over the per-workgroup partials, wave reduction
+__global__ __launch_bounds__(64) void bn_stats_finalize_kernel(const double* __restrict__ part, int nblocks, int64_t M,
+                                                               int C, float eps, float momentum,
+                                                               float* __restrict__ mean, float* __restrict__ invstd,
+                                                               float* __restrict__ running_mean,
+                                                               float* __restrict__ running_var) {
+  const int c = blockIdx.x;
   double s = 0, ss = 0;
-  for (int b = 0; b < nblocks; b++) {
+  for (int b = threadIdx.x; b < nblocks; b += 64) {
     s += part[((int64_t)b * C + c) * 2];
     ss += part[((int64_t)b * C + c) * 2 + 1];
   }
+  s = wave_sum(s);
+  ss = wave_sum(ss);
+  if (threadIdx.x != 0) return;
   const double mu = s / (double)M;
   double var = ss / (double)M - mu * mu;
   if (var < 0) var = 0;
@@ -92,8 +97,8 @@ extern "C" int mval_bn_batch_stats(const float* z, int64_t M, int C, float eps, 
   size_t sh = (size_t)rows * lanes * 4 * 2 * sizeof(double);
   hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(nb), dim3(256), sh, mval_stream(stream), z, ws, M, C);
   MVAL_CHECK_LAUNCH("mval_bn_batch_stats/partial");
-  hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, mval_stream(stream), ws, nb, M, C, eps,
-                     momentum, mean, invstd, running_mean, running_var);
+  hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(C), dim3(64), 0, mval_stream(stream), ws, nb, M, C, eps, momentum,
+                     mean, invstd, running_mean, running_var);
   MVAL_CHECK_LAUNCH("mval_bn_batch_stats/finalize");
   return 0;
 }
@@ -227,15 +232,18 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
 }
 
 // dbeta / dgamma (float, also kept in `sums` for stage 2)
-__global__ void bn_bwd_finalize_kernel(const double* __restrict__ part, int nblocks, int C, float* __restrict__ dbeta,
-                                       float* __restrict__ dgamma, float* __restrict__ sums) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+__global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(const double* __restrict__ part, int nblocks, int C,
+                                                             float* __restrict__ dbeta, float* __restrict__ dgamma,
+                                                             float* __restrict__ sums) {
+  const int c = blockIdx.x;
   double a = 0, b = 0;
-  for (int k = 0; k < nblocks; k++) {
+  for (int k = threadIdx.x; k < nblocks; k += 64) {
     a += part[((int64_t)k * C + c) * 2];
     b += part[((int64_t)k * C + c) * 2 + 1];
   }
+  a = wave_sum(a);
+  b = wave_sum(b);
+  if (threadIdx.x != 0) return;
   if (dbeta) dbeta[c] = (float)a;
   if (dgamma) dgamma[c] = (float)b;
   if (sums) {
@@ -313,8 +321,7 @@ extern "C" int mval_bn_bwd(const float* gout, const float* out, const float* z, 
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nb), dim3(256), sh, s, gout, out, z, mean, invstd, gres1, gres2, gz, ws,
                      N, H, W, C, up, relu, has_bn);
   MVAL_CHECK_LAUNCH("mval_bn_bwd/reduce");
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, s, ws, nb, C, dbeta,
-                     has_bn ? dgamma : nullptr, sums);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, s, ws, nb, C, dbeta, has_bn ? dgamma : nullptr, sums);
   MVAL_CHECK_LAUNCH("mval_bn_bwd/finalize");
   if (has_bn) {
     int64_t total = M * c4n;

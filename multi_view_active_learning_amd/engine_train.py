@@ -20,7 +20,8 @@ import ctypes as C
 import torch
 
 from . import _lib
-from .engine import ALGO_DIRECT, ALGO_MFMA, PACK_HWIO, PACK_MFMA16, MvalOp, _align, _mfma_ok
+from .engine import (ALGO_DIRECT, ALGO_MFMA, ALGO_MFMA_BF3, PACK_HWIO, PACK_MFMA16, _PACK_OF, MvalOp, _align,
+                     _conv_mode, _mfma_ok)
 
 BN_MOMENTUM = 0.1
 BN_EPS = 1e-5
@@ -100,13 +101,17 @@ class TrainPlan:
             m.hin, m.win, m.hout, m.wout = hin, win, hout, wout
             m.up, m.relu, m.in_nchw, m.out_nchw = op.up, int(op.relu), int(in_nchw), int(out_nchw)
             m.algo = ALGO_DIRECT
+            bf3 = _conv_mode() == "bf3"
             if _mfma_ok(op, in_nchw) and lib.mval_op_mfma_supported(C.byref(m), C.c_int(n)):
                 m.algo = ALGO_MFMA
+                if (bf3 and op.k == 3 and op.cin % 32 == 0
+                        and lib.mval_op_algo_supported(C.byref(m), C.c_int(n), C.c_int(ALGO_MFMA_BF3))):
+                    m.algo = ALGO_MFMA_BF3
             m.in_off = -1 if op.src == g.input else act_off[op.src]
             m.out_off = -1 if op.dst == g.output else act_off[op.dst]
             m.res1_off = -1 if op.res1 is None else act_off[op.res1]
             m.res2_off = -1 if op.res2 is None else act_off[op.res2]
-            fpack = PACK_MFMA16 if m.algo == ALGO_MFMA else PACK_HWIO
+            fpack = _PACK_OF[m.algo]
             nw = int(lib.mval_packed_weight_floats(C.c_int(fpack), C.c_int(op.cout), C.c_int(op.cin), C.c_int(op.k)))
             m.w_off = ptop
             ptop += _align(nw)
@@ -127,7 +132,10 @@ class TrainPlan:
             if t.gin_off >= 0:
                 ok = op.cout % 16 == 0 and op.k in (1, 3) and op.stride in (1, 2) and op.pad == op.k // 2
                 t.dgrad_algo = ALGO_MFMA if ok else ALGO_DIRECT
-                dpack = PACK_MFMA16 if ok else PACK_HWIO
+                # stride-1 3x3 data gradients are plain 3x3 convs with cin' = cout: bf16x3-split kernel
+                if ok and bf3 and op.k == 3 and op.stride == 1 and op.cout % 32 == 0:
+                    t.dgrad_algo = ALGO_MFMA_BF3
+                dpack = _PACK_OF[t.dgrad_algo]
                 # the data-gradient conv has cin' = cout, cout' = cin
                 nd = int(lib.mval_packed_weight_floats(C.c_int(dpack), C.c_int(op.cin), C.c_int(op.cout), C.c_int(op.k)))
                 t.wd_off = ptop
