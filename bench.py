@@ -12,10 +12,11 @@ One step = one pass of the hot path over one batch.  Frames are independent, so 
 frames with NO data-path collective (weak scaling: per-GPU work is fixed).
 
 Prints ONE JSON line on rank 0 with the driver's contract fields plus
-  roofline     dominant kernel family = fused conv on the fp32 matrix cores: algorithmic conv
-               FLOPs of one step / time spent in those launches (hipEvents around every launch
-               on the launch stream, mval_net_forward_timed), against the 157.3 TFLOP/s dense
-               fp32-MFMA peak;
+  roofline     dominant kernel family (by time) = fused 3x3 conv on the matrix cores: algorithmic
+               conv FLOPs of one step / time spent in those launches (hipEvents around every launch
+               on the launch stream, mval_net_forward_timed) against its peak (bf16x3-split kernel:
+               2500 / 6 = 416.7 TFLOP/s; exact-fp32 MFMA kernel: 157.3), the other conv family
+               under "other_kernels", HBM bytes per launch from the committed rocprofv3 PMC passes;
   cpu_baseline the CPU oracle (stock torch fp32 HRNet-W32 + numpy RANSAC-DLT restatement,
                oracle/) timed on the host on a bounded sample of the same workload.
 """
@@ -50,6 +51,12 @@ WORKLOADS = {
     # (64 images) of the unlabeled pool: heat-maps + arg-max + RANSAC-DLT + MPE entropy scoring
     "c4": dict(arch="hrnet_w48", v=8, h=384, w=288, frames=8, j=19, train=False, score="MPE",
                desc="HRNet-W48 8-view 384x288 pool scoring: heat-maps + triangulation + MPE entropy, 8 frames/step"),
+    # BASELINE.json configs[4] shape: core-set selection pass over a FIXED pool sharded across the
+    # ranks (strong scaling): per-rank heat-maps + triangulation, ONE RCCL all_gather of the fp32
+    # 3-D predictions, then the replicated k-center (100 picks against 200 labeled poses)
+    "c5": dict(arch="hrnet_w48", v=8, h=384, w=288, frames=8, j=19, train=False, pool=256, labeled=200, picks=100,
+               desc="HRNet-W48 8-view 384x288 core-set pass: 256-frame pool sharded over ranks, all_gather of "
+                    "3-D predictions, k-center select 100"),
 }
 FLOP_PER_IMAGE["hrnet_w48_384x288"] = 70.615e9
 
@@ -82,10 +89,11 @@ def cpu_baseline(wl, sd_np, seconds_target=20.0):
     valid = np.ones(j, dtype=bool)
     done, t0 = 0, time.perf_counter()
     with torch.no_grad():
-        models.hrnet_forward(sd, imgs[:v], models.HRNET_W32)  # warm-up (page-in, thread pool)
+        arch = models.HRNET_W48 if wl["arch"] == "hrnet_w48" else models.HRNET_W32
+        models.hrnet_forward(sd, imgs[:v], arch)  # warm-up (page-in, thread pool)
         t0 = time.perf_counter()
         while True:
-            hm = models.hrnet_forward(sd, imgs, models.HRNET_W32).numpy().reshape(frames_per_call, v, j, h // 4, w // 4)
+            hm = models.hrnet_forward(sd, imgs, arch).numpy().reshape(frames_per_call, v, j, h // 4, w // 4)
             for b in range(frames_per_call):
                 geometry.triangulation(hm[b], proj[b], 4, valid)
             done += frames_per_call
@@ -95,7 +103,7 @@ def cpu_baseline(wl, sd_np, seconds_target=20.0):
     return dict(
         value=done * v / el, unit="frames*views/s", cores=torch.get_num_threads(), kind="port",
         sample=f"{done} frames x {v} views ({done * v} images) of the same workload, {el:.1f} s, "
-               f"stock torch fp32 HRNet-W32 + numpy RANSAC-DLT (oracle/), {torch.get_num_threads()} threads",
+               f"stock torch fp32 {wl['arch']} + numpy RANSAC-DLT (oracle/), {torch.get_num_threads()} threads",
     )
 
 
@@ -145,6 +153,27 @@ def main():
         gt = torch.rand(frames * v, j, h // 4, w // 4, device=dev)
         pv = torch.ones(frames * v, j, 1, 1, dtype=torch.uint8, device=dev)
 
+    def coreset_pass():
+        """One whole selection pass over the fixed pool (this rank's shard re-uses the resident batch
+        as synthetic content for every local batch)."""
+        from multi_view_active_learning_amd import parallel
+        from multi_view_active_learning_amd.utils.coreset import CoreSet
+
+        lo, hi = parallel.shard_range(wl["pool"], rank, world)
+        preds = []
+        for f0 in range(lo, hi, frames):
+            nb = min(frames, hi - f0)
+            hm = model(images[: nb * v]).reshape(nb, v, j, h // 4, w // 4)
+            preds.append(triangulate_batch(hm, proj[:nb], 4, valid[:nb])["keypoints_3d"].to(torch.float32))
+        local = torch.cat(preds) if preds else torch.zeros((0, j, 3), device=dev)
+        pool = parallel.all_gather_cat(local)  # ONE collective: (pool, J, 3) fp32 over xGMI
+        cs = CoreSet.from_tensors(pool, labeled_pose, 2)
+        picks = cs.select_batch(wl["picks"])
+        return {"keypoints_3d": pool, "picks": picks}
+
+    if wl.get("pool"):
+        labeled_pose = torch.from_numpy(np.random.default_rng(5).standard_normal((wl["labeled"], j, 3)) * 300.0).to(dev)
+
     def step():
         if train:
             opt.zero_grad()
@@ -152,6 +181,8 @@ def main():
             loss.backward()
             opt.step()
             return {"keypoints_3d": loss.detach().reshape(1)}
+        if wl.get("pool"):
+            return coreset_pass()
         hm = model(images).reshape(frames, v, j, h // 4, w // 4)
         r = triangulate_batch(hm, proj, 4, valid)
         if wl.get("score"):
@@ -243,9 +274,12 @@ def main():
 
     if rank == 0:
         total_units = world * frames * v * args.steps
+        if wl.get("pool"):
+            total_units = wl["pool"] * v * args.steps
         out = {
             "metric": ("frames*views/sec (training step) HRNet-W32 4-view 256x256" if train else
                        "frames*views/sec (pool scoring) HRNet-W48 8-view 384x288" if wl.get("score") else
+                       "frames*views/sec (core-set selection pass over a fixed pool) HRNet-W48 8-view 384x288" if wl.get("pool") else
                        "frames*views/sec (heatmap->triangulated 3D) HRNet-W32 4-view 256x256"),
             "value": round(total_units / el, 2),
             "unit": "frames*views/s",
@@ -254,7 +288,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(el / args.steps * 1e3, 3),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if wl.get("pool") else "weak",
             "vs_baseline": None,
             "dtype": "f32" if _conv_mode() == "fp32" else "f32 (3x3 convs: exact 3-way bf16 split on bf16 MFMA, fp32 accumulate)",
             "data": "synthetic (random variance-preserving weights, N(0,1) frames, ring cameras)",

@@ -40,6 +40,91 @@ __device__ __forceinline__ void conv_store(const ConvArgs& a, int n, int y, int 
   }
 }
 
+// Second half of the MFMA kernels' epilogue: the BN'd output tile sits in LDS as
+// ot[pixel][NTILE + 4]; add the residual(s), ReLU and store with float4 lanes along channels.
+// All residual loads of a thread are issued before the first store (MT*NTILE/1024 float4 loads
+// in flight per thread) -- with one load per iteration the memory-bound layers (1x1 convs,
+// 32-channel 3x3) sat at 2.8 TB/s, latency- rather than bandwidth-bound.
+typedef float conv_f32x4 __attribute__((ext_vector_type(4)));
+
+template <int MT, int NTILE>
+__device__ __forceinline__ void conv_tile_store(const ConvArgs& a, const float* ot, int tid, int n0, int oy0, int ox0,
+                                                int cbase) {
+  constexpr int LDW = NTILE + 4;
+  const int Ho = a.Hout << a.up, Wo = a.Wout << a.up, rep = 1 << a.up;
+  if (!a.out_nchw && (a.Cout & 3) == 0) {
+    constexpr int Q = NTILE / 4;
+    constexpr int IT = (MT * Q + 255) / 256;
+    if (a.up == 0) {
+      int64_t off[IT];
+      conv_f32x4 r1[IT], r2[IT];
+#pragma unroll
+      for (int i = 0; i < IT; i++) {
+        const int e = tid + 256 * i;
+        const int p = e / Q, c4 = e % Q;
+        const int c = cbase + c4 * 4;
+        const int tni = p >> a.thw_log2;
+        const int rem = p & ((1 << a.thw_log2) - 1);
+        const int y = oy0 + (rem >> a.tw_log2), x = ox0 + (rem & ((1 << a.tw_log2) - 1));
+        const int n = n0 + tni;
+        const bool ok = e < MT * Q && c < a.Cout && n < a.N && y < a.Hout && x < a.Wout;
+        off[i] = ok ? (((int64_t)n * a.Hout + y) * a.Wout + x) * a.Cout + c : -1;
+        r1[i] = (ok && a.res1) ? *reinterpret_cast<const conv_f32x4*>(a.res1 + off[i]) : (conv_f32x4){0.f, 0.f, 0.f, 0.f};
+        r2[i] = (ok && a.res2) ? *reinterpret_cast<const conv_f32x4*>(a.res2 + off[i]) : (conv_f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int i = 0; i < IT; i++) {
+        if (off[i] < 0) continue;
+        const int e = tid + 256 * i;
+        conv_f32x4 r = *reinterpret_cast<const conv_f32x4*>(ot + (e / Q) * LDW + (e % Q) * 4);
+        if (a.res1) r += r1[i];
+        if (a.res2) r += r2[i];
+        if (a.relu) {
+          r.x = fmaxf(r.x, 0.f); r.y = fmaxf(r.y, 0.f); r.z = fmaxf(r.z, 0.f); r.w = fmaxf(r.w, 0.f);
+        }
+        *reinterpret_cast<conv_f32x4*>(a.out + off[i]) = r;
+      }
+      return;
+    }
+    for (int e = tid; e < MT * Q; e += 256) {  // fused nearest upsample: 2^up x 2^up replicas
+      const int p = e / Q, c4 = e % Q;
+      const int c = cbase + c4 * 4;
+      if (c >= a.Cout) continue;
+      const int tni = p >> a.thw_log2;
+      const int rem = p & ((1 << a.thw_log2) - 1);
+      const int y = oy0 + (rem >> a.tw_log2), x = ox0 + (rem & ((1 << a.tw_log2) - 1));
+      const int n = n0 + tni;
+      if (n >= a.N || y >= a.Hout || x >= a.Wout) continue;
+      const conv_f32x4 v = *reinterpret_cast<const conv_f32x4*>(ot + p * LDW + c4 * 4);
+      for (int dy = 0; dy < rep; dy++)
+        for (int dx = 0; dx < rep; dx++) {
+          const int64_t o = (((int64_t)n * Ho + (y << a.up) + dy) * Wo + (x << a.up) + dx) * a.Cout + c;
+          conv_f32x4 r = v;
+          if (a.res1) r += *reinterpret_cast<const conv_f32x4*>(a.res1 + o);
+          if (a.res2) r += *reinterpret_cast<const conv_f32x4*>(a.res2 + o);
+          if (a.relu) {
+            r.x = fmaxf(r.x, 0.f); r.y = fmaxf(r.y, 0.f); r.z = fmaxf(r.z, 0.f); r.w = fmaxf(r.w, 0.f);
+          }
+          *reinterpret_cast<conv_f32x4*>(a.out + o) = r;
+        }
+    }
+    return;
+  }
+  // scalar path (NCHW heat-map output, odd channel counts): pixel-fastest so that NCHW rows are
+  // written in contiguous runs
+  for (int e = tid; e < MT * NTILE; e += 256) {
+    const int cl = e / MT, p = e % MT;
+    const int c = cbase + cl;
+    if (c >= a.Cout) continue;
+    const int tni = p >> a.thw_log2;
+    const int rem = p & ((1 << a.thw_log2) - 1);
+    const int y = oy0 + (rem >> a.tw_log2), x = ox0 + (rem & ((1 << a.tw_log2) - 1));
+    const int n = n0 + tni;
+    if (n >= a.N || y >= a.Hout || x >= a.Wout) continue;
+    conv_store(a, n, y, x, c, ot[p * LDW + cl]);
+  }
+}
+
 int mval_launch_conv_mfma(const ConvArgs& a, hipStream_t s);  // conv_mfma.hip; returns 1 if unsupported
 int mval_conv_mfma_supported(const ConvArgs& a);            // same selection logic, no launch
 int mval_launch_conv_bf3(const ConvArgs& a, hipStream_t s);   // conv_mfma_bf3.hip; returns 1 if unsupported

@@ -206,45 +206,7 @@ __global__ __launch_bounds__(256) void conv_bf3_kernel(ConvArgs a) {
     }
   }
   __syncthreads();
-  const int cbase = blockIdx.y * NTILE;
-  const int Ho = a.Hout << a.up, Wo = a.Wout << a.up, rep = 1 << a.up;
-  if (!a.out_nchw && (a.Cout & 3) == 0) {
-    constexpr int Q = NTILE / 4;
-    for (int e = tid; e < MT * Q; e += 256) {
-      const int p = e / Q, c4 = e % Q;
-      const int c = cbase + c4 * 4;
-      if (c >= a.Cout) continue;
-      const int tni = p >> a.thw_log2;
-      const int rem = p & ((1 << a.thw_log2) - 1);
-      const int y = oy0 + (rem >> a.tw_log2), x = ox0 + (rem & ((1 << a.tw_log2) - 1));
-      const int n = n0 + tni;
-      if (n >= a.N || y >= a.Hout || x >= a.Wout) continue;
-      const f32x4 v = *reinterpret_cast<const f32x4*>(ot + p * LDW + c4 * 4);
-      for (int dy = 0; dy < rep; dy++)
-        for (int dx = 0; dx < rep; dx++) {
-          const int64_t o = (((int64_t)n * Ho + (y << a.up) + dy) * Wo + (x << a.up) + dx) * a.Cout + c;
-          f32x4 r = v;
-          if (a.res1) r += *reinterpret_cast<const f32x4*>(a.res1 + o);
-          if (a.res2) r += *reinterpret_cast<const f32x4*>(a.res2 + o);
-          if (a.relu) {
-            r.x = fmaxf(r.x, 0.f); r.y = fmaxf(r.y, 0.f); r.z = fmaxf(r.z, 0.f); r.w = fmaxf(r.w, 0.f);
-          }
-          *reinterpret_cast<f32x4*>(a.out + o) = r;
-        }
-    }
-  } else {
-    for (int e = tid; e < MT * NTILE; e += 256) {
-      const int cl = e / MT, p = e % MT;
-      const int c = cbase + cl;
-      if (c >= a.Cout) continue;
-      const int tni = p >> a.thw_log2;
-      const int rem = p & ((1 << a.thw_log2) - 1);
-      const int y = oy0 + (rem >> a.tw_log2), x = ox0 + (rem & ((1 << a.tw_log2) - 1));
-      const int n = n0 + tni;
-      if (n >= a.N || y >= a.Hout || x >= a.Wout) continue;
-      conv_store(a, n, y, x, c, ot[p * LDW + cl]);
-    }
-  }
+  conv_tile_store<MT, NTILE>(a, ot, tid, n0, oy0, ox0, blockIdx.y * NTILE);
 }
 
 static thread_local int g_bf3_dry = 0;
@@ -295,6 +257,10 @@ static int dispatch_bf3(const ConvArgs& a, hipStream_t s) {
   if (cfg < 0) {
     const char* e = getenv("MVAL_BF3_CFG");
     cfg = e ? atoi(e) : 0;
+  }
+  if (cfg == 3 && a.NS_total <= 2) {  // 64-pixel tiles for the 32-cout layers: 29 KB LDS, 5 WGs/CU
+    bf3_pick_tile(a.Hout, a.Wout, 64, &th, &tw, &tn);
+    return launch_bf3<KS, S, 2, 2, 1, 2>(a, th, tw, tn, s);
   }
   if (cfg == 1 || cfg == 2) {
     if (a.NS_total <= 2) {  // 128 px x 32 couts, every wave both cout blocks
