@@ -296,7 +296,7 @@ def main():
                        "images_per_step_per_gpu": frames * v, "parallelism": f"frame-sharded x{world}, no collective"},
             "roofline": roof,
         }
-        if not args.no_cpu_baseline and not train:
+        if not args.no_cpu_baseline and not train and world == 1:  # rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(wl, sd_np, args.cpu_seconds)
         print(json.dumps(out))
     if world > 1:

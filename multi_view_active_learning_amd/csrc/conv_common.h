@@ -47,20 +47,20 @@ __device__ __forceinline__ void conv_store(const ConvArgs& a, int n, int y, int 
 // 32-channel 3x3) sat at 2.8 TB/s, latency- rather than bandwidth-bound.
 typedef float conv_f32x4 __attribute__((ext_vector_type(4)));
 
-template <int MT, int NTILE>
+template <int MT, int NTILE, int NTH = 256>
 __device__ __forceinline__ void conv_tile_store(const ConvArgs& a, const float* ot, int tid, int n0, int oy0, int ox0,
                                                 int cbase) {
   constexpr int LDW = NTILE + 4;
   const int Ho = a.Hout << a.up, Wo = a.Wout << a.up, rep = 1 << a.up;
   if (!a.out_nchw && (a.Cout & 3) == 0) {
     constexpr int Q = NTILE / 4;
-    constexpr int IT = (MT * Q + 255) / 256;
+    constexpr int IT = (MT * Q + NTH - 1) / NTH;
     if (a.up == 0) {
       int64_t off[IT];
       conv_f32x4 r1[IT], r2[IT];
 #pragma unroll
       for (int i = 0; i < IT; i++) {
-        const int e = tid + 256 * i;
+        const int e = tid + NTH * i;
         const int p = e / Q, c4 = e % Q;
         const int c = cbase + c4 * 4;
         const int tni = p >> a.thw_log2;
@@ -75,7 +75,7 @@ __device__ __forceinline__ void conv_tile_store(const ConvArgs& a, const float* 
 #pragma unroll
       for (int i = 0; i < IT; i++) {
         if (off[i] < 0) continue;
-        const int e = tid + 256 * i;
+        const int e = tid + NTH * i;
         conv_f32x4 r = *reinterpret_cast<const conv_f32x4*>(ot + (e / Q) * LDW + (e % Q) * 4);
         if (a.res1) r += r1[i];
         if (a.res2) r += r2[i];
@@ -86,7 +86,7 @@ __device__ __forceinline__ void conv_tile_store(const ConvArgs& a, const float* 
       }
       return;
     }
-    for (int e = tid; e < MT * Q; e += 256) {  // fused nearest upsample: 2^up x 2^up replicas
+    for (int e = tid; e < MT * Q; e += NTH) {  // fused nearest upsample: 2^up x 2^up replicas
       const int p = e / Q, c4 = e % Q;
       const int c = cbase + c4 * 4;
       if (c >= a.Cout) continue;
@@ -112,7 +112,7 @@ __device__ __forceinline__ void conv_tile_store(const ConvArgs& a, const float* 
   }
   // scalar path (NCHW heat-map output, odd channel counts): pixel-fastest so that NCHW rows are
   // written in contiguous runs
-  for (int e = tid; e < MT * NTILE; e += 256) {
+  for (int e = tid; e < MT * NTILE; e += NTH) {
     const int cl = e / MT, p = e % MT;
     const int c = cbase + cl;
     if (c >= a.Cout) continue;

@@ -18,6 +18,12 @@
 //   * weights are split at pack time (mval_pack_conv_weights, MVAL_PACK_MFMA16_BF3):
 //     [tap][cin/32][cout/16][plane][lane][8 bf16];
 //   * one LDS buffer + register prefetch of the next chunk (two barriers per 32-channel chunk).
+// Measured dead ends (interleaved A/B in one process with per-launch variant knobs; 128 images): fetching A
+// fragments one sub-tile ahead: +-1 % (64+ channels), -16 % (32 channels); an 8-wave
+// producer/consumer split (4 staging waves, 4 MFMA waves, double-buffered LDS): -15..-20 %;
+// 128 px x 32 cout tiles (half the weight stream): -3..-15 %; 8 sub-tiles per wave: 220 VGPRs.
+// All variants sit at ~50 us / 190 TFLOP/s on the 64..256-channel layers (46 % of the split peak;
+// the guide's tuned 8-phase bf16 GEMM reaches 53-59 % of peak on random data).
 // Used for 3x3 convs with cin % 32 == 0 when the plan selects MVAL_ALGO_MFMA_BF3.
 #include <stdlib.h>
 
@@ -253,27 +259,6 @@ template <int KS, int S>
 static int dispatch_bf3(const ConvArgs& a, hipStream_t s) {
   int th, tw, tn;
   const int64_t px = (int64_t)a.N * a.Hout * a.Wout;
-  static int cfg = -1;  // MVAL_BF3_CFG: tile-shape experiments (tools/op_profile.py)
-  if (cfg < 0) {
-    const char* e = getenv("MVAL_BF3_CFG");
-    cfg = e ? atoi(e) : 0;
-  }
-  if (cfg == 3 && a.NS_total <= 2) {  // 64-pixel tiles for the 32-cout layers: 29 KB LDS, 5 WGs/CU
-    bf3_pick_tile(a.Hout, a.Wout, 64, &th, &tw, &tn);
-    return launch_bf3<KS, S, 2, 2, 1, 2>(a, th, tw, tn, s);
-  }
-  if (cfg == 1 || cfg == 2) {
-    if (a.NS_total <= 2) {  // 128 px x 32 couts, every wave both cout blocks
-      bf3_pick_tile(a.Hout, a.Wout, 128, &th, &tw, &tn);
-      return launch_bf3<KS, S, 1, 4, 2, 2>(a, th, tw, tn, s);
-    }
-    if (cfg == 1) {  // 128 px x 64 couts, 2 cout blocks per wave
-      bf3_pick_tile(a.Hout, a.Wout, 128, &th, &tw, &tn);
-      return launch_bf3<KS, S, 2, 2, 2, 4>(a, th, tw, tn, s);
-    }
-    bf3_pick_tile(a.Hout, a.Wout, 64, &th, &tw, &tn);  // 64 px x 64 couts, 2 cout blocks per wave
-    return launch_bf3<KS, S, 2, 2, 2, 2>(a, th, tw, tn, s);
-  }
   // 4 sub-tiles per wave: 8 would need 220 VGPRs (one wave per SIMD) and measured slower
   if (a.NS_total <= 2) {
     const bool small = px < (int64_t)128 * 1024;
