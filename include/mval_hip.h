@@ -213,13 +213,14 @@ int mval_bn_batch_stats(const float* z, int64_t M, int C, float eps, float momen
 int mval_bn_apply_fwd(const float* z, const float* mean, const float* invstd, const float* gamma, const float* beta,
                       const float* res1, const float* res2, float* out, int N, int H, int W, int C, int up, int relu,
                       void* stream);
-/* Backward of the above: masks gout by (out > 0) when relu, adds it into gres1/gres2, window-sums
+/* Backward of the above: masks gout by (out > 0) when relu, adds it into gres1/gres2 (stores it
+ * instead where `overwrite` bit 0 / bit 1 is set: the first writer of a gradient slot), window-sums
  * it to the conv resolution, then (has_bn) dgamma/dbeta and dz = gamma*invstd*(g - dbeta/M -
  * xhat*dgamma/M) written to gz; without BN gz is the masked/window-summed gradient and dbeta its
  * per-channel sum (bias gradient).  ws >= 512*C*2 doubles, sums >= 2*C floats. */
 int mval_bn_bwd(const float* gout, const float* out, const float* z, const float* mean, const float* invstd,
                 const float* gamma, float* gres1, float* gres2, float* gz, float* dgamma, float* dbeta, double* ws,
-                float* sums, int N, int H, int W, int C, int up, int relu, int has_bn, void* stream);
+                float* sums, int N, int H, int W, int C, int up, int relu, int has_bn, int overwrite, void* stream);
 /* Weight gradient dw [cout][cin][k][k] of a conv: x NHWC (NCHW when x_nchw), dz NHWC.
  * ws >= mval_conv_wgrad_workspace_floats(cin, cout, k) floats. */
 size_t mval_conv_wgrad_workspace_floats(int cin, int cout, int k);
@@ -243,7 +244,7 @@ typedef struct mval_train_op {
   int64_t z_off;      /* raw conv output at conv resolution (arena); unused when has_bn == 0 */
   int64_t gin_off, gout_off, gres1_off, gres2_off; /* garena; -1 = no gradient needed */
   int64_t wd_off;     /* params: weights packed for the data-gradient conv (-1: none) */
-  int32_t has_bn, dgrad_algo, reserved0, reserved1;
+  int32_t has_bn, dgrad_algo, first_touch, reserved1;
   float* gamma; float* beta; float* running_mean; float* running_var; /* device pointers */
   float* mean; float* invstd;            /* saved batch statistics [cout] */
   float* dweight; float* dgamma; float* dbeta; /* gradient outputs (dbeta = bias grad w/o BN) */

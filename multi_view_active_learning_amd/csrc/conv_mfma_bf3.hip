@@ -21,7 +21,10 @@
 // Measured dead ends (interleaved A/B in one process with per-launch variant knobs; 128 images): fetching A
 // fragments one sub-tile ahead: +-1 % (64+ channels), -16 % (32 channels); an 8-wave
 // producer/consumer split (4 staging waves, 4 MFMA waves, double-buffered LDS): -15..-20 %;
-// 128 px x 32 cout tiles (half the weight stream): -3..-15 %; 8 sub-tiles per wave: 220 VGPRs.
+// 128 px x 32 cout tiles (half the weight stream): -3..-15 %; 8 sub-tiles per wave: 220 VGPRs;
+// persistent workgroups that fetch the next tile's patch during the MFMA loop (32-channel layers):
+// 78 vs 76 us -- those layers are not exposed-latency-bound (dropping the residual read changes
+// 76 -> 74 us) but LDS-read / issue-bound.
 // All variants sit at ~50 us / 190 TFLOP/s on the 64..256-channel layers (46 % of the split peak;
 // the guide's tuned 8-phase bf16 GEMM reaches 53-59 % of peak on random data).
 // Used for 3x3 convs with cin % 32 == 0 when the plan selects MVAL_ALGO_MFMA_BF3.
@@ -50,7 +53,12 @@ __device__ __forceinline__ void split3(const f32x4 v, bf16x4& h, bf16x4& m, bf16
   }
 }
 
-template <int KS, int S, int WN, int WM, int NT, int MS, int NE>
+// RS ("row sharing", 3x3 stride 1, 16-pixel-wide tiles): the wave's MS sub-tiles are consecutive
+// tile rows, so the A fragment of patch row pr at column tap kx serves every (sub-tile ms, row tap
+// ky) with ms + ky == pr.  Looping (kx, pr) instead of (tap, ms) reads (MS + 2) * 3 fragments per
+// chunk instead of MS * 9 -- half the LDS traffic at MS = 4 -- with the three row taps' weights
+// of one column live at a time.
+template <int KS, int S, int WN, int WM, int NT, int MS, int NE, bool RS = false>
 __global__ __launch_bounds__(256) void conv_bf3_kernel(ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   constexpr int MT = 16 * MS * WM;
@@ -141,7 +149,68 @@ __global__ __launch_bounds__(256) void conv_bf3_kernel(ConvArgs a) {
   for (int ch = 0; ch < nchunks; ch++) {
     const bool more = ch + 1 < nchunks;
     if (more) load_chunk((ch + 1) * BF_KC);
-    if (wave_active) {
+    if constexpr (RS) {
+      if (wave_active) {
+        static_assert(!RS || (KS == 3 && S == 1), "row sharing is for 3x3 stride 1");
+        bf16x8 B[3][NT][3], Bn[3][NT][3];
+#pragma unroll
+        for (int ky = 0; ky < 3; ky++)
+#pragma unroll
+          for (int nt = 0; nt < NT; nt++) {
+            const bf16x8* bp = wq + ((int64_t)((ky * 3) * nchunks + ch) * a.NS_total + min(ns0 + nt, a.NS_total - 1)) * 192;
+#pragma unroll
+            for (int p = 0; p < 3; p++) B[ky][nt][p] = bp[p * 64];
+          }
+#pragma unroll
+        for (int kx = 0; kx < 3; kx++) {
+#pragma unroll
+          for (int pr = 0; pr < MS + 2; pr++) {
+            if (kx + 1 < 3) {
+              // next column's weights, each row tap fetched once the registers of the previous
+              // column's same-or-earlier tap are dead
+              const int kyl = pr == 0 ? 0 : pr == MS ? 1 : pr == MS + 1 ? 2 : -1;
+              if (kyl >= 0) {
+#pragma unroll
+                for (int nt = 0; nt < NT; nt++) {
+                  const bf16x8* bp =
+                      wq + ((int64_t)((kyl * 3 + kx + 1) * nchunks + ch) * a.NS_total + min(ns0 + nt, a.NS_total - 1)) * 192;
+#pragma unroll
+                  for (int p = 0; p < 3; p++) Bn[kyl][nt][p] = bp[p * 64];
+                }
+              }
+            }
+            const char* ap = planes + abase[0] + (pr * PW + kx) * (BF_ROW * 2);
+            const bf16x8 ah = *reinterpret_cast<const bf16x8*>(ap);
+            const bf16x8 am = *reinterpret_cast<const bf16x8*>(ap + plane_bytes);
+            const bf16x8 al = *reinterpret_cast<const bf16x8*>(ap + 2 * plane_bytes);
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++) {
+              // the six products in small-to-large order, interleaved over the (up to three)
+              // independent accumulators this fragment feeds
+#pragma unroll
+              for (int t = 0; t < 6; t++) {
+#pragma unroll
+                for (int ky = 0; ky < 3; ky++) {
+                  const int ms = pr - ky;
+                  if (ms < 0 || ms >= MS) continue;
+                  const bf16x8 av = (t == 0) ? al : (t == 2 || t == 3) ? am : ah;
+                  const int bi = (t == 0 || t == 3 || t == 5) ? 0 : (t == 1) ? 2 : 1;
+                  acc[ms][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, B[ky][nt][bi], acc[ms][nt], 0, 0, 0);
+                }
+              }
+            }
+          }
+          if (kx + 1 < 3) {
+#pragma unroll
+            for (int ky = 0; ky < 3; ky++)
+#pragma unroll
+              for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+                for (int p = 0; p < 3; p++) B[ky][nt][p] = Bn[ky][nt][p];
+          }
+        }
+      }
+    } else if (wave_active) {
       // weight fragment blocks: ((tap * G32 + g32) * NS + ns) * 3 planes * 64 lanes (16-byte units)
       bf16x8 bcur[NT][3], bnxt[NT][3];
 #pragma unroll
@@ -217,6 +286,15 @@ __global__ __launch_bounds__(256) void conv_bf3_kernel(ConvArgs a) {
 
 static thread_local int g_bf3_dry = 0;
 
+static int bf3_row_sharing() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("MVAL_BF3_RS");
+    v = e ? atoi(e) : 1;
+  }
+  return v;
+}
+
 template <int KS, int S, int WN, int WM, int NT, int MS>
 static int launch_bf3(ConvArgs a, int th, int tw, int tn, hipStream_t s) {
   a.th = th; a.tw = tw; a.tn = tn;
@@ -236,6 +314,12 @@ static int launch_bf3(ConvArgs a, int th, int tw, int tn, hipStream_t s) {
   if (ne > 10) return 1;
   if (g_bf3_dry) return 0;
   dim3 grid((unsigned)(a.tiles_x * a.tiles_y * ngroups), (unsigned)((a.NS_total + WN * NT - 1) / (WN * NT)));
+  if constexpr (KS == 3 && S == 1) {
+    if (tw == 16 && tn == 1 && ne <= 6 && bf3_row_sharing()) {
+      hipLaunchKernelGGL((conv_bf3_kernel<KS, S, WN, WM, NT, MS, 6, true>), grid, dim3(256), smem, s, a);
+      return 0;
+    }
+  }
   if (ne <= 6)
     hipLaunchKernelGGL((conv_bf3_kernel<KS, S, WN, WM, NT, MS, 6>), grid, dim3(256), smem, s, a);
   else

@@ -80,8 +80,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
       const int n = n0 + tni;
       const int c = co0 + q * 4;
       f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (n < a.N && y < a.Hout && x < a.Wout && c < a.Cout)
-        v = *reinterpret_cast<const f32x4*>(a.dz + (((int64_t)n * a.Hout + y) * a.Wout + x) * a.Cout + c);
+      if (n < a.N && y < a.Hout && x < a.Wout && c < a.Cout) {
+        const float* src = a.dz + (((int64_t)n * a.Hout + y) * a.Wout + x) * a.Cout + c;
+        if ((a.Cout & 3) == 0) {
+          v = *reinterpret_cast<const f32x4*>(src);
+        } else {  // 19-joint final layer: rows are not 16-byte aligned
+#pragma unroll
+          for (int j = 0; j < 4; j++)
+            if (c + j < a.Cout) v[j] = src[j];
+        }
+      }
       *reinterpret_cast<f32x4*>(dzt + p * WG_LD + q * 4) = v;
     }
     __syncthreads();
@@ -134,7 +142,87 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   }
 }
 
-// ---- direct wgrad for tiny operators (cin = 3 NCHW stem, odd cout) -----------------------
+// ---- stem conv1 (3 NCHW input channels, 3x3 stride 2) on the matrix cores ------------------
+// GEMM rows = (cin, tap) = 27 (two 16-row tiles, 5 rows idle), columns = cout (one 16-wide tile
+// per wave), K = output pixels.  The NCHW patch sits in LDS as [ci][PH][PW]; a row's (ci, ky, kx)
+// is a constant offset, the pixel another, so A operands are plain ds_read_b32 gathers.
+#define WS_LDZ 80  // dz tile row stride (floats), 64 cout + 16: == 16 mod 32 banks
+
+template <int MT>
+__global__ __launch_bounds__(256) void conv_wgrad_stem_kernel(WgradArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int PH = a.th * 2 + 1, PW = a.tw * 2 + 1;
+  float* patch = smem;                 // [3][PH][PW]
+  float* dzt = smem + ((3 * PH * PW + 3) & ~3);  // [MT][WS_LDZ]
+  const int co0 = wave * 16;
+  const bool wave_active = co0 < a.Cout;
+  int roff[2];
+  bool rok[2];
+#pragma unroll
+  for (int mt = 0; mt < 2; mt++) {
+    const int i = mt * 16 + (lane & 15);
+    rok[mt] = i < 27;
+    const int ci = i / 9, t = i % 9;
+    roff[mt] = rok[mt] ? (ci * PH + t / 3) * PW + t % 3 : 0;
+  }
+  f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+  const int c4n = a.Cout >> 2;
+  for (int tile = blockIdx.x; tile < a.ntiles; tile += a.PS) {
+    int t = tile;
+    const int txi = t % a.tiles_x;
+    t /= a.tiles_x;
+    const int tyi = t % a.tiles_y;
+    const int n = t / a.tiles_y;
+    const int oy0 = tyi * a.th, ox0 = txi * a.tw;
+    const int iy0 = oy0 * 2 - 1, ix0 = ox0 * 2 - 1;
+    __syncthreads();
+    for (int e = tid; e < 3 * PH * PW; e += 256) {
+      const int pxx = e % PW;
+      const int r = e / PW;
+      const int pyy = r % PH, ci = r / PH;
+      const int iy = iy0 + pyy, ix = ix0 + pxx;
+      patch[e] = (iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win)
+                     ? a.x[(((int64_t)n * 3 + ci) * a.Hin + iy) * a.Win + ix]
+                     : 0.f;
+    }
+    for (int e = tid; e < MT * c4n; e += 256) {
+      const int p = e / c4n, q = e % c4n;
+      const int y = oy0 + (p >> a.tw_log2), x = ox0 + (p & ((1 << a.tw_log2) - 1));
+      f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (y < a.Hout && x < a.Wout)
+        v = *reinterpret_cast<const f32x4*>(a.dz + (((int64_t)n * a.Hout + y) * a.Wout + x) * a.Cout + q * 4);
+      *reinterpret_cast<f32x4*>(dzt + p * WS_LDZ + q * 4) = v;
+    }
+    __syncthreads();
+    if (wave_active) {
+#pragma unroll 4
+      for (int st = 0; st < MT / 4; st++) {
+        const int p = st * 4 + (lane >> 4);
+        const int poff = ((p >> a.tw_log2) * 2) * PW + (p & ((1 << a.tw_log2) - 1)) * 2;
+        const float b = dzt[p * WS_LDZ + co0 + (lane & 15)];
+        const float a0 = rok[0] ? patch[roff[0] + poff] : 0.f;
+        const float a1 = rok[1] ? patch[roff[1] + poff] : 0.f;
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b, acc[1], 0, 0, 0);
+      }
+    }
+  }
+  // slab[ps][t][ci][co]
+  if (wave_active) {
+    const int co = co0 + (lane & 15);
+#pragma unroll
+    for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int i = mt * 16 + (lane >> 4) * 4 + r;
+        if (i < 27 && co < a.Cout)
+          a.slabs[(((int64_t)blockIdx.x * 9 + i % 9) * 3 + i / 9) * a.Cout + co] = acc[mt][r];
+      }
+  }
+}
+
+// ---- direct wgrad for whatever is left (odd shapes; not on the HRNet / PoseResNet hot path) ------
 struct WgradDirectArgs {
   const float* x;
   const float* dz;
@@ -214,10 +302,25 @@ extern "C" int mval_conv_wgrad(const float* x, const float* dz, float* dw, float
   hipStream_t s = mval_stream(stream);
   const int T = k * k;
   const int64_t n_out = (int64_t)T * Cin * Cout;
-  const bool mfma = !x_nchw && (Cin & 3) == 0 && (Cout & 3) == 0 && (k == 1 || k == 3) && (stride == 1 || stride == 2) &&
-                    pad == k / 2 && Cin >= 16;
+  const bool mfma = !x_nchw && (Cin & 3) == 0 && (k == 1 || k == 3) && (stride == 1 || stride == 2) && pad == k / 2 &&
+                    Cin >= 16;
+  const bool stem = x_nchw && Cin == 3 && k == 3 && stride == 2 && pad == 1 && (Cout & 15) == 0 && Cout <= 64;
   int PS;
-  if (mfma) {
+  if (stem) {
+    WgradArgs a;
+    a.x = x; a.dz = dz; a.slabs = ws;
+    a.N = N; a.Hin = Hin; a.Win = Win; a.Cin = Cin; a.Hout = Hout; a.Wout = Wout; a.Cout = Cout; a.pad = pad;
+    a.th = 8; a.tw = 16; a.tn = 1;
+    a.tw_log2 = 4; a.thw_log2 = 7;
+    a.tiles_x = (Wout + 15) / 16;
+    a.tiles_y = (Hout + 7) / 8;
+    a.ntiles = a.tiles_x * a.tiles_y * N;
+    PS = a.ntiles < 512 ? a.ntiles : 512;
+    a.PS = PS;
+    const size_t smem = (size_t)(((3 * 17 * 33 + 3) & ~3) + 128 * WS_LDZ) * sizeof(float);
+    hipLaunchKernelGGL((conv_wgrad_stem_kernel<128>), dim3(PS), dim3(256), smem, s, a);
+    MVAL_CHECK_LAUNCH("mval_conv_wgrad/stem");
+  } else if (mfma) {
     WgradArgs a;
     a.x = x; a.dz = dz; a.slabs = ws;
     a.N = N; a.Hin = Hin; a.Win = Win; a.Cin = Cin; a.Hout = Hout; a.Wout = Wout; a.Cout = Cout; a.pad = pad;

@@ -10,8 +10,10 @@
 //             data gradient = the SAME forward MFMA kernel on tap-flipped, channel-swapped
 //             weights (stride-2 convs read dz as a zero-dilated input), accumulated in place
 //             into the producer's gradient buffer.
-// Activation gradients accumulate into a zero-filled arena, so fan-out (residual skips, HRNet
-// fuse layers, transitions) needs no special casing.
+// Activation gradients accumulate in an arena laid out like the activations; the plan marks the
+// first writer of every slot (mval_train_op.first_touch: bit 0 data gradient, bit 1 / 2 residual
+// gradients), which stores instead of accumulating, so the arena is never zero-filled and fan-out
+// (residual skips, HRNet fuse layers, transitions) needs no special casing.
 #include "conv_common.h"
 
 extern "C" int mval_bn_batch_stats(const float*, int64_t, int, float, float, float*, float*, float*, float*, double*,
@@ -114,14 +116,15 @@ extern "C" int mval_train_backward(const mval_train_op* ops, int n_ops, int n_im
     int rc = mval_bn_bwd(garena + t.gout_off, outp, t.has_bn ? arena + t.z_off : nullptr, t.mean, t.invstd, t.gamma,
                          t.gres1_off >= 0 ? garena + t.gres1_off : nullptr,
                          t.gres2_off >= 0 ? garena + t.gres2_off : nullptr, gz, t.dgamma, t.dbeta, ws, sums, n_images,
-                         op.hout, op.wout, op.cout, op.up, op.relu, t.has_bn, stream);
+                         op.hout, op.wout, op.cout, op.up, op.relu, t.has_bn, t.first_touch >> 1, stream);
     if (rc) return rc;
     const float* x = op.in_off >= 0 ? arena + op.in_off : input_nchw;
     rc = mval_conv_wgrad(x, gz, t.dweight, wsf, n_images, op.hin, op.win, op.cin, op.hout, op.wout, op.cout, op.k,
                          op.stride, op.pad, op.in_nchw, stream);
     if (rc) return rc;
     if (t.gin_off >= 0) {
-      rc = mval_conv_dgrad(gz, params + t.wd_off, params + ones_off, params + zeros_off, garena + t.gin_off, 1, n_images,
+      rc = mval_conv_dgrad(gz, params + t.wd_off, params + ones_off, params + zeros_off, garena + t.gin_off,
+                           !(t.first_touch & 1), n_images,
                            op.hin, op.win, op.cin, op.hout, op.wout, op.cout, op.k, op.stride, op.pad, t.dgrad_algo,
                            stream);
       if (rc) return rc;

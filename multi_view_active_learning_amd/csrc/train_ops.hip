@@ -162,7 +162,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
                                                             const float* __restrict__ invstd, float* __restrict__ gres1,
                                                             float* __restrict__ gres2, float* __restrict__ gz,
                                                             double* __restrict__ part, int N, int H, int W, int C, int up,
-                                                            int relu, int has_bn) {
+                                                            int relu, int has_bn, int overwrite) {
   extern __shared__ double sh[];
   const int c4n = C >> 2;
   const int lanes = min(c4n, 256);
@@ -194,8 +194,14 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
               g.x = ov.x > 0.f ? g.x : 0.f; g.y = ov.y > 0.f ? g.y : 0.f;
               g.z = ov.z > 0.f ? g.z : 0.f; g.w = ov.w > 0.f ? g.w : 0.f;
             }
-            if (gres1) *reinterpret_cast<f32x4*>(gres1 + o) += g;
-            if (gres2) *reinterpret_cast<f32x4*>(gres2 + o) += g;
+            if (gres1) {
+              if (overwrite & 1) *reinterpret_cast<f32x4*>(gres1 + o) = g;
+              else *reinterpret_cast<f32x4*>(gres1 + o) += g;
+            }
+            if (gres2) {
+              if (overwrite & 2) *reinterpret_cast<f32x4*>(gres2 + o) = g;
+              else *reinterpret_cast<f32x4*>(gres2 + o) += g;
+            }
             acc += g;
           }
         *reinterpret_cast<f32x4*>(gz + p * C + q * 4) = acc;
@@ -301,7 +307,7 @@ __global__ __launch_bounds__(256) void bias_bwd_scalar_kernel(const float* __res
 extern "C" int mval_bn_bwd(const float* gout, const float* out, const float* z, const float* mean, const float* invstd,
                            const float* gamma, float* gres1, float* gres2, float* gz, float* dgamma, float* dbeta,
                            double* ws, float* sums, int N, int H, int W, int C, int up, int relu, int has_bn,
-                           void* stream) {
+                           int overwrite, void* stream) {
   MVAL_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && up >= 0, "mval_bn_bwd: bad dims");
   if (C & 3) {
     MVAL_REQUIRE(!has_bn && up == 0 && !gres1 && !gres2, "mval_bn_bwd: odd channel count only for plain conv+bias");
@@ -319,7 +325,7 @@ extern "C" int mval_bn_bwd(const float* gout, const float* out, const float* z, 
   size_t sh = (size_t)rows * lanes * 4 * 2 * sizeof(double);
   hipStream_t s = mval_stream(stream);
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nb), dim3(256), sh, s, gout, out, z, mean, invstd, gres1, gres2, gz, ws,
-                     N, H, W, C, up, relu, has_bn);
+                     N, H, W, C, up, relu, has_bn, overwrite);
   MVAL_CHECK_LAUNCH("mval_bn_bwd/reduce");
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, s, ws, nb, C, dbeta, has_bn ? dgamma : nullptr, sums);
   MVAL_CHECK_LAUNCH("mval_bn_bwd/finalize");

@@ -36,7 +36,7 @@ class MvalTrainOp(C.Structure):
         ("z_off", C.c_int64),
         ("gin_off", C.c_int64), ("gout_off", C.c_int64), ("gres1_off", C.c_int64), ("gres2_off", C.c_int64),
         ("wd_off", C.c_int64),
-        ("has_bn", C.c_int32), ("dgrad_algo", C.c_int32), ("reserved0", C.c_int32), ("reserved1", C.c_int32),
+        ("has_bn", C.c_int32), ("dgrad_algo", C.c_int32), ("first_touch", C.c_int32), ("reserved1", C.c_int32),
         ("gamma", C.c_void_p), ("beta", C.c_void_p), ("running_mean", C.c_void_p), ("running_var", C.c_void_p),
         ("mean", C.c_void_p), ("invstd", C.c_void_p),
         ("dweight", C.c_void_p), ("dgamma", C.c_void_p), ("dbeta", C.c_void_p),
@@ -145,6 +145,19 @@ class TrainPlan:
             stat_top += 2 * _align(op.cout)
             gz_max = max(gz_max, n * hout * wout * op.cout)
             wsf_max = max(wsf_max, int(lib.mval_conv_wgrad_workspace_floats(C.c_int(op.cin), C.c_int(op.cout), C.c_int(op.k))))
+        # first writer of every activation-gradient slot (backward order) stores, later ones accumulate;
+        # slots nobody writes (activations without a consumer) are the only ones zero-filled
+        touched = {g.output}
+        for i in range(len(g.ops) - 1, -1, -1):
+            op, t = g.ops[i], self.ops[i]
+            mask = 0
+            for bit, act in ((2, op.res1), (4, op.res2), (1, None if op.src == g.input else op.src)):
+                if act is not None and act not in touched:
+                    touched.add(act)
+                    mask |= bit
+            t.first_touch = mask
+        self.zero_slots = [(act_off[a], n * dims[a][0] * dims[a][1] * g.acts[a].channels)
+                           for a in act_off if a not in touched]
         self.ones_off = ptop
         ptop += _align(maxc)
         self.zeros_off = ptop
@@ -240,7 +253,8 @@ class TrainPlan:
             t.dweight = gb + 4 * slots["w"]
             t.dgamma = gb + 4 * slots["g"] if "g" in slots else None
             t.dbeta = gb + 4 * (slots["be"] if "be" in slots else slots["b"]) if ("be" in slots or "b" in slots) else None
-        self.garena.zero_()
+        for off, cnt in self.zero_slots:
+            self.garena[off : off + cnt].zero_()
         last = self.ops[len(self.ops) - 1]
         gn = gout_nchw.to(torch.float32).permute(0, 2, 3, 1).contiguous()
         self.garena[last.gout_off : last.gout_off + gn.numel()] = gn.reshape(-1)

@@ -76,11 +76,18 @@ def test_bn_train_ops_vs_torch(dev):
         dg, db = torch.empty(c, device=dev), torch.empty(c, device=dev)
         _lib._check(lib.mval_bn_bwd(p(goutd), p(outd), p(zd), p(mean), p(invstd), p(gd), p(gres[0]) if nres > 0 else p(None),
                                     p(gres[1]) if nres > 1 else p(None), p(gz), p(dg), p(db), p(ws), p(sums), C.c_int(n),
-                                    C.c_int(h), C.c_int(w), C.c_int(c), C.c_int(up), C.c_int(int(relu)), C.c_int(1), st), "bwd")
+                                    C.c_int(h), C.c_int(w), C.c_int(c), C.c_int(up), C.c_int(int(relu)), C.c_int(1), C.c_int(0), st), "bwd")
         np.testing.assert_allclose(gz.permute(0, 3, 1, 2).cpu().numpy(), z.grad.numpy(), rtol=2e-4, atol=2e-5)
         np.testing.assert_allclose(dg.cpu().numpy(), gamma.grad.numpy(), rtol=2e-4, atol=2e-4)
         np.testing.assert_allclose(db.cpu().numpy(), beta.grad.numpy(), rtol=2e-4, atol=2e-4)
         for r, gr in zip(res, gres):
+            np.testing.assert_allclose(gr.permute(0, 3, 1, 2).cpu().numpy(), r.grad.numpy(), rtol=1e-6, atol=1e-6)
+        # first-touch mode: the residual gradients are stored, not accumulated (stale contents ignored)
+        stale = [torch.full_like(r, 7.0) for r in resd]
+        _lib._check(lib.mval_bn_bwd(p(goutd), p(outd), p(zd), p(mean), p(invstd), p(gd), p(stale[0]) if nres > 0 else p(None),
+                                    p(stale[1]) if nres > 1 else p(None), p(gz), p(dg), p(db), p(ws), p(sums), C.c_int(n),
+                                    C.c_int(h), C.c_int(w), C.c_int(c), C.c_int(up), C.c_int(int(relu)), C.c_int(1), C.c_int(3), st), "bwd")
+        for r, gr in zip(res, stale):
             np.testing.assert_allclose(gr.permute(0, 3, 1, 2).cpu().numpy(), r.grad.numpy(), rtol=1e-6, atol=1e-6)
 
 
@@ -114,6 +121,32 @@ def test_conv_wgrad_and_dgrad_vs_torch(dev, case):
     if cout % 16 == 0:
         got = ops.conv_dgrad(dzd, wt.detach().to(dev), (h, w), stride=s)
         assert _rel(got.permute(0, 3, 1, 2).cpu().numpy(), x.grad.numpy()) < 2e-5
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 64, 48), (3, 32, 40, 72), (1, 16, 18, 34)], ids=lambda s: "n%d_co%d_%dx%d" % s)
+def test_conv_wgrad_stem_nchw_vs_torch(dev, shape):
+    """Weight gradient of the stem's first conv (3 NCHW input channels, 3x3 stride 2): MFMA kernel
+    with (cin, tap) rows, including ragged tiles and odd sizes."""
+    import ctypes as C
+
+    from multi_view_active_learning_amd import _lib
+
+    n, cout, h, w = shape
+    rng = np.random.default_rng(3)
+    x = torch.from_numpy(rng.standard_normal((n, 3, h, w)).astype(np.float32))
+    wt = torch.zeros((cout, 3, 3, 3), requires_grad=True)
+    y = F.conv2d(x, wt, None, stride=2, padding=1)
+    dz = torch.from_numpy(rng.standard_normal(y.shape).astype(np.float32))
+    y.backward(dz)
+    ho, wo = y.shape[2:]
+    xd, dzd = x.to(dev), dz.permute(0, 2, 3, 1).contiguous().to(dev)
+    lib, st, p = _lib.lib(), _lib._stream(), _lib._p
+    lib.mval_conv_wgrad_workspace_floats.restype = C.c_size_t
+    ws = torch.empty(int(lib.mval_conv_wgrad_workspace_floats(C.c_int(3), C.c_int(cout), C.c_int(3))) + 64, device=dev)
+    dw = torch.empty((cout, 3, 3, 3), device=dev)
+    _lib._check(lib.mval_conv_wgrad(p(xd), p(dzd), p(dw), p(ws), C.c_int(n), C.c_int(h), C.c_int(w), C.c_int(3), C.c_int(ho),
+                                    C.c_int(wo), C.c_int(cout), C.c_int(3), C.c_int(2), C.c_int(1), C.c_int(1), st), "wgrad")
+    assert _rel(dw.cpu().numpy(), wt.grad.numpy()) < 2e-5
 
 
 def _train_once(c, dev):
