@@ -7,7 +7,8 @@
 // v_mfma_f32_16x16x4_f32 (exact fp32):
 //   * a workgroup owns a (32 cin x 32 cout) block for ALL k*k taps -- 4 waves = 2 cin tiles x
 //     2 cout tiles, each wave keeps k*k accumulator tiles in registers -- and walks a strided
-//     share of the pixel tiles (split-K over workgroups);
+//     share of the pixel tiles (split-K over workgroups); the next tile's operands are fetched
+//     global -> registers during the current tile's MFMA loop;
 //   * per pixel tile the x patch (with halo, 32 cin) and the dz tile (32 cout) are staged in LDS
 //     with row stride 48 floats (== 16 mod 32 banks, so the 4 pixel-quads of a ds_read_b32 do
 //     not collide); a tap is a constant LDS offset into the patch, so each 4-pixel step costs
@@ -31,15 +32,17 @@ struct WgradArgs {
   int th, tw, tn, tw_log2, thw_log2, tiles_x, tiles_y, ntiles, PS;
 };
 
-template <int KS, int S, int MT>
+template <int KS, int S, int MT, int NEX>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int T = KS * KS;
+  constexpr int NEZ = MT * (WG_CB / 4) / 256;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ci_t = wave & 1, co_t = wave >> 1;
   const int ci0 = blockIdx.y * WG_CB, co0 = blockIdx.z * WG_CB;
   const int PH = (a.th - 1) * S + KS, PW = (a.tw - 1) * S + KS;
   const int patch_px = a.tn * PH * PW;
+  const int patch_e = patch_px * (WG_CB / 4);
   float* patch = smem;                    // [patch_px][WG_LD]
   float* dzt = smem + patch_px * WG_LD;   // [MT][WG_LD]
 
@@ -47,53 +50,72 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
 #pragma unroll
   for (int t = 0; t < T; t++) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  for (int tile = blockIdx.x; tile < a.ntiles; tile += a.PS) {
-    int t = tile;
+  // tile-invariant position of every staged element (row << 20 | column << 8 | image)
+  int pkx[NEX], pkz[NEZ];
+#pragma unroll
+  for (int i = 0; i < NEX; i++) {
+    const int e = tid + 256 * i;
+    int r = e >> 3;
+    const int pxx = r % PW;
+    r /= PW;
+    pkx[i] = e < patch_e ? ((r % PH) << 20) | (pxx << 8) | (r / PH) : -1;
+  }
+#pragma unroll
+  for (int i = 0; i < NEZ; i++) {
+    const int p = (tid + 256 * i) >> 3;
+    const int rem = p & ((1 << a.thw_log2) - 1);
+    pkz[i] = ((rem >> a.tw_log2) << 20) | ((rem & ((1 << a.tw_log2) - 1)) << 8) | (p >> a.thw_log2);
+  }
+  const int q4 = (tid & 7) * 4;
+  const bool cx_ok = ci0 + q4 < a.Cin, cz_ok = co0 + q4 < a.Cout;
+
+  // next tile's x patch and dz tile travel global -> registers while the current one is multiplied
+  f32x4 xr[NEX], zr[NEZ];
+  auto load_tile = [&](int t) {
     const int txi = t % a.tiles_x;
     t /= a.tiles_x;
-    const int tyi = t % a.tiles_y;
-    const int n0 = (t / a.tiles_y) * a.tn;
-    const int oy0 = tyi * a.th, ox0 = txi * a.tw;
+    const int oy0 = (t % a.tiles_y) * a.th, ox0 = txi * a.tw, n0 = (t / a.tiles_y) * a.tn;
     const int iy0 = oy0 * S - a.pad, ix0 = ox0 * S - a.pad;
-    __syncthreads();
-    // x patch: 32 cin of this block, zero outside the image / channel range
-    for (int e = tid; e < patch_px * (WG_CB / 4); e += 256) {
-      const int px = e >> 3, q = e & 7;
-      int r = px;
-      const int pxx = r % PW;
-      r /= PW;
-      const int pyy = r % PH;
-      const int tni = r / PH;
-      const int iy = iy0 + pyy, ix = ix0 + pxx, n = n0 + tni;
-      const int c = ci0 + q * 4;
-      f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (n < a.N && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win && c < a.Cin)
-        v = *reinterpret_cast<const f32x4*>(a.x + (((int64_t)n * a.Hin + iy) * a.Win + ix) * a.Cin + c);
-      *reinterpret_cast<f32x4*>(patch + px * WG_LD + q * 4) = v;
+#pragma unroll
+    for (int i = 0; i < NEX; i++) {
+      const int iy = iy0 + (pkx[i] >> 20), ix = ix0 + ((pkx[i] >> 8) & 0xfff), n = n0 + (pkx[i] & 0xff);
+      const bool ok = pkx[i] >= 0 && cx_ok && n < a.N && (unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win;
+      xr[i] = ok ? *reinterpret_cast<const f32x4*>(a.x + (((int64_t)n * a.Hin + iy) * a.Win + ix) * a.Cin + ci0 + q4)
+                 : (f32x4){0.f, 0.f, 0.f, 0.f};
     }
-    // dz tile: 32 cout of this block
-    for (int e = tid; e < MT * (WG_CB / 4); e += 256) {
-      const int p = e >> 3, q = e & 7;
-      const int tni = p >> a.thw_log2;
-      const int rem = p & ((1 << a.thw_log2) - 1);
-      const int y = oy0 + (rem >> a.tw_log2), x = ox0 + (rem & ((1 << a.tw_log2) - 1));
-      const int n = n0 + tni;
-      const int c = co0 + q * 4;
+#pragma unroll
+    for (int i = 0; i < NEZ; i++) {
+      const int y = oy0 + (pkz[i] >> 20), x = ox0 + ((pkz[i] >> 8) & 0xfff), n = n0 + (pkz[i] & 0xff);
       f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (n < a.N && y < a.Hout && x < a.Wout && c < a.Cout) {
-        const float* src = a.dz + (((int64_t)n * a.Hout + y) * a.Wout + x) * a.Cout + c;
+      if (cz_ok && n < a.N && y < a.Hout && x < a.Wout) {
+        const float* src = a.dz + (((int64_t)n * a.Hout + y) * a.Wout + x) * a.Cout + co0 + q4;
         if ((a.Cout & 3) == 0) {
           v = *reinterpret_cast<const f32x4*>(src);
         } else {  // 19-joint final layer: rows are not 16-byte aligned
 #pragma unroll
           for (int j = 0; j < 4; j++)
-            if (c + j < a.Cout) v[j] = src[j];
+            if (co0 + q4 + j < a.Cout) v[j] = src[j];
         }
       }
-      *reinterpret_cast<f32x4*>(dzt + p * WG_LD + q * 4) = v;
+      zr[i] = v;
     }
+  };
+
+  int tile = blockIdx.x;
+  if (tile < a.ntiles) load_tile(tile);
+  for (; tile < a.ntiles; tile += a.PS) {
     __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NEX; i++) {
+      const int e = tid + 256 * i;
+      if (e < patch_e) *reinterpret_cast<f32x4*>(patch + (e >> 3) * WG_LD + q4) = xr[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NEZ; i++) *reinterpret_cast<f32x4*>(dzt + ((tid + 256 * i) >> 3) * WG_LD + q4) = zr[i];
+    __syncthreads();
+    if (tile + a.PS < a.ntiles) load_tile(tile + a.PS);
     // K loop over the tile's pixels, 4 per MFMA (pixel = 4*step + (lane >> 4))
+#pragma unroll 2
     for (int st = 0; st < MT / 4; st++) {
       const int p = st * 4 + (lane >> 4);
       const int tni = p >> a.thw_log2;
@@ -120,21 +142,31 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     }
 }
 
-// dW[co][ci][t] = sum_ps slab[ps][t][ci][co]; 64 outputs x 4 split-lanes per workgroup so that the
-// (up to 512) slabs are walked by 4 lanes per output instead of one long dependent chain
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slabs, int PS, int T, int Cin,
-                                                           int Cout, float* __restrict__ dw) {
-  __shared__ double red[256];
+// dW[co][ci][t] = sum_ps slab[ps][t][ci][co].  A workgroup owns 64 consecutive outputs and walks the
+// slabs with `parts` = blockDim / 64 lanes per output (up to 16, four loads in flight each): the
+// 32-channel layers have only 9216 outputs but 512 slabs, and with 4 lanes per output their
+// reduction was a 128-deep dependent chain on 144 workgroups (45 us for 19 MB).
+__global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restrict__ slabs, int PS, int T, int Cin,
+                                                            int Cout, float* __restrict__ dw) {
+  __shared__ double red[1024];
   const int64_t n = (int64_t)T * Cin * Cout;
   const int64_t i = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63);
-  const int part = threadIdx.x >> 6;
+  const int part = threadIdx.x >> 6, parts = blockDim.x >> 6;
   double s = 0;
-  if (i < n)
-    for (int p = part; p < PS; p += 4) s += (double)slabs[(int64_t)p * n + i];
+  if (i < n) {
+    int p = part;
+    for (; p + 3 * parts < PS; p += 4 * parts) {
+      const float v0 = slabs[(int64_t)p * n + i], v1 = slabs[(int64_t)(p + parts) * n + i];
+      const float v2 = slabs[(int64_t)(p + 2 * parts) * n + i], v3 = slabs[(int64_t)(p + 3 * parts) * n + i];
+      s += ((double)v0 + (double)v1) + ((double)v2 + (double)v3);
+    }
+    for (; p < PS; p += parts) s += (double)slabs[(int64_t)p * n + i];
+  }
   red[threadIdx.x] = s;
   __syncthreads();
   if (part == 0 && i < n) {
-    s = (red[threadIdx.x] + red[threadIdx.x + 64]) + (red[threadIdx.x + 128] + red[threadIdx.x + 192]);
+    s = 0;
+    for (int k = 0; k < parts; k++) s += red[k * 64 + threadIdx.x];
     const int co = (int)(i % Cout);
     const int ci = (int)((i / Cout) % Cin);
     const int t = (int)(i / ((int64_t)Cout * Cin));
@@ -283,16 +315,16 @@ static void wg_pick_tile(int H, int W, int mt, int* th, int* tw, int* tn) {
   *th = h; *tw = w; *tn = n;
 }
 
-static int wg_splits(int cin, int cout) {
+static int wg_splits(int cin, int cout, int target) {
   const int cb = ((cin + WG_CB - 1) / WG_CB) * ((cout + WG_CB - 1) / WG_CB);
-  int ps = 1024 / cb;  // ~1024 workgroups in flight
+  int ps = target / cb;
   if (ps < 1) ps = 1;
   if (ps > 512) ps = 512;
   return ps;
 }
 
 extern "C" size_t mval_conv_wgrad_workspace_floats(int cin, int cout, int k) {
-  return (size_t)wg_splits(cin, cout) * k * k * cin * cout;  // PS slabs of [tap][cin][cout]
+  return (size_t)wg_splits(cin, cout, 1024) * k * k * cin * cout;  // PS slabs of [tap][cin][cout]
 }
 
 // x NHWC (or NCHW when x_nchw), dz NHWC, dw [cout][cin][k][k]; ws >= mval_conv_wgrad_workspace_floats
@@ -331,21 +363,27 @@ extern "C" int mval_conv_wgrad(const float* x, const float* dz, float* dw, float
     a.tiles_x = (Wout + a.tw - 1) / a.tw;
     a.tiles_y = (Hout + a.th - 1) / a.th;
     a.ntiles = a.tiles_x * a.tiles_y * ((N + a.tn - 1) / a.tn);
-    PS = wg_splits(Cin, Cout);
+    // workgroups in flight: 128-pixel tiles hold 59 KB of LDS (2 per CU -> 512 resident: one round and
+    // half the slab traffic of 1024), 64-pixel tiles fit 4 per CU
+    PS = wg_splits(Cin, Cout, mt == 128 ? 512 : 1024);
     if (PS > a.ntiles) PS = a.ntiles;
     a.PS = PS;
     const int PH = (a.th - 1) * stride + k, PW = (a.tw - 1) * stride + k;
     size_t smem = (size_t)(a.tn * PH * PW + mt) * WG_LD * sizeof(float);
     MVAL_REQUIRE(smem <= 128 * 1024, "mval_conv_wgrad: tile does not fit LDS");
     dim3 grid(PS, (Cin + WG_CB - 1) / WG_CB, (Cout + WG_CB - 1) / WG_CB);
-#define WG_LAUNCH(KS_, S_, MT_) \
-  hipLaunchKernelGGL((conv_wgrad_kernel<KS_, S_, MT_>), grid, dim3(256), smem, s, a)
-    if (k == 3 && stride == 1 && mt == 128) WG_LAUNCH(3, 1, 128);
-    else if (k == 3 && stride == 1) WG_LAUNCH(3, 1, 64);
-    else if (k == 3 && stride == 2) WG_LAUNCH(3, 2, 64);
-    else if (k == 1 && stride == 1 && mt == 128) WG_LAUNCH(1, 1, 128);
-    else if (k == 1 && stride == 1) WG_LAUNCH(1, 1, 64);
-    else WG_LAUNCH(1, 2, 64);
+#define WG_LAUNCH(KS_, S_, MT_, NEX_)                                                                      \
+  do {                                                                                                     \
+    MVAL_REQUIRE(a.tn * PH * PW * 8 <= 256 * NEX_, "mval_conv_wgrad: patch of %d pixels exceeds the staging registers", \
+                 a.tn * PH * PW);                                                                          \
+    hipLaunchKernelGGL((conv_wgrad_kernel<KS_, S_, MT_, NEX_>), grid, dim3(256), smem, s, a);              \
+  } while (0)
+    if (k == 3 && stride == 1 && mt == 128) WG_LAUNCH(3, 1, 128, 6);
+    else if (k == 3 && stride == 1) WG_LAUNCH(3, 1, 64, 6);
+    else if (k == 3 && stride == 2) WG_LAUNCH(3, 2, 64, 12);
+    else if (k == 1 && stride == 1 && mt == 128) WG_LAUNCH(1, 1, 128, 4);
+    else if (k == 1 && stride == 1) WG_LAUNCH(1, 1, 64, 2);
+    else WG_LAUNCH(1, 2, 64, 8);
 #undef WG_LAUNCH
     MVAL_CHECK_LAUNCH("mval_conv_wgrad/mfma");
   } else {
@@ -361,8 +399,10 @@ extern "C" int mval_conv_wgrad(const float* x, const float* dz, float* dw, float
     hipLaunchKernelGGL(conv_wgrad_direct_kernel, dim3(PS), dim3(256), 0, s, a);
     MVAL_CHECK_LAUNCH("mval_conv_wgrad/direct");
   }
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n_out + 63) / 64)), dim3(256), 0, s, ws, PS, T, Cin, Cout,
-                     dw);
+  int parts = PS / 8;  // >= 8 slabs per lane
+  parts = parts < 1 ? 1 : parts > 16 ? 16 : parts;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n_out + 63) / 64)), dim3(64 * parts), 0, s, ws, PS, T, Cin,
+                     Cout, dw);
   MVAL_CHECK_LAUNCH("mval_conv_wgrad/reduce");
   return 0;
 }

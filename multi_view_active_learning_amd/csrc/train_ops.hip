@@ -10,6 +10,8 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define TR_BLOCKS 512
+#define TR_UNROLL 8
+#define TR_EW 4  // pixels per thread and pass in the backward reduction
 
 // ---- batch statistics -----------------------------------------------------------------
 // partial[block][c][2] = (sum, sum of squares) over the block's pixel slice
@@ -24,13 +26,21 @@ __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __re
     const int q = cb + col;
     double s[4] = {0, 0, 0, 0}, ss[4] = {0, 0, 0, 0};
     if (q < c4n && row < rows) {
-      for (int64_t p = (int64_t)blockIdx.x * rows + row; p < M; p += (int64_t)gridDim.x * rows) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(z + p * C + q * 4);
+      // TR_UNROLL independent 16-byte loads in flight per thread: 512 workgroups x 256 threads with
+      // one load each keep only 2 MB in flight, far below what HBM needs to stream
+      const int64_t G = (int64_t)gridDim.x * rows;
+      for (int64_t p = (int64_t)blockIdx.x * rows + row; p < M; p += TR_UNROLL * G) {
+        f32x4 v[TR_UNROLL];
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-          s[k] += (double)v[k];
-          ss[k] += (double)v[k] * (double)v[k];
-        }
+        for (int u = 0; u < TR_UNROLL; u++)
+          v[u] = p + u * G < M ? *reinterpret_cast<const f32x4*>(z + (p + u * G) * C + q * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < TR_UNROLL; u++)
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            s[k] += (double)v[u][k];
+            ss[k] += (double)v[u][k] * (double)v[u][k];
+          }
       }
     }
     // fold the rows of this block through LDS
@@ -180,37 +190,77 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
         mu = *reinterpret_cast<const f32x4*>(mean + q * 4);
         is = *reinterpret_cast<const f32x4*>(invstd + q * 4);
       }
-      for (int64_t p = (int64_t)blockIdx.x * rows + row; p < M; p += (int64_t)gridDim.x * rows) {
-        const int x = (int)(p % W);
-        const int y = (int)((p / W) % H);
-        const int n = (int)(p / ((int64_t)W * H));
-        f32x4 acc = (f32x4){0, 0, 0, 0};
-        for (int dy = 0; dy < rep; dy++)
-          for (int dx = 0; dx < rep; dx++) {
-            const int64_t o = (((int64_t)n * Ho + (y << up) + dy) * Wo + (x << up) + dx) * C + q * 4;
-            f32x4 g = *reinterpret_cast<const f32x4*>(gout + o);
-            if (relu) {
-              const f32x4 ov = *reinterpret_cast<const f32x4*>(out + o);
-              g.x = ov.x > 0.f ? g.x : 0.f; g.y = ov.y > 0.f ? g.y : 0.f;
-              g.z = ov.z > 0.f ? g.z : 0.f; g.w = ov.w > 0.f ? g.w : 0.f;
-            }
-            if (gres1) {
-              if (overwrite & 1) *reinterpret_cast<f32x4*>(gres1 + o) = g;
-              else *reinterpret_cast<f32x4*>(gres1 + o) += g;
-            }
-            if (gres2) {
-              if (overwrite & 2) *reinterpret_cast<f32x4*>(gres2 + o) = g;
-              else *reinterpret_cast<f32x4*>(gres2 + o) += g;
-            }
-            acc += g;
-          }
-        *reinterpret_cast<f32x4*>(gz + p * C + q * 4) = acc;
-        f32x4 xh = (f32x4){0, 0, 0, 0};
-        if (has_bn) xh = (*reinterpret_cast<const f32x4*>(z + p * C + q * 4) - mu) * is;
+      const int G = gridDim.x * rows;
+      if (up == 0) {
+        // plain stream: TR_EW pixels per pass, every load issued before the first use
+        for (int p0 = blockIdx.x * rows + row; p0 < (int)M; p0 += TR_EW * G) {
+          f32x4 g[TR_EW], ov[TR_EW], zv[TR_EW], a1[TR_EW], a2[TR_EW];
+          const f32x4 zero = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-          sb[k] += (double)acc[k];
-          sg[k] += (double)acc[k] * (double)xh[k];
+          for (int u = 0; u < TR_EW; u++) {
+            const int p = p0 + u * G;
+            const bool ok = p < (int)M;
+            const int64_t o = (int64_t)p * C + q * 4;
+            g[u] = ok ? *reinterpret_cast<const f32x4*>(gout + o) : zero;
+            ov[u] = (ok && relu) ? *reinterpret_cast<const f32x4*>(out + o) : zero;
+            zv[u] = (ok && has_bn) ? *reinterpret_cast<const f32x4*>(z + o) : zero;
+            a1[u] = (ok && gres1 && !(overwrite & 1)) ? *reinterpret_cast<const f32x4*>(gres1 + o) : zero;
+            a2[u] = (ok && gres2 && !(overwrite & 2)) ? *reinterpret_cast<const f32x4*>(gres2 + o) : zero;
+          }
+#pragma unroll
+          for (int u = 0; u < TR_EW; u++) {
+            const int p = p0 + u * G;
+            if (p >= (int)M) break;
+            const int64_t o = (int64_t)p * C + q * 4;
+            f32x4 gv = g[u];
+            if (relu) {
+              gv.x = ov[u].x > 0.f ? gv.x : 0.f; gv.y = ov[u].y > 0.f ? gv.y : 0.f;
+              gv.z = ov[u].z > 0.f ? gv.z : 0.f; gv.w = ov[u].w > 0.f ? gv.w : 0.f;
+            }
+            if (gres1) *reinterpret_cast<f32x4*>(gres1 + o) = a1[u] + gv;
+            if (gres2) *reinterpret_cast<f32x4*>(gres2 + o) = a2[u] + gv;
+            *reinterpret_cast<f32x4*>(gz + o) = gv;
+            const f32x4 xh = has_bn ? (zv[u] - mu) * is : zero;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+              sb[k] += (double)gv[k];
+              sg[k] += (double)gv[k] * (double)xh[k];
+            }
+          }
+        }
+      } else {
+        for (int p = blockIdx.x * rows + row; p < (int)M; p += G) {
+          const int x = p % W;
+          const int y = (p / W) % H;
+          const int n = p / (W * H);
+          f32x4 acc = (f32x4){0, 0, 0, 0};
+          for (int dy = 0; dy < rep; dy++)
+            for (int dx = 0; dx < rep; dx++) {
+              const int64_t o = (((int64_t)n * Ho + (y << up) + dy) * Wo + (x << up) + dx) * C + q * 4;
+              f32x4 g = *reinterpret_cast<const f32x4*>(gout + o);
+              if (relu) {
+                const f32x4 ov = *reinterpret_cast<const f32x4*>(out + o);
+                g.x = ov.x > 0.f ? g.x : 0.f; g.y = ov.y > 0.f ? g.y : 0.f;
+                g.z = ov.z > 0.f ? g.z : 0.f; g.w = ov.w > 0.f ? g.w : 0.f;
+              }
+              if (gres1) {
+                if (overwrite & 1) *reinterpret_cast<f32x4*>(gres1 + o) = g;
+                else *reinterpret_cast<f32x4*>(gres1 + o) += g;
+              }
+              if (gres2) {
+                if (overwrite & 2) *reinterpret_cast<f32x4*>(gres2 + o) = g;
+                else *reinterpret_cast<f32x4*>(gres2 + o) += g;
+              }
+              acc += g;
+            }
+          *reinterpret_cast<f32x4*>(gz + (int64_t)p * C + q * 4) = acc;
+          f32x4 xh = (f32x4){0, 0, 0, 0};
+          if (has_bn) xh = (*reinterpret_cast<const f32x4*>(z + (int64_t)p * C + q * 4) - mu) * is;
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            sb[k] += (double)acc[k];
+            sg[k] += (double)acc[k] * (double)xh[k];
+          }
         }
       }
     }
@@ -309,6 +359,8 @@ extern "C" int mval_bn_bwd(const float* gout, const float* out, const float* z, 
                            double* ws, float* sums, int N, int H, int W, int C, int up, int relu, int has_bn,
                            int overwrite, void* stream) {
   MVAL_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && up >= 0, "mval_bn_bwd: bad dims");
+  MVAL_REQUIRE((int64_t)N * (H << up) * (W << up) * C < ((int64_t)1 << 33), "mval_bn_bwd: more than 2^31 float4 elements");
+  MVAL_REQUIRE(!gres1 || gres1 != gres2, "mval_bn_bwd: the two residual gradients must be distinct buffers");
   if (C & 3) {
     MVAL_REQUIRE(!has_bn && up == 0 && !gres1 && !gres2, "mval_bn_bwd: odd channel count only for plain conv+bias");
     hipLaunchKernelGGL(bias_bwd_scalar_kernel, dim3(C), dim3(256), 0, mval_stream(stream), gout, out, gz, dbeta,
