@@ -59,7 +59,8 @@ __device__ __forceinline__ void split3(const f32x4 v, bf16x4& h, bf16x4& m, bf16
 // chunk instead of MS * 9 -- half the LDS traffic at MS = 4 -- with the three row taps' weights
 // of one column live at a time.
 template <int KS, int S, int WN, int WM, int NT, int MS, int NE, bool RS = false>
-__global__ __launch_bounds__(256) void conv_bf3_kernel(ConvArgs a) {
+__global__ __launch_bounds__(64 * WN * WM) void conv_bf3_kernel(ConvArgs a) {
+  constexpr int NTH = 64 * WN * WM;  // 256 threads, or 192 for the 48-channel-granular (HRNet-W48) tiles
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   constexpr int MT = 16 * MS * WM;
   constexpr int NTILE = 16 * NT * WN;
@@ -98,7 +99,7 @@ __global__ __launch_bounds__(256) void conv_bf3_kernel(ConvArgs a) {
   int goff[NE];
 #pragma unroll
   for (int i = 0; i < NE; i++) {
-    const int e = tid + 256 * i;
+    const int e = tid + NTH * i;
     const int px = e >> 3, q = e & 7;
     int r = px;
     const int pxx = r % PW;
@@ -119,18 +120,20 @@ __global__ __launch_bounds__(256) void conv_bf3_kernel(ConvArgs a) {
     for (int nt = 0; nt < NT; nt++) acc[ms][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const bf16x8* wq = reinterpret_cast<const bf16x8*>(a.w) + lane;
-  const int nchunks = a.Cin / BF_KC;
+  const int nchunks = (a.Cin + BF_KC - 1) / BF_KC;  // the last chunk may be half empty (cin = 48)
+  const int q4 = (tid & 7) * 4;                     // NTH % 8 == 0: a thread always stages the same channel quad
   f32x4 stage[NE];
 
   auto load_chunk = [&](int c0) {
 #pragma unroll
     for (int i = 0; i < NE; i++)
-      stage[i] = goff[i] >= 0 ? *reinterpret_cast<const f32x4*>(a.in + goff[i] + c0) : (f32x4){0.f, 0.f, 0.f, 0.f};
+      stage[i] = (goff[i] >= 0 && c0 + q4 < a.Cin) ? *reinterpret_cast<const f32x4*>(a.in + goff[i] + c0)
+                                                   : (f32x4){0.f, 0.f, 0.f, 0.f};
   };
   auto store_chunk = [&]() {
 #pragma unroll
     for (int i = 0; i < NE; i++) {
-      const int e = tid + 256 * i;
+      const int e = tid + NTH * i;
       if (e < patch_e) {
         bf16x4 h, m, l;
         split3(stage[i], h, m, l);
@@ -281,7 +284,7 @@ __global__ __launch_bounds__(256) void conv_bf3_kernel(ConvArgs a) {
     }
   }
   __syncthreads();
-  conv_tile_store<MT, NTILE>(a, ot, tid, n0, oy0, ox0, blockIdx.y * NTILE);
+  conv_tile_store<MT, NTILE, NTH>(a, ot, tid, n0, oy0, ox0, blockIdx.y * NTILE);
 }
 
 static thread_local int g_bf3_dry = 0;
@@ -310,20 +313,21 @@ static int launch_bf3(ConvArgs a, int th, int tw, int tn, hipStream_t s) {
   const size_t otile = (size_t)MT * (NTILE + OPAD) * sizeof(float);
   if (otile > smem) smem = otile;
   if (smem > 128 * 1024) return 1;
-  const int ne = (patch_px * 8 + 255) / 256;
+  constexpr int NTH = 64 * WN * WM;
+  const int ne = (patch_px * 8 + NTH - 1) / NTH;
   if (ne > 10) return 1;
   if (g_bf3_dry) return 0;
   dim3 grid((unsigned)(a.tiles_x * a.tiles_y * ngroups), (unsigned)((a.NS_total + WN * NT - 1) / (WN * NT)));
   if constexpr (KS == 3 && S == 1) {
     if (tw == 16 && tn == 1 && ne <= 6 && bf3_row_sharing()) {
-      hipLaunchKernelGGL((conv_bf3_kernel<KS, S, WN, WM, NT, MS, 6, true>), grid, dim3(256), smem, s, a);
+      hipLaunchKernelGGL((conv_bf3_kernel<KS, S, WN, WM, NT, MS, 6, true>), grid, dim3(NTH), smem, s, a);
       return 0;
     }
   }
   if (ne <= 6)
-    hipLaunchKernelGGL((conv_bf3_kernel<KS, S, WN, WM, NT, MS, 6>), grid, dim3(256), smem, s, a);
+    hipLaunchKernelGGL((conv_bf3_kernel<KS, S, WN, WM, NT, MS, 6>), grid, dim3(NTH), smem, s, a);
   else
-    hipLaunchKernelGGL((conv_bf3_kernel<KS, S, WN, WM, NT, MS, 10>), grid, dim3(256), smem, s, a);
+    hipLaunchKernelGGL((conv_bf3_kernel<KS, S, WN, WM, NT, MS, 10>), grid, dim3(NTH), smem, s, a);
   return 0;
 }
 
@@ -351,11 +355,14 @@ static int dispatch_bf3(const ConvArgs& a, hipStream_t s) {
     return launch_bf3<KS, S, 2, 2, 1, 4>(a, th, tw, tn, s);
   }
   bf3_pick_tile(a.Hout, a.Wout, 64, &th, &tw, &tn);
+  // 48 / 96 output channels (3 / 6 sub-tiles): three cout waves per workgroup, no idle wave
+  if (a.NS_total % 3 == 0 && a.NS_total % 4 != 0) return launch_bf3<KS, S, 3, 1, 1, 4>(a, th, tw, tn, s);
   return launch_bf3<KS, S, 4, 1, 1, 4>(a, th, tw, tn, s);
 }
 
 int mval_launch_conv_bf3(const ConvArgs& a, hipStream_t s) {
-  if (a.in_nchw || a.Cin % BF_KC != 0 || a.k != 3 || a.pad != 1) return 1;
+  // cin a multiple of 32, or 48 (HRNet-W48's first branch: second chunk half empty, 25 % padding)
+  if (a.in_nchw || (a.Cin % BF_KC != 0 && a.Cin != 48) || a.k != 3 || a.pad != 1) return 1;
   if ((int64_t)a.N * a.Hin * a.Win * a.Cin >= (int64_t)1 << 31) return 1;
   if (a.stride == 1 && a.dil == 1) return dispatch_bf3<3, 1>(a, s);
   // stride 2: the patch is ~4x larger per output pixel, so 32-pixel tiles (44 KB of LDS planes);
