@@ -27,7 +27,7 @@
 // 76 -> 74 us) but LDS-read / issue-bound.
 // All variants sit at ~50 us / 190 TFLOP/s on the 64..256-channel layers (46 % of the split peak;
 // the guide's tuned 8-phase bf16 GEMM reaches 53-59 % of peak on random data).
-// Used for 3x3 convs with cin % 32 == 0 when the plan selects MVAL_ALGO_MFMA_BF3.
+// Used for 3x3 convs with cin % 32 == 0 (or cin = 48) when the plan selects MVAL_ALGO_MFMA_BF3.
 #include <stdlib.h>
 
 #include "conv_common.h"
@@ -377,6 +377,7 @@ int mval_launch_conv_bf3(const ConvArgs& a, hipStream_t s) {
     int th, tw, tn;
     bf3_pick_tile(a.Hout, a.Wout, 32, &th, &tw, &tn);
     if (a.NS_total <= 2) return launch_bf3<3, 2, 2, 2, 1, 1>(a, th, tw, tn, s);
+    if (a.NS_total % 3 == 0 && a.NS_total % 4 != 0) return launch_bf3<3, 2, 3, 1, 1, 2>(a, th, tw, tn, s);
     return launch_bf3<3, 2, 4, 1, 1, 2>(a, th, tw, tn, s);
   }
   return 1;
