@@ -25,6 +25,13 @@
 // persistent workgroups that fetch the next tile's patch during the MFMA loop (32-channel layers):
 // 78 vs 76 us -- those layers are not exposed-latency-bound (dropping the residual read changes
 // 76 -> 74 us) but LDS-read / issue-bound.
+// a pixel-major LDS layout [pixel][h|m|l|pad] (one address register + immediate offsets per fragment
+// triple, 28 % less LDS): the compiler then sinks the weight prefetch loads next to their uses
+// (vmcnt(0..1) waits inside the MFMA loop, 50 -> 66 us at 128 channels) and neither
+// sched_barrier masks nor an SGPR-pinned block address bring the early issue back.  Instruction
+// mix of the chunk loop (ISA): ~0.9 vector instructions per MFMA, i.e. under the 2-per-MFMA issue
+// budget; LDS fragment reads are conflict-free for the hardware's b128 lane groups on 16-wide
+// stride-1 tiles (2-way on 8-wide and stride-2 tiles, <= 3 ms of launches together).
 // All variants sit at ~50 us / 190 TFLOP/s on the 64..256-channel layers (46 % of the split peak;
 // the guide's tuned 8-phase bf16 GEMM reaches 53-59 % of peak on random data).
 // Used for 3x3 convs with cin % 32 == 0 (or cin = 48) when the plan selects MVAL_ALGO_MFMA_BF3.
@@ -362,8 +369,14 @@ static int dispatch_bf3(const ConvArgs& a, hipStream_t s) {
 
 int mval_launch_conv_bf3(const ConvArgs& a, hipStream_t s) {
   // cin a multiple of 32, or 48 (HRNet-W48's first branch: second chunk half empty, 25 % padding)
-  if (a.in_nchw || (a.Cin % BF_KC != 0 && a.Cin != 48) || a.k != 3 || a.pad != 1) return 1;
+  if (a.in_nchw || (a.Cin % BF_KC != 0 && a.Cin != 48)) return 1;
   if ((int64_t)a.N * a.Hin * a.Win * a.Cin >= (int64_t)1 << 31) return 1;
+  // 1x1 channel GEMMs (bottleneck blocks, fuse up-paths): at the fp32-MFMA rate they are as
+  // MFMA-bound as HBM-bound; here only HBM is left (202 vs 242 us for 256->64 on 128 64x64 maps, 3.3 TB/s;
+  // keeping two chunks in flight instead of one measured slower, 226 us)
+  if (a.k == 1 && a.pad == 0 && a.stride == 1 && a.dil == 1 && !a.out_nchw && (a.Cout & 15) == 0)
+    return dispatch_bf3<1, 1>(a, s);
+  if (a.k != 3 || a.pad != 1) return 1;
   if (a.stride == 1 && a.dil == 1) return dispatch_bf3<3, 1>(a, s);
   // stride 2: the patch is ~4x larger per output pixel, so 32-pixel tiles (44 KB of LDS planes);
   // 64-pixel tiles (87 KB, 196 VGPRs) measured slower than the exact-fp32 kernel

@@ -150,7 +150,7 @@ class InferencePlan:
             if _mfma_ok(op, in_nchw) and lib.mval_op_mfma_supported(C.byref(m), C.c_int(n)):
                 m.algo = ALGO_MFMA
                 # 3x3 convs: fp32-accurate bf16x3 split on the bf16 matrix cores (2.67x MFMA rate)
-                if (_conv_mode() == "bf3" and op.k == 3 and (op.cin % 32 == 0 or op.cin == 48)
+                if (_conv_mode() == "bf3" and op.k in (1, 3) and (op.cin % 32 == 0 or op.cin == 48)
                         and lib.mval_op_algo_supported(C.byref(m), C.c_int(n), C.c_int(ALGO_MFMA_BF3))):
                     m.algo = ALGO_MFMA_BF3
             m.in_off = -1 if op.src == g.input else offset[op.src]

@@ -104,7 +104,7 @@ class TrainPlan:
             bf3 = _conv_mode() == "bf3"
             if _mfma_ok(op, in_nchw) and lib.mval_op_mfma_supported(C.byref(m), C.c_int(n)):
                 m.algo = ALGO_MFMA
-                if (bf3 and op.k == 3 and (op.cin % 32 == 0 or op.cin == 48)
+                if (bf3 and op.k in (1, 3) and (op.cin % 32 == 0 or op.cin == 48)
                         and lib.mval_op_algo_supported(C.byref(m), C.c_int(n), C.c_int(ALGO_MFMA_BF3))):
                     m.algo = ALGO_MFMA_BF3
             m.in_off = -1 if op.src == g.input else act_off[op.src]
@@ -132,8 +132,8 @@ class TrainPlan:
             if t.gin_off >= 0:
                 ok = op.cout % 16 == 0 and op.k in (1, 3) and op.stride in (1, 2) and op.pad == op.k // 2
                 t.dgrad_algo = ALGO_MFMA if ok else ALGO_DIRECT
-                # stride-1 3x3 data gradients are plain 3x3 convs with cin' = cout: bf16x3-split kernel
-                if ok and bf3 and op.k == 3 and op.stride == 1 and (op.cout % 32 == 0 or op.cout == 48):
+                # stride-1 data gradients are plain convs with cin' = cout: bf16x3-split kernel
+                if ok and bf3 and op.stride == 1 and (op.cout % 32 == 0 or op.cout == 48) and (op.k == 3 or op.cin % 16 == 0):
                     t.dgrad_algo = ALGO_MFMA_BF3
                 dpack = _PACK_OF[t.dgrad_algo]
                 # the data-gradient conv has cin' = cout, cout' = cin

@@ -76,8 +76,8 @@ def test_fused_conv_vs_torch_cpu(dev, algo, case):
     from multi_view_active_learning_amd import ops
 
     n, cin, cout, h, w, k, stride, relu, r1, r2, up, out_nchw = case
-    if algo == "bf3" and (k != 3 or (cin % 32 and cin != 48)):
-        pytest.skip("the bf16x3-split kernel covers 3x3 convs with cin % 32 == 0 (or 48)")
+    if algo == "bf3" and ((cin % 32 and cin != 48) or (k == 1 and (stride != 1 or cout % 16 or out_nchw))):
+        pytest.skip("the bf16x3-split kernel covers 3x3 and stride-1 1x1 convs with cin % 32 == 0 (or 48)")
     rng = np.random.default_rng(hash(case) % 2**31)
     x = torch.from_numpy(rng.standard_normal((n, cin, h, w)).astype(np.float32))
     wt = torch.from_numpy((rng.standard_normal((cout, cin, k, k)) * np.sqrt(2.0 / (cin * k * k))).astype(np.float32))
