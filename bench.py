@@ -12,11 +12,14 @@ One step = one pass of the hot path over one batch.  Frames are independent, so 
 frames with NO data-path collective (weak scaling: per-GPU work is fixed).
 
 Prints ONE JSON line on rank 0 with the driver's contract fields plus
-  roofline     dominant kernel family (by time) = fused 3x3 conv on the matrix cores: algorithmic
-               conv FLOPs of one step / time spent in those launches (hipEvents around every launch
-               on the launch stream, mval_net_forward_timed) against its peak (bf16x3-split kernel:
-               2500 / 6 = 416.7 TFLOP/s; exact-fp32 MFMA kernel: 157.3), the other conv family
-               under "other_kernels", HBM bytes per launch from the committed rocprofv3 PMC passes;
+  roofline     dominant kernel (by time) = the fused 3x3 stride-1 conv on the matrix cores
+               (conv_bf3_kernel<3, 1, ...>): algorithmic conv FLOPs of its launches in one step / time
+               spent in them (hipEvents around every launch on the launch stream,
+               mval_net_forward_timed) against its peak (bf16x3-split: 2500 / 6 = 416.7 TFLOP/s);
+               the other kernels of the step under "other_kernels", each against its own bound
+               (stride-2 split conv and exact-fp32 MFMA conv: matrix-core peaks; 1x1 channel GEMMs
+               and the stem: algorithmic bytes / time against HBM); HBM bytes per launch from the
+               committed rocprofv3 PMC passes;
   cpu_baseline the CPU oracle (stock torch fp32 HRNet-W32 + numpy RANSAC-DLT restatement,
                oracle/) timed on the host on a bounded sample of the same workload.
 """
@@ -36,6 +39,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, dense fp32-input MFMA
+PEAK_HBM_GBPS = 8000.0  # same guide: HBM3E
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # same guide: dense bf16 MFMA (the 5 PF headline includes 2:1 sparsity)
 FLOP_PER_IMAGE = {"hrnet_w32_256": 20.387e9}  # conv FLOPs (2*MAC) per frame x view
 
@@ -241,15 +245,41 @@ def main():
                         launches_per_step=n, avg_launch_us=round(t / n * 1e6, 2), flops_per_step=f,
                         seconds_in_kernel_per_step=round(t, 6))
 
+        def hbm_family(mask, name):
+            """HBM-bound operators: algorithmic bytes (input + output + residual reads, fp32) / time."""
+            n = int(mask.sum())
+            if n == 0:
+                return None
+            t = float(ms[mask].sum()) * 1e-3
+            nimg = plan.n
+            b = 0.0
+            for o, m_ in zip(plan.ops, mask):
+                if m_:
+                    outp = (o.hout << o.up) * (o.wout << o.up) * o.cout
+                    b += 4.0 * nimg * (o.hin * o.win * o.cin + outp * (1 + (o.res1_off >= 0) + (o.res2_off >= 0)))
+            return dict(bound="hbm", achieved=round(b / t / 1e9, 1), peak=PEAK_HBM_GBPS, unit="GB/s",
+                        frac=round(b / t / 1e9 / PEAK_HBM_GBPS, 4), traffic=None, kernel=name,
+                        peak_note="HBM3E ~8 TB/s (guide); ~6.3 TB/s achievable",
+                        launches_per_step=n, avg_launch_us=round(t / n * 1e6, 2), bytes_per_step=b,
+                        seconds_in_kernel_per_step=round(t, 6))
+
         conv = np.asarray([o.kind == 0 for o in plan.ops])
         bf3 = np.asarray([o.algo == ALGO_MFMA_BF3 for o in plan.ops]) & conv
         f32 = np.asarray([o.algo == ALGO_MFMA for o in plan.ops]) & conv
+        k3 = np.asarray([o.k == 3 for o in plan.ops])
+        s1 = np.asarray([o.stride == 1 for o in plan.ops])
+        stem = np.asarray([o.kind == 0 and o.in_nchw == 1 for o in plan.ops])
+        split_note = "dense bf16 MFMA peak 2500 TFLOP/s / 6 MFMA products per algorithmic product"
         fams = [
-            family(bf3, "conv_bf3_kernel (fused 3x3 conv+BN+residual+ReLU; fp32 values as exact 3-way bf16 splits, "
-                        "6 x v_mfma_f32_16x16x32_bf16 per 32-deep step, fp32 accumulate)", PEAK_BF16_MFMA_TFLOPS / 6.0,
-                   "dense bf16 MFMA peak 2500 TFLOP/s / 6 MFMA products per algorithmic product"),
-            family(f32, "conv_mfma_kernel (fused 1x1 / strided conv+BN+residual+ReLU, v_mfma_f32_16x16x4_f32)",
-                   PEAK_FP32_MFMA_TFLOPS, "dense fp32-input MFMA peak"),
+            family(bf3 & k3 & s1, "conv_bf3_kernel<3, 1, ...> (fused 3x3 stride-1 conv+BN+residual+ReLU; fp32 values as exact "
+                                  "3-way bf16 splits, 6 x v_mfma_f32_16x16x32_bf16 per 32-deep step, fp32 accumulate)",
+                   PEAK_BF16_MFMA_TFLOPS / 6.0, split_note),
+            family(bf3 & k3 & ~s1, "conv_bf3_kernel<3, 2, ...> (same, stride 2)", PEAK_BF16_MFMA_TFLOPS / 6.0, split_note),
+            hbm_family(bf3 & ~k3, "conv_bf3_kernel<1, 1, ...> (fused 1x1 conv+BN+residual+ReLU(+upsample): channel GEMMs of "
+                                  "the bottleneck blocks and fuse up-paths)"),
+            family(f32, "conv_mfma_kernel (exact-fp32 v_mfma_f32_16x16x4_f32: heat-map layer and shapes the split kernel "
+                        "does not cover)", PEAK_FP32_MFMA_TFLOPS, "dense fp32-input MFMA peak"),
+            hbm_family(stem, "conv_stem_kernel (3-channel NCHW stem conv, VALU)"),
         ]
         fams = sorted([f for f in fams if f], key=lambda f: -f["seconds_in_kernel_per_step"])
         roof = fams[0]
@@ -258,12 +288,14 @@ def main():
         # the process, so this is the committed rocprofv3 measurement of THIS command (separate
         # --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE x2 gfx950 correction; tools/pmc_summary.py)
         try:
-            with open(os.path.join(ROOT, "profiles", "r01", "bench_c2_v3_summary.json")) as f:
-                pmc = {r["kernel"]: r for r in json.load(f)["hbm_traffic_per_launch"]}
-            key = "conv_bf3_kernel" if "conv_bf3" in roof["kernel"] else "conv_mfma_kernel"
-            if args.workload == "c2" and key in pmc:
-                roof["traffic"] = pmc[key]["total_bytes"]
-                roof["traffic_source"] = "profiles/r01/bench_c2_v3_summary.json (rocprofv3 --pmc, per launch)"
+            with open(os.path.join(ROOT, "profiles", "r01", "bench_c2_v4_summary.json")) as f:
+                rows = [r for r in json.load(f)["hbm_traffic_by_instantiation"]
+                        if r["kernel"].startswith(roof["kernel"].split(" ...>")[0])]
+            if args.workload == "c2" and rows:
+                nl = sum(r["launches"] for r in rows)
+                roof["traffic"] = round(sum(r["launches"] * r["total_bytes"] for r in rows) / nl)
+                roof["traffic_source"] = ("profiles/r01/bench_c2_v4_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, "
+                                          "launch-weighted mean over this kernel's instantiations)")
         except (OSError, KeyError, ValueError):
             pass
         allc = bf3 | f32

@@ -12,13 +12,16 @@
 #include "conv_common.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 #define ST_TH 8
 #define ST_TW 16
 #define ST_P 8  // consecutive output pixels per lane
 
+// (waves_per_eu: left alone the compiler unrolls all 27 taps, hoists every LDS read and ends at 256
+// VGPRs = one wave per SIMD -- measured 500 us / 1.3 TB/s at the BASELINE batch)
 template <int KS>
-__global__ __launch_bounds__(256) void conv_stem_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void conv_stem_kernel(ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int S = 2;
   constexpr int PH = (ST_TH - 1) * S + KS, PW = (ST_TW - 1) * S + KS;
@@ -56,7 +59,9 @@ __global__ __launch_bounds__(256) void conv_stem_kernel(ConvArgs a) {
     f32x4 acc[ST_P];
 #pragma unroll
     for (int p = 0; p < ST_P; p++) acc[p] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
     for (int ky = 0; ky < KS; ky++) {
+#pragma unroll
       for (int kx = 0; kx < KS; kx++) {
 #pragma unroll
         for (int c = 0; c < 3; c++) {
@@ -64,11 +69,11 @@ __global__ __launch_bounds__(256) void conv_stem_kernel(ConvArgs a) {
           const float* row = patch + (c * PH + ty * S + ky) * PWP + tx0 * S + kx;
 #pragma unroll
           for (int p = 0; p < ST_P; p++) {
-            const float v = row[p * S];
-            acc[p].x = fmaf(v, w4.x, acc[p].x);
-            acc[p].y = fmaf(v, w4.y, acc[p].y);
-            acc[p].z = fmaf(v, w4.z, acc[p].z);
-            acc[p].w = fmaf(v, w4.w, acc[p].w);
+            // two v_pk_fma_f32 per pixel (the layer is VALU-bound before it is HBM-bound)
+            const f32x2 vv = {row[p * S], row[p * S]};
+            const f32x2 lo = __builtin_elementwise_fma(vv, (f32x2){w4.x, w4.y}, (f32x2){acc[p].x, acc[p].y});
+            const f32x2 hi = __builtin_elementwise_fma(vv, (f32x2){w4.z, w4.w}, (f32x2){acc[p].z, acc[p].w});
+            acc[p] = (f32x4){lo.x, lo.y, hi.x, hi.y};
           }
         }
       }

@@ -15,12 +15,18 @@ def fam(n):
             "conv_stem_kernel" if "conv_stem" in n else n.split("(")[0][:48])
 
 
-def agg(path, counter):
+def inst(n):
+    """kernel name with its template arguments, without the parameter list"""
+    n = n.split("(")[0]
+    return n[5:] if n.startswith("void ") else n
+
+
+def agg(path, counter, key=fam):
     d = collections.defaultdict(lambda: [0, 0.0, 0.0])
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] != counter:
             continue
-        g = d[fam(r["Kernel_Name"])]
+        g = d[key(r["Kernel_Name"])]
         g[0] += 1
         g[1] += float(r["Counter_Value"])
         g[2] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
@@ -48,4 +54,16 @@ for n in ("conv_bf3_kernel", "conv_mfma_kernel", "conv_stem_kernel"):
                                                   fetch_bytes_corrected=round(rd), write_bytes=round(wr),
                                                   total_bytes=round(rd + wr),
                                                   GBps=round((rd + wr) / (tf / nf), 1)))
+# the same per template instantiation of the conv kernels (bench.py picks the 3x3 stride-1 ones)
+fi, wi = agg(fetch, "FETCH_SIZE", inst), agg(write, "WRITE_SIZE", inst)
+out["hbm_traffic_by_instantiation"] = []
+for n in sorted(fi, key=lambda n: -fi[n][2]):
+    if "conv_" not in n or n not in wi:
+        continue
+    nf, fs, tf = fi[n]
+    nw, ws, _ = wi[n]
+    rd, wr = 2.0 * fs / nf * 1024, ws / nw * 1024
+    out["hbm_traffic_by_instantiation"].append(dict(kernel=n, launches=nf, avg_us_under_pmc=round(tf / nf / 1e3, 2),
+                                                    fetch_bytes_corrected=round(rd), write_bytes=round(wr),
+                                                    total_bytes=round(rd + wr), GBps=round((rd + wr) / (tf / nf), 1)))
 print(json.dumps(out, indent=1))
