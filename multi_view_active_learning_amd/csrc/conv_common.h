@@ -17,6 +17,7 @@ struct ConvArgs {
   // MFMA tiling (filled by the launcher)
   int th, tw, tn, tw_log2, thw_log2;
   int tiles_x, tiles_y;
+  unsigned pw_magic, ph_magic;  // ceil(2^20 / PW), ceil(2^20 / PH): patch index -> (row, column) without a divide
   int G_total, NS_total;
 };
 
@@ -39,6 +40,9 @@ __device__ __forceinline__ void conv_store(const ConvArgs& a, int n, int y, int 
     }
   }
 }
+
+// floor(v / d) for v < 4096 and d < 256 with magic = ceil(2^20 / d) (exact: v * (d - 1) < 2^20)
+__device__ __forceinline__ int conv_div20(int v, unsigned magic) { return (int)(((unsigned)v * magic) >> 20); }
 
 // Second half of the MFMA kernels' epilogue: the BN'd output tile sits in LDS as
 // ot[pixel][NTILE + 4]; add the residual(s), ReLU and store with float4 lanes along channels.

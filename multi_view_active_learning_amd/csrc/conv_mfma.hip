@@ -79,11 +79,10 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
   for (int i = 0; i < NE; i++) {
     const int e = tid + 256 * i;
     const int px = e / C4, q = e % C4;
-    int r = px;
-    const int pxx = r % PW;
-    r /= PW;
-    const int pyy = r % PH;
-    const int tni = r / PH;
+    const int prow = conv_div20(px, a.pw_magic);  // multiply-shift instead of runtime divides
+    const int pxx = px - prow * PW;
+    const int tni = conv_div20(prow, a.ph_magic);
+    const int pyy = prow - tni * PH;
     const int iy = iy0 + pyy, ix = ix0 + pxx, n = n0 + tni;
     // dil == 2: (iy, ix) index the zero-dilated input; only even positions carry data
     const int dsh = a.dil - 1;
@@ -237,6 +236,9 @@ static int launch_cfg(ConvArgs a, int th, int tw, int tn, hipStream_t s) {
   a.tiles_y = (a.Hout + th - 1) / th;
   const int ngroups = (a.N + tn - 1) / tn;
   const int PH = (th - 1) * S + KS, PW = (tw - 1) * S + KS;
+  a.pw_magic = ((1u << 20) + PW - 1) / PW;
+  a.ph_magic = ((1u << 20) + PH - 1) / PH;
+  if (tn * PH * PW >= 4096 || PW >= 256 || PH >= 256) return 1;  // conv_div20 range
   constexpr int MT = 16 * MS * WM, NTILE = 16 * NT * WN;
   const int patch_floats = tn * PH * PW * (KC + KPAD);
   const int ne = (tn * PH * PW * (KC / 4) + 255) / 256;

@@ -108,11 +108,10 @@ __global__ __launch_bounds__(64 * WN * WM) void conv_bf3_kernel(ConvArgs a) {
   for (int i = 0; i < NE; i++) {
     const int e = tid + NTH * i;
     const int px = e >> 3, q = e & 7;
-    int r = px;
-    const int pxx = r % PW;
-    r /= PW;
-    const int pyy = r % PH;
-    const int tni = r / PH;
+    const int prow = conv_div20(px, a.pw_magic);  // patch row over all images of the tile
+    const int pxx = px - prow * PW;
+    const int tni = conv_div20(prow, a.ph_magic);
+    const int pyy = prow - tni * PH;
     const int iy = iy0 + pyy, ix = ix0 + pxx, n = n0 + tni;
     const int dsh = a.dil - 1;
     const int sy = iy >> dsh, sx = ix >> dsh;
@@ -314,6 +313,8 @@ static int launch_bf3(ConvArgs a, int th, int tw, int tn, hipStream_t s) {
   a.tiles_y = (a.Hout + th - 1) / th;
   const int ngroups = (a.N + tn - 1) / tn;
   const int PH = (th - 1) * S + KS, PW = (tw - 1) * S + KS;
+  a.pw_magic = ((1u << 20) + PW - 1) / PW;
+  a.ph_magic = ((1u << 20) + PH - 1) / PH;
   constexpr int MT = 16 * MS * WM, NTILE = 16 * NT * WN;
   const int patch_px = tn * PH * PW;
   size_t smem = (size_t)3 * patch_px * BF_ROW * 2;
@@ -322,7 +323,7 @@ static int launch_bf3(ConvArgs a, int th, int tw, int tn, hipStream_t s) {
   if (smem > 128 * 1024) return 1;
   constexpr int NTH = 64 * WN * WM;
   const int ne = (patch_px * 8 + NTH - 1) / NTH;
-  if (ne > 10) return 1;
+  if (ne > 10 || patch_px >= 4096 || tn * PH >= 4096) return 1;
   if (g_bf3_dry) return 0;
   dim3 grid((unsigned)(a.tiles_x * a.tiles_y * ngroups), (unsigned)((a.NS_total + WN * NT - 1) / (WN * NT)));
   if constexpr (KS == 3 && S == 1) {
