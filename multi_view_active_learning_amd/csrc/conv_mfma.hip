@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wn = wave % WN, wm = wave / WN;
   const int PH = (a.th - 1) * S + KS, PW = (a.tw - 1) * S + KS;
-  constexpr int pad = (KS - 1) / 2;
+  const int pad = a.pad;  // (KS - 1) / 2 for the 3x3 / 1x1 convs; 2 / 1 for the k4 transposed-conv forms
 
   // tile origin
   int t = blockIdx.x;
@@ -299,10 +299,24 @@ static int dispatch(const ConvArgs& a, hipStream_t s) {
   return kc32 ? launch_cfg<KS, S, 32, 4, 1, 1, 8>(a, th, tw, tn, s) : launch_cfg<KS, S, 16, 4, 1, 1, 8>(a, th, tw, tn, s);
 }
 
+// k = 4 forms of ConvTranspose2d(k4, s2, p1) (PoseResNet head, pose_resnet.py:88-117): the forward
+// is a stride-1 conv over the zero-dilated input with pad 2 (tap-flipped, channel-swapped weights,
+// pack mode 2), its data gradient a plain stride-2 conv with pad 1.  One tile shape each: 64 pixels
+// x 64 couts, 16-channel chunks.
+template <int S>
+static int dispatch_k4(const ConvArgs& a, hipStream_t s) {
+  int th, tw, tn;
+  pick_tile(a.Hout, a.Wout, 64, &th, &tw, &tn);
+  return launch_cfg<4, S, 16, 4, 1, 1, 4>(a, th, tw, tn, s);
+}
+
 int mval_launch_conv_mfma(const ConvArgs& a, hipStream_t s) {
-  if (a.in_nchw || a.Cin % 16 != 0 || a.pad != (a.k - 1) / 2) return 1;
+  if (a.in_nchw || a.Cin % 16 != 0) return 1;
   // 32-bit element offsets inside the staging loop
   if ((int64_t)a.N * a.Hin * a.Win * a.Cin >= (int64_t)1 << 31) return 1;  // TODO(next round): 64-bit path
+  if (a.k == 4 && a.stride == 1 && a.dil == 2 && a.pad == 2) return dispatch_k4<1>(a, s);
+  if (a.k == 4 && a.stride == 2 && a.dil == 1 && a.pad == 1) return dispatch_k4<2>(a, s);
+  if (a.pad != (a.k - 1) / 2) return 1;
   if (a.k == 3 && a.stride == 1) return dispatch<3, 1>(a, s);
   if (a.k == 3 && a.stride == 2) return dispatch<3, 2>(a, s);
   if (a.k == 1 && a.stride == 1) return dispatch<1, 1>(a, s);

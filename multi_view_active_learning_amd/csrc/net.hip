@@ -237,12 +237,21 @@ static void fill_geometry(ConvArgs& a, const mval_op* op, int n_images) {
   a.NS_total = (op->cout + 15) / 16;
 }
 
+// ConvTranspose2d on the matrix cores = stride-1 conv over the zero-dilated input with pad k-1-p
+// (weights packed with mode 2: tap-flipped, channel-swapped)
+static void deconv_as_conv(ConvArgs& a, const mval_op* op) {
+  a.dil = op->stride;
+  a.stride = 1;
+  a.pad = op->k - 1 - op->pad;
+}
+
 extern "C" int mval_op_mfma_supported(const mval_op* op, int n_images) {
-  if (!op || op->kind != MVAL_OP_CONV || n_images <= 0) return 0;
+  if (!op || (op->kind != MVAL_OP_CONV && op->kind != MVAL_OP_DECONV) || n_images <= 0) return 0;
   ConvArgs a;
   a.in = a.w = a.scale = a.shift = a.res1 = a.res2 = nullptr;
   a.out = nullptr;
   fill_geometry(a, op, n_images);
+  if (op->kind == MVAL_OP_DECONV) deconv_as_conv(a, op);
   return mval_conv_mfma_supported(a);
 }
 
@@ -274,8 +283,9 @@ extern "C" int mval_op_launch(const mval_op* op, int n_images, float* workspace,
     int rc = mval_launch_conv_bf3(a, s);
     MVAL_REQUIRE(rc == 0, "mval_op_launch: no bf16x3 MFMA kernel for conv k%d s%d cin%d cout%d", op->k, op->stride, op->cin,
                  op->cout);
-  } else if (op->kind == MVAL_OP_CONV && op->algo == MVAL_ALGO_MFMA) {
+  } else if ((op->kind == MVAL_OP_CONV || op->kind == MVAL_OP_DECONV) && op->algo == MVAL_ALGO_MFMA) {
     MVAL_REQUIRE(!force_direct(), "MVAL_FORCE_DIRECT=1 but the plan was packed for the MFMA kernels");
+    if (op->kind == MVAL_OP_DECONV) deconv_as_conv(a, op);
     int rc = mval_launch_conv_mfma(a, s);
     MVAL_REQUIRE(rc == 0, "mval_op_launch: no MFMA kernel for conv k%d s%d cin%d cout%d", op->k, op->stride, op->cin,
                  op->cout);

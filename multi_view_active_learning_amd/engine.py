@@ -64,8 +64,19 @@ def _conv_mode():
 def _mfma_ok(op, in_nchw):
     if os.environ.get("MVAL_FORCE_DIRECT") == "1":
         return False
+    if op.kind == "deconv":  # ConvTranspose2d(k4, s2, p1): stride-1 conv over the zero-dilated input
+        return op.cin % 16 == 0 and (op.k, op.stride, op.pad) == (4, 2, 1)
     return (op.kind == "conv" and not in_nchw and op.cin % 16 == 0 and op.k in (1, 3)
             and op.stride in (1, 2) and op.pad == op.k // 2)
+
+
+def _pack_mode(op, pack):
+    """mval_pack_conv_weights `transposed` argument: 0 Conv2d weights; ConvTranspose2d weights are read as
+    (cin, cout, k, k) -- 1 for the direct kernel, 2 (tap-flipped: the stride-1 conv over the zero-dilated
+    input) for the MFMA kernels."""
+    if op.kind != "deconv":
+        return 0
+    return 1 if pack == _PACK_OF[ALGO_DIRECT] else 2
 
 
 class InferencePlan:
@@ -208,7 +219,7 @@ class InferencePlan:
             w = w.contiguous()
             _lib._check(
                 lib.mval_pack_conv_weights(
-                    C.c_int(pack), C.c_int(1 if op.kind == "deconv" else 0), C.c_void_p(w.data_ptr()),
+                    C.c_int(pack), C.c_int(_pack_mode(op, pack)), C.c_void_p(w.data_ptr()),
                     C.c_void_p(base + 4 * w_off), C.c_int(op.cout), C.c_int(op.cin), C.c_int(op.k), st),
                 "mval_pack_conv_weights")
             if op.bn:

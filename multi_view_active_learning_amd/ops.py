@@ -20,11 +20,14 @@ def pack_weights(weight, algo, transposed=False):
     else:
         cout, cin, k, _ = weight.shape
     pack = _PACK_OF[algo]
+    # ConvTranspose2d: as stored for the direct kernel (1), tap-flipped for the MFMA kernels (2), which
+    # run it as a stride-1 conv over the zero-dilated input
+    mode = 0 if not transposed else (1 if algo == ALGO_DIRECT else 2)
     n = int(lib.mval_packed_weight_floats(C.c_int(pack), C.c_int(cout), C.c_int(cin), C.c_int(k)))
     out = torch.empty(n, dtype=torch.float32, device=weight.device)
     w = weight.detach().contiguous()
     _lib._check(
-        lib.mval_pack_conv_weights(C.c_int(pack), C.c_int(int(transposed)), _lib._p(w), _lib._p(out), C.c_int(cout),
+        lib.mval_pack_conv_weights(C.c_int(pack), C.c_int(mode), _lib._p(w), _lib._p(out), C.c_int(cout),
                                    C.c_int(cin), C.c_int(k), _lib._stream()),
         "mval_pack_conv_weights")
     return out

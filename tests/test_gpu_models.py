@@ -139,6 +139,26 @@ def test_stem_maxpool_deconv_direct(dev):
     np.testing.assert_allclose(got.permute(0, 3, 1, 2).cpu().numpy(), want.numpy(), rtol=1e-4, atol=2e-5)
 
 
+@pytest.mark.parametrize("shape", [(2, 64, 32, 8, 6), (3, 256, 256, 16, 12), (1, 2048, 256, 8, 6), (2, 32, 48, 5, 7)],
+                         ids=lambda s: "n%d_c%d-%d_%dx%d" % s)
+def test_deconv_mfma_vs_torch_cpu(dev, shape):
+    """ConvTranspose2d(k4, s2, p1) + BN + ReLU (PoseResNet head) on the matrix cores: stride-1 conv over the
+    zero-dilated input with tap-flipped weights."""
+    from multi_view_active_learning_amd import ops
+
+    n, cin, cout, h, w = shape
+    rng = np.random.default_rng(11)
+    x = torch.from_numpy(rng.standard_normal((n, cin, h, w)).astype(np.float32))
+    wt = torch.from_numpy((rng.standard_normal((cin, cout, 4, 4)) * np.sqrt(2.0 / (cin * 4))).astype(np.float32))
+    sc = torch.from_numpy(rng.uniform(0.5, 1.5, cout).astype(np.float32))
+    sh = torch.from_numpy(rng.standard_normal(cout).astype(np.float32))
+    want = _ref_conv(x, wt, sc, sh, 2, True, None, None, 0, transposed=True)
+    got = ops.fused_conv(x.permute(0, 2, 3, 1).contiguous().to(dev), wt.to(dev), sc.to(dev), sh.to(dev), stride=2, pad=1,
+                         relu=True, kind=ops.OP_DECONV, algo=ops.ALGO_MFMA)
+    assert tuple(got.shape) == (n, 2 * h, 2 * w, cout)
+    np.testing.assert_allclose(got.permute(0, 3, 1, 2).cpu().numpy(), want.numpy(), rtol=1e-4, atol=3e-5)
+
+
 def _load(c, dev):
     m = cases.product_model(c)
     sd = {k: torch.from_numpy(v) for k, v in cases.model_state_dict(c).items()}
