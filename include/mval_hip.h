@@ -227,6 +227,11 @@ size_t mval_conv_wgrad_workspace_floats(int cin, int cout, int k);
 int mval_conv_wgrad(const float* x, const float* dz, float* dw, float* ws, int N, int Hin, int Win, int Cin,
                     int Hout, int Wout, int Cout, int k, int stride, int pad, int x_nchw, void* stream);
 int mval_slab_reduce(const float* slabs, int S, int64_t n, float* out, int accumulate, void* stream);
+/* Backward of MaxPool2d(k, stride, pad) (pose_resnet.py:35 under autograd): gin (+)= gout routed to the
+ * first maximum of each window in ATen's scan order (NaN wins); x / gin NHWC [N,Hin,Win,C], gout
+ * [N,Hout,Wout,C], C % 4 == 0; accumulate = 0 stores. */
+int mval_maxpool_bwd(const float* gout, const float* x, float* gin, int N, int Hin, int Win, int C, int Hout,
+                     int Wout, int k, int stride, int pad, int accumulate, void* stream);
 /* Data gradient of a conv (geometry given in FORWARD terms: x [N,hin,win,cin] -> z
  * [N,hout,wout,cout], k/stride/pad): dx (+)= conv(dz zero-dilated by the stride, flipped W^T).
  * w_packed: mval_pack_conv_weights(pack, transposed = 2, w, ..., cout' = cin, cin' = cout, k);

@@ -174,31 +174,34 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restr
   }
 }
 
-// ---- stem conv1 (3 NCHW input channels, 3x3 stride 2) on the matrix cores ------------------
-// GEMM rows = (cin, tap) = 27 (two 16-row tiles, 5 rows idle), columns = cout (one 16-wide tile
+// ---- stem conv1 (3 NCHW input channels, 3x3 or 7x7 stride 2) on the matrix cores ---------------
+// GEMM rows = (cin, tap) = 27 / 147 (two / ten 16-row tiles), columns = cout (one 16-wide tile
 // per wave), K = output pixels.  The NCHW patch sits in LDS as [ci][PH][PW]; a row's (ci, ky, kx)
 // is a constant offset, the pixel another, so A operands are plain ds_read_b32 gathers.
 #define WS_LDZ 80  // dz tile row stride (floats), 64 cout + 16: == 16 mod 32 banks
 
-template <int MT>
+template <int KS, int MT>
 __global__ __launch_bounds__(256) void conv_wgrad_stem_kernel(WgradArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int T = KS * KS, ROWS = 3 * T, NR = (ROWS + 15) / 16;  // (cin, tap) rows: 27 -> 2 tiles, 147 -> 10
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int PH = a.th * 2 + 1, PW = a.tw * 2 + 1;
+  const int PH = (a.th - 1) * 2 + KS, PW = (a.tw - 1) * 2 + KS;
   float* patch = smem;                 // [3][PH][PW]
   float* dzt = smem + ((3 * PH * PW + 3) & ~3);  // [MT][WS_LDZ]
   const int co0 = wave * 16;
   const bool wave_active = co0 < a.Cout;
-  int roff[2];
-  bool rok[2];
+  int roff[NR];
+  bool rok[NR];
 #pragma unroll
-  for (int mt = 0; mt < 2; mt++) {
+  for (int mt = 0; mt < NR; mt++) {
     const int i = mt * 16 + (lane & 15);
-    rok[mt] = i < 27;
-    const int ci = i / 9, t = i % 9;
-    roff[mt] = rok[mt] ? (ci * PH + t / 3) * PW + t % 3 : 0;
+    rok[mt] = i < ROWS;
+    const int ci = i / T, t = i % T;
+    roff[mt] = rok[mt] ? (ci * PH + t / KS) * PW + t % KS : 0;
   }
-  f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+  f32x4 acc[NR];
+#pragma unroll
+  for (int mt = 0; mt < NR; mt++) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
   const int c4n = a.Cout >> 2;
   for (int tile = blockIdx.x; tile < a.ntiles; tile += a.PS) {
     int t = tile;
@@ -207,7 +210,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_stem_kernel(WgradArgs a) {
     const int tyi = t % a.tiles_y;
     const int n = t / a.tiles_y;
     const int oy0 = tyi * a.th, ox0 = txi * a.tw;
-    const int iy0 = oy0 * 2 - 1, ix0 = ox0 * 2 - 1;
+    const int iy0 = oy0 * 2 - a.pad, ix0 = ox0 * 2 - a.pad;
     __syncthreads();
     for (int e = tid; e < 3 * PH * PW; e += 256) {
       const int pxx = e % PW;
@@ -228,15 +231,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_stem_kernel(WgradArgs a) {
     }
     __syncthreads();
     if (wave_active) {
-#pragma unroll 4
+#pragma unroll 2
       for (int st = 0; st < MT / 4; st++) {
         const int p = st * 4 + (lane >> 4);
         const int poff = ((p >> a.tw_log2) * 2) * PW + (p & ((1 << a.tw_log2) - 1)) * 2;
         const float b = dzt[p * WS_LDZ + co0 + (lane & 15)];
-        const float a0 = rok[0] ? patch[roff[0] + poff] : 0.f;
-        const float a1 = rok[1] ? patch[roff[1] + poff] : 0.f;
-        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b, acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b, acc[1], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < NR; mt++) {
+          const float av = rok[mt] ? patch[roff[mt] + poff] : 0.f;
+          acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b, acc[mt], 0, 0, 0);
+        }
       }
     }
   }
@@ -244,12 +248,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_stem_kernel(WgradArgs a) {
   if (wave_active) {
     const int co = co0 + (lane & 15);
 #pragma unroll
-    for (int mt = 0; mt < 2; mt++)
+    for (int mt = 0; mt < NR; mt++)
 #pragma unroll
       for (int r = 0; r < 4; r++) {
         const int i = mt * 16 + (lane >> 4) * 4 + r;
-        if (i < 27 && co < a.Cout)
-          a.slabs[(((int64_t)blockIdx.x * 9 + i % 9) * 3 + i / 9) * a.Cout + co] = acc[mt][r];
+        if (i < ROWS && co < a.Cout)
+          a.slabs[(((int64_t)blockIdx.x * T + i % T) * 3 + i / T) * a.Cout + co] = acc[mt][r];
       }
   }
 }
@@ -334,9 +338,11 @@ extern "C" int mval_conv_wgrad(const float* x, const float* dz, float* dw, float
   hipStream_t s = mval_stream(stream);
   const int T = k * k;
   const int64_t n_out = (int64_t)T * Cin * Cout;
-  const bool mfma = !x_nchw && (Cin & 3) == 0 && (k == 1 || k == 3) && (stride == 1 || stride == 2) && pad == k / 2 &&
-                    Cin >= 16;
-  const bool stem = x_nchw && Cin == 3 && k == 3 && stride == 2 && pad == 1 && (Cout & 15) == 0 && Cout <= 64;
+  // k = 4, stride 2, pad 1: the weight gradient of ConvTranspose2d(k4, s2, p1) with the roles of the
+  // activations swapped (x := dz of the transposed conv, dz := its input)
+  const bool mfma = !x_nchw && (Cin & 3) == 0 && Cin >= 16 &&
+                    (((k == 1 || k == 3) && (stride == 1 || stride == 2) && pad == k / 2) || (k == 4 && stride == 2 && pad == 1));
+  const bool stem = x_nchw && Cin == 3 && (k == 3 || k == 7) && stride == 2 && pad == k / 2 && (Cout & 15) == 0 && Cout <= 64;
   int PS;
   if (stem) {
     WgradArgs a;
@@ -349,8 +355,12 @@ extern "C" int mval_conv_wgrad(const float* x, const float* dz, float* dw, float
     a.ntiles = a.tiles_x * a.tiles_y * N;
     PS = a.ntiles < 512 ? a.ntiles : 512;
     a.PS = PS;
-    const size_t smem = (size_t)(((3 * 17 * 33 + 3) & ~3) + 128 * WS_LDZ) * sizeof(float);
-    hipLaunchKernelGGL((conv_wgrad_stem_kernel<128>), dim3(PS), dim3(256), smem, s, a);
+    const int PH = 14 + k, PW = 30 + k;
+    const size_t smem = (size_t)(((3 * PH * PW + 3) & ~3) + 128 * WS_LDZ) * sizeof(float);
+    if (k == 3)
+      hipLaunchKernelGGL((conv_wgrad_stem_kernel<3, 128>), dim3(PS), dim3(256), smem, s, a);
+    else
+      hipLaunchKernelGGL((conv_wgrad_stem_kernel<7, 128>), dim3(PS), dim3(256), smem, s, a);
     MVAL_CHECK_LAUNCH("mval_conv_wgrad/stem");
   } else if (mfma) {
     WgradArgs a;
@@ -381,6 +391,7 @@ extern "C" int mval_conv_wgrad(const float* x, const float* dz, float* dw, float
     if (k == 3 && stride == 1 && mt == 128) WG_LAUNCH(3, 1, 128, 6);
     else if (k == 3 && stride == 1) WG_LAUNCH(3, 1, 64, 6);
     else if (k == 3 && stride == 2) WG_LAUNCH(3, 2, 64, 12);
+    else if (k == 4) WG_LAUNCH(4, 2, 64, 12);
     else if (k == 1 && stride == 1 && mt == 128) WG_LAUNCH(1, 1, 128, 4);
     else if (k == 1 && stride == 1) WG_LAUNCH(1, 1, 64, 2);
     else WG_LAUNCH(1, 2, 64, 8);

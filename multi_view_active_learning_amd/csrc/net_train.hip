@@ -34,6 +34,13 @@ static void geometry(ConvArgs& a, const mval_op& op, int n_images) {
   a.res1 = a.res2 = nullptr;
 }
 
+// ConvTranspose2d forward on the matrix cores: stride-1 conv over the zero-dilated input (net.hip)
+static void deconv_as_conv(ConvArgs& a, const mval_op& op) {
+  a.dil = op.stride;
+  a.stride = 1;
+  a.pad = op.k - 1 - op.pad;
+}
+
 static int run_conv(const ConvArgs& a, int algo, hipStream_t s, const char* what) {
   if (algo == MVAL_ALGO_MFMA_BF3) {
     if (mval_launch_conv_bf3(a, s)) {
@@ -64,10 +71,20 @@ extern "C" int mval_train_forward(const mval_train_op* ops, int n_ops, int n_ima
   for (int i = 0; i < n_ops; i++) {
     const mval_train_op& t = ops[i];
     const mval_op& op = t.op;
-    MVAL_REQUIRE(op.kind == MVAL_OP_CONV, "mval_train_forward: op %d: only conv operators are trainable here", i);
     ConvArgs a;
     geometry(a, op, n_images);
     a.in = op.in_off >= 0 ? arena + op.in_off : input_nchw;
+    if (op.kind == MVAL_OP_MAXPOOL) {
+      MVAL_REQUIRE(op.out_off >= 0 && op.in_off >= 0, "mval_train_forward: op %d: max-pool on an external buffer", i);
+      a.w = a.scale = a.shift = nullptr;
+      a.out = arena + op.out_off;
+      mval_launch_conv_direct(a, MVAL_OP_MAXPOOL, s);
+      continue;
+    }
+    if (op.kind == MVAL_OP_DECONV) {
+      MVAL_REQUIRE(t.has_bn && op.algo == MVAL_ALGO_MFMA, "mval_train_forward: op %d: transposed conv needs BN + the MFMA form", i);
+      deconv_as_conv(a, op);
+    }
     a.w = params + op.w_off;
     float* out = op.out_off >= 0 ? arena + op.out_off : output_nchw;
     if (t.has_bn) {
@@ -110,6 +127,14 @@ extern "C" int mval_train_backward(const mval_train_op* ops, int n_ops, int n_im
     const mval_train_op& t = ops[i];
     const mval_op& op = t.op;
     MVAL_REQUIRE(t.gout_off >= 0, "mval_train_backward: op %d has no output gradient slot", i);
+    if (op.kind == MVAL_OP_MAXPOOL) {
+      if (t.gin_off >= 0) {
+        int rc = mval_maxpool_bwd(garena + t.gout_off, arena + op.in_off, garena + t.gin_off, n_images, op.hin, op.win,
+                                  op.cin, op.hout, op.wout, op.k, op.stride, op.pad, !(t.first_touch & 1), stream);
+        if (rc) return rc;
+      }
+      continue;
+    }
     // the output activation is only needed for the ReLU mask; NCHW outputs (final layer) have none
     const float* outp = op.out_off >= 0 ? arena + op.out_off : nullptr;
     MVAL_REQUIRE(!(op.relu && !outp), "mval_train_backward: op %d: ReLU on an external output", i);
@@ -119,6 +144,37 @@ extern "C" int mval_train_backward(const mval_train_op* ops, int n_ops, int n_im
                          op.hout, op.wout, op.cout, op.up, op.relu, t.has_bn, t.first_touch >> 1, stream);
     if (rc) return rc;
     const float* x = op.in_off >= 0 ? arena + op.in_off : input_nchw;
+    if (op.kind == MVAL_OP_DECONV) {
+      // ConvTranspose2d(k, s, p): y = scatter of x through W[cin][cout][k][k].  With the roles swapped it
+      // is the conv  x' = conv(y', W as [cout' = cin][cin' = cout], stride s, pad p), so
+      //   dW = weight gradient of that conv with input dz (at the output resolution) and "dz" = x;
+      //   dx = that conv applied to dz (plain stride-2 conv on the matrix cores).
+      rc = mval_conv_wgrad(gz, x, t.dweight, wsf, n_images, op.hout, op.wout, op.cout, op.hin, op.win, op.cin, op.k,
+                           op.stride, op.pad, 0, stream);
+      if (rc) return rc;
+      if (t.gin_off >= 0) {
+        ConvArgs a;
+        a.N = n_images;
+        a.Hin = op.hout; a.Win = op.wout; a.Cin = op.cout;
+        a.Hout = op.hin; a.Wout = op.win; a.Cout = op.cin;
+        a.k = op.k; a.stride = op.stride; a.pad = op.pad;
+        a.up = 0; a.relu = 0; a.in_nchw = 0; a.out_nchw = 0;
+        a.dil = 1;
+        a.th = a.tw = a.tn = a.tw_log2 = a.thw_log2 = a.tiles_x = a.tiles_y = 0;
+        a.G_total = (op.cout + 15) / 16;
+        a.NS_total = (op.cin + 15) / 16;
+        a.in = gz;
+        a.w = params + t.wd_off;
+        a.scale = params + ones_off;
+        a.shift = params + zeros_off;
+        a.out = garena + t.gin_off;
+        a.res1 = (t.first_touch & 1) ? nullptr : a.out;
+        a.res2 = nullptr;
+        rc = run_conv(a, MVAL_ALGO_MFMA, s, "mval_train_backward/deconv dgrad");
+        if (rc) return rc;
+      }
+      continue;
+    }
     rc = mval_conv_wgrad(x, gz, t.dweight, wsf, n_images, op.hin, op.win, op.cin, op.hout, op.wout, op.cout, op.k,
                          op.stride, op.pad, op.in_nchw, stream);
     if (rc) return rc;

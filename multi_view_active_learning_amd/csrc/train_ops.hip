@@ -391,6 +391,67 @@ extern "C" int mval_bn_bwd(const float* gout, const float* out, const float* z, 
   return 0;
 }
 
+// ---- max-pool backward (PoseResNet stem, pose_resnet.py:35: MaxPool2d(3, 2, 1)) ----------------
+// gin[n, iy, ix, c] (+)= sum of gout over the output windows whose arg-max is (iy, ix).  Gather form
+// (one thread per input float4, no atomics): each of the <= 4 windows covering the element is
+// re-scanned in ATen's order (rows, then columns, strictly-greater update, so the FIRST maximum wins
+// -- after a ReLU whole windows tie at 0) and contributes when its arg-max is this element.
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ gout, const float* __restrict__ x,
+                                                          float* __restrict__ gin, int N, int Hin, int Win, int C,
+                                                          int Hout, int Wout, int k, int stride, int pad,
+                                                          int accumulate) {
+  const int c4n = C >> 2;
+  const int64_t total = (int64_t)N * Hin * Win * c4n;
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+    const int q = (int)(t % c4n);
+    int64_t p = t / c4n;
+    const int ix = (int)(p % Win);
+    const int iy = (int)((p / Win) % Hin);
+    const int n = (int)(p / ((int64_t)Win * Hin));
+    f32x4 g = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // windows (oy, ox) with oy * stride - pad <= iy < oy * stride - pad + k
+    const int oy_lo = max(0, (iy + pad - k + stride) / stride), oy_hi = min(Hout - 1, (iy + pad) / stride);
+    const int ox_lo = max(0, (ix + pad - k + stride) / stride), ox_hi = min(Wout - 1, (ix + pad) / stride);
+    for (int oy = oy_lo; oy <= oy_hi; oy++)
+      for (int ox = ox_lo; ox <= ox_hi; ox++) {
+        const int y0 = max(0, oy * stride - pad), y1 = min(Hin, oy * stride - pad + k);
+        const int x0 = max(0, ox * stride - pad), x1 = min(Win, ox * stride - pad + k);
+        f32x4 best = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        int by[4] = {y0, y0, y0, y0}, bx[4] = {x0, x0, x0, x0};
+        for (int yy = y0; yy < y1; yy++)
+          for (int xx = x0; xx < x1; xx++) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(x + (((int64_t)n * Hin + yy) * Win + xx) * C + q * 4);
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+              if (v[j] > best[j] || v[j] != v[j]) {
+                best[j] = v[j];
+                by[j] = yy;
+                bx[j] = xx;
+              }
+          }
+        const f32x4 go = *reinterpret_cast<const f32x4*>(gout + (((int64_t)n * Hout + oy) * Wout + ox) * C + q * 4);
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+          if (by[j] == iy && bx[j] == ix) g[j] += go[j];
+      }
+    f32x4* dst = reinterpret_cast<f32x4*>(gin + p * C + q * 4);
+    *dst = accumulate ? *dst + g : g;
+  }
+}
+
+extern "C" int mval_maxpool_bwd(const float* gout, const float* x, float* gin, int N, int Hin, int Win, int C, int Hout,
+                                int Wout, int k, int stride, int pad, int accumulate, void* stream) {
+  MVAL_REQUIRE(gout && x && gin && N > 0 && C > 0 && (C & 3) == 0 && k > 0 && stride > 0 && k >= stride,
+               "mval_maxpool_bwd: bad arguments (C must be a multiple of 4, k >= stride)");
+  const int64_t total = (int64_t)N * Hin * Win * (C >> 2);
+  int nb = (int)((total + 255) / 256);
+  if (nb > 16384) nb = 16384;
+  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(nb), dim3(256), 0, mval_stream(stream), gout, x, gin, N, Hin, Win, C, Hout,
+                     Wout, k, stride, pad, accumulate);
+  MVAL_CHECK_LAUNCH("mval_maxpool_bwd");
+  return 0;
+}
+
 // sum of S slabs of n floats (float64 accumulation), deterministic split-K reduction
 __global__ void slab_reduce_kernel(const float* __restrict__ slabs, int S, int64_t n, float* __restrict__ out,
                                    int accumulate) {

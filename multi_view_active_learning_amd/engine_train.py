@@ -11,7 +11,9 @@ node as inputs, so DDP's hooks fire as usual.
 The plan keeps every operator's raw conv output z and activation (no arena reuse: backward needs
 them) and a mirror arena for activation gradients; forward and backward are one C call each
 (``mval_train_forward`` / ``mval_train_backward``), with weights (re)packed on device only when a
-parameter version changes.  PoseResNet (max-pool / transposed conv) training is not wired yet.
+parameter version changes.  PoseResNet trains through the same plan: max-pool backward routes gradients to the window arg-max,
+ConvTranspose2d(k4, s2, p1) runs forward as a conv over the zero-dilated input and backward as a plain
+stride-2 conv (data gradient) / a k4 stride-2 weight gradient with the activations' roles swapped.
 """
 from __future__ import annotations
 
@@ -20,7 +22,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from .engine import (ALGO_DIRECT, ALGO_MFMA, ALGO_MFMA_BF3, PACK_HWIO, PACK_MFMA16, _PACK_OF, MvalOp, _align,
+from .engine import (ALGO_DIRECT, ALGO_MFMA, ALGO_MFMA_BF3, PACK_HWIO, PACK_MFMA16, _KIND, _PACK_OF, MvalOp, _align,
                      _conv_mode, _mfma_ok)
 
 BN_MOMENTUM = 0.1
@@ -46,16 +48,16 @@ class MvalTrainOp(C.Structure):
 class TrainPlan:
     def __init__(self, model, n, h, w, device):
         g = model._graph
-        if any(op.kind != "conv" for op in g.ops):
-            raise NotImplementedError("training on the HIP engine covers conv/BN graphs (HRNet); PoseResNet's max-pool / "
-                                      "transposed-conv backward is not wired yet")
         self.model, self.graph, self.n, self.device = model, g, n, device
         lib = _lib.lib()
         dims = {g.input: (h, w)}
         geo = []
         for op in g.ops:
             hin, win = dims[op.src]
-            hout, wout = (hin + 2 * op.pad - op.k) // op.stride + 1, (win + 2 * op.pad - op.k) // op.stride + 1
+            if op.kind == "deconv":
+                hout, wout = (hin - 1) * op.stride - 2 * op.pad + op.k, (win - 1) * op.stride - 2 * op.pad + op.k
+            else:
+                hout, wout = (hin + 2 * op.pad - op.k) // op.stride + 1, (win + 2 * op.pad - op.k) // op.stride + 1
             full = (hout << op.up, wout << op.up)
             for r in (op.res1, op.res2):
                 if r is not None and dims[r] != full:
@@ -96,7 +98,7 @@ class TrainPlan:
             out_nchw = g.acts[op.dst].layout == "nchw"
             t = self.ops[i]
             m = t.op
-            m.kind = 0
+            m.kind = _KIND[op.kind]
             m.k, m.stride, m.pad, m.cin, m.cout = op.k, op.stride, op.pad, op.cin, op.cout
             m.hin, m.win, m.hout, m.wout = hin, win, hout, wout
             m.up, m.relu, m.in_nchw, m.out_nchw = op.up, int(op.relu), int(in_nchw), int(out_nchw)
@@ -104,22 +106,14 @@ class TrainPlan:
             bf3 = _conv_mode() == "bf3"
             if _mfma_ok(op, in_nchw) and lib.mval_op_mfma_supported(C.byref(m), C.c_int(n)):
                 m.algo = ALGO_MFMA
-                if (bf3 and op.k in (1, 3) and (op.cin % 32 == 0 or op.cin == 48)
+                if (bf3 and op.kind == "conv" and op.k in (1, 3) and (op.cin % 32 == 0 or op.cin == 48)
                         and lib.mval_op_algo_supported(C.byref(m), C.c_int(n), C.c_int(ALGO_MFMA_BF3))):
                     m.algo = ALGO_MFMA_BF3
             m.in_off = -1 if op.src == g.input else act_off[op.src]
             m.out_off = -1 if op.dst == g.output else act_off[op.dst]
             m.res1_off = -1 if op.res1 is None else act_off[op.res1]
             m.res2_off = -1 if op.res2 is None else act_off[op.res2]
-            fpack = _PACK_OF[m.algo]
-            nw = int(lib.mval_packed_weight_floats(C.c_int(fpack), C.c_int(op.cout), C.c_int(op.cin), C.c_int(op.k)))
-            m.w_off = ptop
-            ptop += _align(nw)
-            m.scale_off = -1
-            m.shift_off = -1
-            if not op.bn:  # conv + bias
-                m.shift_off = ptop
-                ptop += _align(op.cout)
+            m.w_off = m.scale_off = m.shift_off = -1
             t.z_off = z_off[i]
             t.has_bn = int(bool(op.bn))
             t.gout_off = act_off[op.dst]
@@ -128,7 +122,35 @@ class TrainPlan:
             t.gres2_off = -1 if op.res2 is None else act_off[op.res2]
             t.wd_off = -1
             t.dgrad_algo = ALGO_DIRECT
+            if op.kind == "maxpool":  # no parameters; backward routes the gradient to the window arg-max
+                self.jobs.append((i, None, None))
+                self.stat_off.append(stat_top)
+                continue
+            if op.kind == "deconv" and (m.algo != ALGO_MFMA or not op.bn):
+                raise NotImplementedError(f"training a transposed conv needs the MFMA form (k4 s2 p1, cin % 16 == 0) + BN: {op.conv}")
+            fpack = _PACK_OF[m.algo]
+            nw = int(lib.mval_packed_weight_floats(C.c_int(fpack), C.c_int(op.cout), C.c_int(op.cin), C.c_int(op.k)))
+            m.w_off = ptop
+            ptop += _align(nw)
+            if not op.bn:  # conv + bias
+                m.shift_off = ptop
+                ptop += _align(op.cout)
             dpack = None
+            if op.kind == "deconv":
+                # data gradient of ConvTranspose2d = plain stride-2 conv (k4, p1) of dz with the stored
+                # (cin, cout, k, k) weights read as Conv2d weights (cout' = cin, cin' = cout)
+                if t.gin_off >= 0:
+                    t.dgrad_algo = ALGO_MFMA
+                    dpack = _PACK_OF[ALGO_MFMA]
+                    nd = int(lib.mval_packed_weight_floats(C.c_int(dpack), C.c_int(op.cin), C.c_int(op.cout), C.c_int(op.k)))
+                    t.wd_off = ptop
+                    ptop += _align(nd)
+                self.jobs.append((i, fpack, dpack))
+                self.stat_off.append(stat_top)
+                stat_top += 2 * _align(op.cout)
+                gz_max = max(gz_max, n * hout * wout * op.cout)
+                wsf_max = max(wsf_max, int(lib.mval_conv_wgrad_workspace_floats(C.c_int(op.cout), C.c_int(op.cin), C.c_int(op.k))))
+                continue
             if t.gin_off >= 0:
                 ok = op.cout % 16 == 0 and op.k in (1, 3) and op.stride in (1, 2) and op.pad == op.k // 2
                 t.dgrad_algo = ALGO_MFMA if ok else ALGO_DIRECT
@@ -182,11 +204,14 @@ class TrainPlan:
         self.param_list, self.grad_slots = [], []
         gtop = 0
         for op in g.ops:
+            if op.kind == "maxpool":
+                self.grad_slots.append({})
+                continue
             conv = holders[op.conv]
             slots = {"w": gtop}
             self.param_list.append(conv.weight)
             gtop += _align(conv.weight.numel(), 4)
-            if conv.bias is not None:
+            if getattr(conv, "bias", None) is not None:
                 slots["b"] = gtop
                 self.param_list.append(conv.bias)
                 gtop += _align(op.cout, 4)
@@ -210,18 +235,23 @@ class TrainPlan:
         sbase = self.stats.data_ptr()
         for (i, fpack, dpack), op in zip(self.jobs, self.graph.ops):
             t = self.ops[i]
+            if op.kind == "maxpool":
+                continue
             conv = holders[op.conv]
             w = conv.weight
             if not w.is_cuda:
                 raise _lib.MvalError("model parameters must be on the HIP device (call .cuda())")
             if repack:
                 wp = C.c_void_p(w.detach().contiguous().data_ptr())
-                _lib._check(lib.mval_pack_conv_weights(C.c_int(fpack), C.c_int(0), wp, C.c_void_p(base + 4 * t.op.w_off),
+                # Conv2d: forward as stored (0), data gradient tap-flipped / channel-swapped (2);
+                # ConvTranspose2d: the other way round (forward = conv over the zero-dilated input)
+                fmode, dmode = (2, 0) if op.kind == "deconv" else (0, 2)
+                _lib._check(lib.mval_pack_conv_weights(C.c_int(fpack), C.c_int(fmode), wp, C.c_void_p(base + 4 * t.op.w_off),
                                                        C.c_int(op.cout), C.c_int(op.cin), C.c_int(op.k), st), "pack fwd")
                 if dpack is not None:
-                    _lib._check(lib.mval_pack_conv_weights(C.c_int(dpack), C.c_int(2), wp, C.c_void_p(base + 4 * t.wd_off),
+                    _lib._check(lib.mval_pack_conv_weights(C.c_int(dpack), C.c_int(dmode), wp, C.c_void_p(base + 4 * t.wd_off),
                                                            C.c_int(op.cin), C.c_int(op.cout), C.c_int(op.k), st), "pack dgrad")
-                if conv.bias is not None:
+                if getattr(conv, "bias", None) is not None:
                     self.params[t.op.shift_off : t.op.shift_off + op.cout] = conv.bias.detach()
             if op.bn:
                 bn = holders[op.bn]
@@ -250,6 +280,8 @@ class TrainPlan:
         grads = torch.empty(self.grad_floats, dtype=torch.float32, device=self.device)
         gb = grads.data_ptr()
         for t, slots, op in zip(self.ops, self.grad_slots, g.ops):
+            if not slots:
+                continue
             t.dweight = gb + 4 * slots["w"]
             t.dgamma = gb + 4 * slots["g"] if "g" in slots else None
             t.dbeta = gb + 4 * (slots["be"] if "be" in slots else slots["b"]) if ("be" in slots or "b" in slots) else None
@@ -269,6 +301,8 @@ class TrainPlan:
         out = []
         holders = self.model._holders
         for slots, op in zip(self.grad_slots, g.ops):
+            if not slots:
+                continue
             conv = holders[op.conv]
             out.append(grads[slots["w"] : slots["w"] + conv.weight.numel()].view_as(conv.weight))
             if "b" in slots:

@@ -149,6 +149,31 @@ def test_conv_wgrad_stem_nchw_vs_torch(dev, shape):
     assert _rel(dw.cpu().numpy(), wt.grad.numpy()) < 2e-5
 
 
+def test_maxpool_backward_vs_torch(dev):
+    """MaxPool2d(3, 2, 1) backward: first-maximum routing (ties after a ReLU), ragged sizes, store and
+    accumulate modes."""
+    import ctypes as C
+
+    from multi_view_active_learning_amd import _lib
+
+    rng = np.random.default_rng(5)
+    for (n, c, h, w) in [(2, 64, 32, 24), (1, 8, 7, 9), (3, 16, 6, 6)]:
+        x = torch.from_numpy(np.maximum(rng.standard_normal((n, c, h, w)), 0).astype(np.float32)).requires_grad_(True)
+        y = F.max_pool2d(x, 3, 2, 1)
+        g = torch.from_numpy(rng.standard_normal(y.shape).astype(np.float32))
+        y.backward(g)
+        ho, wo = y.shape[2:]
+        nhwc = lambda t: t.detach().permute(0, 2, 3, 1).contiguous().to(dev)
+        gin = torch.full((n, h, w, c), 3.0, device=dev)
+        gd, xd = nhwc(g), nhwc(x)  # keep the device tensors alive across the launches
+        lib, st, p = _lib.lib(), _lib._stream(), _lib._p
+        for acc in (0, 1):
+            _lib._check(lib.mval_maxpool_bwd(p(gd), p(xd), p(gin), C.c_int(n), C.c_int(h), C.c_int(w), C.c_int(c),
+                                             C.c_int(ho), C.c_int(wo), C.c_int(3), C.c_int(2), C.c_int(1), C.c_int(acc), st), "bwd")
+            want = x.grad.numpy() * (1 + acc)
+            np.testing.assert_allclose(gin.permute(0, 3, 1, 2).cpu().numpy(), want, rtol=1e-6, atol=1e-6)
+
+
 def _train_once(c, dev):
     m = cases.product_model(c)
     sd = {k: torch.from_numpy(v) for k, v in cases.model_state_dict(c).items()}
@@ -166,14 +191,14 @@ def _train_once(c, dev):
     return m, opt, hm, loss, sd
 
 
-def test_train_step_vs_reference_golden(dev):
-    """One training step of HRNet-W32 (train-mode BN, masked MSE, backward, Adam) against the
-    reference's values.  Tolerances: loss 1e-5 relative; gradients 2e-3 relative L2 (fp32
-    through ~60 BN layers with batch statistics over 4 images amplifies reordering noise)."""
-    c = cases.train_cases()["w32_train"]
+@pytest.mark.parametrize("name", ["w32_train", "r50_train"])
+def test_train_step_vs_reference_golden(dev, name):
+    """One training step of HRNet-W32 / PoseResNet-50 (train-mode BN, masked MSE, backward, Adam)
+    against the reference's values.  Tolerances: loss 1e-5 relative; gradients 2e-3 relative L2
+    (fp32 through ~60 BN layers with batch statistics over 2-4 images amplifies reordering noise)."""
+    c = cases.train_cases()[name]
     z = np.load(os.path.join(G, "train_step.npz"))
     m, opt, hm, loss, _ = _train_once(c, dev)
-    name = "w32_train"
     assert abs(loss.item() - float(z[name + "/loss"])) <= 1e-5 * float(z[name + "/loss"])
     np.testing.assert_allclose(hm.detach().reshape(-1)[:64].cpu().numpy(), z[name + "/heatmaps_head"], rtol=1e-3, atol=2e-4)
     named = dict(m.named_parameters())
@@ -186,8 +211,11 @@ def test_train_step_vs_reference_golden(dev):
         head = g.reshape(-1)[:16].cpu().numpy()
         want = z[f"{name}/grad_head/{k}"]
         # element-wise: torch-CPU fp32 itself is only ~1e-2 from an fp64 run on these tensors
-        # (see test_all_gradients_vs_cpu_oracle), so 5e-2 of the head's magnitude
-        assert np.abs(head - want).max() <= 5e-2 * np.abs(want).max() + 1e-7, (k, head, want)
+        # (see test_all_gradients_vs_cpu_oracle), so 5e-2 of the head's magnitude; the ResNet case
+        # normalises layer4 over 2 images x 4 x 3 pixels = 24 samples per channel, which doubles
+        # that noise on the early layers (norms still agree to 2e-3)
+        tol = 1e-1 if name == "r50_train" else 5e-2
+        assert np.abs(head - want).max() <= tol * np.abs(want).max() + 1e-7, (k, head, want)
     sd = m.state_dict()
     for k in c["bn_keys"]:
         np.testing.assert_allclose(sd[k + ".running_mean"].cpu().numpy(), z[f"{name}/running_mean/{k}"], rtol=1e-4, atol=1e-5)
@@ -203,10 +231,11 @@ def test_train_step_vs_reference_golden(dev):
         assert np.abs(got - want).max() <= 2.1e-3 and np.median(np.abs(got - want)) <= 1e-5, k
 
 
-def test_all_gradients_vs_cpu_oracle(dev):
-    """Every parameter gradient of a small HRNet-W32 step against torch-CPU autograd on the
-    functional oracle model."""
-    c = dict(arch="hrnet_w32", seed=5, n=3, h=64, w=64, j=7)
+@pytest.mark.parametrize("c", [dict(arch="hrnet_w32", seed=5, n=3, h=64, w=64, j=7),
+                               dict(arch="resnet50", seed=7, n=2, h=128, w=96, j=7)], ids=lambda c: c["arch"])
+def test_all_gradients_vs_cpu_oracle(dev, c):
+    """Every parameter gradient of a small HRNet-W32 / PoseResNet-50 step (max-pool and transposed-conv
+    backward included) against torch-CPU autograd on the functional oracle model."""
     m, _, hm, loss, sd = _train_once(c, dev)
     x, gt, valid = cases.train_input(c)
 
@@ -215,7 +244,10 @@ def test_all_gradients_vs_cpu_oracle(dev):
         for k, v in sdc.items():
             if v.dtype.is_floating_point and "running" not in k:
                 v.requires_grad_(True)
-        hm_c = models.hrnet_forward(sdc, torch.from_numpy(x).to(dt), models.HRNET_W32, training=True)
+        if c["arch"] == "resnet50":
+            hm_c = models.pose_resnet_forward(sdc, torch.from_numpy(x).to(dt), training=True)
+        else:
+            hm_c = models.hrnet_forward(sdc, torch.from_numpy(x).to(dt), models.HRNET_W32, training=True)
         l = models.pose_2d_mse(hm_c, torch.from_numpy(gt).to(dt), torch.from_numpy(valid).reshape(hm_c.shape[0], -1, 1, 1))
         l.backward()
         return l.item(), sdc
