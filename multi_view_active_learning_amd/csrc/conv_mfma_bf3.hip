@@ -378,7 +378,9 @@ int mval_launch_conv_bf3(const ConvArgs& a, hipStream_t s) {
   if (a.k == 1 && a.pad == 0 && a.stride == 1 && a.dil == 1 && !a.out_nchw && (a.Cout & 15) == 0)
     return dispatch_bf3<1, 1>(a, s);
   if (a.k != 3 || a.pad != 1) return 1;
-  if (a.stride == 1 && a.dil == 1) return dispatch_bf3<3, 1>(a, s);
+  // dil == 2: data gradient of a stride-2 conv (dz read as a zero-dilated input: 3 of 4 staged values
+  // are zeros, still ~2x the exact-fp32 MFMA kernel)
+  if (a.stride == 1 && (a.dil == 1 || a.dil == 2)) return dispatch_bf3<3, 1>(a, s);
   // stride 2: the patch is ~4x larger per output pixel, so 32-pixel tiles (44 KB of LDS planes);
   // 64-pixel tiles (87 KB, 196 VGPRs) measured slower than the exact-fp32 kernel
   if (a.stride == 2 && a.dil == 1) {

@@ -195,7 +195,8 @@ extern "C" int mval_conv_dgrad(const float* dz, const float* w_packed, const flo
                                int accumulate, int N, int hin, int win, int cin, int hout, int wout, int cout, int k,
                                int stride, int pad, int algo, void* stream) {
   MVAL_REQUIRE(dz && w_packed && ones && zeros && dx && N > 0, "mval_conv_dgrad: bad arguments");
-  MVAL_REQUIRE(algo == MVAL_ALGO_MFMA || stride == 1, "mval_conv_dgrad: strided data gradient needs the MFMA kernel");
+  MVAL_REQUIRE(algo == MVAL_ALGO_MFMA || algo == MVAL_ALGO_MFMA_BF3 || stride == 1,
+               "mval_conv_dgrad: strided data gradient needs an MFMA kernel");
   ConvArgs a;
   a.N = N;
   a.Hin = hout; a.Win = wout; a.Cin = cout;

@@ -155,7 +155,7 @@ class TrainPlan:
                 ok = op.cout % 16 == 0 and op.k in (1, 3) and op.stride in (1, 2) and op.pad == op.k // 2
                 t.dgrad_algo = ALGO_MFMA if ok else ALGO_DIRECT
                 # stride-1 data gradients are plain convs with cin' = cout: bf16x3-split kernel
-                if ok and bf3 and op.stride == 1 and (op.cout % 32 == 0 or op.cout == 48) and (op.k == 3 or op.cin % 16 == 0):
+                if ok and bf3 and (op.cout % 32 == 0 or op.cout == 48) and ((op.k == 3 and op.cin % 16 == 0) or (op.stride == 1 and op.cin % 16 == 0)):
                     t.dgrad_algo = ALGO_MFMA_BF3
                 dpack = _PACK_OF[t.dgrad_algo]
                 # the data-gradient conv has cin' = cout, cout' = cin

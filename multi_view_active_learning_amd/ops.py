@@ -105,7 +105,7 @@ def conv_dgrad(dz, weight, in_hw, stride=1, algo=ALGO_MFMA, accumulate_into=None
     cout, cin, k, _ = weight.shape
     n, ho, wo, _ = dz.shape
     h, w = in_hw
-    pack = PACK_MFMA16 if algo == ALGO_MFMA else PACK_HWIO
+    pack = _PACK_OF[algo]
     nw = int(lib.mval_packed_weight_floats(C.c_int(pack), C.c_int(cin), C.c_int(cout), C.c_int(k)))
     wp = torch.empty(nw, dtype=torch.float32, device=dz.device)
     wt = weight.detach().contiguous()

@@ -121,6 +121,9 @@ def test_conv_wgrad_and_dgrad_vs_torch(dev, case):
     if cout % 16 == 0:
         got = ops.conv_dgrad(dzd, wt.detach().to(dev), (h, w), stride=s)
         assert _rel(got.permute(0, 3, 1, 2).cpu().numpy(), x.grad.numpy()) < 2e-5
+    if cout % 32 == 0 and (k == 3 or s == 1):  # split-bf16 kernel (stride 2: dz read zero-dilated)
+        got = ops.conv_dgrad(dzd, wt.detach().to(dev), (h, w), stride=s, algo=ops.ALGO_MFMA_BF3)
+        assert _rel(got.permute(0, 3, 1, 2).cpu().numpy(), x.grad.numpy()) < 2e-5
 
 
 @pytest.mark.parametrize("shape", [(2, 64, 64, 48), (3, 32, 40, 72), (1, 16, 18, 34)], ids=lambda s: "n%d_co%d_%dx%d" % s)
