@@ -169,8 +169,11 @@ typedef struct mval_op {
  * MVAL_PACK_MFMA16_BF3: the exact three-way bf16 split of every weight in
  * v_mfma_f32_16x16x32_bf16 B-fragment order [k*k][cin/32][cout/16][plane h,m,l][lane][8 bf16]
  * (conv_mfma_bf3.hip).  `transposed`: 0 = Conv2d weight [cout,cin,k,k]; 1 = ConvTranspose2d
- * weight [cin,cout,k,k]; 2 = data-gradient form of a Conv2d weight (channel roles swapped, taps
- * flipped; pass cout' = cin, cin' = cout). */
+ * weight [cin,cout,k,k] as the direct kernel reads it; 2 = a [cin,cout,k,k] tensor with the taps
+ * flipped: the data-gradient form of a Conv2d weight (pass cout' = cin, cin' = cout) and the
+ * forward form of a ConvTranspose2d weight on the MFMA kernels, which run MVAL_OP_DECONV as a
+ * stride-1 conv over the zero-dilated input (pass cout, cin as stored).  A ConvTranspose2d's data
+ * gradient is a plain conv with its weight read as [cout' = cin][cin' = cout]: transposed = 0. */
 size_t mval_packed_weight_floats(int pack, int cout, int cin, int k);
 int mval_pack_conv_weights(int pack, int transposed, const float* w, float* packed, int cout, int cin, int k,
                            void* stream);
@@ -235,7 +238,8 @@ int mval_maxpool_bwd(const float* gout, const float* x, float* gin, int N, int H
 /* Data gradient of a conv (geometry given in FORWARD terms: x [N,hin,win,cin] -> z
  * [N,hout,wout,cout], k/stride/pad): dx (+)= conv(dz zero-dilated by the stride, flipped W^T).
  * w_packed: mval_pack_conv_weights(pack, transposed = 2, w, ..., cout' = cin, cin' = cout, k);
- * ones / zeros: >= cin floats of 1.0 / 0.0; algo = MVAL_ALGO_MFMA needs cout % 16 == 0. */
+ * ones / zeros: >= cin floats of 1.0 / 0.0; algo = MVAL_ALGO_MFMA needs cout % 16 == 0,
+ * MVAL_ALGO_MFMA_BF3 cout % 32 == 0 (or 48) and k = 3, or k = 1 with stride 1. */
 int mval_conv_dgrad(const float* dz, const float* w_packed, const float* ones, const float* zeros, float* dx,
                     int accumulate, int N, int hin, int win, int cin, int hout, int wout, int cout, int k,
                     int stride, int pad, int algo, void* stream);
@@ -243,7 +247,12 @@ int mval_conv_dgrad(const float* dz, const float* w_packed, const float* ones, c
 /* One operator of the training graph: the forward geometry / arena offsets (`op`, as in
  * inference, weights packed for the forward kernel at op.w_off; op.shift_off = bias for a conv
  * without BatchNorm) plus what backward needs.  Offsets are floats into `arena` (activations,
- * no reuse), `garena` (activation gradients, zero-filled by the caller) and `params`. */
+ * no reuse), `garena` (activation gradients, same layout) and `params`.  garena is NOT zero-filled:
+ * `first_touch` marks the gradient slots this op writes FIRST in backward order (bit 0 data
+ * gradient, bit 1 res1, bit 2 res2): those are stored, later writers accumulate; the caller
+ * zero-fills only slots that no op writes and places the loss gradient in the last op's gout.
+ * op.kind may be MVAL_OP_CONV, MVAL_OP_MAXPOOL (no parameters) or MVAL_OP_DECONV (k4 s2 p1 with
+ * BatchNorm, MVAL_ALGO_MFMA; wd_off = its weight packed as a Conv2d weight, transposed = 0). */
 typedef struct mval_train_op {
   mval_op op;
   int64_t z_off;      /* raw conv output at conv resolution (arena); unused when has_bn == 0 */
