@@ -32,6 +32,8 @@
 // mix of the chunk loop (ISA): ~0.9 vector instructions per MFMA, i.e. under the 2-per-MFMA issue
 // budget; LDS fragment reads are conflict-free for the hardware's b128 lane groups on 16-wide
 // stride-1 tiles (2-way on 8-wide and stride-2 tiles, <= 3 ms of launches together).
+// 8-wave workgroups (128 px x 64 couts, the two wave rows re-reading each weight block through L1, i.e.
+// half the L2 weight stream, which PMC puts at ~10 TB/s of the ~17-19 TB/s L2 can deliver): -6..-15 %.
 // All variants sit at ~50 us / 190 TFLOP/s on the 64..256-channel layers (46 % of the split peak;
 // the guide's tuned 8-phase bf16 GEMM reaches 53-59 % of peak on random data).
 // Used for 3x3 convs with cin % 32 == 0 (or cin = 48) when the plan selects MVAL_ALGO_MFMA_BF3.
