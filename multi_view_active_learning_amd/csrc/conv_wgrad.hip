@@ -20,8 +20,8 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-int mval_launch_wgrad_bf3(const float* x, const float* dz, float* slabs, int N, int H, int W, int Cin, int Cout,
-                          int max_slabs, hipStream_t s);  // conv_wgrad_bf3.hip
+int mval_launch_wgrad_bf3(const float* x, const float* dz, float* slabs, int N, int Hin, int Win, int Cin, int Hout,
+                          int Wout, int Cout, int k, int stride, int max_slabs, hipStream_t s);  // conv_wgrad_bf3.hip
 
 #define WG_CB 32   // cin / cout block
 #define WG_LD 48   // LDS row stride (floats)
@@ -347,8 +347,8 @@ extern "C" int mval_conv_wgrad(const float* x, const float* dz, float* dw, float
                     (((k == 1 || k == 3) && (stride == 1 || stride == 2) && pad == k / 2) || (k == 4 && stride == 2 && pad == 1));
   const bool stem = x_nchw && Cin == 3 && (k == 3 || k == 7) && stride == 2 && pad == k / 2 && (Cout & 15) == 0 && Cout <= 64;
   int PS = 0;
-  if (!x_nchw && k == 3 && stride == 1 && pad == 1)  // split-bf16 kernel (conv_wgrad_bf3.hip); 0 = not covered
-    PS = mval_launch_wgrad_bf3(x, dz, ws, N, Hin, Win, Cin, Cout, wg_splits(Cin, Cout, 1024), s);
+  if (!x_nchw && pad == k / 2)  // split-bf16 kernel (conv_wgrad_bf3.hip); 0 = shape not covered
+    PS = mval_launch_wgrad_bf3(x, dz, ws, N, Hin, Win, Cin, Hout, Wout, Cout, k, stride, wg_splits(Cin, Cout, 1024), s);
   if (PS > 0) {
     MVAL_CHECK_LAUNCH("mval_conv_wgrad/bf3");
   } else if (stem) {

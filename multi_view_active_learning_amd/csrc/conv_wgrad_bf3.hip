@@ -1,5 +1,5 @@
-// Weight gradient of the 3x3 stride-1 convs on the bf16 matrix cores with the exact three-way
-// bf16 split (see conv_mfma_bf3.hip): 2.67x the MFMA rate of the exact-fp32 kernel in
+// Weight gradient of the 3x3 (stride 1 / 2) and wide 1x1 convs on the bf16 matrix cores with the exact
+// three-way bf16 split (see conv_mfma_bf3.hip): 2.67x the MFMA rate of the exact-fp32 kernel in
 // conv_wgrad.hip, same results to fp32 rounding.
 //
 //   dW[tap][ci][co] = sum over pixels p of  x[p + tap][ci] * dz[p][co]
@@ -16,7 +16,8 @@
 //     rows of the image apart, which is conflict-free for 96-byte and 160-byte rows;
 //   * a workgroup owns 32 cin x (32 or 64) cout x 9 taps: wave = (cin tile, cout tile pair), nine
 //     taps x NT accumulator tiles in registers; per k-step and wave 54 + 6 NT transposed reads feed
-//     54 NT MFMAs;
+//     54 NT MFMAs (1x1 convs: 64 cin x 64 cout per workgroup, 2 x 2 tiles per wave; stride 2: 32-pixel
+//     tiles, fragment pixels two patch rows apart -- 2-way bank conflicts, accepted);
 //   * split-K over workgroups, per-split slabs and the float64 slab reduction exactly as in
 //     conv_wgrad.hip (same slab layout, same reduce kernel); the next tile's operands travel
 //     global -> registers during the MFMA loop.
@@ -33,13 +34,11 @@ typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
 
-#define WB_XROW 96  // bytes per patch pixel and plane: 32 cin bf16 + 32 pad
-
 struct WgradBf3Args {
-  const float* x;   // NHWC (N, H, W, Cin)
-  const float* dz;  // NHWC (N, H, W, Cout)
-  float* slabs;     // [PS][9][Cin][Cout]
-  int N, H, W, Cin, Cout;
+  const float* x;   // NHWC (N, Hin, Win, Cin)
+  const float* dz;  // NHWC (N, H, W, Cout): the conv's output resolution
+  float* slabs;     // [PS][k*k][Cin][Cout]
+  int N, Hin, Win, H, W, Cin, Cout;
   int tiles_x, tiles_y, ntiles, PS;
 };
 
@@ -70,26 +69,31 @@ __device__ __forceinline__ bf16x8 wb_frag(const char* lo, const char* hi) {
   return __builtin_bit_cast(bf16x8, v);
 }
 
-template <int TW, int NT>
+// KS x KS taps, stride S, tile TH x TW output pixels, NT cout tiles and MI cin tiles (of 16) per wave
+template <int KS, int S, int TH, int TW, int NT, int MI>
 __global__ __launch_bounds__(256) void conv_wgrad_bf3_kernel(WgradBf3Args a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int TH = 64 / TW, MT = 64;
-  constexpr int PH = TH + 2, PW = TW + 2, PPX = PH * PW;
-  constexpr int CO = 32 * NT;               // couts per workgroup
-  constexpr int ZROW = CO * 2 + 32;         // bytes per dz pixel and plane (96 / 160)
-  constexpr int XPLANE = PPX * WB_XROW, ZPLANE = MT * ZROW;
-  constexpr int NEX = (PPX * 8 + 255) / 256, NEZ = MT * (CO / 4) / 256;
-  char* xl = smem;                 // [3][PPX][WB_XROW]
+  constexpr int T = KS * KS, MT = TH * TW;
+  constexpr int PH = (TH - 1) * S + KS, PW = (TW - 1) * S + KS, PPX = PH * PW;
+  constexpr int CI = 32 * MI, CO = 32 * NT;   // channels per workgroup
+  constexpr int XROW = CI * 2 + 32, ZROW = CO * 2 + 32;  // bytes per pixel and plane (96 / 160)
+  constexpr int XPLANE = PPX * XROW, ZPLANE = MT * ZROW;
+  constexpr int XQ = CI / 4, ZQ = CO / 4;     // float4 per pixel
+  constexpr int NEX = (PPX * XQ + 255) / 256, NEZ = (MT * ZQ + 255) / 256;
+  char* xl = smem;                 // [3][PPX][XROW]
   char* zl = smem + 3 * XPLANE;    // [3][MT][ZROW]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int ci_t = wave & 1, co_p = wave >> 1;  // cin tile (16) / cout group (16 * NT) of this wave
-  const int ci0 = blockIdx.y * 32, co0 = blockIdx.z * CO;
+  const int ci_g = wave & 1, co_g = wave >> 1;  // cin group (16 * MI) / cout group (16 * NT) of this wave
+  const int ci0 = blockIdx.y * CI, co0 = blockIdx.z * CO;
+  const int pad = KS / 2;
 
-  f32x4 acc[9][NT];
+  f32x4 acc[T][MI][NT];
 #pragma unroll
-  for (int t = 0; t < 9; t++)
+  for (int t = 0; t < T; t++)
 #pragma unroll
-    for (int nt = 0; nt < NT; nt++) acc[t][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int mi = 0; mi < MI; mi++)
+#pragma unroll
+      for (int nt = 0; nt < NT; nt++) acc[t][mi][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   // transposed-read lane roles: group g = k-group, q = which of the block's 4 pixels this lane
   // addresses, p = which 4-channel quarter of the 16 channels
@@ -101,21 +105,20 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf3_kernel(WgradBf3Args a) {
     px_lo = 4 * (g & 1) + q; py_lo = g >> 1; py_step = 2;
   }
   constexpr int KROWS = (TW == 16) ? 2 : 4;  // tile rows per k-step
-  const int xoff = (py_lo * PW + px_lo) * WB_XROW + ci_t * 32 + p * 8;
-  const int zoff = (py_lo * TW + px_lo) * ZROW + co_p * (32 * NT) + p * 8;
+  static_assert(TH % KROWS == 0, "tile height must hold whole k-steps");
+  const int xoff = (py_lo * S * PW + px_lo * S) * XROW + ci_g * (32 * MI) + p * 8;
+  const int zoff = (py_lo * TW + px_lo) * ZROW + co_g * (32 * NT) + p * 8;
 
   // staging slots (tile-invariant)
-  const int q4 = (tid & 7) * 4;
   int xrow[NEX], xcol[NEX];
 #pragma unroll
   for (int i = 0; i < NEX; i++) {
-    const int e = tid + 256 * i, px = e >> 3;
+    const int px = (tid + 256 * i) / XQ;
     xrow[i] = px / PW;
     xcol[i] = px - xrow[i] * PW;
   }
-  constexpr int ZQ = CO / 4;  // float4 per dz pixel
-  const int zq4 = (tid % ZQ) * 4;
-  const bool cx_ok = ci0 + q4 < a.Cin, cz_ok = co0 + zq4 < a.Cout;
+  const int xq4 = (tid % XQ) * 4, zq4 = (tid % ZQ) * 4;  // 256 % XQ == 0 == 256 % ZQ
+  const bool cx_ok = ci0 + xq4 < a.Cin, cz_ok = co0 + zq4 < a.Cout;
 
   f32x4 xr[NEX], zr[NEZ];
   auto load_tile = [&](int t) {
@@ -124,16 +127,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf3_kernel(WgradBf3Args a) {
     const int oy0 = (t % a.tiles_y) * TH, ox0 = txi * TW, n = t / a.tiles_y;
 #pragma unroll
     for (int i = 0; i < NEX; i++) {
-      const int iy = oy0 - 1 + xrow[i], ix = ox0 - 1 + xcol[i];
-      const bool ok = tid + 256 * i < PPX * 8 && cx_ok && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-      xr[i] = ok ? *reinterpret_cast<const f32x4*>(a.x + (((int64_t)n * a.H + iy) * a.W + ix) * a.Cin + ci0 + q4)
+      const int iy = oy0 * S - pad + xrow[i], ix = ox0 * S - pad + xcol[i];
+      const bool ok = tid + 256 * i < PPX * XQ && cx_ok && (unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win;
+      xr[i] = ok ? *reinterpret_cast<const f32x4*>(a.x + (((int64_t)n * a.Hin + iy) * a.Win + ix) * a.Cin + ci0 + xq4)
                  : (f32x4){0.f, 0.f, 0.f, 0.f};
     }
 #pragma unroll
     for (int i = 0; i < NEZ; i++) {
       const int pz = (tid + 256 * i) / ZQ;
       const int y = oy0 + pz / TW, x = ox0 + pz % TW;
-      zr[i] = (cz_ok && y < a.H && x < a.W)
+      zr[i] = (tid + 256 * i < MT * ZQ && cz_ok && y < a.H && x < a.W)
                   ? *reinterpret_cast<const f32x4*>(a.dz + (((int64_t)n * a.H + y) * a.W + x) * a.Cout + co0 + zq4)
                   : (f32x4){0.f, 0.f, 0.f, 0.f};
     }
@@ -146,12 +149,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf3_kernel(WgradBf3Args a) {
 #pragma unroll
     for (int i = 0; i < NEX; i++) {
       const int e = tid + 256 * i;
-      if (e < PPX * 8) wb_split_store(xr[i], xl + (e >> 3) * WB_XROW + (e & 7) * 8, XPLANE);
+      if (e < PPX * XQ) wb_split_store(xr[i], xl + (e / XQ) * XROW + (e % XQ) * 8, XPLANE);
     }
 #pragma unroll
     for (int i = 0; i < NEZ; i++) {
       const int e = tid + 256 * i;
-      wb_split_store(zr[i], zl + (e / ZQ) * ZROW + (e % ZQ) * 8, ZPLANE);
+      if (e < MT * ZQ) wb_split_store(zr[i], zl + (e / ZQ) * ZROW + (e % ZQ) * 8, ZPLANE);
     }
     __syncthreads();
     if (tile + a.PS < a.ntiles) load_tile(tile + a.PS);
@@ -165,23 +168,26 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf3_kernel(WgradBf3Args a) {
 #pragma unroll
         for (int pl = 0; pl < 3; pl++)
           zf[nt][pl] = wb_frag(zb + pl * ZPLANE + nt * 32, zb + pl * ZPLANE + nt * 32 + py_step * TW * ZROW);
-      const char* xb = xl + xoff + ks * KROWS * PW * WB_XROW;
+      const char* xb = xl + xoff + ks * KROWS * S * PW * XROW;
 #pragma unroll
-      for (int t = 0; t < 9; t++) {
-        const char* xt = xb + ((t / 3) * PW + t % 3) * WB_XROW;
-        const bf16x8 xh = wb_frag(xt, xt + py_step * PW * WB_XROW);
-        const bf16x8 xm = wb_frag(xt + XPLANE, xt + XPLANE + py_step * PW * WB_XROW);
-        const bf16x8 xlo = wb_frag(xt + 2 * XPLANE, xt + 2 * XPLANE + py_step * PW * WB_XROW);
+      for (int t = 0; t < T; t++) {
 #pragma unroll
-        for (int nt = 0; nt < NT; nt++) {
-          f32x4 c = acc[t][nt];  // small terms first
-          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xlo, zf[nt][0], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, zf[nt][2], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xm, zf[nt][1], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xm, zf[nt][0], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, zf[nt][1], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, zf[nt][0], c, 0, 0, 0);
-          acc[t][nt] = c;
+        for (int mi = 0; mi < MI; mi++) {
+          const char* xt = xb + ((t / KS) * PW + t % KS) * XROW + mi * 32;
+          const bf16x8 xh = wb_frag(xt, xt + py_step * S * PW * XROW);
+          const bf16x8 xm = wb_frag(xt + XPLANE, xt + XPLANE + py_step * S * PW * XROW);
+          const bf16x8 xlo = wb_frag(xt + 2 * XPLANE, xt + 2 * XPLANE + py_step * S * PW * XROW);
+#pragma unroll
+          for (int nt = 0; nt < NT; nt++) {
+            f32x4 c = acc[t][mi][nt];  // small terms first
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xlo, zf[nt][0], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, zf[nt][2], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xm, zf[nt][1], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xm, zf[nt][0], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, zf[nt][1], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, zf[nt][0], c, 0, 0, 0);
+            acc[t][mi][nt] = c;
+          }
         }
       }
     }
@@ -189,49 +195,71 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf3_kernel(WgradBf3Args a) {
   // slab[ps][t][ci][co]; C layout: row (cin) = (lane >> 4) * 4 + r, col (cout) = lane & 15
 #pragma unroll
   for (int nt = 0; nt < NT; nt++) {
-    const int co = co0 + co_p * (16 * NT) + nt * 16 + (lane & 15);
+    const int co = co0 + co_g * (16 * NT) + nt * 16 + (lane & 15);
 #pragma unroll
-    for (int t = 0; t < 9; t++)
+    for (int mi = 0; mi < MI; mi++)
 #pragma unroll
-      for (int r = 0; r < 4; r++) {
-        const int ci = ci0 + ci_t * 16 + (lane >> 4) * 4 + r;
-        if (ci < a.Cin && co < a.Cout)
-          a.slabs[(((int64_t)blockIdx.x * 9 + t) * a.Cin + ci) * a.Cout + co] = acc[t][nt][r];
-      }
+      for (int t = 0; t < T; t++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int ci = ci0 + ci_g * (16 * MI) + mi * 16 + (lane >> 4) * 4 + r;
+          if (ci < a.Cin && co < a.Cout)
+            a.slabs[(((int64_t)blockIdx.x * T + t) * a.Cin + ci) * a.Cout + co] = acc[t][mi][nt][r];
+        }
   }
 }
 
-// Launches the split-bf16 weight gradient of a 3x3 stride-1 pad-1 conv into `slabs`
-// ([PS][9][Cin][Cout]); returns the number of slabs written, or 0 when the shape is not covered
-// (the caller then uses the exact-fp32 kernel).  max_slabs bounds PS (workspace size).
-int mval_launch_wgrad_bf3(const float* x, const float* dz, float* slabs, int N, int H, int W, int Cin, int Cout,
-                          int max_slabs, hipStream_t s) {
+template <int KS, int S, int TH, int TW, int NT, int MI>
+static void wb_launch(const WgradBf3Args& a, dim3 grid, hipStream_t s) {
+  constexpr int PPX = ((TH - 1) * S + KS) * ((TW - 1) * S + KS);
+  constexpr size_t smem = (size_t)3 * PPX * (64 * MI + 32) + (size_t)3 * TH * TW * (64 * NT + 32);
+  hipLaunchKernelGGL((conv_wgrad_bf3_kernel<KS, S, TH, TW, NT, MI>), grid, dim3(256), smem, s, a);
+}
+
+// Launches the split-bf16 weight gradient of a conv (3x3 stride 1 / 2, pad 1; 1x1 stride 1 with >= 64
+// channels on both sides) into `slabs` ([PS][k*k][Cin][Cout]); returns the number of slabs written, or
+// 0 when the shape is not covered (the caller then uses the exact-fp32 kernel).  max_slabs bounds PS
+// (workspace size).  x is (N, Hin, Win, Cin), dz (N, Hout, Wout, Cout).
+int mval_launch_wgrad_bf3(const float* x, const float* dz, float* slabs, int N, int Hin, int Win, int Cin, int Hout,
+                          int Wout, int Cout, int k, int stride, int max_slabs, hipStream_t s) {
   static int enabled = -1;
   if (enabled < 0) {
     const char* e = getenv("MVAL_CONV");
     enabled = (e && e[0] == 'f') ? 0 : 1;  // MVAL_CONV=fp32: exact-fp32 MFMA kernels everywhere
   }
   if (!enabled || (Cin & 3) || (Cout & 3) || Cin < 16 || Cout < 16) return 0;
+  const bool k3 = k == 3 && (stride == 1 || stride == 2);
+  const bool k1 = k == 1 && stride == 1 && Cin >= 64 && Cout >= 64;
+  if (!k3 && !k1) return 0;
   WgradBf3Args a;
   a.x = x; a.dz = dz; a.slabs = slabs;
-  a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
-  const int tw = W > 8 ? 16 : 8, th = 64 / tw;
-  a.tiles_x = (W + tw - 1) / tw;
-  a.tiles_y = (H + th - 1) / th;
+  a.N = N; a.Hin = Hin; a.Win = Win; a.H = Hout; a.W = Wout; a.Cin = Cin; a.Cout = Cout;
+  const int tw = Wout > 8 ? 16 : 8;
+  const int th = (stride == 2 ? 32 : 64) / tw;  // stride-2 patches are ~4x larger per pixel: 32-pixel tiles
+  a.tiles_x = (Wout + tw - 1) / tw;
+  a.tiles_y = (Hout + th - 1) / th;
   a.ntiles = a.tiles_x * a.tiles_y * N;
-  const int nt = Cout > 32 ? 2 : 1;
-  const int cb = ((Cin + 31) / 32) * ((Cout + 32 * nt - 1) / (32 * nt));
+  const int nt = (k1 || Cout > 32) ? 2 : 1, mi = k1 ? 2 : 1;
+  const int cb = ((Cin + 32 * mi - 1) / (32 * mi)) * ((Cout + 32 * nt - 1) / (32 * nt));
   int PS = 768 / cb;  // ~3 workgroups per CU resident (50-62 KB of LDS each)
   if (PS < 1) PS = 1;
   if (PS > max_slabs) PS = max_slabs;
   if (PS > a.ntiles) PS = a.ntiles;
   a.PS = PS;
-  const int ppx = (th + 2) * (tw + 2);
-  const size_t smem = (size_t)3 * ppx * WB_XROW + (size_t)3 * 64 * (64 * nt + 32);
-  dim3 grid(PS, (Cin + 31) / 32, (Cout + 32 * nt - 1) / (32 * nt));
-  if (tw == 16 && nt == 2) hipLaunchKernelGGL((conv_wgrad_bf3_kernel<16, 2>), grid, dim3(256), smem, s, a);
-  else if (tw == 16) hipLaunchKernelGGL((conv_wgrad_bf3_kernel<16, 1>), grid, dim3(256), smem, s, a);
-  else if (nt == 2) hipLaunchKernelGGL((conv_wgrad_bf3_kernel<8, 2>), grid, dim3(256), smem, s, a);
-  else hipLaunchKernelGGL((conv_wgrad_bf3_kernel<8, 1>), grid, dim3(256), smem, s, a);
+  dim3 grid(PS, (Cin + 32 * mi - 1) / (32 * mi), (Cout + 32 * nt - 1) / (32 * nt));
+  if (k1) {
+    if (tw == 16) wb_launch<1, 1, 4, 16, 2, 2>(a, grid, s);
+    else wb_launch<1, 1, 8, 8, 2, 2>(a, grid, s);
+  } else if (stride == 1) {
+    if (tw == 16 && nt == 2) wb_launch<3, 1, 4, 16, 2, 1>(a, grid, s);
+    else if (tw == 16) wb_launch<3, 1, 4, 16, 1, 1>(a, grid, s);
+    else if (nt == 2) wb_launch<3, 1, 8, 8, 2, 1>(a, grid, s);
+    else wb_launch<3, 1, 8, 8, 1, 1>(a, grid, s);
+  } else {
+    if (tw == 16 && nt == 2) wb_launch<3, 2, 2, 16, 2, 1>(a, grid, s);
+    else if (tw == 16) wb_launch<3, 2, 2, 16, 1, 1>(a, grid, s);
+    else if (nt == 2) wb_launch<3, 2, 4, 8, 2, 1>(a, grid, s);
+    else wb_launch<3, 2, 4, 8, 1, 1>(a, grid, s);
+  }
   return PS;
 }

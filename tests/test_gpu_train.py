@@ -92,7 +92,9 @@ def test_bn_train_ops_vs_torch(dev):
 
 
 WG_CASES = [(2, 32, 32, 16, 16, 3, 1), (2, 64, 32, 16, 16, 3, 2), (3, 32, 64, 8, 8, 1, 1), (2, 128, 128, 8, 8, 3, 1),
-            (2, 48, 96, 12, 9, 3, 1), (2, 32, 19, 16, 16, 1, 1), (4, 64, 64, 32, 32, 3, 1)]
+            (2, 48, 96, 12, 9, 3, 1), (2, 32, 19, 16, 16, 1, 1), (4, 64, 64, 32, 32, 3, 1),
+            (2, 64, 128, 16, 16, 1, 1), (3, 256, 64, 8, 8, 1, 1), (2, 64, 96, 20, 12, 1, 1), (2, 64, 64, 16, 8, 3, 2),
+            (3, 32, 128, 24, 40, 3, 2), (2, 128, 256, 16, 16, 3, 2)]
 
 
 @pytest.mark.parametrize("case", WG_CASES, ids=lambda c: "n%d_c%d-%d_%dx%d_k%ds%d" % c)
