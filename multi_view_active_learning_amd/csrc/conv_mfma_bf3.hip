@@ -34,6 +34,9 @@
 // stride-1 tiles (2-way on 8-wide and stride-2 tiles, <= 3 ms of launches together).
 // 8-wave workgroups (128 px x 64 couts, the two wave rows re-reading each weight block through L1, i.e.
 // half the L2 weight stream, which PMC puts at ~10 TB/s of the ~17-19 TB/s L2 can deliver): -6..-15 %.
+// weight fragments issued as asm loads a whole tap column (72 MFMAs) ahead instead of the ~18 MFMAs the
+// compiler leaves after sinking them: -7 % (168 VGPRs, small spills) -- L2 latency is already hidden by the
+// three waves per SIMD.
 // All variants sit at ~50 us / 190 TFLOP/s on the 64..256-channel layers (46 % of the split peak;
 // the guide's tuned 8-phase bf16 GEMM reaches 53-59 % of peak on random data).
 // Used for 3x3 convs with cin % 32 == 0 (or cin = 48) when the plan selects MVAL_ALGO_MFMA_BF3.
