@@ -14,6 +14,13 @@ struct ConvArgs {
   int k, stride, pad;
   int up, relu, in_nchw, out_nchw;
   int dil;  // 1, or 2: the input is read as if zero-dilated by 2 (data gradient of a stride-2 conv)
+  // Views (all 0 = plain conv; ConvArgs is zero-initialised by its creators):
+  //   org_dy / org_dx  extra shift of the input window on top of -pad (asymmetric windows);
+  //   os_log2, ooy, oox  the (Hout, Wout) grid is written to pixel (y << os_log2) + ooy, (x << os_log2) + oox
+  //                      of an (Hout << os_log2) x (Wout << os_log2) tensor (parity planes of a transposed conv)
+  //   in_sub_log2  the input is read at pixels (y << in_sub_log2, x << in_sub_log2): a stride-2 1x1 conv is
+  //                a stride-1 1x1 conv on that subsampled view (nothing else is staged)
+  int org_dy, org_dx, os_log2, ooy, oox, in_sub_log2;
   // MFMA tiling (filled by the launcher)
   int th, tw, tn, tw_log2, thw_log2;
   int tiles_x, tiles_y;
@@ -72,7 +79,9 @@ __device__ __forceinline__ void conv_tile_store(const ConvArgs& a, const float* 
         const int y = oy0 + (rem >> a.tw_log2), x = ox0 + (rem & ((1 << a.tw_log2) - 1));
         const int n = n0 + tni;
         const bool ok = e < MT * Q && c < a.Cout && n < a.N && y < a.Hout && x < a.Wout;
-        off[i] = ok ? (((int64_t)n * a.Hout + y) * a.Wout + x) * a.Cout + c : -1;
+        off[i] = ok ? (((int64_t)n * (a.Hout << a.os_log2) + (y << a.os_log2) + a.ooy) * (a.Wout << a.os_log2) +
+                       (x << a.os_log2) + a.oox) * a.Cout + c
+                    : -1;
         r1[i] = (ok && a.res1) ? *reinterpret_cast<const conv_f32x4*>(a.res1 + off[i]) : (conv_f32x4){0.f, 0.f, 0.f, 0.f};
         r2[i] = (ok && a.res2) ? *reinterpret_cast<const conv_f32x4*>(a.res2 + off[i]) : (conv_f32x4){0.f, 0.f, 0.f, 0.f};
       }

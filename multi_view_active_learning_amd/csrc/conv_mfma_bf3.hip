@@ -77,7 +77,7 @@ __global__ __launch_bounds__(64 * WN * WM) void conv_bf3_kernel(ConvArgs a) {
   constexpr int MT = 16 * MS * WM;
   constexpr int NTILE = 16 * NT * WN;
   constexpr int LDW = NTILE + OPAD;
-  constexpr int pad = (KS - 1) / 2;
+  constexpr int pad = KS / 2;  // 3x3: 1, 1x1: 0; the 2x2 parity kernels of a transposed conv: 1 (+ org_dy / org_dx)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wn = wave % WN, wm = wave / WN;
   const int PH = (a.th - 1) * S + KS, PW = (a.tw - 1) * S + KS;
@@ -88,7 +88,7 @@ __global__ __launch_bounds__(64 * WN * WM) void conv_bf3_kernel(ConvArgs a) {
   const int tyi = t % a.tiles_y;
   const int n0 = (t / a.tiles_y) * a.tn;
   const int oy0 = tyi * a.th, ox0 = txi * a.tw;
-  const int iy0 = oy0 * S - pad, ix0 = ox0 * S - pad;
+  const int iy0 = oy0 * S - pad + a.org_dy, ix0 = ox0 * S - pad + a.org_dx;
 
   const int ns0 = (blockIdx.y * WN + wn) * NT;
   const bool wave_active = ns0 < a.NS_total;
@@ -120,8 +120,9 @@ __global__ __launch_bounds__(64 * WN * WM) void conv_bf3_kernel(ConvArgs a) {
     const int iy = iy0 + pyy, ix = ix0 + pxx, n = n0 + tni;
     const int dsh = a.dil - 1;
     const int sy = iy >> dsh, sx = ix >> dsh;
-    const bool ok = e < patch_e && n < a.N && iy >= 0 && ix >= 0 && ((iy | ix) & dsh) == 0 && sy < a.Hin && sx < a.Win;
-    goff[i] = ok ? ((n * a.Hin + sy) * a.Win + sx) * a.Cin + q * 4 : -1;
+    const int ay = sy << a.in_sub_log2, ax = sx << a.in_sub_log2;  // subsampled input view (stride-2 1x1 convs)
+    const bool ok = e < patch_e && n < a.N && iy >= 0 && ix >= 0 && ((iy | ix) & dsh) == 0 && ay < a.Hin && ax < a.Win;
+    goff[i] = ok ? ((n * a.Hin + ay) * a.Win + ax) * a.Cin + q * 4 : -1;
   }
 
   f32x4 acc[MS][NT];
@@ -382,6 +383,16 @@ int mval_launch_conv_bf3(const ConvArgs& a, hipStream_t s) {
   // keeping two chunks in flight instead of one measured slower, 226 us)
   if (a.k == 1 && a.pad == 0 && a.stride == 1 && a.dil == 1 && !a.out_nchw && (a.Cout & 15) == 0)
     return dispatch_bf3<1, 1>(a, s);
+  // stride-2 1x1 conv (ResNet downsample paths) = stride-1 1x1 conv on the even pixels
+  if (a.k == 1 && a.pad == 0 && a.stride == 2 && a.dil == 1 && !a.out_nchw && (a.Cout & 15) == 0 && a.in_sub_log2 == 0) {
+    ConvArgs b = a;
+    b.stride = 1;
+    b.in_sub_log2 = 1;
+    return dispatch_bf3<1, 1>(b, s);
+  }
+  // 2x2 parity kernel of a transposed conv (weights packed with mode 3, one parity's 4 taps at a.w)
+  if (a.k == 2 && a.pad == 1 && a.stride == 1 && a.dil == 1 && !a.out_nchw && a.up == 0 && (a.Cout & 3) == 0)
+    return dispatch_bf3<2, 1>(a, s);
   if (a.k != 3 || a.pad != 1) return 1;
   // dil == 2: data gradient of a stride-2 conv (dz read as a zero-dilated input: 3 of 4 staged values
   // are zeros, still ~2x the exact-fp32 MFMA kernel)
@@ -429,7 +440,14 @@ __global__ void pack_bf3_kernel(const float* __restrict__ w, unsigned short* __r
   float v = 0.f;
   if (co < cout && ci < cin) {
     const int T = k * k;
-    if (mode == 2) v = w[((int64_t)ci * cout + co) * T + (T - 1 - t)];       // data-gradient form
+    if (mode == 3) {
+      // ConvTranspose2d(k4, s2, p1) as four 2x2 stride-1 convs, one per output parity (py, px):
+      // t = parity * 4 + (dy * 2 + dx); window row dy of parity py reads kernel row 3 - 2 dy (py = 0:
+      // input rows a - 1, a) or 2 - 2 dy (py = 1: rows a, a + 1); columns alike
+      const int pp = t >> 2, dy = (t >> 1) & 1, dx = t & 1;
+      const int ky = (pp >> 1) ? 2 - 2 * dy : 3 - 2 * dy, kx = (pp & 1) ? 2 - 2 * dx : 3 - 2 * dx;
+      v = w[((int64_t)ci * cout + co) * 16 + ky * 4 + kx];
+    } else if (mode == 2) v = w[((int64_t)ci * cout + co) * T + (T - 1 - t)];       // data-gradient form
     else if (mode == 1) v = w[((int64_t)ci * cout + co) * T + t];           // ConvTranspose2d layout
     else v = w[((int64_t)co * cin + ci) * T + t];
   }

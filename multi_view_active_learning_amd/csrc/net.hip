@@ -247,7 +247,7 @@ static void deconv_as_conv(ConvArgs& a, const mval_op* op) {
 
 extern "C" int mval_op_mfma_supported(const mval_op* op, int n_images) {
   if (!op || (op->kind != MVAL_OP_CONV && op->kind != MVAL_OP_DECONV) || n_images <= 0) return 0;
-  ConvArgs a;
+  ConvArgs a = {};
   a.in = a.w = a.scale = a.shift = a.res1 = a.res2 = nullptr;
   a.out = nullptr;
   fill_geometry(a, op, n_images);
@@ -255,20 +255,34 @@ extern "C" int mval_op_mfma_supported(const mval_op* op, int n_images) {
   return mval_conv_mfma_supported(a);
 }
 
+// ConvTranspose2d(k4, s2, p1) on the split-bf16 kernel: four 2x2 stride-1 convs, one per output parity
+// (py, px), each over the (hin, win) grid and scattered to rows 2a + py, columns 2b + px.  Weights:
+// pack mode 3 ([parity][2x2 taps]...), one parity = a quarter of the k = 4 packed buffer.
+static void deconv_parity(ConvArgs& a, const mval_op* op, int parity, const float* w_packed) {
+  a.k = 2; a.stride = 1; a.pad = 1; a.dil = 1;
+  a.Hout = op->hin; a.Wout = op->win;
+  a.org_dy = parity >> 1; a.org_dx = parity & 1;
+  a.os_log2 = 1; a.ooy = parity >> 1; a.oox = parity & 1;
+  if (w_packed) a.w = w_packed + (size_t)parity * (mval_packed_weight_floats(MVAL_PACK_MFMA16_BF3, op->cout, op->cin, 4) / 4);
+}
+
 extern "C" int mval_op_algo_supported(const mval_op* op, int n_images, int algo) {
   if (algo == MVAL_ALGO_MFMA) return mval_op_mfma_supported(op, n_images);
-  if (algo != MVAL_ALGO_MFMA_BF3 || !op || op->kind != MVAL_OP_CONV || n_images <= 0) return 0;
-  ConvArgs a;
-  a.in = a.w = a.scale = a.shift = a.res1 = a.res2 = nullptr;
-  a.out = nullptr;
+  if (algo != MVAL_ALGO_MFMA_BF3 || !op || n_images <= 0) return 0;
+  if (op->kind != MVAL_OP_CONV && op->kind != MVAL_OP_DECONV) return 0;
+  ConvArgs a = {};
   fill_geometry(a, op, n_images);
+  if (op->kind == MVAL_OP_DECONV) {
+    if (op->k != 4 || op->stride != 2 || op->pad != 1 || op->up || op->out_nchw) return 0;
+    deconv_parity(a, op, 0, nullptr);
+  }
   return mval_conv_bf3_supported(a);
 }
 
 extern "C" int mval_op_launch(const mval_op* op, int n_images, float* workspace, const float* params,
                               const float* net_input, float* net_output, void* stream) {
   MVAL_REQUIRE(op && n_images > 0, "mval_op_launch: bad arguments");
-  ConvArgs a;
+  ConvArgs a = {};
   a.in = op->in_off >= 0 ? workspace + op->in_off : net_input;
   a.out = op->out_off >= 0 ? workspace + op->out_off : net_output;
   a.res1 = op->res1_off >= 0 ? workspace + op->res1_off : nullptr;
@@ -279,7 +293,14 @@ extern "C" int mval_op_launch(const mval_op* op, int n_images, float* workspace,
   fill_geometry(a, op, n_images);
   MVAL_REQUIRE(a.in && a.out, "mval_op_launch: missing input/output buffer");
   hipStream_t s = mval_stream(stream);
-  if (op->kind == MVAL_OP_CONV && op->algo == MVAL_ALGO_MFMA_BF3) {
+  if (op->kind == MVAL_OP_DECONV && op->algo == MVAL_ALGO_MFMA_BF3) {
+    const float* wp = a.w;
+    for (int parity = 0; parity < 4; parity++) {
+      deconv_parity(a, op, parity, wp);
+      int rc = mval_launch_conv_bf3(a, s);
+      MVAL_REQUIRE(rc == 0, "mval_op_launch: no bf16x3 MFMA kernel for the transposed conv cin%d cout%d", op->cin, op->cout);
+    }
+  } else if (op->kind == MVAL_OP_CONV && op->algo == MVAL_ALGO_MFMA_BF3) {
     int rc = mval_launch_conv_bf3(a, s);
     MVAL_REQUIRE(rc == 0, "mval_op_launch: no bf16x3 MFMA kernel for conv k%d s%d cin%d cout%d", op->k, op->stride, op->cin,
                  op->cout);

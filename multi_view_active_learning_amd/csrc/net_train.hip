@@ -71,7 +71,7 @@ extern "C" int mval_train_forward(const mval_train_op* ops, int n_ops, int n_ima
   for (int i = 0; i < n_ops; i++) {
     const mval_train_op& t = ops[i];
     const mval_op& op = t.op;
-    ConvArgs a;
+    ConvArgs a = {};
     geometry(a, op, n_images);
     a.in = op.in_off >= 0 ? arena + op.in_off : input_nchw;
     if (op.kind == MVAL_OP_MAXPOOL) {
@@ -153,7 +153,7 @@ extern "C" int mval_train_backward(const mval_train_op* ops, int n_ops, int n_im
                            op.stride, op.pad, 0, stream);
       if (rc) return rc;
       if (t.gin_off >= 0) {
-        ConvArgs a;
+        ConvArgs a = {};
         a.N = n_images;
         a.Hin = op.hout; a.Win = op.wout; a.Cin = op.cout;
         a.Hout = op.hin; a.Wout = op.win; a.Cout = op.cin;
@@ -197,7 +197,7 @@ extern "C" int mval_conv_dgrad(const float* dz, const float* w_packed, const flo
   MVAL_REQUIRE(dz && w_packed && ones && zeros && dx && N > 0, "mval_conv_dgrad: bad arguments");
   MVAL_REQUIRE(algo == MVAL_ALGO_MFMA || algo == MVAL_ALGO_MFMA_BF3 || stride == 1,
                "mval_conv_dgrad: strided data gradient needs an MFMA kernel");
-  ConvArgs a;
+  ConvArgs a = {};
   a.N = N;
   a.Hin = hout; a.Win = wout; a.Cin = cout;
   a.Hout = hin; a.Wout = win; a.Cout = cin;

@@ -76,7 +76,9 @@ def _pack_mode(op, pack):
     input) for the MFMA kernels."""
     if op.kind != "deconv":
         return 0
-    return 1 if pack == _PACK_OF[ALGO_DIRECT] else 2
+    # direct kernel: as stored (1); exact-fp32 MFMA: tap-flipped conv over the zero-dilated input (2);
+    # split-bf16 MFMA: four 2x2 parity kernels (3)
+    return {PACK_HWIO: 1, PACK_MFMA16: 2, PACK_MFMA16_BF3: 3}[pack]
 
 
 class InferencePlan:
@@ -161,7 +163,7 @@ class InferencePlan:
             if _mfma_ok(op, in_nchw) and lib.mval_op_mfma_supported(C.byref(m), C.c_int(n)):
                 m.algo = ALGO_MFMA
                 # 3x3 convs: fp32-accurate bf16x3 split on the bf16 matrix cores (2.67x MFMA rate)
-                if (_conv_mode() == "bf3" and op.k in (1, 3) and (op.cin % 32 == 0 or op.cin == 48)
+                if (_conv_mode() == "bf3" and (op.k in (1, 3) or op.kind == "deconv") and (op.cin % 32 == 0 or op.cin == 48)
                         and lib.mval_op_algo_supported(C.byref(m), C.c_int(n), C.c_int(ALGO_MFMA_BF3))):
                     m.algo = ALGO_MFMA_BF3
             m.in_off = -1 if op.src == g.input else offset[op.src]

@@ -22,7 +22,7 @@ def pack_weights(weight, algo, transposed=False):
     pack = _PACK_OF[algo]
     # ConvTranspose2d: as stored for the direct kernel (1), tap-flipped for the MFMA kernels (2), which
     # run it as a stride-1 conv over the zero-dilated input
-    mode = 0 if not transposed else (1 if algo == ALGO_DIRECT else 2)
+    mode = 0 if not transposed else {ALGO_DIRECT: 1, ALGO_MFMA: 2, ALGO_MFMA_BF3: 3}[algo]
     n = int(lib.mval_packed_weight_floats(C.c_int(pack), C.c_int(cout), C.c_int(cin), C.c_int(k)))
     out = torch.empty(n, dtype=torch.float32, device=weight.device)
     w = weight.detach().contiguous()

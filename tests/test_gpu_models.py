@@ -76,8 +76,8 @@ def test_fused_conv_vs_torch_cpu(dev, algo, case):
     from multi_view_active_learning_amd import ops
 
     n, cin, cout, h, w, k, stride, relu, r1, r2, up, out_nchw = case
-    if algo == "bf3" and ((cin % 32 and cin != 48) or (k == 1 and (stride != 1 or cout % 16 or out_nchw))):
-        pytest.skip("the bf16x3-split kernel covers 3x3 and stride-1 1x1 convs with cin % 32 == 0 (or 48)")
+    if algo == "bf3" and ((cin % 32 and cin != 48) or (k == 1 and (cout % 16 or out_nchw))):
+        pytest.skip("the bf16x3-split kernel covers 3x3 and 1x1 convs with cin % 32 == 0 (or 48)")
     rng = np.random.default_rng(hash(case) % 2**31)
     x = torch.from_numpy(rng.standard_normal((n, cin, h, w)).astype(np.float32))
     wt = torch.from_numpy((rng.standard_normal((cout, cin, k, k)) * np.sqrt(2.0 / (cin * k * k))).astype(np.float32))
@@ -141,9 +141,11 @@ def test_stem_maxpool_deconv_direct(dev):
 
 @pytest.mark.parametrize("shape", [(2, 64, 32, 8, 6), (3, 256, 256, 16, 12), (1, 2048, 256, 8, 6), (2, 32, 48, 5, 7)],
                          ids=lambda s: "n%d_c%d-%d_%dx%d" % s)
-def test_deconv_mfma_vs_torch_cpu(dev, shape):
-    """ConvTranspose2d(k4, s2, p1) + BN + ReLU (PoseResNet head) on the matrix cores: stride-1 conv over the
-    zero-dilated input with tap-flipped weights."""
+@pytest.mark.parametrize("algo", ["mfma", "bf3"])
+def test_deconv_mfma_vs_torch_cpu(dev, shape, algo):
+    """ConvTranspose2d(k4, s2, p1) + BN + ReLU (PoseResNet head) on the matrix cores: exact-fp32 MFMA as a
+    stride-1 conv over the zero-dilated input with tap-flipped weights; split-bf16 MFMA as four 2x2
+    parity convs scattered to the even / odd output rows and columns."""
     from multi_view_active_learning_amd import ops
 
     n, cin, cout, h, w = shape
@@ -154,7 +156,7 @@ def test_deconv_mfma_vs_torch_cpu(dev, shape):
     sh = torch.from_numpy(rng.standard_normal(cout).astype(np.float32))
     want = _ref_conv(x, wt, sc, sh, 2, True, None, None, 0, transposed=True)
     got = ops.fused_conv(x.permute(0, 2, 3, 1).contiguous().to(dev), wt.to(dev), sc.to(dev), sh.to(dev), stride=2, pad=1,
-                         relu=True, kind=ops.OP_DECONV, algo=ops.ALGO_MFMA)
+                         relu=True, kind=ops.OP_DECONV, algo=ops.ALGO_MFMA if algo == "mfma" else ops.ALGO_MFMA_BF3)
     assert tuple(got.shape) == (n, 2 * h, 2 * w, cout)
     np.testing.assert_allclose(got.permute(0, 3, 1, 2).cpu().numpy(), want.numpy(), rtol=1e-4, atol=3e-5)
 
