@@ -45,6 +45,12 @@ FLOP_PER_IMAGE = {"hrnet_w32_256": 20.387e9}  # conv FLOPs (2*MAC) 
 
 WORKLOADS = {
     # name: (arch, views, H, W, frames per step, joints, train?)
+    # BASELINE.json configs[0], the reference's own CPU-runnable plumbing case (8 images per step:
+    # launch-latency bound on a GPU; "c1x16" is the same network at 64 frames per step)
+    "c1": dict(arch="resnet50", v=2, h=256, w=192, frames=4, j=19, train=False,
+               desc="PoseResNet-50 2-view 256x192 batch-4 forward heat-maps + arg-max + RANSAC-DLT triangulation"),
+    "c1x16": dict(arch="resnet50", v=2, h=256, w=192, frames=64, j=19, train=False,
+                  desc="PoseResNet-50 2-view 256x192 batch-64 forward heat-maps + arg-max + RANSAC-DLT triangulation"),
     "c2": dict(arch="hrnet_w32", v=4, h=256, w=256, frames=32, j=19, train=False,
                desc="HRNet-W32 4-view 256x256 batch-32 forward heat-maps + arg-max + RANSAC-DLT triangulation"),
     # BASELINE.json configs[2]: same shapes, one training step (train-mode BN forward, masked MSE,
@@ -93,11 +99,15 @@ def cpu_baseline(wl, sd_np, seconds_target=20.0):
     valid = np.ones(j, dtype=bool)
     done, t0 = 0, time.perf_counter()
     with torch.no_grad():
-        arch = models.HRNET_W48 if wl["arch"] == "hrnet_w48" else models.HRNET_W32
-        models.hrnet_forward(sd, imgs[:v], arch)  # warm-up (page-in, thread pool)
+        if wl["arch"] == "resnet50":
+            fwd = lambda x: models.pose_resnet_forward(sd, x)
+        else:
+            arch = models.HRNET_W48 if wl["arch"] == "hrnet_w48" else models.HRNET_W32
+            fwd = lambda x: models.hrnet_forward(sd, x, arch)
+        fwd(imgs[:v])  # warm-up (page-in, thread pool)
         t0 = time.perf_counter()
         while True:
-            hm = models.hrnet_forward(sd, imgs, arch).numpy().reshape(frames_per_call, v, j, h // 4, w // 4)
+            hm = fwd(imgs).numpy().reshape(frames_per_call, v, j, h // 4, w // 4)
             for b in range(frames_per_call):
                 geometry.triangulation(hm[b], proj[b], 4, valid)
             done += frames_per_call
@@ -309,7 +319,8 @@ def main():
         if wl.get("pool"):
             total_units = wl["pool"] * v * args.steps
         out = {
-            "metric": ("frames*views/sec (training step) HRNet-W32 4-view 256x256" if train else
+            "metric": ("frames*views/sec (heatmap->triangulated 3D) PoseResNet-50 2-view 256x192" if wl["arch"] == "resnet50" else
+                       "frames*views/sec (training step) HRNet-W32 4-view 256x256" if train else
                        "frames*views/sec (pool scoring) HRNet-W48 8-view 384x288" if wl.get("score") else
                        "frames*views/sec (core-set selection pass over a fixed pool) HRNet-W48 8-view 384x288" if wl.get("pool") else
                        "frames*views/sec (heatmap->triangulated 3D) HRNet-W32 4-view 256x256"),
