@@ -112,6 +112,14 @@ int mval_masked_mse_bwd(const float* h, const float* g, const uint8_t* valid, co
  * per_sample [S] f32 = the same metric evaluated on each sample alone (strategy.py:1134). */
 int mval_mkpe(const float* pred, const float* gt, const float* valid, float* out, float* per_sample,
               int64_t S, int J, int gt_rows, void* stream);
+/* 3-D PCK / PCKh counters (utils/evaluation.py:150-195 compute_3d_pckh / compute_3d_pck, called from
+ * strategy.py:638-649).  pred [S,J,3], gt [S,gt_rows,J] (rows 0..2 = x,y,z), valid [S,J] (mode 0) f32;
+ * thresholds [T] f64 (device).  mode 0 = PCK in mm over valid joints, mode 1 = PCKh (threshold x the
+ * distance between gt joints 0 and 1, every joint).  hits [T,J] and counts [J] are int64; the fraction
+ * hits/counts is formed by the caller.  float32 distances with torch's operation order, so the counts
+ * equal the reference's. */
+int mval_pck3d(const float* pred, const float* gt, const float* valid, const double* thresholds, int T, int mode,
+               long long* hits, long long* counts, int64_t S, int J, int gt_rows, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Core-set selection (utils/coreset.py:35-95)

@@ -213,6 +213,24 @@ def mkpe(pred, gt, valid, s, j, gt_rows):
     return out, per
 
 
+def pck3d(pred, gt, valid, thresholds, mode):
+    """3-D PCK (mode 0, mm thresholds over valid joints) / PCKh (mode 1) counters: pred (S,J,3) f32, gt (S,R,J) f32,
+    valid (S,J) f32 or None -> hits (T,J) int64, counts (J,) int64 (device)."""
+    s, j, _ = pred.shape
+    thr = torch.as_tensor(list(thresholds), dtype=torch.float64).to(pred.device)
+    hits = torch.empty((thr.numel(), j), dtype=torch.int64, device=pred.device)
+    counts = torch.empty((j,), dtype=torch.int64, device=pred.device)
+    _check(
+        lib().mval_pck3d(
+            _p(_req(pred, torch.float32, "pred")), _p(_req(gt, torch.float32, "gt")),
+            _p(_req(valid, torch.float32, "valid")) if valid is not None else _p(None), _p(thr), C.c_int(thr.numel()),
+            C.c_int(mode), _p(hits), _p(counts), C.c_longlong(s), C.c_int(j), C.c_int(gt.shape[1]), _stream(),
+        ),
+        "mval_pck3d",
+    )
+    return hits, counts
+
+
 # --------------------------------------------------------------------------
 # core-set (k-center greedy)
 # --------------------------------------------------------------------------

@@ -145,3 +145,66 @@ extern "C" int mval_mkpe(const float* pred, const float* gt, const float* valid,
   }
   return 0;
 }
+
+// ---- 3-D PCK / PCKh --------------------------------------------------------------------------
+// utils/evaluation.py:150-195 (compute_3d_pckh / compute_3d_pck), the counters of _evaluate_all
+// (strategy.py:638-649).  Distances are float32 with torch's operation order -- ((dx^2 + dy^2) + dz^2),
+// every operation rounded separately (no FMA contraction), then sqrt -- because the result is an
+// integer count of strict `<` comparisons:
+//   mode 0 (PCK):  valid joints only; hit when (double)dis < threshold[t]; counts[j] = #valid samples
+//   mode 1 (PCKh): every joint; hit when dis < (float32)(head * (float)threshold[t]) with head = the
+//                  distance between gt joints 0 and 1; counts[j] = S
+// One workgroup per (threshold, joint); integer sums, so the result is order-independent.
+__device__ __forceinline__ float pck_dist(float ax, float ay, float az, float bx, float by, float bz) {
+  const float dx = __fsub_rn(ax, bx), dy = __fsub_rn(ay, by), dz = __fsub_rn(az, bz);
+  return __fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz)));
+}
+
+__global__ __launch_bounds__(256) void pck3d_kernel(const float* __restrict__ pred, const float* __restrict__ gt,
+                                                    const float* __restrict__ valid,
+                                                    const double* __restrict__ thresholds, int mode,
+                                                    long long* __restrict__ hits, long long* __restrict__ counts,
+                                                    int64_t S, int J, int gt_rows) {
+  __shared__ long long sh[2][256];
+  const int j = blockIdx.x, t = blockIdx.y;
+  const double thr = thresholds[t];
+  long long h = 0, c = 0;
+  for (int64_t s = threadIdx.x; s < S; s += 256) {
+    const float* g = gt + s * gt_rows * J;
+    const float* pr = pred + (s * J + j) * 3;
+    if (mode == 0 && valid[s * J + j] == 0.0f) continue;
+    const float dis = pck_dist(pr[0], pr[1], pr[2], g[j], g[J + j], g[2 * J + j]);
+    c++;
+    if (mode == 0) {
+      h += (double)dis < thr;
+    } else {
+      const float head = pck_dist(g[0], g[J], g[2 * J], g[1], g[J + 1], g[2 * J + 1]);
+      h += dis < __fmul_rn(head, (float)thr);
+    }
+  }
+  sh[0][threadIdx.x] = h;
+  sh[1][threadIdx.x] = c;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) {
+      sh[0][threadIdx.x] += sh[0][threadIdx.x + o];
+      sh[1][threadIdx.x] += sh[1][threadIdx.x + o];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    hits[(int64_t)t * J + j] = sh[0][0];
+    if (t == 0) counts[j] = sh[1][0];
+  }
+}
+
+extern "C" int mval_pck3d(const float* pred, const float* gt, const float* valid, const double* thresholds, int T,
+                          int mode, long long* hits, long long* counts, int64_t S, int J, int gt_rows, void* stream) {
+  MVAL_REQUIRE(pred && gt && thresholds && hits && counts && S >= 0 && J >= 2 && T > 0 && gt_rows >= 3 &&
+                   (mode == 1 || (mode == 0 && valid)),
+               "mval_pck3d: bad arguments");
+  hipLaunchKernelGGL(pck3d_kernel, dim3(J, T), dim3(256), 0, mval_stream(stream), pred, gt, valid, thresholds, mode, hits,
+                     counts, S, J, gt_rows);
+  MVAL_CHECK_LAUNCH("mval_pck3d");
+  return 0;
+}

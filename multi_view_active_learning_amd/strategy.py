@@ -261,4 +261,18 @@ class ActiveLearningStrategy:
 
         pred, gt, valid = all_gather_cat(pred), all_gather_cat(gt), all_gather_cat(valid)
         out, _ = _lib.mkpe(pred.contiguous(), gt.contiguous(), valid.contiguous(), pred.shape[0], pred.shape[1], gt.shape[1])
+        self._eval_tables = (pred, gt, valid)
         return out
+
+    def evaluate_all(self, data_loader, pose_estimator):
+        """_evaluate_all (strategy.py:584-649): MKPE + 3-D PCK at 1..5 mm (+ PCKh for panoptic data) over the
+        whole loader; returns the reference's result dict."""
+        mkpe = self.evaluate_mkpe(data_loader, pose_estimator)
+        pred, gt, valid = self._eval_tables
+        j = pred.shape[1]
+        thresholds, pcks = evaluation.compute_3d_pck_figure(pred, gt, valid, j)
+        results = {"mkpe": mkpe.item(), "thresholds": thresholds, "pcks": pcks}
+        if self.al_cfg.DATA.TYPE == "panoptic":
+            t, p = evaluation.compute_3d_pckh_figure(pred, gt, j)
+            results["pckh_thresholds"], results["pckh_pcks"] = t, p
+        return results

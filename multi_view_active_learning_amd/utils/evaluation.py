@@ -59,3 +59,46 @@ def mkpe_per_sample(pred, gt, valid):
         s, j, gt.shape[1],
     )
     return per
+
+
+def _stack3(pred_3d_labels, gt_3d_labels, valid_joints=None):
+    pred = torch.stack([torch.as_tensor(p) for p in pred_3d_labels]).to(torch.float32)
+    gt = torch.stack([torch.as_tensor(g) for g in gt_3d_labels]).to(torch.float32)
+    if not pred.is_cuda:
+        raise _lib.MvalError("3-D PCK: inputs must be HIP tensors")
+    valid = None
+    if valid_joints is not None:
+        valid = torch.stack([torch.as_tensor(v) for v in valid_joints]).to(pred.device, torch.float32).contiguous()
+    return pred.contiguous(), gt.to(pred.device).contiguous(), valid
+
+
+def _fractions(hits, counts, num_keypoints):
+    """[hits / count per joint] per threshold as Python floats (int / int, like the reference's k / c)."""
+    h, c = hits.cpu().tolist(), counts.cpu().tolist()
+    return [[row[k] / c[k] for k in range(num_keypoints)] for row in h]  # ZeroDivisionError as in the reference
+
+
+def compute_3d_pck_figure(pred_3d_labels, gt_3d_labels, valid_joints, num_keypoints, thresholds=(1, 2, 3, 4, 5)):
+    """utils/evaluation.py:134-147: (thresholds, [per-joint PCK list per threshold]) -- ONE kernel launch for all
+    thresholds instead of S x J x T ``.item()`` round trips."""
+    pred, gt, valid = _stack3(pred_3d_labels, gt_3d_labels, valid_joints)
+    hits, counts = _lib.pck3d(pred, gt, valid, thresholds, 0)
+    return thresholds, _fractions(hits, counts, num_keypoints)
+
+
+def compute_3d_pck(pred_3d_labels, gt_3d_labels, valid_joints, threshold_mm, num_keypoints):
+    """utils/evaluation.py:177-195."""
+    return compute_3d_pck_figure(pred_3d_labels, gt_3d_labels, valid_joints, num_keypoints, (threshold_mm,))[1][0]
+
+
+def compute_3d_pckh_figure(pred_3d_labels, gt_3d_labels, num_keypoints,
+                           thresholds=(0.1, 0.2, 0.3, 0.4, 0.5, 0.6, 0.7, 0.8, 0.9, 1.0)):
+    """utils/evaluation.py:121-131."""
+    pred, gt, _ = _stack3(pred_3d_labels, gt_3d_labels)
+    hits, counts = _lib.pck3d(pred, gt, None, thresholds, 1)
+    return thresholds, _fractions(hits, counts, num_keypoints)
+
+
+def compute_3d_pckh(pred_3d_labels, gt_3d_labels, threshold, num_keypoints):
+    """utils/evaluation.py:150-174."""
+    return compute_3d_pckh_figure(pred_3d_labels, gt_3d_labels, num_keypoints, (threshold,))[1][0]

@@ -157,3 +157,39 @@ def compute_mkpe(pred_list, gt_list, valid_list):
         kpe = kpe + torch.sqrt(torch.sum(d, dim=0))
         count = count + valid
     return torch.mean(kpe / count)
+
+
+def _dist3_f32(pred, gt):
+    """float32 distances with the reference's operation order: sqrt(((dx^2 + dy^2) + dz^2)), pred (S,J,3),
+    gt (S,>=3,J) -> (S,J) (utils/evaluation.py:162-166,188-192: 0-d tensor arithmetic, each op rounded)."""
+    import numpy as np
+
+    p = np.asarray(pred, dtype=np.float32)
+    g = np.asarray(gt, dtype=np.float32)
+    dx = p[:, :, 0] - g[:, 0, :]
+    dy = p[:, :, 1] - g[:, 1, :]
+    dz = p[:, :, 2] - g[:, 2, :]
+    return np.sqrt((dx * dx + dy * dy) + dz * dz, dtype=np.float32)
+
+
+def compute_3d_pck(pred_3d_labels, gt_3d_labels, valid_joints, threshold_mm, num_keypoints):
+    """utils/evaluation.py:177-195: per joint, the fraction of VALID samples with distance < threshold_mm."""
+    import numpy as np
+
+    d = _dist3_f32(np.stack([np.asarray(p) for p in pred_3d_labels]), np.stack([np.asarray(g) for g in gt_3d_labels]))
+    v = np.stack([np.asarray(x) for x in valid_joints]).astype(bool)[:, :num_keypoints]
+    hit = (d[:, :num_keypoints].astype(np.float64) < float(threshold_mm)) & v
+    return [int(k) / int(c) for k, c in zip(hit.sum(0), v.sum(0))]  # ZeroDivisionError if a joint is never valid
+
+
+def compute_3d_pckh(pred_3d_labels, gt_3d_labels, threshold, num_keypoints):
+    """utils/evaluation.py:150-174: threshold x the gt distance between joints 0 and 1 (float32 product), every
+    joint of every sample counted."""
+    import numpy as np
+
+    g = np.stack([np.asarray(x, dtype=np.float32) for x in gt_3d_labels])
+    d = _dist3_f32(np.stack([np.asarray(p) for p in pred_3d_labels]), g)
+    hx, hy, hz = g[:, 0, 0] - g[:, 0, 1], g[:, 1, 0] - g[:, 1, 1], g[:, 2, 0] - g[:, 2, 1]
+    head = np.sqrt((hx * hx + hy * hy) + hz * hz, dtype=np.float32) * np.float32(threshold)
+    hit = d[:, :num_keypoints] < head[:, None]
+    return [int(k) / len(g) for k in hit.sum(0)]

@@ -240,3 +240,26 @@ def build_reference_model(ns, c):
     sd = {k: torch.from_numpy(v) for k, v in model_state_dict(c).items()}
     m.load_state_dict(sd, strict=True)
     return m
+
+
+def pck_cases():
+    return OrderedDict(
+        small=dict(seed=11, s=37, j=19, noise=2.0, p_valid=0.8),
+        panoptic=dict(seed=12, s=256, j=19, noise=40.0, p_valid=0.95),
+        ties=dict(seed=13, s=64, j=5, noise=0.0, p_valid=1.0),  # integer offsets: distances land ON thresholds
+    )
+
+
+def pck_arrays(c):
+    """pred (S,J,3) f32, gt (S,4,J) f32 (rows x,y,z,confidence like the panoptic labels), valid (S,J) f32."""
+    rng = np.random.default_rng(c["seed"])
+    gt3 = (rng.standard_normal((c["s"], 3, c["j"])) * 300.0).astype(np.float32)
+    gt = np.concatenate([gt3, np.ones((c["s"], 1, c["j"]), np.float32)], axis=1)
+    if c["noise"] > 0:
+        pred = gt3.transpose(0, 2, 1) + (rng.standard_normal((c["s"], c["j"], 3)) * c["noise"]).astype(np.float32)
+    else:
+        gt[:, :3] = np.round(gt[:, :3])
+        pred = gt[:, :3].transpose(0, 2, 1) + rng.integers(-3, 4, size=(c["s"], c["j"], 3)).astype(np.float32)
+    valid = (rng.uniform(size=(c["s"], c["j"])) < c["p_valid"]).astype(np.float32)
+    valid[0] = 1.0  # every joint valid at least once (the reference divides by the valid count)
+    return np.ascontiguousarray(pred.astype(np.float32)), gt, valid

@@ -17,6 +17,7 @@ What is pinned:
   coreset.npz                CoreSet.select_batch picks (+ boundary gaps from the restatement)
   models.npz                 eval heat-maps of HRNet-W32 / W48 / PoseResNet-50 with synthetic weights
   train_step.npz             train-mode loss, gradient norms, BN running stats after one step
+  pck.npz                    compute_3d_pck_figure / compute_3d_pckh_figure (utils/evaluation.py:121-195)
 """
 from __future__ import annotations
 
@@ -242,9 +243,28 @@ def gen_train(ns):
     np.savez(os.path.join(HERE, "train_step.npz"), versions=versions(), **out)
 
 
+def gen_pck(ns):
+    """compute_3d_pck_figure / compute_3d_pckh_figure (utils/evaluation.py:121-195) with their default
+    thresholds, plus the mm thresholds 10..150 the panoptic-scale noise needs."""
+    out = {}
+    ev = ns.evaluation
+    for name, c in cases.pck_cases().items():
+        pred, gt, valid = cases.pck_arrays(c)
+        pl, gl, vl = [torch.from_numpy(p) for p in pred], [torch.from_numpy(g) for g in gt], [torch.from_numpy(v) for v in valid]
+        for tag, thr in (("pck", (1, 2, 3, 4, 5)), ("pck_wide", (10, 25, 50, 100, 150))):
+            t, pcks = ev.compute_3d_pck_figure(pl, gl, vl, c["j"], thresholds=thr)
+            out[f"{name}/{tag}"] = np.asarray(pcks, dtype=np.float64)
+        t, pcks = ev.compute_3d_pckh_figure(pl, gl, c["j"])
+        out[f"{name}/pckh"] = np.asarray(pcks, dtype=np.float64)
+        out[f"{name}/pckh_thresholds"] = np.asarray(t, dtype=np.float64)
+    np.savez(os.path.join(HERE, "pck.npz"), versions=versions(), **out)
+
+
 def main():
     ns = ref_harness.load()
-    which = sys.argv[1:] or ["tri", "scoring", "sal", "coreset", "models", "train"]
+    which = sys.argv[1:] or ["tri", "scoring", "sal", "coreset", "models", "train", "pck"]
+    if "pck" in which:
+        gen_pck(ns)
     if "tri" in which:
         gen_triangulation(ns)
     if "scoring" in which:

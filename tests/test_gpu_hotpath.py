@@ -280,3 +280,65 @@ def test_sal_dict_vs_reference_golden(dev, name):
     st = ActiveLearningStrategy(cfg)
     if c["strategy"] != "CORESET":
         assert st.select_al_guids(sal, c["select"]) == want["nlargest"]
+
+
+@pytest.mark.parametrize("name", list(cases.pck_cases()))
+def test_pck3d_vs_reference_golden(dev, name):
+    """3-D PCK / PCKh counters on the device against the reference's golden fractions: exact equality (the
+    kernel rounds every float32 operation like torch does; counts are integers)."""
+    from multi_view_active_learning_amd.utils import evaluation
+
+    z = np.load(os.path.join(G, "pck.npz"))
+    c = cases.pck_cases()[name]
+    pred, gt, valid = cases.pck_arrays(c)
+    pl = [torch.from_numpy(p).to(dev) for p in pred]
+    gl = [torch.from_numpy(g).to(dev) for g in gt]
+    vl = [torch.from_numpy(v).to(dev) for v in valid]
+    for tag, thr in (("pck", (1, 2, 3, 4, 5)), ("pck_wide", (10, 25, 50, 100, 150))):
+        t, got = evaluation.compute_3d_pck_figure(pl, gl, vl, c["j"], thresholds=thr)
+        assert t == thr
+        np.testing.assert_array_equal(np.asarray(got), z[f"{name}/{tag}"])
+    t, got = evaluation.compute_3d_pckh_figure(pl, gl, c["j"])
+    np.testing.assert_array_equal(np.asarray(got), z[f"{name}/pckh"])
+    # single-threshold entry points
+    assert evaluation.compute_3d_pck(pl, gl, vl, 3, c["j"]) == list(z[f"{name}/pck"][2])
+    assert evaluation.compute_3d_pckh(pl, gl, 0.5, c["j"]) == list(z[f"{name}/pckh"][4])
+    # a joint that is never valid: the reference divides by zero
+    v0 = [v.clone() for v in vl]
+    for v in v0:
+        v[1] = 0
+    with pytest.raises(ZeroDivisionError):
+        evaluation.compute_3d_pck(pl, gl, v0, 3, c["j"])
+
+
+def test_evaluate_all_vs_oracle(dev):
+    """_evaluate_all's result dict (MKPE + 3-D PCK at 1..5 mm + PCKh, strategy.py:584-649) over a fake loader
+    against the oracle chain: triangulation restatement -> float32 rounding -> metric restatements."""
+    from multi_view_active_learning_amd.config import get_default_configs
+    from multi_view_active_learning_amd.strategy import ActiveLearningStrategy
+
+    name = next(iter(cases.sal_cases()))
+    c = cases.sal_cases()[name]
+    cfg = get_default_configs()
+    cfg.POSE_ESTIMATOR.STRIDE = c["stride"]
+    loader, heatmaps = cases.build_sal_loader(c)
+    it = iter(heatmaps)
+    tl = [{k: torch.from_numpy(v) for k, v in dp.items()} for dp in loader]
+    got = ActiveLearningStrategy(cfg).evaluate_all(tl, lambda images: torch.from_numpy(next(it)).to(dev))
+    preds, gts, valids = [], [], []
+    for dp, hm in zip(loader, heatmaps):
+        b = dp["proj_matrices"].shape[0]
+        hm = hm.reshape((b, -1) + hm.shape[1:])
+        for i in range(b):
+            r = geometry.triangulation(hm[i], dp["proj_matrices"][i], c["stride"], dp["joint_valid"][i].astype(bool))
+            preds.append(torch.from_numpy(r["keypoints_3d"].astype(np.float32)))
+            gts.append(torch.from_numpy(dp["3d_keypoints"][i].astype(np.float32)))
+            valids.append(torch.from_numpy(dp["joint_valid"][i].astype(np.float32)))
+    j = preds[0].shape[0]
+    want_mkpe = models.compute_mkpe(preds, gts, valids).item()
+    assert abs(got["mkpe"] - want_mkpe) <= 1e-5 * abs(want_mkpe)
+    assert got["thresholds"] == (1, 2, 3, 4, 5)
+    for t, row in zip(got["thresholds"], got["pcks"]):
+        assert row == models.compute_3d_pck(preds, gts, valids, t, j)
+    for t, row in zip(got["pckh_thresholds"], got["pckh_pcks"]):
+        assert row == models.compute_3d_pckh(preds, gts, t, j)

@@ -166,3 +166,19 @@ def test_sal_dict_fixture_is_consistent():
         e = z[name]
         assert list(e["al_metric"]) == ["0-0", "1-3", "7-100", "8-103"]
         assert scoring.select_top_n(e["al_metric"], c["select"]) == e["nlargest"]
+
+
+@pytest.mark.parametrize("name", list(cases.pck_cases()))
+def test_pck_restatement_vs_reference_golden(name):
+    """3-D PCK / PCKh (utils/evaluation.py:121-195): the oracle's vectorised float32 restatement gives the
+    reference's fractions EXACTLY (integer counts), including distances that land on a threshold."""
+    from oracle import models
+
+    z = np.load(os.path.join(G, "pck.npz"))
+    c = cases.pck_cases()[name]
+    pred, gt, valid = cases.pck_arrays(c)
+    for tag, thr in (("pck", (1, 2, 3, 4, 5)), ("pck_wide", (10, 25, 50, 100, 150))):
+        got = np.asarray([models.compute_3d_pck(pred, gt, valid, t, c["j"]) for t in thr])
+        np.testing.assert_array_equal(got, z[f"{name}/{tag}"])
+    got = np.asarray([models.compute_3d_pckh(pred, gt, float(t), c["j"]) for t in z[f"{name}/pckh_thresholds"]])
+    np.testing.assert_array_equal(got, z[f"{name}/pckh"])
