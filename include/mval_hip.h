@@ -107,6 +107,25 @@ int mval_masked_mse_fwd(const float* h, const float* g, const uint8_t* valid, fl
 int mval_masked_mse_bwd(const float* h, const float* g, const uint8_t* valid, const float* grad_out,
                         float* grad_h, int64_t lead, int64_t hw, double denom, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Per-view input pipeline (dataset/dataset.py:158-220 prepare_single_view, pixel work only)
+ * ------------------------------------------------------------------------------------------- */
+typedef struct mval_view_desc {
+  const uint8_t* img;               /* decoded RGB image [h0][w0][3] (device) */
+  int32_t h0, w0;
+  int32_t left, top, right, bottom; /* square / scaled box (utils/triangulation.py:96-134); may leave the image */
+  int64_t tmp_off;                  /* byte offset of this view's [bottom-top][in_w][3] slab in the workspace */
+} mval_view_desc;
+/* ws >= mval_prepare_views_workspace_bytes(n_views, sum of the views' crop heights, in_w, in_h). */
+size_t mval_prepare_views_workspace_bytes(int n_views, int64_t total_crop_rows, int in_w, int in_h);
+/* BGR flip + zero-filled crop + PIL LANCZOS resize (Pillow's 8-bit fixed-point algorithm, bit-exact) +
+ * ImageNet normalisation: out [n_views][3][in_h][in_w] f32.  views: DEVICE array. */
+int mval_prepare_views(const mval_view_desc* views, int n_views, int max_crop_h, int max_crop_w, int in_w, int in_h,
+                       float* out, void* ws, void* stream);
+/* Gaussian ground-truth heat-maps (dataset.py:198-207): pt [n][2] f64 (x, y in heat-map pixels) ->
+ * out [n][h][w] f32 = (float) exp(-((x - px)^2 + (y - py)^2) / (2 sigma^2)) evaluated in float64. */
+int mval_gt_heatmaps(const double* pt, int64_t n, double sigma, int h, int w, float* out, void* stream);
+
 /* utils/evaluation.py:198-208 compute_mkpe over S samples: pred [S,J,3] f32, gt [S,gt_rows,J]
  * f32 (rows 0..2 used), valid [S,J] f32 ; out [1] f32 = mean_j (sum_s d_sj / sum_s valid_sj) ;
  * per_sample [S] f32 = the same metric evaluated on each sample alone (strategy.py:1134). */

@@ -263,3 +263,27 @@ def pck_arrays(c):
     valid = (rng.uniform(size=(c["s"], c["j"])) < c["p_valid"]).astype(np.float32)
     valid[0] = 1.0  # every joint valid at least once (the reference divides by the valid count)
     return np.ascontiguousarray(pred.astype(np.float32)), gt, valid
+
+
+def preprocess_cases():
+    """raw image size (h0, w0), detection box (left, top, right, bottom), SCALE_BBOX, network input (w, h),
+    heat-map stride, sigma, distortion or not."""
+    return OrderedDict(
+        inside=dict(seed=21, h0=240, w0=320, box=(60, 30, 200, 190), scale=1.0, in_w=64, in_h=64, stride=4, sigma=1.0, dist=False),
+        outside=dict(seed=22, h0=180, w0=260, box=(-20, 40, 150, 230), scale=1.2, in_w=64, in_h=48, stride=4, sigma=1.0, dist=True),
+        upscale=dict(seed=23, h0=90, w0=90, box=(20, 25, 60, 70), scale=1.0, in_w=96, in_h=96, stride=4, sigma=2.0, dist=False),
+        wide=dict(seed=24, h0=300, w0=500, box=(100, 120, 420, 200), scale=1.0, in_w=128, in_h=128, stride=4, sigma=1.0, dist=False),
+    )
+
+
+def preprocess_inputs(c):
+    """Smooth-plus-noise RGB image (so that resampling matters), a camera looking at the joints, J = 19."""
+    rng = np.random.default_rng(c["seed"])
+    yy, xx = np.mgrid[0 : c["h0"], 0 : c["w0"]]
+    img = np.stack([127 + 120 * np.sin(xx / 9.0 + c["seed"]), 127 + 120 * np.cos(yy / 7.0), (3 * xx + 5 * yy) % 256], -1)
+    img = np.clip(img + rng.normal(0, 12, img.shape), 0, 255).astype(np.uint8)
+    kp3d = np.concatenate([rng.normal(0, 200, (3, 19)), np.ones((1, 19))], 0)  # (4, J): x, y, z, confidence
+    cam = dict(R=np.eye(3).tolist(), t=[[0.0], [0.0], [2500.0]],
+               K=[[600.0, 0.0, c["w0"] / 2.0], [0.0, 600.0, c["h0"] / 2.0], [0.0, 0.0, 1.0]],
+               dist=[0.05, -0.01, 0.001, 0.002, 0.0] if c["dist"] else None)
+    return img, kp3d, cam

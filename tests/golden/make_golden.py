@@ -18,6 +18,7 @@ What is pinned:
   models.npz                 eval heat-maps of HRNet-W32 / W48 / PoseResNet-50 with synthetic weights
   train_step.npz             train-mode loss, gradient norms, BN running stats after one step
   pck.npz                    compute_3d_pck_figure / compute_3d_pckh_figure (utils/evaluation.py:121-195)
+  preprocess.npz             prepare_single_view (dataset/dataset.py:158-220): crop / LANCZOS resize / normalise / GT heat-maps
 """
 from __future__ import annotations
 
@@ -260,11 +261,46 @@ def gen_pck(ns):
     np.savez(os.path.join(HERE, "pck.npz"), versions=versions(), **out)
 
 
+def gen_preprocess(ns):
+    """The reference's own ``ActiveLearningDataset.prepare_single_view`` (dataset/dataset.py:158-220) run
+    unbound on an in-memory PNG per case: normalised image, projection matrix, 2-D key points and the
+    Gaussian ground-truth heat-maps."""
+    import io
+    import types
+
+    from dataset import dataset as ref_ds  # type: ignore  (reference module, harness path)
+    from PIL import Image
+
+    out = {}
+    for name, c in cases.preprocess_cases().items():
+        img, kp3d, cam = cases.preprocess_inputs(c)
+        buf = io.BytesIO()
+        Image.fromarray(img).save(buf, format="PNG")
+        fake = types.SimpleNamespace(
+            _pathmgr=types.SimpleNamespace(open=lambda path, mode: io.BytesIO(buf.getvalue())),
+            _logger=types.SimpleNamespace(debug=lambda *a, **k: None),
+            data_cfg=types.SimpleNamespace(SCALE_BBOX=c["scale"], INPUT_WIDTH=c["in_w"], INPUT_HEIGHT=c["in_h"]),
+            gt_stride=c["stride"], split="val", augmentation=None)
+        view = {"path": "mem.png", "box": list(c["box"]), "camera": cam, "camera_name": "cam0"}
+        v = ref_ds.ActiveLearningDataset.prepare_single_view(fake, view, kp3d, c["sigma"])
+        out[f"{name}/images"] = v["images"].numpy()
+        out[f"{name}/gt_heatmap"] = v["gt_heatmap"].numpy()
+        out[f"{name}/proj_matrices"] = v["proj_matrices"].numpy()
+        out[f"{name}/2d_keypoints"] = v["2d_keypoints"].numpy()
+        out[f"{name}/2d_after_crop"] = v["2d_after_crop"].numpy()
+        out[f"{name}/square_box"] = v["square_box"].numpy()
+    import PIL
+
+    np.savez_compressed(os.path.join(HERE, "preprocess.npz"), versions=versions(), pillow=PIL.__version__, **out)
+
+
 def main():
     ns = ref_harness.load()
-    which = sys.argv[1:] or ["tri", "scoring", "sal", "coreset", "models", "train", "pck"]
+    which = sys.argv[1:] or ["tri", "scoring", "sal", "coreset", "models", "train", "pck", "preprocess"]
     if "pck" in which:
         gen_pck(ns)
+    if "preprocess" in which:
+        gen_preprocess(ns)
     if "tri" in which:
         gen_triangulation(ns)
     if "scoring" in which:
