@@ -219,6 +219,10 @@ int mval_op_launch(const mval_op* op, int n_images, float* workspace, const floa
 
 void* mval_net_create(const mval_op* ops, int n_ops);
 void mval_net_destroy(void* net);
+/* Branch concurrency of mval_net_forward: -1 = decided by the MVAL_STREAMS environment variable (default:
+ * on), 0 = every op on the caller's stream, 1 = fork / join over private streams.  Both forms can be
+ * captured into a hipGraph (the fork / join uses events recorded on the capturing stream). */
+int mval_net_set_multi_stream(void* net, int mode);
 int mval_net_forward(void* net, int n_images, float* workspace, const float* params,
                      const float* input_nchw, float* output_nchw, void* stream);
 /* Same, with a hipEvent recorded on `stream` around every op; blocks until the stream has

@@ -331,6 +331,7 @@ struct MvalNet {
   hipEvent_t fork_ev = nullptr;
   hipEvent_t join_ev[MVAL_MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};
   int n_lanes = 1;
+  int lanes_override = -1;  // -1: MVAL_STREAMS decides; 0 / 1: forced off / on (mval_net_set_multi_stream)
 };
 
 static int multi_stream_enabled() {
@@ -353,6 +354,12 @@ extern "C" void* mval_net_create(const mval_op* ops, int n_ops) {
     if (o.lane + 1 > n->n_lanes) n->n_lanes = o.lane + 1;
   if (n->n_lanes > MVAL_MAX_LANES) n->n_lanes = MVAL_MAX_LANES;
   return n;
+}
+
+extern "C" int mval_net_set_multi_stream(void* net, int mode) {
+  MVAL_REQUIRE(net && mode >= -1 && mode <= 1, "mval_net_set_multi_stream: bad arguments");
+  reinterpret_cast<MvalNet*>(net)->lanes_override = mode;
+  return 0;
 }
 
 extern "C" void mval_net_destroy(void* net) {
@@ -381,7 +388,7 @@ extern "C" int mval_net_forward(void* net, int n_images, float* workspace, const
   MVAL_REQUIRE(net, "mval_net_forward: null net");
   MvalNet* n = reinterpret_cast<MvalNet*>(net);
   hipStream_t main_s = mval_stream(stream);
-  const bool multi = n->n_lanes > 1 && multi_stream_enabled();
+  const bool multi = n->n_lanes > 1 && (n->lanes_override < 0 ? multi_stream_enabled() : n->lanes_override != 0);
   if (multi) MVAL_REQUIRE(ensure_streams(n) == 0, "mval_net_forward: could not create side streams");
   bool used[MVAL_MAX_LANES] = {false, false, false, false};
   int phase = n->ops.empty() ? 0 : n->ops[0].phase;

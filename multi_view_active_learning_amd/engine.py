@@ -186,6 +186,7 @@ class InferencePlan:
         self.arena = torch.empty(self.arena_floats, dtype=torch.float32, device=device)
         self.params = torch.zeros(self.param_floats, dtype=torch.float32, device=device)
         self.param_sig = None
+        self._graph, self._graph_failed = None, False
         self.net = lib.mval_net_create(self.ops, C.c_int(len(g.ops)))
         if not self.net:
             raise _lib.MvalError("mval_net_create failed: " + lib.mval_last_error().decode())
@@ -242,15 +243,52 @@ class InferencePlan:
         self.param_sig = sig
 
     # ---- run ---------------------------------------------------------------------------------
-    def forward(self, x):
-        self.refresh_params()
-        out = torch.empty((self.n, self.out_channels) + tuple(self.out_hw), dtype=torch.float32, device=self.device)
+    def _launch(self, x, out):
         _lib._check(
             _lib.lib().mval_net_forward(
                 C.c_void_p(self.net), C.c_int(self.n), C.c_void_p(self.arena.data_ptr()),
                 C.c_void_p(self.params.data_ptr()), C.c_void_p(x.data_ptr()), C.c_void_p(out.data_ptr()),
                 _lib._stream()),
             "mval_net_forward")
+
+    def _graph_wanted(self):
+        """The reference's default batches are 2 frames (config.py:67,87): ~300 launches of a few microseconds
+        of work each, i.e. launch-bound.  Small plans therefore replay a captured hipGraph (MVAL_GRAPH=0
+        disables, MVAL_GRAPH=1 forces it for every size)."""
+        mode = os.environ.get("MVAL_GRAPH", "auto")
+        if mode == "0" or self._graph_failed:
+            return False
+        return mode == "1" or self.n * self.h * self.w <= 32 * 256 * 256
+
+    def _capture(self, x):
+        self._gx = torch.empty_like(x)
+        self._gout = torch.empty((self.n, self.out_channels) + tuple(self.out_hw), dtype=torch.float32, device=self.device)
+        self._gx.copy_(x)
+        side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(side):  # warm-up outside the capture (lazy stream / event creation)
+            self._launch(self._gx, self._gout)
+        torch.cuda.current_stream(self.device).wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            self._launch(self._gx, self._gout)
+        self._graph = graph
+
+    def forward(self, x):
+        self.refresh_params()
+        if self._graph_wanted():
+            if self._graph is None:
+                try:
+                    self._capture(x)
+                except Exception:  # capture unsupported in this context: fall back to eager launches for good
+                    self._graph, self._graph_failed = None, True
+                    torch.cuda.synchronize(self.device)
+            if self._graph is not None:
+                self._gx.copy_(x)
+                self._graph.replay()
+                return self._gout.clone()
+        out = torch.empty((self.n, self.out_channels) + tuple(self.out_hw), dtype=torch.float32, device=self.device)
+        self._launch(x, out)
         return out
 
     def forward_timed(self, x):
