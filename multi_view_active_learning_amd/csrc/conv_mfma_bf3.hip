@@ -37,6 +37,9 @@
 // weight fragments issued as asm loads a whole tap column (72 MFMAs) ahead instead of the ~18 MFMAs the
 // compiler leaves after sinking them: -7 % (168 VGPRs, small spills) -- L2 latency is already hidden by the
 // three waves per SIMD.
+// a weight-stationary persistent kernel for the 32 -> 32 layers (8 waves, the wave's 27 weight fragments
+// held in 108 VGPRs for all tiles, double-buffered patch planes, one barrier per tile, no weight stream at
+// all): 75.4 vs 73.5 us -- the same time from a completely different structure.
 // All variants sit at ~50 us / 190 TFLOP/s on the 64..256-channel layers (46 % of the split peak;
 // the guide's tuned 8-phase bf16 GEMM reaches 53-59 % of peak on random data).
 // Used for 3x3 convs with cin % 32 == 0 (or cin = 48) when the plan selects MVAL_ALGO_MFMA_BF3.
