@@ -73,7 +73,7 @@ __device__ __forceinline__ void split3(const f32x4 v, bf16x4& h, bf16x4& m, bf16
 // ky) with ms + ky == pr.  Looping (kx, pr) instead of (tap, ms) reads (MS + 2) * 3 fragments per
 // chunk instead of MS * 9 -- half the LDS traffic at MS = 4 -- with the three row taps' weights
 // of one column live at a time.
-template <int KS, int S, int WN, int WM, int NT, int MS, int NE, bool RS = false>
+template <int KS, int S, int WN, int WM, int NT, int MS, int NE, bool RS = false, bool PA = false>
 __global__ __launch_bounds__(64 * WN * WM) void conv_bf3_kernel(ConvArgs a) {
   constexpr int NTH = 64 * WN * WM;  // 256 threads, or 192 for the 48-channel-granular (HRNet-W48) tiles
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -128,11 +128,22 @@ __global__ __launch_bounds__(64 * WN * WM) void conv_bf3_kernel(ConvArgs a) {
     goff[i] = ok ? ((n * a.Hin + ay) * a.Win + ax) * a.Cin + q * 4 : -1;
   }
 
-  f32x4 acc[MS][NT];
+  // PA ("precise accumulate", the training plans): two accumulators per output tile, the leading product
+  // (h x h) and the five correction products.  The bf16 MFMA aligns its dot product to the accumulator and
+  // drops (floors) what falls below a few guard bits; corrections are 2^-8 .. 2^-16 of the leading term, so
+  // adding them to the big accumulator biases every output by about -1 ulp -- invisible in forward values
+  // (same max / mean error as the exact-fp32 MFMA chain) but coherent, and amplified 25-100x in HRNet-W48's
+  // training gradients (BatchNorm over a dozen samples per channel).  Summed separately and joined once in
+  // the epilogue the bias is gone and the mean error drops 2.6x below the fp32 chain's; it costs 16
+  // accumulator registers (~10 % time), so inference plans keep the single accumulator.
+  f32x4 acc[MS][NT], accl[PA ? MS : 1][PA ? NT : 1];
 #pragma unroll
   for (int ms = 0; ms < MS; ms++)
 #pragma unroll
-    for (int nt = 0; nt < NT; nt++) acc[ms][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int nt = 0; nt < NT; nt++) {
+      acc[ms][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if constexpr (PA) accl[ms][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
 
   const bf16x8* wq = reinterpret_cast<const bf16x8*>(a.w) + lane;
   const int nchunks = (a.Cin + BF_KC - 1) / BF_KC;  // the last chunk may be half empty (cin = 48)
@@ -213,7 +224,11 @@ __global__ __launch_bounds__(64 * WN * WM) void conv_bf3_kernel(ConvArgs a) {
                   if (ms < 0 || ms >= MS) continue;
                   const bf16x8 av = (t == 0) ? al : (t == 2 || t == 3) ? am : ah;
                   const int bi = (t == 0 || t == 3 || t == 5) ? 0 : (t == 1) ? 2 : 1;
-                  acc[ms][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, B[ky][nt][bi], acc[ms][nt], 0, 0, 0);
+                  if (!PA || t == 5)
+                    acc[ms][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, B[ky][nt][bi], acc[ms][nt], 0, 0, 0);
+                  else
+                    accl[PA ? ms : 0][PA ? nt : 0] =
+                        __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, B[ky][nt][bi], accl[PA ? ms : 0][PA ? nt : 0], 0, 0, 0);
                 }
               }
             }
@@ -258,14 +273,17 @@ __global__ __launch_bounds__(64 * WN * WM) void conv_bf3_kernel(ConvArgs a) {
           const bf16x8 al = *reinterpret_cast<const bf16x8*>(ap + 2 * plane_bytes);
 #pragma unroll
           for (int nt = 0; nt < NT; nt++) {
-            f32x4 c = acc[ms][nt];
+            f32x4 c = PA ? accl[PA ? ms : 0][PA ? nt : 0] : acc[ms][nt];  // corrections, small terms first
             c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bcur[nt][0], c, 0, 0, 0);
             c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bcur[nt][2], c, 0, 0, 0);
             c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bcur[nt][1], c, 0, 0, 0);
             c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bcur[nt][0], c, 0, 0, 0);
             c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bcur[nt][1], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bcur[nt][0], c, 0, 0, 0);
-            acc[ms][nt] = c;
+            if constexpr (PA) {
+              accl[ms][nt] = c;
+              c = acc[ms][nt];
+            }
+            acc[ms][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bcur[nt][0], c, 0, 0, 0);
           }
         }
 #pragma unroll
@@ -294,7 +312,7 @@ __global__ __launch_bounds__(64 * WN * WM) void conv_bf3_kernel(ConvArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; r++) {
           const int p = (wm * MS + ms) * 16 + (lane >> 4) * 4 + r;
-          ot[p * LDW + cl] = acc[ms][nt][r] * sc + sh;
+          ot[p * LDW + cl] = (PA ? acc[ms][nt][r] + accl[PA ? ms : 0][PA ? nt : 0][r] : acc[ms][nt][r]) * sc + sh;
         }
     }
   }
@@ -337,9 +355,19 @@ static int launch_bf3(ConvArgs a, int th, int tw, int tn, hipStream_t s) {
   dim3 grid((unsigned)(a.tiles_x * a.tiles_y * ngroups), (unsigned)((a.NS_total + WN * NT - 1) / (WN * NT)));
   if constexpr (KS == 3 && S == 1) {
     if (tw == 16 && tn == 1 && ne <= 6 && bf3_row_sharing()) {
-      hipLaunchKernelGGL((conv_bf3_kernel<KS, S, WN, WM, NT, MS, 6, true>), grid, dim3(NTH), smem, s, a);
+      if (a.precise)
+        hipLaunchKernelGGL((conv_bf3_kernel<KS, S, WN, WM, NT, MS, 6, true, true>), grid, dim3(NTH), smem, s, a);
+      else
+        hipLaunchKernelGGL((conv_bf3_kernel<KS, S, WN, WM, NT, MS, 6, true>), grid, dim3(NTH), smem, s, a);
       return 0;
     }
+  }
+  if (a.precise) {
+    if (ne <= 6)
+      hipLaunchKernelGGL((conv_bf3_kernel<KS, S, WN, WM, NT, MS, 6, false, true>), grid, dim3(NTH), smem, s, a);
+    else
+      hipLaunchKernelGGL((conv_bf3_kernel<KS, S, WN, WM, NT, MS, 10, false, true>), grid, dim3(NTH), smem, s, a);
+    return 0;
   }
   if (ne <= 6)
     hipLaunchKernelGGL((conv_bf3_kernel<KS, S, WN, WM, NT, MS, 6>), grid, dim3(NTH), smem, s, a);

@@ -32,6 +32,7 @@ static void geometry(ConvArgs& a, const mval_op& op, int n_images) {
   a.G_total = (op.cin + 15) / 16;
   a.NS_total = (op.cout + 15) / 16;
   a.res1 = a.res2 = nullptr;
+  a.precise = 1;  // bias-free accumulation: training gradients amplify a coherent -1 ulp (conv_mfma_bf3.hip)
 }
 
 // ConvTranspose2d forward on the matrix cores: stride-1 conv over the zero-dilated input (net.hip)
@@ -207,6 +208,7 @@ extern "C" int mval_conv_dgrad(const float* dz, const float* w_packed, const flo
   a.th = a.tw = a.tn = a.tw_log2 = a.thw_log2 = a.tiles_x = a.tiles_y = 0;
   a.G_total = (cout + 15) / 16;
   a.NS_total = (cin + 15) / 16;
+  a.precise = 0;  // measured: only the FORWARD needs bias-free accumulation (its outputs enter batch statistics)
   a.in = dz;
   a.w = w_packed;
   a.scale = ones;

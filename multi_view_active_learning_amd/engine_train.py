@@ -18,6 +18,7 @@ stride-2 conv (data gradient) / a k4 stride-2 weight gradient with the activatio
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import torch
 

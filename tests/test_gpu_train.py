@@ -94,7 +94,10 @@ def test_bn_train_ops_vs_torch(dev):
 WG_CASES = [(2, 32, 32, 16, 16, 3, 1), (2, 64, 32, 16, 16, 3, 2), (3, 32, 64, 8, 8, 1, 1), (2, 128, 128, 8, 8, 3, 1),
             (2, 48, 96, 12, 9, 3, 1), (2, 32, 19, 16, 16, 1, 1), (4, 64, 64, 32, 32, 3, 1),
             (2, 64, 128, 16, 16, 1, 1), (3, 256, 64, 8, 8, 1, 1), (2, 64, 96, 20, 12, 1, 1), (2, 64, 64, 16, 8, 3, 2),
-            (3, 32, 128, 24, 40, 3, 2), (2, 128, 256, 16, 16, 3, 2)]
+            (3, 32, 128, 24, 40, 3, 2), (2, 128, 256, 16, 16, 3, 2),
+            # HRNet-W48 widths on tiny maps (several images per tile, maps smaller than a tile)
+            (2, 384, 384, 2, 3, 3, 1), (2, 192, 192, 4, 6, 3, 1), (2, 96, 48, 8, 12, 1, 1), (2, 48, 48, 16, 24, 3, 1),
+            (2, 192, 384, 4, 6, 3, 2), (2, 384, 48, 2, 3, 1, 1), (2, 48, 96, 16, 24, 3, 2)]
 
 
 @pytest.mark.parametrize("case", WG_CASES, ids=lambda c: "n%d_c%d-%d_%dx%d_k%ds%d" % c)
@@ -123,7 +126,7 @@ def test_conv_wgrad_and_dgrad_vs_torch(dev, case):
     if cout % 16 == 0:
         got = ops.conv_dgrad(dzd, wt.detach().to(dev), (h, w), stride=s)
         assert _rel(got.permute(0, 3, 1, 2).cpu().numpy(), x.grad.numpy()) < 2e-5
-    if cout % 32 == 0 and (k == 3 or s == 1):  # split-bf16 kernel (stride 2: dz read zero-dilated)
+    if (cout % 32 == 0 or cout == 48) and (k == 3 or s == 1):  # split-bf16 kernel (stride 2: dz read zero-dilated)
         got = ops.conv_dgrad(dzd, wt.detach().to(dev), (h, w), stride=s, algo=ops.ALGO_MFMA_BF3)
         assert _rel(got.permute(0, 3, 1, 2).cpu().numpy(), x.grad.numpy()) < 2e-5
 
@@ -237,7 +240,8 @@ def test_train_step_vs_reference_golden(dev, name):
 
 
 @pytest.mark.parametrize("c", [dict(arch="hrnet_w32", seed=5, n=3, h=64, w=64, j=7),
-                               dict(arch="resnet50", seed=7, n=2, h=128, w=96, j=7)], ids=lambda c: c["arch"])
+                               dict(arch="resnet50", seed=7, n=2, h=128, w=96, j=7),
+                               dict(arch="hrnet_w48", seed=8, n=2, h=64, w=96, j=5)], ids=lambda c: c["arch"])
 def test_all_gradients_vs_cpu_oracle(dev, c):
     """Every parameter gradient of a small HRNet-W32 / PoseResNet-50 step (max-pool and transposed-conv
     backward included) against torch-CPU autograd on the functional oracle model."""
@@ -252,7 +256,8 @@ def test_all_gradients_vs_cpu_oracle(dev, c):
         if c["arch"] == "resnet50":
             hm_c = models.pose_resnet_forward(sdc, torch.from_numpy(x).to(dt), training=True)
         else:
-            hm_c = models.hrnet_forward(sdc, torch.from_numpy(x).to(dt), models.HRNET_W32, training=True)
+            arch = models.HRNET_W48 if c["arch"] == "hrnet_w48" else models.HRNET_W32
+            hm_c = models.hrnet_forward(sdc, torch.from_numpy(x).to(dt), arch, training=True)
         l = models.pose_2d_mse(hm_c, torch.from_numpy(gt).to(dt), torch.from_numpy(valid).reshape(hm_c.shape[0], -1, 1, 1))
         l.backward()
         return l.item(), sdc
