@@ -332,26 +332,31 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(float* __restrict__ g
 }
 
 // channel counts that are not a multiple of 4 (the 19-joint heat-map layer): plain conv with
-// bias, no BN / residual / upsample -- copy the (masked) gradient and sum it per channel
+// bias, no BN / residual / upsample -- copy the (masked) gradient and sum it per channel.
+// thread = (pixel row r of the workgroup, channel c): a workgroup reads rows * C contiguous floats per
+// pass (coalesced), partial sums per (workgroup, channel) go through the two-stage reduction.
 __global__ __launch_bounds__(256) void bias_bwd_scalar_kernel(const float* __restrict__ gout,
                                                               const float* __restrict__ out, float* __restrict__ gz,
-                                                              float* __restrict__ dbias, int64_t M, int C, int relu) {
+                                                              double* __restrict__ part, int64_t M, int C, int relu) {
   __shared__ double red[256];
-  const int c = blockIdx.x;
+  const int rows = 256 / C;
+  const int r = threadIdx.x / C, c = threadIdx.x % C;
   double acc = 0;
-  for (int64_t p = threadIdx.x; p < M; p += 256) {
-    float g = gout[p * C + c];
-    if (relu && !(out[p * C + c] > 0.f)) g = 0.f;
-    gz[p * C + c] = g;
-    acc += (double)g;
-  }
+  if (r < rows)
+    for (int64_t p = (int64_t)blockIdx.x * rows + r; p < M; p += (int64_t)gridDim.x * rows) {
+      float g = gout[p * C + c];
+      if (relu && !(out[p * C + c] > 0.f)) g = 0.f;
+      gz[p * C + c] = g;
+      acc += (double)g;
+    }
   red[threadIdx.x] = acc;
   __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
-    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
-    __syncthreads();
+  if (threadIdx.x < C) {
+    double a = 0;
+    for (int k = 0; k < rows; k++) a += red[k * C + threadIdx.x];
+    part[((int64_t)blockIdx.x * C + threadIdx.x) * 2] = a;
+    part[((int64_t)blockIdx.x * C + threadIdx.x) * 2 + 1] = 0.0;
   }
-  if (threadIdx.x == 0 && dbias) dbias[c] = (float)red[0];
 }
 
 extern "C" int mval_bn_bwd(const float* gout, const float* out, const float* z, const float* mean, const float* invstd,
@@ -363,9 +368,15 @@ extern "C" int mval_bn_bwd(const float* gout, const float* out, const float* z, 
   MVAL_REQUIRE(!gres1 || gres1 != gres2, "mval_bn_bwd: the two residual gradients must be distinct buffers");
   if (C & 3) {
     MVAL_REQUIRE(!has_bn && up == 0 && !gres1 && !gres2, "mval_bn_bwd: odd channel count only for plain conv+bias");
-    hipLaunchKernelGGL(bias_bwd_scalar_kernel, dim3(C), dim3(256), 0, mval_stream(stream), gout, out, gz, dbeta,
-                       (int64_t)N * H * W, C, relu);
+    MVAL_REQUIRE(C <= 256, "mval_bn_bwd: odd channel count above 256");
+    const int64_t Mp = (int64_t)N * H * W;
+    const int rows_s = 256 / C;
+    int nbs = (int)((Mp + rows_s - 1) / rows_s);
+    if (nbs > TR_BLOCKS) nbs = TR_BLOCKS;
+    hipLaunchKernelGGL(bias_bwd_scalar_kernel, dim3(nbs), dim3(256), 0, mval_stream(stream), gout, out, gz, ws, Mp, C, relu);
     MVAL_CHECK_LAUNCH("mval_bn_bwd/scalar");
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, mval_stream(stream), ws, nbs, C, dbeta, nullptr, nullptr);
+    MVAL_CHECK_LAUNCH("mval_bn_bwd/scalar finalize");
     return 0;
   }
   const int64_t M = (int64_t)N * H * W;
