@@ -12,7 +12,7 @@ def cpu(dt):
     sdc = {k: (v.clone().to(dt) if v.dtype.is_floating_point else v.clone()) for k, v in sd.items()}
     for k, v in sdc.items():
         if v.dtype.is_floating_point and "running" not in k: v.requires_grad_(True)
-    h = models.hrnet_forward(sdc, torch.from_numpy(x).to(dt), models.HRNET_W48 if c["arch"] == "hrnet_w48" else models.HRNET_W32, training=True)
+    h = (models.pose_resnet_forward(sdc, torch.from_numpy(x).to(dt), training=True) if c["arch"] == "resnet50" else models.hrnet_forward(sdc, torch.from_numpy(x).to(dt), models.HRNET_W48 if c["arch"] == "hrnet_w48" else models.HRNET_W32, training=True))
     l = models.pose_2d_mse(h, torch.from_numpy(gt).to(dt), torch.from_numpy(valid).reshape(h.shape[0], -1, 1, 1)); l.backward()
     return sdc, h.detach(), l.item()
 (s64, h64, l64), (s32, h32, l32) = cpu(torch.float64), cpu(torch.float32)
