@@ -313,3 +313,37 @@ def test_train_step_guard_and_eval_after_train(dev):
     with torch.no_grad():
         y = m(torch.from_numpy(x).to(dev))
     assert torch.isfinite(y).all()
+
+
+def test_training_under_ddp_matches_plain(dev):
+    """workflow.py:125-139 wraps the model in DistributedDataParallel: one step with and without the wrapper
+    (world size 1, RCCL) gives the same loss and bit-identical gradients -- parameters are real
+    nn.Parameters whose autograd hooks fire from the single-node backward."""
+    import torch.distributed as dist
+
+    from multi_view_active_learning_amd.pose_estimators import Pose2DMeanSquaredError
+
+    if dist.is_initialized():
+        pytest.skip("a process group already exists in this process")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29547")
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        c = dict(arch="hrnet_w32", seed=12, n=4, h=64, w=64, j=19)
+        x, gt, valid = cases.train_input(c)
+        sd = {k: torch.from_numpy(v) for k, v in cases.model_state_dict(c).items()}
+        out = []
+        for wrap in (False, True):
+            m = cases.product_model(c)
+            m.load_state_dict(sd, strict=True)
+            m = m.to(dev).train()
+            net = torch.nn.parallel.DistributedDataParallel(m, device_ids=[dev.index or 0], broadcast_buffers=True) if wrap else m
+            loss = Pose2DMeanSquaredError().pose_2d_mse(
+                net(torch.from_numpy(x).to(dev)), torch.from_numpy(gt).to(dev),
+                torch.from_numpy(valid).reshape(c["n"], -1, 1, 1).to(dev))
+            loss.backward()
+            out.append((loss.item(), torch.cat([p.grad.reshape(-1) for p in m.parameters()]).cpu()))
+        assert out[0][0] == out[1][0]
+        assert torch.equal(out[0][1], out[1][1])
+    finally:
+        dist.destroy_process_group()
