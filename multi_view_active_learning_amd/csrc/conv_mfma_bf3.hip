@@ -39,7 +39,8 @@
 // three waves per SIMD.
 // a weight-stationary persistent kernel for the 32 -> 32 layers (8 waves, the wave's 27 weight fragments
 // held in 108 VGPRs for all tiles, double-buffered patch planes, one barrier per tile, no weight stream at
-// all): 75.4 vs 73.5 us -- the same time from a completely different structure.
+// all): 75.4 vs 73.5 us -- the same time from a completely different structure; fetching the tile's residual
+// before its MFMA loop as well: 74.4 vs 75.2 us.
 // All variants sit at ~50 us / 190 TFLOP/s on the 64..256-channel layers (46 % of the split peak;
 // the guide's tuned 8-phase bf16 GEMM reaches 53-59 % of peak on random data).
 // Used for 3x3 convs with cin % 32 == 0 (or cin = 48) when the plan selects MVAL_ALGO_MFMA_BF3.
