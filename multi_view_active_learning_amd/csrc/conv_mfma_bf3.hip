@@ -41,6 +41,14 @@
 // held in 108 VGPRs for all tiles, double-buffered patch planes, one barrier per tile, no weight stream at
 // all): 75.4 vs 73.5 us -- the same time from a completely different structure; fetching the tile's residual
 // before its MFMA loop as well: 74.4 vs 75.2 us.
+// Phase stripping (same kernel with its MFMA loop and / or its store epilogue skipped) shows where the time is:
+// 32 -> 32 on 128 64x64 maps: staging 22 us + MFMA loop 35 us + epilogue 17 us = the measured 74 us;
+// 128 -> 128 on 16x16 maps: 10.7 + 33.6 + 4.4 = 48.7 us -- the phases of the workgroups sharing a CU simply
+// add up, and the MFMA loop alone runs at 287 TFLOP/s (69 % of the split peak, ~86 % of what the clock under
+// MFMA load allows).  Staggering the co-resident workgroups (s_sleep offsets) only adds the sleep; per tile the
+// vector work (split, addressing, epilogue: 1.4-2.3 instructions per MFMA) needs about as many issue cycles as
+// the MFMAs themselves (an MFMA holds the SIMD's vector issue for 8 of its 16 cycles), so what remains to be
+// gained is in removing vector instructions, not in overlapping phases.
 // All variants sit at ~50 us / 190 TFLOP/s on the 64..256-channel layers (46 % of the split peak;
 // the guide's tuned 8-phase bf16 GEMM reaches 53-59 % of peak on random data).
 // Used for 3x3 convs with cin % 32 == 0 (or cin = 48) when the plan selects MVAL_ALGO_MFMA_BF3.
