@@ -333,7 +333,7 @@ def main():
             "higher_is_better": True,
             "scaling": "strong" if wl.get("pool") else "weak",
             "vs_baseline": None,
-            "dtype": "f32" if _conv_mode() == "fp32" else "f32 (3x3 convs: exact 3-way bf16 split on bf16 MFMA, fp32 accumulate)",
+            "dtype": "f32" if _conv_mode() == "fp32" else "f32 (convs: fp32 values as exact 3-way bf16 splits on the bf16 MFMA, fp32 accumulate)",
             "data": "synthetic (random variance-preserving weights, N(0,1) frames, ring cameras)",
             "config": {"workload": wl["desc"], "frames_per_step_per_gpu": frames, "views": v,
                        "images_per_step_per_gpu": frames * v, "parallelism": f"frame-sharded x{world}, no collective"},
