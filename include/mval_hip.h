@@ -148,6 +148,10 @@ int mval_pck3d(const float* pred, const float* gt, const float* valid, const dou
  * feat [n,3J] f64 = [x_0-x_r .. , y_0-y_r .. , z_0-z_r ..]. */
 int mval_coreset_features(const double* pose, double* feat, int64_t n, int J, int rows, int root, void* stream);
 
+/* strategy.py:981-989 (cluster-balanced pseudo-labelling): label [n] i32 = index of the nearest of K
+ * cluster centres [K,D] f64 for every feature row feat [n,D] f64 (first minimum, as KMeans.predict). */
+int mval_nearest_center(const double* feat, const double* centers, int64_t n, int D, int K, int* label, void* stream);
+
 size_t mval_kcenter_workspace_bytes(int64_t n_obs, int D);
 
 /* utils/coreset.py:49-95 greedy k-center on feat [n_obs,D] f64 with sklearn's expanded

@@ -260,6 +260,18 @@ def kcenter_select(feat, labeled_idx, n_select, min_dist=None):
     return picks, md
 
 
+def nearest_center(feat, centers):
+    """feat (n, D) f64, centers (K, D) f64 (device) -> (n,) int32 labels."""
+    n, d = feat.shape
+    out = torch.empty((n,), dtype=torch.int32, device=feat.device)
+    _check(
+        lib().mval_nearest_center(_p(_req(feat, torch.float64, "feat")), _p(_req(centers, torch.float64, "centers")),
+                                  C.c_longlong(n), C.c_int(d), C.c_int(centers.shape[0]), _p(out), _stream()),
+        "mval_nearest_center",
+    )
+    return out
+
+
 def coreset_features(pose, root_idx, n, j, rows):
     """pose (n, j, rows>=3) f64 [joint, coord] -> (n, 3j) f64 root-relative, coord-major."""
     out = torch.empty((n, 3 * j), dtype=torch.float64, device=pose.device)

@@ -225,3 +225,40 @@ extern "C" int mval_coreset_features(const double* pose, double* feat, int64_t n
   MVAL_CHECK_LAUNCH("mval_coreset_features");
   return 0;
 }
+
+// ---- nearest cluster centre (strategy.py:981-989: ``self.kmeans.predict([kp])`` per pseudo-label candidate)
+// label[i] = argmin_k ||feat_i - centre_k||^2 (float64, first minimum), evaluated like sklearn's KMeans.predict
+// as ||c_k||^2 - 2 feat_i . c_k (the ||feat_i||^2 term does not change the argmin).  One thread per sample.
+__global__ __launch_bounds__(256) void nearest_center_kernel(const double* __restrict__ feat,
+                                                             const double* __restrict__ centers, int64_t n, int D, int K,
+                                                             int* __restrict__ label) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double* x = feat + i * D;
+  double best = 0.0;
+  int bk = 0;
+  for (int k = 0; k < K; k++) {
+    const double* c = centers + (int64_t)k * D;
+    double cc = 0.0, xc = 0.0;
+    for (int d = 0; d < D; d++) {
+      cc += c[d] * c[d];
+      xc += x[d] * c[d];
+    }
+    const double v = cc - 2.0 * xc;
+    if (k == 0 || v < best) {
+      best = v;
+      bk = k;
+    }
+  }
+  label[i] = bk;
+}
+
+extern "C" int mval_nearest_center(const double* feat, const double* centers, int64_t n, int D, int K, int* label,
+                                   void* stream) {
+  MVAL_REQUIRE(feat && centers && label && n >= 0 && D > 0 && K > 0, "mval_nearest_center: bad arguments");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(nearest_center_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, mval_stream(stream), feat,
+                     centers, n, D, K, label);
+  MVAL_CHECK_LAUNCH("mval_nearest_center");
+  return 0;
+}

@@ -240,6 +240,46 @@ class ActiveLearningStrategy:
             return cs.select_batch(al_num_frames)
         return nlargest(al_num_frames, al_metric_dict, key=al_metric_dict.get)
 
+    def select_sal_guids(self, sal_dict, al_guids, pseudo_label_guids, pseudo_num_frames, kmeans_centers=None,
+                         device=None):
+        """Pseudo-label filter of _sal_pseudo_labeling (strategy.py:952-1001): keep frames that were not
+        sampled by AL, are not pseudo-labelled yet, have a finite sal_metric and MORE than SAL.INLIER_THRESHOLD
+        inliers; sort ascending by sal_metric (stable); then either fill SAL.NUM_CLUSTERS pose clusters with
+        pseudo_num_frames // NUM_CLUSTERS frames each (cluster of a frame = nearest of ``kmeans_centers``,
+        (K, 3J) float64, to its root-relative pose -- ONE device launch for all candidates instead of a
+        ``kmeans.predict`` per frame) or, without clusters, ``random.sample`` of the best 2 N (python's
+        global RNG, exactly like the reference)."""
+        import random
+
+        al = set(al_guids)
+        done = set(pseudo_label_guids)
+        thr = self.al_cfg.SAL.INLIER_THRESHOLD
+        sal_metric_dict = {
+            g: m for g, m in sal_dict["sal_metric"].items()
+            if g not in al and not math.isnan(m) and g not in done and sal_dict["inlier_count"][g] > thr
+        }
+        sal_guids = sorted(sal_metric_dict, key=sal_metric_dict.get)
+        if kmeans_centers is None:
+            return random.sample(sal_guids[: 2 * pseudo_num_frames], pseudo_num_frames)
+        k = self.al_cfg.SAL.NUM_CLUSTERS
+        if not sal_guids:
+            return []
+        if device is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        pose = torch.as_tensor(np.asarray([sal_dict["pred_3d_keypoints"][g] for g in sal_guids], dtype=np.float64)).to(device)
+        n, j, rows = pose.shape
+        feat = _lib.coreset_features(pose.contiguous(), self.joint_root_index, n, j, rows)
+        centers = torch.as_tensor(np.asarray(kmeans_centers, dtype=np.float64)).to(device).contiguous()
+        labels = _lib.nearest_center(feat, centers).cpu().tolist()
+        counter = [0] * k
+        per_cluster_count = pseudo_num_frames // k
+        out = []
+        for g, c in zip(sal_guids, labels):
+            if counter[c] < per_cluster_count:
+                counter[c] += 1
+                out.append(g)
+        return out
+
     # ---- evaluation core (strategy.py:597-636) ----------------------------------------
     def evaluate_mkpe(self, data_loader, pose_estimator):
         """_evaluate_all's MKPE path: heat-maps -> hard arg-max triangulation -> MPJPE over the

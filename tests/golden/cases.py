@@ -287,3 +287,34 @@ def preprocess_inputs(c):
                K=[[600.0, 0.0, c["w0"] / 2.0], [0.0, 600.0, c["h0"] / 2.0], [0.0, 0.0, 1.0]],
                dist=[0.05, -0.01, 0.001, 0.002, 0.0] if c["dist"] else None)
     return img, kp3d, cam
+
+
+def sal_filter_cases():
+    return OrderedDict(
+        clusters=dict(seed=31, n=300, j=19, al_num=20, pseudo_num=40, clusters=10, thr=7, use_clusters=True, pseudo_done=15),
+        random=dict(seed=32, n=200, j=19, al_num=10, pseudo_num=30, clusters=10, thr=7, use_clusters=False, pseudo_done=5),
+        few=dict(seed=33, n=60, j=19, al_num=5, pseudo_num=20, clusters=4, thr=9, use_clusters=True, pseudo_done=0),
+    )
+
+
+def sal_filter_inputs(c):
+    """A synthetic sal_dict as _compute_sal_dict returns it (guid -> python floats / ints / J x 3 lists of
+    float32-valued floats), with NaNs, plus the guids that are already pseudo-labelled."""
+    rng = np.random.default_rng(c["seed"])
+    guids = ["%d-%d" % (int(p), int(f)) for p, f in zip(rng.integers(0, 4, c["n"]), rng.permutation(c["n"]))]
+    al = rng.uniform(0, 1, c["n"])
+    al[rng.uniform(size=c["n"]) < 0.05] = np.nan
+    salm = rng.uniform(0.5, 30, c["n"]).astype(np.float32).astype(np.float64)
+    salm[rng.uniform(size=c["n"]) < 0.05] = np.nan
+    inl = rng.integers(3, 13, c["n"])
+    modes = rng.normal(0, 300, (c["clusters"], c["j"], 3))
+    kp = (modes[rng.integers(0, c["clusters"], c["n"])] + rng.normal(0, 40, (c["n"], c["j"], 3))).astype(np.float32)
+    d = {
+        "al_metric": OrderedDict((g, float(v)) for g, v in zip(guids, al)),
+        "sal_metric": OrderedDict((g, float(v)) for g, v in zip(guids, salm)),
+        "inlier_count": OrderedDict((g, int(v)) for g, v in zip(guids, inl)),
+        "pred_3d_keypoints": OrderedDict((g, k.astype(np.float64).tolist()) for g, k in zip(guids, kp)),
+        "mkpe": OrderedDict((g, 0.0) for g in guids),
+    }
+    done = [guids[i] for i in rng.permutation(c["n"])[: c["pseudo_done"]]]
+    return d, done

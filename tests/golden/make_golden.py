@@ -18,6 +18,7 @@ What is pinned:
   models.npz                 eval heat-maps of HRNet-W32 / W48 / PoseResNet-50 with synthetic weights
   train_step.npz             train-mode loss, gradient norms, BN running stats after one step
   pck.npz                    compute_3d_pck_figure / compute_3d_pckh_figure (utils/evaluation.py:121-195)
+  sal_filter.json            _sal_pseudo_labeling (strategy.py:915-1001): AL picks + pseudo-label filter (clusters / random.sample)
   preprocess.npz             prepare_single_view (dataset/dataset.py:158-220): crop / LANCZOS resize / normalise / GT heat-maps
 """
 from __future__ import annotations
@@ -294,13 +295,68 @@ def gen_preprocess(ns):
     np.savez_compressed(os.path.join(HERE, "preprocess.npz"), versions=versions(), pillow=PIL.__version__, **out)
 
 
+def gen_sal_filter(ns):
+    """The reference's ``_sal_pseudo_labeling`` (strategy.py:915-1001) run unbound on a fake strategy /
+    dataset around a prepared sal_dict: AL picks, then the pseudo-label filter with KMeans cluster balancing
+    (centres fitted here and stored) or ``random.sample`` (python's RNG seeded with the case seed)."""
+    import random
+    import types
+
+    from sklearn.cluster import KMeans
+
+    out = {"versions": versions()}
+    for name, c in cases.sal_filter_cases().items():
+        sal, done = cases.sal_filter_inputs(c)
+        cfg = ns.config.get_cfg_defaults() if hasattr(ns.config, "get_cfg_defaults") else ns.config._C.clone()
+        cfg.AL.STRATEGY = "HP"
+        cfg.EXPR_TYPE = "SAL"
+        cfg.SAL.INLIER_THRESHOLD = c["thr"]
+        cfg.SAL.NUM_CLUSTERS = c["clusters"]
+        cfg.SAL.CLUSTER_FILE_PATH = "fitted-in-the-generator" if c["use_clusters"] else ""
+        root = 2
+        feats = []
+        for g in sal["pred_3d_keypoints"]:
+            kp = np.array(sal["pred_3d_keypoints"][g]).T
+            feats.append((kp[0:3, :] - kp[0:3, root : root + 1]).flatten())
+        km = KMeans(n_clusters=c["clusters"], n_init=3, random_state=c["seed"]).fit(np.asarray(feats))
+        labelled = {}
+
+        class FakeDataset:
+            pseudo_label_guids = list(done)
+
+            def resample_unlabeled_data(self):
+                pass
+
+            def get_al_dict_for_coreset(self):
+                return {}
+
+            def label_by_frame_guids(self, guids):
+                labelled["al"] = list(guids)
+
+            def pseudo_label_by_frame_guids(self, guids, preds):
+                labelled["sal"] = list(guids)
+
+        fake = types.SimpleNamespace(
+            al_cfg=cfg, joint_root_index=root, kmeans=km,
+            _logger=types.SimpleNamespace(info=lambda *a, **k: None),
+            _get_dataloader=lambda *a, **k: None, _compute_sal_dict=lambda *a, **k: sal)
+        random.seed(c["seed"])
+        _, al_guids, sal_guids, _ = ns.strategy.ActiveLearningStrategy._sal_pseudo_labeling(
+            fake, FakeDataset(), c["al_num"], c["pseudo_num"], None)
+        out[name] = dict(al_guids=list(al_guids), sal_guids=list(sal_guids), centers=km.cluster_centers_.tolist())
+    with open(os.path.join(HERE, "sal_filter.json"), "w") as f:
+        json.dump(out, f)
+
+
 def main():
     ns = ref_harness.load()
-    which = sys.argv[1:] or ["tri", "scoring", "sal", "coreset", "models", "train", "pck", "preprocess"]
+    which = sys.argv[1:] or ["tri", "scoring", "sal", "coreset", "models", "train", "pck", "preprocess", "sal_filter"]
     if "pck" in which:
         gen_pck(ns)
     if "preprocess" in which:
         gen_preprocess(ns)
+    if "sal_filter" in which:
+        gen_sal_filter(ns)
     if "tri" in which:
         gen_triangulation(ns)
     if "scoring" in which:

@@ -212,3 +212,21 @@ def test_lanczos_restatement_vs_pillow():
         img = rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8)
         want = np.asarray(Image.fromarray(img).resize((ow, oh), resample=Image.LANCZOS))
         np.testing.assert_array_equal(opp.resize_lanczos_u8(img, ow, oh), want)
+
+
+@pytest.mark.parametrize("name", list(cases.sal_filter_cases()))
+def test_sal_filter_restatement_vs_reference_golden(name):
+    """Pseudo-label filter of _sal_pseudo_labeling (strategy.py:952-1001), cluster-balanced and random.sample
+    variants, against what the reference itself selected."""
+    import random
+
+    from oracle import selection
+
+    with open(os.path.join(G, "sal_filter.json")) as f:
+        want = json.load(f)[name]
+    c = cases.sal_filter_cases()[name]
+    sal, done = cases.sal_filter_inputs(c)
+    random.seed(c["seed"])
+    got = selection.sal_pseudo_label_guids(sal, want["al_guids"], done, c["pseudo_num"], c["thr"], 2,
+                                           want["centers"] if c["use_clusters"] else None, c["clusters"])
+    assert got == want["sal_guids"]
