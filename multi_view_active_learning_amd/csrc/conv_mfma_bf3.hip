@@ -49,6 +49,9 @@
 // vector work (split, addressing, epilogue: 1.4-2.3 instructions per MFMA) needs about as many issue cycles as
 // the MFMAs themselves (an MFMA holds the SIMD's vector issue for 8 of its 16 cycles), so what remains to be
 // gained is in removing vector instructions, not in overlapping phases.
+// A 16-deep tail step for the 48-channel layers (v_mfma_f32_16x16x16_bf16 on the half-empty second chunk)
+// cannot pay: tools/micro/mfma_rate.hip measures 8.2 ns per MFMA per SIMD for the 16-deep form against 8.4 ns
+// for the 32-deep one (1019 vs 1998 TFLOP/s chip-wide) -- same issue slot, half the work.
 // All variants sit at ~50 us / 190 TFLOP/s on the 64..256-channel layers (46 % of the split peak;
 // the guide's tuned 8-phase bf16 GEMM reaches 53-59 % of peak on random data).
 // Used for 3x3 convs with cin % 32 == 0 (or cin = 48) when the plan selects MVAL_ALGO_MFMA_BF3.
