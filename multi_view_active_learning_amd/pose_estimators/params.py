@@ -83,6 +83,12 @@ def attach_parameters(root: nn.Module, graph) -> dict:
             b = BatchNormStats(op.cout)
             _attach(root, op.bn, b)
             holders[op.bn] = b
+    # ops are listed in execution order (the projection shortcut runs before conv3); the reference registers a
+    # block's ``downsample`` last (hrnet.py:58-73, pose_resnet.py:195-209), and ``parameters()`` order is what an
+    # optimizer state_dict is indexed by -- keep it identical so checkpoints carry over in both directions
+    for scope in root.modules():
+        if isinstance(scope, _Scope) and "downsample" in scope._modules and "conv3" in scope._modules:
+            scope._modules["downsample"] = scope._modules.pop("downsample")
     return holders
 
 

@@ -121,3 +121,171 @@ def test_tables_to_sal_dict_gather_order():
     assert list(d["al_metric"]) == ["0-0", "1-0", "0-1", "1-1", "0-2", "1-2"]
     assert d["inlier_count"]["1-1"] == 2.0 and np.isnan(d["mkpe"]["1-1"])
     assert d["pred_3d_keypoints"]["0-0"] == [[0.5, 0.5, 0.5], [0.5, 0.5, 0.5]]
+
+
+# ---- on-disk formats: tests/golden/formats.json holds what the reference's own writers produced ----
+def _formats():
+    import json
+
+    with open(os.path.join(os.path.dirname(__file__), "golden", "formats.json")) as f:
+        return json.load(f)
+
+
+def test_iteration_files_match_reference_text(tmp_path):
+    """write_iteration leaves the same files, byte for byte, as the reference's rank-0 branch of sample_next_batch
+    (strategy.py:54-135) did for the same guids / score dictionaries."""
+    import json
+
+    from multi_view_active_learning_amd.utils import experiment_io as eio
+
+    g = _formats()
+    sal = json.loads(g["files"]["SAL-DICT-ITER-1"])
+    eio.write_iteration(str(tmp_path), "expr", 0, g["seed_guids"])
+    eio.write_iteration(str(tmp_path), "expr", 1, g["al_guids"], g["sal_guids"], sal)
+    got = {n: open(os.path.join(tmp_path, "expr", n)).read() for n in sorted(os.listdir(tmp_path / "expr"))}
+    assert got == g["files"]
+    # an empty pseudo-label list writes no SAL-GUID file (strategy.py:73: `if len(sal_guids) != 0`)
+    eio.write_iteration(str(tmp_path), "expr", 2, g["al_guids"], [], sal)
+    assert not os.path.exists(eio.sal_guid_path(str(tmp_path), "expr", 2))
+    assert os.path.exists(eio.sal_dict_path(str(tmp_path), "expr", 2))
+
+
+def test_sal_dict_text_from_packed_tables():
+    """The packed per-rank table -> five dicts -> json.dumps reproduces the reference's SAL-DICT text exactly: the
+    values leave the table as python floats of the same fp32 / fp64 numbers the reference's ``.data.item()`` gives."""
+    import json
+
+    from multi_view_active_learning_amd.strategy import tables_to_sal_dict
+
+    g = _formats()
+    text = g["files"]["SAL-DICT-ITER-1"]
+    sal = json.loads(text)
+    guids = list(sal["al_metric"])
+    rows = []
+    for guid in guids:
+        pose, frame = guid.split("-")
+        rows.append([float(pose), float(frame), sal["al_metric"][guid], sal["sal_metric"][guid], sal["inlier_count"][guid],
+                     sal["mkpe"][guid]] + list(np.asarray(sal["pred_3d_keypoints"][guid]).reshape(-1)))
+    table = np.asarray(rows, dtype=np.float64)
+    assert json.dumps(tables_to_sal_dict([table], [2, 2])) == text
+
+
+def test_restore_guids_matches_reference_restore_dataset(tmp_path):
+    from multi_view_active_learning_amd.utils import experiment_io as eio
+
+    g = _formats()
+    for name, text in g["files"].items():
+        p = tmp_path / "expr" / name
+        p.parent.mkdir(exist_ok=True)
+        p.write_text(text)
+    labeled, pseudo = eio.restore_guids(str(tmp_path), "expr", 2, expr_type="SAL")
+    assert labeled == g["restore"]["labeled"] and pseudo == g["restore"]["pseudo"]
+    assert eio.restore_guids(str(tmp_path), "expr", 2, expr_type="AL")[1] is None
+    assert eio.restore_guids(str(tmp_path), "expr", 1, expr_type="SAL") == ([g["seed_guids"]], None)
+    assert eio.read_sal_dict(eio.sal_dict_path(str(tmp_path), "expr", 1))["al_metric"] == __import__("json").loads(
+        g["files"]["SAL-DICT-ITER-1"])["al_metric"]
+
+
+@pytest.mark.parametrize("kind", ["POSE_RESNET", "HRNET"])
+def test_checkpoint_structure_matches_reference(tmp_path, kind):
+    """save_checkpoint writes what _save_checkpoints (strategy.py:681-711) writes: same file name, top-level keys,
+    state_dict names / shapes / dtypes IN THE SAME ORDER (the optimizer state is indexed by that order), same Adam
+    state layout; and it loads back strictly, with or without the DistributedDataParallel ``module.`` prefix."""
+    import hashlib
+
+    import torch
+
+    from multi_view_active_learning_amd.pose_estimators import PoseHighResolutionNet, PoseResNet
+    from multi_view_active_learning_amd.utils import experiment_io as eio
+
+    g = _formats()["checkpoint"][kind]
+    assert g["reference_loads_ours"] and g["ours_loads_reference"]  # checked live by make_golden.py
+    make = (lambda: PoseResNet(19, 50)) if kind == "POSE_RESNET" else (lambda: PoseHighResolutionNet(19))
+    model = make()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    for p in model.parameters():
+        p.grad = torch.zeros_like(p)
+    opt.step()
+    path = eio.save_checkpoint(str(tmp_path / "checkpoints"), 3, 17, model, opt)
+    assert os.path.basename(path) == g["file"] == eio.checkpoint_name(3, 17)
+    assert eio.checkpoint_name(3, 17, mkpe=41.256) == "CKPT-E17-MKPE41.26.pth"
+    blob = eio.load_checkpoint(path)
+    assert list(blob.keys()) == g["top_keys"] and (blob["epoch"], blob["global_step"]) == (g["epoch"], g["global_step"])
+    lines = "".join("%s:%s:%s\n" % (k, list(v.shape), v.dtype) for k, v in blob["state_dict"].items())
+    assert len(blob["state_dict"]) == g["n_entries"]
+    assert hashlib.sha256(lines.encode()).hexdigest() == g["state_dict_sha256"]
+    if "state_dict" in g:
+        assert [[k, list(v.shape), str(v.dtype)] for k, v in blob["state_dict"].items()] == g["state_dict"]
+    osd = blob["optimizer"]
+    assert sorted(osd["param_groups"][0].keys()) == g["param_group_keys"]
+    assert sorted(osd["state"][0].keys()) == g["optimizer_state_keys"]
+    assert len(osd["param_groups"][0]["params"]) == g["n_optimizer_params"]
+    # overwrite in place, then restore into a fresh model + optimizer
+    assert eio.save_checkpoint(str(tmp_path / "checkpoints"), 3, 17, model, opt) == path
+    fresh = make()
+    fopt = torch.optim.Adam(fresh.parameters(), lr=1e-3)
+    assert eio.restore_checkpoint(path, fresh, fopt) == (3, 17)
+    assert all(torch.equal(a, b) for a, b in zip(fresh.state_dict().values(), model.state_dict().values()))
+    assert all(fopt.state[p]["exp_avg"].shape == p.shape for p in fresh.parameters())
+    # a checkpoint written from a DDP wrapper ("module." keys) loads into a bare model and the other way round
+    wrapped = {"module." + k: v for k, v in blob["state_dict"].items()}
+    torch.save(dict(blob, state_dict=wrapped), str(tmp_path / "ddp.pth"))
+    assert eio.load_weights(make(), restore_from=str(tmp_path / "ddp.pth")) == "restored"
+
+    class Wrapper(torch.nn.Module):
+        def __init__(self, m):
+            super().__init__()
+            self.module = m
+
+    assert eio.load_weights(Wrapper(make()), restore_from=path) == "restored"
+    assert eio.load_weights(make()) == "scratch"
+
+
+def test_init_weight_filtering(tmp_path):
+    """_load_weights' INIT_WEIGHT branch (strategy.py:723-741): PoseResNet drops the final layer of the pretrained
+    file; HRNet keeps only entries under ``pretrained_layers``."""
+    import torch
+
+    from multi_view_active_learning_amd.pose_estimators import PoseHighResolutionNet, PoseResNet
+    from multi_view_active_learning_amd.utils import experiment_io as eio
+
+    src = PoseResNet(19, 50)
+    with torch.no_grad():
+        for p in src.parameters():
+            p.fill_(0.25)
+    torch.save(src.state_dict(), str(tmp_path / "r50.pth"))
+    dst = PoseResNet(19, 50)
+    before = dst.state_dict()["final_layer.weight"].clone()
+    assert eio.load_weights(dst, init_weight=str(tmp_path / "r50.pth"), estimator_type="POSE_RESNET") == "initialized"
+    sd = dst.state_dict()
+    assert torch.equal(sd["final_layer.weight"], before) and float(sd["conv1.weight"].flatten()[0]) == 0.25
+
+    hsrc = PoseHighResolutionNet(19)
+    with torch.no_grad():
+        for p in hsrc.parameters():
+            p.fill_(0.5)
+    torch.save(hsrc.state_dict(), str(tmp_path / "hr.pth"))
+    hdst = PoseHighResolutionNet(19)
+    layers = hdst.pretrained_layers
+    keep_all = layers[0] == "*"
+    eio.load_weights(hdst, init_weight=str(tmp_path / "hr.pth"), estimator_type="HRNET")
+    for k, v in hdst.state_dict().items():
+        if k.endswith("weight") and v.dim() == 4:
+            loaded = float(v.flatten()[0]) == 0.5
+            assert loaded == (keep_all or k.split(".")[0] in layers), k
+    with pytest.raises(ValueError):
+        eio.load_weights(hdst, init_weight=str(tmp_path / "hr.pth"), estimator_type="OTHER")
+
+
+def test_cluster_file_features(tmp_path):
+    import json
+
+    from multi_view_active_learning_amd.utils import experiment_io as eio
+
+    rng = np.random.default_rng(5)
+    poses = {"3-%d" % i: rng.standard_normal((4, 19)).tolist() for i in range(6)}
+    (tmp_path / "clusters.json").write_text(json.dumps(poses))
+    f = eio.read_cluster_features(str(tmp_path / "clusters.json"), 2)
+    assert f.shape == (6, 57)
+    kp = np.array(poses["3-4"])
+    assert np.array_equal(f[4], (kp[:3] - kp[:3, 2:3]).flatten()) and np.all(f[:, 2] == 0)
