@@ -21,6 +21,9 @@ struct ConvArgs {
   //   in_sub_log2  the input is read at pixels (y << in_sub_log2, x << in_sub_log2): a stride-2 1x1 conv is
   //                a stride-1 1x1 conv on that subsampled view (nothing else is staged)
   int org_dy, org_dx, os_log2, ooy, oox, in_sub_log2;
+  // split-bf16 2x2 parity kernels: != 0 = all four parities of a transposed conv in ONE launch (blockIdx.z = parity
+  // sets org_dy/dx and ooy/oox and advances w by parity * par_w_stride floats)
+  int par_w_stride;
   int precise;  // split-bf16 kernel: separate accumulator for the correction products (training plans)
   // MFMA tiling (filled by the launcher)
   int th, tw, tn, tw_log2, thw_log2;

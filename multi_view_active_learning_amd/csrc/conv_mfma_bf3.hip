@@ -85,8 +85,14 @@ __device__ __forceinline__ void split3(const f32x4 v, bf16x4& h, bf16x4& m, bf16
 // ky) with ms + ky == pr.  Looping (kx, pr) instead of (tap, ms) reads (MS + 2) * 3 fragments per
 // chunk instead of MS * 9 -- half the LDS traffic at MS = 4 -- with the three row taps' weights
 // of one column live at a time.
-template <int KS, int S, int WN, int WM, int NT, int MS, int NE, bool RS = false, bool PA = false>
-__global__ __launch_bounds__(64 * WN * WM) void conv_bf3_kernel(ConvArgs a) {
+// G > 1 (1x1 convs only): G 32-channel chunks are staged per barrier pair instead of one -- a 1x1 conv has a single
+// tap per chunk, i.e. only MS * NT * 6 MFMAs (~0.2 us) between barriers and 8 KB of loads in flight per workgroup;
+// the sub-chunks take the place of the taps in the inner loop.
+template <int KS, int S, int WN, int WM, int NT, int MS, int NE, bool RS = false, bool PA = false, int G = 1>
+__global__ __launch_bounds__(64 * WN * WM)
+    __attribute__((amdgpu_waves_per_eu((KS == 1 && G == 2 && NT == 2) ? (PA ? 3 : 4) : 1, 8))) void conv_bf3_kernel(ConvArgs a) {
+  static_assert(G == 1 || (KS == 1 && S == 1), "multi-chunk staging is for 1x1 convs");
+  constexpr int TAPS = G > 1 ? G : KS * KS;
   constexpr int NTH = 64 * WN * WM;  // 256 threads, or 192 for the 48-channel-granular (HRNet-W48) tiles
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   constexpr int MT = 16 * MS * WM;
@@ -96,6 +102,14 @@ __global__ __launch_bounds__(64 * WN * WM) void conv_bf3_kernel(ConvArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wn = wave % WN, wm = wave / WN;
   const int PH = (a.th - 1) * S + KS, PW = (a.tw - 1) * S + KS;
+  if constexpr (KS == 2) {
+    if (a.par_w_stride) {  // the four parity convs of a transposed conv share one launch
+      const int parity = blockIdx.z;
+      a.org_dy = a.ooy = parity >> 1;
+      a.org_dx = a.oox = parity & 1;
+      a.w += (int64_t)parity * a.par_w_stride;
+    }
+  }
 
   int t = blockIdx.x;
   const int txi = t % a.tiles_x;
@@ -110,8 +124,9 @@ __global__ __launch_bounds__(64 * WN * WM) void conv_bf3_kernel(ConvArgs a) {
 
   const int patch_px = a.tn * PH * PW;
   const int patch_e = patch_px * (BF_KC / 4);
-  const int plane_bytes = patch_px * BF_ROW * 2;
-  char* planes = smem_raw;  // [3][patch_px][BF_ROW] bf16
+  const int sub_bytes = patch_px * BF_ROW * 2;
+  const int plane_bytes = sub_bytes * G;
+  char* planes = smem_raw;  // [3][G][patch_px][BF_ROW] bf16
 
   int abase[MS];  // byte offset inside a plane: pixel row + k quarter
 #pragma unroll
@@ -126,7 +141,9 @@ __global__ __launch_bounds__(64 * WN * WM) void conv_bf3_kernel(ConvArgs a) {
   int goff[NE];
 #pragma unroll
   for (int i = 0; i < NE; i++) {
-    const int e = tid + NTH * i;
+    const int e0 = tid + NTH * i;
+    const int g = G > 1 ? e0 / (MT * 8) : 0;  // sub-chunk (1x1: the patch is the MT-pixel tile)
+    const int e = e0 - g * (MT * 8);
     const int px = e >> 3, q = e & 7;
     const int prow = conv_div20(px, a.pw_magic);  // patch row over all images of the tile
     const int pxx = px - prow * PW;
@@ -136,8 +153,8 @@ __global__ __launch_bounds__(64 * WN * WM) void conv_bf3_kernel(ConvArgs a) {
     const int dsh = a.dil - 1;
     const int sy = iy >> dsh, sx = ix >> dsh;
     const int ay = sy << a.in_sub_log2, ax = sx << a.in_sub_log2;  // subsampled input view (stride-2 1x1 convs)
-    const bool ok = e < patch_e && n < a.N && iy >= 0 && ix >= 0 && ((iy | ix) & dsh) == 0 && ay < a.Hin && ax < a.Win;
-    goff[i] = ok ? ((n * a.Hin + ay) * a.Win + ax) * a.Cin + q * 4 : -1;
+    const bool ok = e < patch_e && g < G && n < a.N && iy >= 0 && ix >= 0 && ((iy | ix) & dsh) == 0 && ay < a.Hin && ax < a.Win;
+    goff[i] = ok ? ((n * a.Hin + ay) * a.Win + ax) * a.Cin + g * BF_KC + q * 4 : -1;
   }
 
   // PA ("precise accumulate", the training plans): two accumulators per output tile, the leading product
@@ -164,18 +181,22 @@ __global__ __launch_bounds__(64 * WN * WM) void conv_bf3_kernel(ConvArgs a) {
 
   auto load_chunk = [&](int c0) {
 #pragma unroll
-    for (int i = 0; i < NE; i++)
-      stage[i] = (goff[i] >= 0 && c0 + q4 < a.Cin) ? *reinterpret_cast<const f32x4*>(a.in + goff[i] + c0)
-                                                   : (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < NE; i++) {
+      const int gc = G > 1 ? ((tid + NTH * i) / (MT * 8)) * BF_KC : 0;
+      stage[i] = (goff[i] >= 0 && c0 + gc + q4 < a.Cin) ? *reinterpret_cast<const f32x4*>(a.in + goff[i] + c0)
+                                                        : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
   };
   auto store_chunk = [&]() {
 #pragma unroll
     for (int i = 0; i < NE; i++) {
-      const int e = tid + NTH * i;
-      if (e < patch_e) {
+      const int e0 = tid + NTH * i;
+      const int g = G > 1 ? e0 / (MT * 8) : 0;
+      const int e = e0 - g * (MT * 8);
+      if (e < patch_e && g < G) {
         bf16x4 h, m, l;
         split3(stage[i], h, m, l);
-        const int off = (e >> 3) * (BF_ROW * 2) + (e & 7) * 8;
+        const int off = g * sub_bytes + (e >> 3) * (BF_ROW * 2) + (e & 7) * 8;
         *reinterpret_cast<bf16x4*>(planes + off) = h;
         *reinterpret_cast<bf16x4*>(planes + plane_bytes + off) = m;
         *reinterpret_cast<bf16x4*>(planes + 2 * plane_bytes + off) = l;
@@ -187,9 +208,10 @@ __global__ __launch_bounds__(64 * WN * WM) void conv_bf3_kernel(ConvArgs a) {
   store_chunk();
   __syncthreads();
 
-  for (int ch = 0; ch < nchunks; ch++) {
-    const bool more = ch + 1 < nchunks;
-    if (more) load_chunk((ch + 1) * BF_KC);
+  const int nstages = nchunks / G;  // the launcher only picks G > 1 when it divides the chunk count
+  for (int ch = 0; ch < nstages; ch++) {
+    const bool more = ch + 1 < nstages;
+    if (more) load_chunk((ch + 1) * BF_KC * G);
     if constexpr (RS) {
       if (wave_active) {
         static_assert(!RS || (KS == 3 && S == 1), "row sharing is for 3x3 stride 1");
@@ -261,22 +283,23 @@ __global__ __launch_bounds__(64 * WN * WM) void conv_bf3_kernel(ConvArgs a) {
 #pragma unroll
       for (int nt = 0; nt < NT; nt++) {
         const int ns = min(ns0 + nt, a.NS_total - 1);
-        const bf16x8* bp = wq + ((int64_t)ch * a.NS_total + ns) * 192;
+        const bf16x8* bp = wq + ((int64_t)(ch * G) * a.NS_total + ns) * 192;
 #pragma unroll
         for (int p = 0; p < 3; p++) bcur[nt][p] = bp[p * 64];
       }
 #pragma unroll
-      for (int tap = 0; tap < KS * KS; tap++) {
-        if (tap + 1 < KS * KS) {
+      for (int tap = 0; tap < TAPS; tap++) {
+        if (tap + 1 < TAPS) {
 #pragma unroll
           for (int nt = 0; nt < NT; nt++) {
             const int ns = min(ns0 + nt, a.NS_total - 1);
-            const bf16x8* bp = wq + ((int64_t)((tap + 1) * nchunks + ch) * a.NS_total + ns) * 192;
+            const int blk = G > 1 ? ch * G + tap + 1 : (tap + 1) * nchunks + ch;
+            const bf16x8* bp = wq + ((int64_t)blk * a.NS_total + ns) * 192;
 #pragma unroll
             for (int p = 0; p < 3; p++) bnxt[nt][p] = bp[p * 64];
           }
         }
-        const int toff = ((tap / KS) * PW + (tap % KS)) * (BF_ROW * 2);
+        const int toff = G > 1 ? tap * sub_bytes : ((tap / KS) * PW + (tap % KS)) * (BF_ROW * 2);
 #pragma unroll
         for (int ms = 0; ms < MS; ms++) {
           const char* ap = planes + abase[ms] + toff;
@@ -343,7 +366,7 @@ static int bf3_row_sharing() {
   return v;
 }
 
-template <int KS, int S, int WN, int WM, int NT, int MS>
+template <int KS, int S, int WN, int WM, int NT, int MS, int G = 1>
 static int launch_bf3(ConvArgs a, int th, int tw, int tn, hipStream_t s) {
   a.th = th; a.tw = tw; a.tn = tn;
   a.tw_log2 = __builtin_ctz(tw);
@@ -356,15 +379,27 @@ static int launch_bf3(ConvArgs a, int th, int tw, int tn, hipStream_t s) {
   a.ph_magic = ((1u << 20) + PH - 1) / PH;
   constexpr int MT = 16 * MS * WM, NTILE = 16 * NT * WN;
   const int patch_px = tn * PH * PW;
-  size_t smem = (size_t)3 * patch_px * BF_ROW * 2;
+  size_t smem = (size_t)3 * G * patch_px * BF_ROW * 2;
   const size_t otile = (size_t)MT * (NTILE + OPAD) * sizeof(float);
   if (otile > smem) smem = otile;
   if (smem > 128 * 1024) return 1;
   constexpr int NTH = 64 * WN * WM;
-  const int ne = (patch_px * 8 + NTH - 1) / NTH;
+  const int ne = (G * patch_px * 8 + NTH - 1) / NTH;
   if (ne > 10 || patch_px >= 4096 || tn * PH >= 4096) return 1;
+  constexpr bool NE10 = MT >= 64 || S == 2;  // the small-problem tiles only exist with 6 staging slots
+  if (!NE10 && ne > 6) return 1;
+  if (G > 1 && (patch_px != MT || ((a.Cin + BF_KC - 1) / BF_KC) % G != 0)) return 1;
   if (g_bf3_dry) return 0;
-  dim3 grid((unsigned)(a.tiles_x * a.tiles_y * ngroups), (unsigned)((a.NS_total + WN * NT - 1) / (WN * NT)));
+  dim3 grid((unsigned)(a.tiles_x * a.tiles_y * ngroups), (unsigned)((a.NS_total + WN * NT - 1) / (WN * NT)),
+            (KS == 2 && a.par_w_stride) ? 4u : 1u);
+  if constexpr (G > 1) {
+    constexpr int NEG = (G * MT * 8 + NTH - 1) / NTH;
+    if (a.precise)
+      hipLaunchKernelGGL((conv_bf3_kernel<KS, S, WN, WM, NT, MS, NEG, false, true, G>), grid, dim3(NTH), smem, s, a);
+    else
+      hipLaunchKernelGGL((conv_bf3_kernel<KS, S, WN, WM, NT, MS, NEG, false, false, G>), grid, dim3(NTH), smem, s, a);
+    return 0;
+  }
   if constexpr (KS == 3 && S == 1) {
     if (tw == 16 && tn == 1 && ne <= 6 && bf3_row_sharing()) {
       if (a.precise)
@@ -377,13 +412,13 @@ static int launch_bf3(ConvArgs a, int th, int tw, int tn, hipStream_t s) {
   if (a.precise) {
     if (ne <= 6)
       hipLaunchKernelGGL((conv_bf3_kernel<KS, S, WN, WM, NT, MS, 6, false, true>), grid, dim3(NTH), smem, s, a);
-    else
+    else if constexpr (NE10)
       hipLaunchKernelGGL((conv_bf3_kernel<KS, S, WN, WM, NT, MS, 10, false, true>), grid, dim3(NTH), smem, s, a);
     return 0;
   }
   if (ne <= 6)
     hipLaunchKernelGGL((conv_bf3_kernel<KS, S, WN, WM, NT, MS, 6>), grid, dim3(NTH), smem, s, a);
-  else
+  else if constexpr (NE10)
     hipLaunchKernelGGL((conv_bf3_kernel<KS, S, WN, WM, NT, MS, 10>), grid, dim3(NTH), smem, s, a);
   return 0;
 }
@@ -400,6 +435,21 @@ static void bf3_pick_tile(int H, int W, int mt, int* th, int* tw, int* tn) {
   *th = h; *tw = w; *tn = n;
 }
 
+// Tile pixels for a small problem: `px` output pixels x `groups` workgroups per pixel tile (see dispatch_bf3).
+static int bf3_small_tile(int ks, int64_t px, int64_t groups) {
+  static int enabled = -1;
+  if (enabled < 0) {
+    const char* e = getenv("MVAL_BF3_SMALL_TILES");
+    enabled = e ? atoi(e) : 1;
+  }
+  if (!enabled) return 64;
+  const int64_t wgs64 = ((px + 63) / 64) * groups;
+  if (ks == 3) return wgs64 <= 64 ? 16 : 64;
+  int mt = 64;
+  while (mt > 16 && ((px + mt - 1) / mt) * groups < 384) mt >>= 1;
+  return mt;
+}
+
 template <int KS, int S>
 static int dispatch_bf3(const ConvArgs& a, hipStream_t s) {
   int th, tw, tn;
@@ -411,9 +461,45 @@ static int dispatch_bf3(const ConvArgs& a, hipStream_t s) {
     if (small) return launch_bf3<KS, S, 2, 2, 1, 2>(a, th, tw, tn, s);
     return launch_bf3<KS, S, 2, 2, 1, 4>(a, th, tw, tn, s);
   }
-  bf3_pick_tile(a.Hout, a.Wout, 64, &th, &tw, &tn);
-  // 48 / 96 output channels (3 / 6 sub-tiles): three cout waves per workgroup, no idle wave
-  if (a.NS_total % 3 == 0 && a.NS_total % 4 != 0) return launch_bf3<KS, S, 3, 1, 1, 4>(a, th, tw, tn, s);
+  // Small problems (a few images, or the deep low-resolution layers): with 64-pixel tiles fewer workgroups than
+  // CUs exist while each walks all of cin serially.  1x1 convs and the 2x2 parity convs of a transposed conv go
+  // down to 32- and 16-pixel tiles until there are a few hundred workgroups (PoseResNet-50 on 8 images:
+  // 2048 -> 512 on 8x6 maps 78 -> 60 us, the 2048 -> 256 transposed conv 637 -> 147 us with its four parities in
+  // one launch); the row-sharing 3x3 kernel gains only from 16-pixel tiles and only when fewer than a quarter of
+  // the CUs had work (512 -> 512 on 8x6: 78 -> 64 us; 32-pixel tiles measured 1.5x SLOWER than 64-pixel ones).
+  const int wn = (a.NS_total % 3 == 0 && a.NS_total % 4 != 0) ? 3 : 4;  // 48 / 96 output channels: three cout waves
+  const int64_t cgroups = (a.NS_total + wn - 1) / wn, par = (KS == 2 && a.par_w_stride) ? 4 : 1;
+  const int mt = bf3_small_tile(KS, px, cgroups * par);
+  bf3_pick_tile(a.Hout, a.Wout, mt, &th, &tw, &tn);
+  const int nch = (a.Cin + BF_KC - 1) / BF_KC;
+  if constexpr (KS == 1) {
+    // 1x1: two 32-channel chunks per barrier pair (16 KB of loads in flight per workgroup, twice the MFMAs
+    // between barriers) and, from 128 output channels on, 128-cout tiles (half the staging redundancy):
+    // 5-19 % on the bottleneck shapes of HRNet's layer1 / PoseResNet-50 (tools/conv1x1_sweep.py; four chunks
+    // per stage cost a workgroup per CU in LDS and measured 20-30 % slower)
+    static int k1 = -1;
+    if (k1 < 0) {
+      const char* e = getenv("MVAL_BF3_K1");
+      k1 = e ? atoi(e) : 1;
+    }
+    if (k1 && wn == 4 && a.NS_total % 4 == 0 && nch % 2 == 0) {
+      // 128-cout tiles only while they still give every CU a few workgroups
+      const int64_t wgs128 = ((px + 63) / 64) * (a.NS_total / 8);
+      if (a.NS_total % 8 == 0 && wgs128 >= 1024) return launch_bf3<KS, S, 4, 1, 2, 4, 2>(a, th, tw, tn, s);
+      if (mt == 16) return launch_bf3<KS, S, 4, 1, 1, 1, 2>(a, th, tw, tn, s);
+      if (mt == 32) return launch_bf3<KS, S, 4, 1, 1, 2, 2>(a, th, tw, tn, s);
+      return launch_bf3<KS, S, 4, 1, 1, 4, 2>(a, th, tw, tn, s);
+    }
+  }
+  if (wn == 3) {
+    if (mt == 16) return launch_bf3<KS, S, 3, 1, 1, 1>(a, th, tw, tn, s);
+    if constexpr (KS != 3)
+      if (mt == 32) return launch_bf3<KS, S, 3, 1, 1, 2>(a, th, tw, tn, s);
+    return launch_bf3<KS, S, 3, 1, 1, 4>(a, th, tw, tn, s);
+  }
+  if (mt == 16) return launch_bf3<KS, S, 4, 1, 1, 1>(a, th, tw, tn, s);
+  if constexpr (KS != 3)
+    if (mt == 32) return launch_bf3<KS, S, 4, 1, 1, 2>(a, th, tw, tn, s);
   return launch_bf3<KS, S, 4, 1, 1, 4>(a, th, tw, tn, s);
 }
 
@@ -452,7 +538,8 @@ int mval_launch_conv_bf3(const ConvArgs& a, hipStream_t s) {
     int th, tw, tn;
     bf3_pick_tile(a.Hout, a.Wout, 32, &th, &tw, &tn);
     if (a.NS_total <= 2) return launch_bf3<3, 2, 2, 2, 1, 1>(a, th, tw, tn, s);
-    if (a.NS_total % 3 == 0 && a.NS_total % 4 != 0) return launch_bf3<3, 2, 3, 1, 1, 2>(a, th, tw, tn, s);
+    const bool w3 = a.NS_total % 3 == 0 && a.NS_total % 4 != 0;
+    if (w3) return launch_bf3<3, 2, 3, 1, 1, 2>(a, th, tw, tn, s);
     return launch_bf3<3, 2, 4, 1, 1, 2>(a, th, tw, tn, s);
   }
   return 1;

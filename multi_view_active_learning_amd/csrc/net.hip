@@ -294,12 +294,11 @@ extern "C" int mval_op_launch(const mval_op* op, int n_images, float* workspace,
   MVAL_REQUIRE(a.in && a.out, "mval_op_launch: missing input/output buffer");
   hipStream_t s = mval_stream(stream);
   if (op->kind == MVAL_OP_DECONV && op->algo == MVAL_ALGO_MFMA_BF3) {
-    const float* wp = a.w;
-    for (int parity = 0; parity < 4; parity++) {
-      deconv_parity(a, op, parity, wp);
-      int rc = mval_launch_conv_bf3(a, s);
-      MVAL_REQUIRE(rc == 0, "mval_op_launch: no bf16x3 MFMA kernel for the transposed conv cin%d cout%d", op->cin, op->cout);
-    }
+    // the four parity convs in one launch (blockIdx.z): on a few images one parity alone leaves most CUs idle
+    deconv_parity(a, op, 0, a.w);
+    a.par_w_stride = (int)(mval_packed_weight_floats(MVAL_PACK_MFMA16_BF3, op->cout, op->cin, 4) / 4);
+    int rc = mval_launch_conv_bf3(a, s);
+    MVAL_REQUIRE(rc == 0, "mval_op_launch: no bf16x3 MFMA kernel for the transposed conv cin%d cout%d", op->cin, op->cout);
   } else if (op->kind == MVAL_OP_CONV && op->algo == MVAL_ALGO_MFMA_BF3) {
     int rc = mval_launch_conv_bf3(a, s);
     MVAL_REQUIRE(rc == 0, "mval_op_launch: no bf16x3 MFMA kernel for conv k%d s%d cin%d cout%d", op->k, op->stride, op->cin,

@@ -67,6 +67,13 @@ CONV_CASES = [
     (2, 512, 512, 8, 6, 3, 1, True, False, False, 0, False),
     (2, 256, 512, 32, 24, 1, 2, False, False, False, 0, False),
     (3, 16, 80, 7, 5, 3, 1, True, True, False, 0, False),
+    # 1x1 tile shapes of the split kernel: 128-cout tiles with two chunks per stage (large problems) ...
+    (16, 64, 256, 64, 64, 1, 1, True, True, False, 0, False),
+    (16, 256, 128, 64, 64, 1, 1, True, False, False, 0, False),
+    # ... and the 32- / 16-pixel tiles of small problems (the 512 -> 512 3x3 case above runs on 16-pixel tiles too)
+    (6, 128, 256, 32, 24, 1, 1, True, True, False, 0, False),
+    (1, 1024, 256, 16, 12, 1, 1, False, True, False, 0, False),
+    (1, 2048, 512, 8, 6, 1, 1, True, False, False, 0, False),
 ]
 
 
