@@ -425,6 +425,15 @@ static int launch_bf3(ConvArgs a, int th, int tw, int tn, hipStream_t s) {
 
 static void bf3_pick_tile(int H, int W, int mt, int* th, int* tw, int* tn) {
   int w = (W > 8) ? 16 : 8;
+  // widths that are no multiple of 16 (72 / 36 / 18 for HRNet-W48 at 384 x 288, 24 for PoseResNet at 256 x 192):
+  // 8-wide tiles waste fewer columns than 16-wide ones, which outweighs the row-sharing kernel they give up
+  // (HRNet-W48 forward 36.4 -> 32.0 ms on 64 images)
+  static int tw8 = -1;
+  if (tw8 < 0) {
+    const char* e = getenv("MVAL_BF3_TW8");
+    tw8 = e ? atoi(e) : 1;
+  }
+  if (tw8 && W > 8 && mt >= 32 && ((W + 7) / 8) * 8 < ((W + 15) / 16) * 16) w = 8;
   int h = mt / w, n = 1;
   int hh = 1;
   while (hh < H) hh <<= 1;
