@@ -234,7 +234,8 @@ int mval_launch_wgrad_bf3(const float* x, const float* dz, float* slabs, int N, 
   WgradBf3Args a;
   a.x = x; a.dz = dz; a.slabs = slabs;
   a.N = N; a.Hin = Hin; a.Win = Win; a.H = Hout; a.W = Wout; a.Cin = Cin; a.Cout = Cout;
-  const int tw = Wout > 8 ? 16 : 8;
+  // 8-wide tiles also for widths like 72 / 36 / 18 / 24 where they waste fewer (zero-padded) columns than 16-wide ones
+  const int tw = (Wout > 8 && ((Wout + 15) / 16) * 16 <= ((Wout + 7) / 8) * 8) ? 16 : 8;
   const int th = (stride == 2 ? 32 : 64) / tw;  // stride-2 patches are ~4x larger per pixel: 32-pixel tiles
   a.tiles_x = (Wout + tw - 1) / tw;
   a.tiles_y = (Hout + th - 1) / th;
