@@ -71,7 +71,7 @@ __device__ __forceinline__ bf16x8 wb_frag(const char* lo, const char* hi) {
 
 // KS x KS taps, stride S, tile TH x TW output pixels, NT cout tiles and MI cin tiles (of 16) per wave
 template <int KS, int S, int TH, int TW, int NT, int MI>
-__global__ __launch_bounds__(256) void conv_wgrad_bf3_kernel(WgradBf3Args a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((KS == 3 && S == 1 && TH == 8 && NT == 2) ? 2 : 1, 8))) void conv_wgrad_bf3_kernel(WgradBf3Args a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int T = KS * KS, MT = TH * TW;
   constexpr int PH = (TH - 1) * S + KS, PW = (TW - 1) * S + KS, PPX = PH * PW;
