@@ -52,6 +52,16 @@
 // A 16-deep tail step for the 48-channel layers (v_mfma_f32_16x16x16_bf16 on the half-empty second chunk)
 // cannot pay: tools/micro/mfma_rate.hip measures 8.2 ns per MFMA per SIMD for the 16-deep form against 8.4 ns
 // for the 32-deep one (1019 vs 1998 TFLOP/s chip-wide) -- same issue slot, half the work.
+// The weight fragment as the MFMA's first operand (a lane then holds four consecutive output channels of one pixel)
+// with BN / residual / ReLU finished in registers and float4 stores straight from the accumulators -- no LDS round
+// trip, no barrier, but 64-byte instead of 256-byte store runs: 32 -> 32 78.8 vs 73.4 us, 128 -> 128 50.2 vs 55.6 us,
+// HRNet-W32 forward unchanged within noise, and the extra live values spill in the register-capped 1x1 variant.
+// Dispatching the cout groups of one pixel tile back to back (shared input tile, adjacent stores): +-1 %.
+// Phase stripping of the write-heavy 1x1 conv 64 -> 256 on 128 64x64 maps (251 us; HBM streams of that size run at
+// 5.3-6.8 TB/s, tools/micro/hbm_rw.py, i.e. ~120 us): skeleton without loads, MFMAs or stores 55 us (dispatching
+// 16384 empty workgroups takes 4.7 us, tools/micro/dispatch_rate.hip -- the rest is setup, split, LDS traffic and
+// barriers), + loads 9, + MFMA loop 43, + stores 75 = 182 us; the remaining 70 us are phases of co-resident
+// workgroups that do not overlap.
 // All variants sit at ~50 us / 190 TFLOP/s on the 64..256-channel layers (46 % of the split peak;
 // the guide's tuned 8-phase bf16 GEMM reaches 53-59 % of peak on random data).
 // Used for 3x3 convs with cin % 32 == 0 (or cin = 48) when the plan selects MVAL_ALGO_MFMA_BF3.
