@@ -56,7 +56,8 @@
 // with BN / residual / ReLU finished in registers and float4 stores straight from the accumulators -- no LDS round
 // trip, no barrier, but 64-byte instead of 256-byte store runs: 32 -> 32 78.8 vs 73.4 us, 128 -> 128 50.2 vs 55.6 us,
 // HRNet-W32 forward unchanged within noise, and the extra live values spill in the register-capped 1x1 variant.
-// Dispatching the cout groups of one pixel tile back to back (shared input tile, adjacent stores): +-1 %.
+// Dispatching the cout groups of one pixel tile back to back (shared input tile, adjacent stores): +-1 %; an
+// XCD-aware tile order (each XCD a contiguous run of tiles, so halo rows hit its own L2): +-1 % as well.
 // Phase stripping of the write-heavy 1x1 conv 64 -> 256 on 128 64x64 maps (251 us; HBM streams of that size run at
 // 5.3-6.8 TB/s, tools/micro/hbm_rw.py, i.e. ~120 us): skeleton without loads, MFMAs or stores 55 us (dispatching
 // 16384 empty workgroups takes 4.7 us, tools/micro/dispatch_rate.hip -- the rest is setup, split, LDS traffic and
