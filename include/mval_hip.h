@@ -208,6 +208,16 @@ typedef struct mval_op {
 size_t mval_packed_weight_floats(int pack, int cout, int cin, int k);
 int mval_pack_conv_weights(int pack, int transposed, const float* w, float* packed, int cout, int cin, int k,
                            void* stream);
+/* Many MVAL_PACK_MFMA16_BF3 packings in ONE launch (a training plan re-packs every conv weight after each optimizer
+ * step, strategy.py:478-484).  jobs_dev: n_jobs descriptors IN DEVICE MEMORY (w / packed are device pointers, mode =
+ * the `transposed` argument above); first_block_dev[j] = 256-thread blocks of the jobs before j, a job has
+ * (k * k * ceil(cin / 32) * ceil(cout / 16) * 512 + 255) / 256 blocks; total_blocks = their sum. */
+typedef struct mval_pack_job {
+  const float* w;
+  void* packed;
+  int mode, cout, cin, k;
+} mval_pack_job;
+int mval_pack_bf3_jobs(const mval_pack_job* jobs_dev, const int* first_block_dev, int n_jobs, int total_blocks, void* stream);
 /* scale = gamma / sqrt(var + eps) ; shift = beta - mean * scale  (all [c] f32). */
 int mval_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var, float eps,
                  float* scale, float* shift, int c, void* stream);

@@ -147,5 +147,6 @@ int mval_conv_mfma_supported(const ConvArgs& a);            // same selection lo
 int mval_launch_conv_bf3(const ConvArgs& a, hipStream_t s);   // conv_mfma_bf3.hip; returns 1 if unsupported
 int mval_conv_bf3_supported(const ConvArgs& a);
 int mval_pack_bf3(int mode, const float* w, float* packed, int cout, int cin, int k, hipStream_t s);
+int mval_pack_bf3_batch(const void* jobs_dev, const int* first_block_dev, int n_jobs, int total_blocks, hipStream_t s);
 int mval_launch_conv_direct(const ConvArgs& a, int kind, hipStream_t s);
 int mval_launch_conv_stem(const ConvArgs& a, hipStream_t s);  // conv_stem.hip; returns 1 if unsupported

@@ -573,10 +573,9 @@ int mval_conv_bf3_supported(const ConvArgs& a) {
 }
 
 // ---- weight packing: [tap][cin/32][cout/16][plane][lane][8 bf16] ---------------------------
-__global__ void pack_bf3_kernel(const float* __restrict__ w, unsigned short* __restrict__ p, int mode, int cout, int cin,
-                                int k) {
+__device__ __forceinline__ void pack_bf3_element(const float* __restrict__ w, unsigned short* __restrict__ p, int mode,
+                                                 int cout, int cin, int k, int64_t i) {
   const int G = (cin + 31) / 32, NS = (cout + 15) / 16;
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t total = (int64_t)k * k * G * NS * 512;  // (lane, j) pairs per block
   if (i >= total) return;
   const int j = (int)(i & 7);
@@ -609,6 +608,38 @@ __global__ void pack_bf3_kernel(const float* __restrict__ w, unsigned short* __r
   p[base] = __builtin_bit_cast(unsigned short, h);
   p[base + 512] = __builtin_bit_cast(unsigned short, m);
   p[base + 1024] = __builtin_bit_cast(unsigned short, l);
+}
+
+__global__ void pack_bf3_kernel(const float* __restrict__ w, unsigned short* __restrict__ p, int mode, int cout, int cin,
+                                int k) {
+  pack_bf3_element(w, p, mode, cout, cin, k, (int64_t)blockIdx.x * blockDim.x + threadIdx.x);
+}
+
+// All weight tensors of a training plan in ONE launch (they are re-packed after every optimizer step: ~580 tiny
+// launches otherwise).  jobs / first_block live in device memory; block b belongs to the last job whose first
+// block is <= b.
+struct PackBf3Job {
+  const float* w;
+  unsigned short* p;
+  int mode, cout, cin, k;
+};
+static_assert(sizeof(PackBf3Job) == 32, "mval_pack_job layout");
+
+__global__ void pack_bf3_batch_kernel(const PackBf3Job* __restrict__ jobs, const int* __restrict__ first_block, int n_jobs) {
+  int lo = 0, hi = n_jobs - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (first_block[mid] <= (int)blockIdx.x) lo = mid;
+    else hi = mid - 1;
+  }
+  const PackBf3Job jb = jobs[lo];
+  pack_bf3_element(jb.w, jb.p, jb.mode, jb.cout, jb.cin, jb.k, (int64_t)(blockIdx.x - first_block[lo]) * blockDim.x + threadIdx.x);
+}
+
+int mval_pack_bf3_batch(const void* jobs_dev, const int* first_block_dev, int n_jobs, int total_blocks, hipStream_t s) {
+  hipLaunchKernelGGL(pack_bf3_batch_kernel, dim3((unsigned)total_blocks), dim3(256), 0, s,
+                     reinterpret_cast<const PackBf3Job*>(jobs_dev), first_block_dev, n_jobs);
+  return 0;
 }
 
 int mval_pack_bf3(int mode, const float* w, float* packed, int cout, int cin, int k, hipStream_t s) {

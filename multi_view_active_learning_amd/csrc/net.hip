@@ -54,6 +54,14 @@ __global__ void pack_mfma16_kernel(const float* __restrict__ w, float* __restric
   p[i] = (co < cout && ci < cin) ? w_at(w, transposed, cout, cin, k, co, ci, t) : 0.f;
 }
 
+extern "C" int mval_pack_bf3_jobs(const mval_pack_job* jobs_dev, const int* first_block_dev, int n_jobs, int total_blocks,
+                                 void* stream) {
+  MVAL_REQUIRE(jobs_dev && first_block_dev && n_jobs > 0 && total_blocks > 0, "mval_pack_bf3_jobs: bad arguments");
+  mval_pack_bf3_batch(jobs_dev, first_block_dev, n_jobs, total_blocks, mval_stream(stream));
+  MVAL_CHECK_LAUNCH("mval_pack_bf3_jobs");
+  return 0;
+}
+
 extern "C" int mval_pack_conv_weights(int pack, int transposed, const float* w, float* packed, int cout, int cin, int k,
                                       void* stream) {
   MVAL_REQUIRE(cout > 0 && cin > 0 && k > 0, "mval_pack_conv_weights: bad dims");

@@ -23,8 +23,8 @@ import os
 import torch
 
 from . import _lib
-from .engine import (ALGO_DIRECT, ALGO_MFMA, ALGO_MFMA_BF3, PACK_HWIO, PACK_MFMA16, _KIND, _PACK_OF, MvalOp, _align,
-                     _conv_mode, _mfma_ok)
+from .engine import (ALGO_DIRECT, ALGO_MFMA, ALGO_MFMA_BF3, PACK_HWIO, PACK_MFMA16, PACK_MFMA16_BF3, _KIND, _PACK_OF, MvalOp,
+                     _align, _conv_mode, _mfma_ok)
 
 BN_MOMENTUM = 0.1
 BN_EPS = 1e-5
@@ -200,6 +200,7 @@ class TrainPlan:
         self.ws = torch.empty(512 * maxc * 2 + 64, dtype=torch.float64, device=device)
         self.sums = torch.empty(2 * maxc + 64, **f32)
         self.param_sig = None
+        self._pack_ptrs, self._pack_jobs = None, None
         # parameter order of the autograd node: conv.weight [, conv.bias] [, bn.weight, bn.bias] per op
         holders = model._holders
         self.param_list, self.grad_slots = [], []
@@ -226,14 +227,57 @@ class TrainPlan:
         self.bn_counters = [holders[op.bn].num_batches_tracked for op in g.ops if op.bn]
 
     # ---- parameters ---------------------------------------------------------------------------
+    def _build_pack_table(self, holders, base):
+        """Device-side job table of every split-bf16 weight packing of the plan (forward and data-gradient
+        forms) for ``mval_pack_bf3_jobs``: rebuilt only when a parameter's storage moves."""
+        import numpy as np
+
+        rows, first, blocks = [], [], 0
+        for (i, fpack, dpack), op in zip(self.jobs, self.graph.ops):
+            if op.kind == "maxpool":
+                continue
+            t = self.ops[i]
+            w = holders[op.conv].weight
+            if not (w.is_cuda and w.is_contiguous()):
+                self._pack_jobs = None
+                return
+            fmode, dmode = (2, 0) if op.kind == "deconv" else (0, 2)
+            todo = []
+            if fpack == PACK_MFMA16_BF3:
+                todo.append((base + 4 * t.op.w_off, fmode, op.cout, op.cin))
+            if dpack == PACK_MFMA16_BF3:
+                todo.append((base + 4 * t.wd_off, dmode, op.cin, op.cout))
+            for dst, mode, cout, cin in todo:
+                total = op.k * op.k * ((cin + 31) // 32) * ((cout + 15) // 16) * 512
+                rows.append((w.data_ptr(), dst, mode, cout, cin, op.k))
+                first.append(blocks)
+                blocks += (total + 255) // 256
+        if not rows:
+            self._pack_jobs = None
+            return
+        table = np.array(rows, dtype=np.dtype([("w", "<u8"), ("p", "<u8"), ("mode", "<i4"), ("cout", "<i4"), ("cin", "<i4"),
+                                               ("k", "<i4")]))
+        assert table.dtype.itemsize == 32
+        self._pack_jobs = torch.from_numpy(table.view(np.uint8).copy()).to(self.device)
+        self._pack_first = torch.tensor(first, dtype=torch.int32, device=self.device)
+        self._pack_n, self._pack_blocks = len(rows), blocks
+
     def _refresh(self):
         holders = self.model._holders
         lib = _lib.lib()
         st = _lib._stream()
-        sig = tuple(p._version for p in self.param_list) + tuple(p.data_ptr() for p in self.param_list)
+        ptrs = tuple(p.data_ptr() for p in self.param_list)
+        sig = tuple(p._version for p in self.param_list) + ptrs
         repack = sig != self.param_sig
         base = self.params.data_ptr()
         sbase = self.stats.data_ptr()
+        if repack and ptrs != self._pack_ptrs:
+            self._build_pack_table(holders, base)
+            self._pack_ptrs = ptrs
+        if repack and self._pack_jobs is not None:
+            # every split-bf16 packing (forward and data-gradient forms) in one launch
+            _lib._check(lib.mval_pack_bf3_jobs(C.c_void_p(self._pack_jobs.data_ptr()), C.c_void_p(self._pack_first.data_ptr()),
+                                               C.c_int(self._pack_n), C.c_int(self._pack_blocks), st), "pack (batched)")
         for (i, fpack, dpack), op in zip(self.jobs, self.graph.ops):
             t = self.ops[i]
             if op.kind == "maxpool":
@@ -243,13 +287,15 @@ class TrainPlan:
             if not w.is_cuda:
                 raise _lib.MvalError("model parameters must be on the HIP device (call .cuda())")
             if repack:
+                batched = self._pack_jobs is not None
                 wp = C.c_void_p(w.detach().contiguous().data_ptr())
                 # Conv2d: forward as stored (0), data gradient tap-flipped / channel-swapped (2);
                 # ConvTranspose2d: the other way round (forward = conv over the zero-dilated input)
                 fmode, dmode = (2, 0) if op.kind == "deconv" else (0, 2)
-                _lib._check(lib.mval_pack_conv_weights(C.c_int(fpack), C.c_int(fmode), wp, C.c_void_p(base + 4 * t.op.w_off),
-                                                       C.c_int(op.cout), C.c_int(op.cin), C.c_int(op.k), st), "pack fwd")
-                if dpack is not None:
+                if not (batched and fpack == PACK_MFMA16_BF3):
+                    _lib._check(lib.mval_pack_conv_weights(C.c_int(fpack), C.c_int(fmode), wp, C.c_void_p(base + 4 * t.op.w_off),
+                                                           C.c_int(op.cout), C.c_int(op.cin), C.c_int(op.k), st), "pack fwd")
+                if dpack is not None and not (batched and dpack == PACK_MFMA16_BF3):
                     _lib._check(lib.mval_pack_conv_weights(C.c_int(dpack), C.c_int(dmode), wp, C.c_void_p(base + 4 * t.wd_off),
                                                            C.c_int(op.cin), C.c_int(op.cout), C.c_int(op.k), st), "pack dgrad")
                 if getattr(conv, "bias", None) is not None:
