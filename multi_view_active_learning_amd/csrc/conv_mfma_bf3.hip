@@ -75,7 +75,10 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 #define BF_KC 32
-#define BF_ROW 48  // bf16 elements per LDS pixel row (32 + 16 pad) = 96 bytes
+// bf16 elements per LDS pixel row: 32 + 16 pad = 96 bytes, or 32 + 8 pad = 80 bytes for the stride-2 kernels (both
+// conflict-free for 16 consecutive pixels; 80 bytes cost the 8-wide stride-1 tiles 5-10 % but let a fourth
+// stride-2 workgroup -- 40 KB of planes -- fit a CU: 10-16 % on those layers)
+#define BF_ROW_OF(S) ((S) == 2 ? 40 : 48)
 #define OPAD 4
 
 __device__ __forceinline__ void split3(const f32x4 v, bf16x4& h, bf16x4& m, bf16x4& l) {
@@ -104,6 +107,7 @@ __global__ __launch_bounds__(64 * WN * WM)
     __attribute__((amdgpu_waves_per_eu((KS == 1 && G == 2 && NT == 2) ? (PA ? 3 : 4) : 1, 8))) void conv_bf3_kernel(ConvArgs a) {
   static_assert(G == 1 || (KS == 1 && S == 1), "multi-chunk staging is for 1x1 convs");
   constexpr int TAPS = G > 1 ? G : KS * KS;
+  constexpr int BF_ROW = BF_ROW_OF(S);
   constexpr int NTH = 64 * WN * WM;  // 256 threads, or 192 for the 48-channel-granular (HRNet-W48) tiles
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   constexpr int MT = 16 * MS * WM;
@@ -390,6 +394,7 @@ static int launch_bf3(ConvArgs a, int th, int tw, int tn, hipStream_t s) {
   a.ph_magic = ((1u << 20) + PH - 1) / PH;
   constexpr int MT = 16 * MS * WM, NTILE = 16 * NT * WN;
   const int patch_px = tn * PH * PW;
+  constexpr int BF_ROW = BF_ROW_OF(S);
   size_t smem = (size_t)3 * G * patch_px * BF_ROW * 2;
   const size_t otile = (size_t)MT * (NTILE + OPAD) * sizeof(float);
   if (otile > smem) smem = otile;
