@@ -29,6 +29,7 @@ struct ConvArgs {
   int th, tw, tn, tw_log2, thw_log2;
   int tiles_x, tiles_y;
   unsigned pw_magic, ph_magic;  // ceil(2^20 / PW), ceil(2^20 / PH): patch index -> (row, column) without a divide
+  unsigned tw_magic;            // != 0: odd tile (tw x th pixels, neither a power of two, tn = 1): ceil(2^20 / tw)
   int G_total, NS_total;
 };
 
@@ -55,6 +56,23 @@ __device__ __forceinline__ void conv_store(const ConvArgs& a, int n, int y, int 
 // floor(v / d) for v < 4096 and d < 256 with magic = ceil(2^20 / d) (exact: v * (d - 1) < 2^20)
 __device__ __forceinline__ int conv_div20(int v, unsigned magic) { return (int)(((unsigned)v * magic) >> 20); }
 
+// Tile-local pixel slot -> (image of the tile, row, column).  Power-of-two tiles decode with shifts; the odd tiles of
+// the split kernel (a.tw_magic != 0: th x tw pixels, one image per tile, slots >= th * tw are padding -> false) with
+// a magic divide.
+__device__ __forceinline__ bool conv_tile_decode(const ConvArgs& a, int p, int& tni, int& ty, int& tx) {
+  if (a.tw_magic) {
+    ty = conv_div20(p, a.tw_magic);
+    tx = p - ty * a.tw;
+    tni = 0;
+    return ty < a.th;
+  }
+  tni = p >> a.thw_log2;
+  const int rem = p & ((1 << a.thw_log2) - 1);
+  ty = rem >> a.tw_log2;
+  tx = rem & ((1 << a.tw_log2) - 1);
+  return true;
+}
+
 // Second half of the MFMA kernels' epilogue: the BN'd output tile sits in LDS as
 // ot[pixel][NTILE + 4]; add the residual(s), ReLU and store with float4 lanes along channels.
 // All residual loads of a thread are issued before the first store (MT*NTILE/1024 float4 loads
@@ -78,11 +96,11 @@ __device__ __forceinline__ void conv_tile_store(const ConvArgs& a, const float* 
         const int e = tid + NTH * i;
         const int p = e / Q, c4 = e % Q;
         const int c = cbase + c4 * 4;
-        const int tni = p >> a.thw_log2;
-        const int rem = p & ((1 << a.thw_log2) - 1);
-        const int y = oy0 + (rem >> a.tw_log2), x = ox0 + (rem & ((1 << a.tw_log2) - 1));
+        int tni, ty, tx;
+        const bool inside = conv_tile_decode(a, p, tni, ty, tx);
+        const int y = oy0 + ty, x = ox0 + tx;
         const int n = n0 + tni;
-        const bool ok = e < MT * Q && c < a.Cout && n < a.N && y < a.Hout && x < a.Wout;
+        const bool ok = inside && e < MT * Q && c < a.Cout && n < a.N && y < a.Hout && x < a.Wout;
         off[i] = ok ? (((int64_t)n * (a.Hout << a.os_log2) + (y << a.os_log2) + a.ooy) * (a.Wout << a.os_log2) +
                        (x << a.os_log2) + a.oox) * a.Cout + c
                     : -1;
@@ -107,9 +125,9 @@ __device__ __forceinline__ void conv_tile_store(const ConvArgs& a, const float* 
       const int p = e / Q, c4 = e % Q;
       const int c = cbase + c4 * 4;
       if (c >= a.Cout) continue;
-      const int tni = p >> a.thw_log2;
-      const int rem = p & ((1 << a.thw_log2) - 1);
-      const int y = oy0 + (rem >> a.tw_log2), x = ox0 + (rem & ((1 << a.tw_log2) - 1));
+      int tni, ty, tx;
+      if (!conv_tile_decode(a, p, tni, ty, tx)) continue;
+      const int y = oy0 + ty, x = ox0 + tx;
       const int n = n0 + tni;
       if (n >= a.N || y >= a.Hout || x >= a.Wout) continue;
       const conv_f32x4 v = *reinterpret_cast<const conv_f32x4*>(ot + p * LDW + c4 * 4);
@@ -133,9 +151,9 @@ __device__ __forceinline__ void conv_tile_store(const ConvArgs& a, const float* 
     const int cl = e / MT, p = e % MT;
     const int c = cbase + cl;
     if (c >= a.Cout) continue;
-    const int tni = p >> a.thw_log2;
-    const int rem = p & ((1 << a.thw_log2) - 1);
-    const int y = oy0 + (rem >> a.tw_log2), x = ox0 + (rem & ((1 << a.tw_log2) - 1));
+    int tni, ty, tx;
+    if (!conv_tile_decode(a, p, tni, ty, tx)) continue;
+    const int y = oy0 + ty, x = ox0 + tx;
     const int n = n0 + tni;
     if (n >= a.N || y >= a.Hout || x >= a.Wout) continue;
     conv_store(a, n, y, x, c, ot[p * LDW + cl]);

@@ -147,9 +147,8 @@ __global__ __launch_bounds__(64 * WN * WM)
 #pragma unroll
   for (int ms = 0; ms < MS; ms++) {
     const int p = (wm * MS + ms) * 16 + (lane & 15);
-    const int tni = p >> a.thw_log2;
-    const int rem = p & ((1 << a.thw_log2) - 1);
-    const int ty = rem >> a.tw_log2, tx = rem & ((1 << a.tw_log2) - 1);
+    int tni, ty, tx;
+    if (!conv_tile_decode(a, p, tni, ty, tx)) ty = tx = 0;  // padding slot of an odd tile: any in-range address
     abase[ms] = ((tni * PH + ty * S) * PW + tx * S) * (BF_ROW * 2) + (lane >> 4) * 16;
   }
 
@@ -386,6 +385,11 @@ static int launch_bf3(ConvArgs a, int th, int tw, int tn, hipStream_t s) {
   a.th = th; a.tw = tw; a.tn = tn;
   a.tw_log2 = __builtin_ctz(tw);
   a.thw_log2 = __builtin_ctz(th * tw);
+  a.tw_magic = 0;
+  if ((tw & (tw - 1)) || (th & (th - 1))) {  // odd tile: th x tw of the MT slots, one image per tile
+    if (tn != 1 || th * tw > 16 * MS * WM || G > 1) return 1;
+    a.tw_magic = ((1u << 20) + tw - 1) / tw;
+  }
   a.tiles_x = (a.Wout + tw - 1) / tw;
   a.tiles_y = (a.Hout + th - 1) / th;
   const int ngroups = (a.N + tn - 1) / tn;
@@ -496,6 +500,35 @@ static int dispatch_bf3(const ConvArgs& a, hipStream_t s) {
   const int64_t cgroups = (a.NS_total + wn - 1) / wn, par = (KS == 2 && a.par_w_stride) ? 4 : 1;
   const int mt = bf3_small_tile(KS, px, cgroups * par);
   bf3_pick_tile(a.Hout, a.Wout, mt, &th, &tw, &tn);
+  if constexpr (KS == 3) {
+    // Maps like 24 x 18 or 12 x 9 (HRNet-W48 at 384 x 288) fill power-of-two tiles badly (25 % / 44 % padding):
+    // an odd tile -- tw = W, W / 2 or W / 3 columns by floor(64 / tw) rows, decoded with a magic divide -- is
+    // taken when it needs at least 10 % fewer workgroups.
+    static int odd = -1;
+    if (odd < 0) {
+      const char* e = getenv("MVAL_BF3_ODD_TILES");
+      odd = e ? atoi(e) : 1;
+    }
+    if (odd && mt == 64) {
+      const int64_t wgs2 = (int64_t)((a.Wout + tw - 1) / tw) * ((a.Hout + th - 1) / th) * ((a.N + tn - 1) / tn);
+      int64_t best = wgs2;
+      int bth = 0, btw = 0;
+      for (int d = 1; d <= 3; d++) {
+        const int ctw = (a.Wout + d - 1) / d;
+        if (ctw < 3 || ctw > 32) continue;
+        int cth = 64 / ctw;
+        if (cth > a.Hout) cth = a.Hout;
+        const int64_t w = (int64_t)((a.Wout + ctw - 1) / ctw) * ((a.Hout + cth - 1) / cth) * a.N;
+        if (w < best) {
+          best = w;
+          bth = cth; btw = ctw;
+        }
+      }
+      if (btw && best * 10 <= wgs2 * 9) {
+        th = bth; tw = btw; tn = 1;
+      }
+    }
+  }
   const int nch = (a.Cin + BF_KC - 1) / BF_KC;
   if constexpr (KS == 1) {
     // 1x1: two 32-channel chunks per barrier pair (16 KB of loads in flight per workgroup, twice the MFMAs
