@@ -464,6 +464,35 @@ static void bf3_pick_tile(int H, int W, int mt, int* th, int* tw, int* tn) {
   *th = h; *tw = w; *tn = n;
 }
 
+// Maps like 24 x 18 or 12 x 9 (HRNet-W48 at 384 x 288) fill power-of-two tiles badly (25 % / 44 % padding): an odd
+// tile -- tw = W, W / 2 or W / 3 columns by floor(mt / tw) rows, decoded with a magic divide -- replaces the
+// power-of-two one in (th, tw, tn) when it needs at least 10 % fewer workgroups.
+static void bf3_odd_tile(int H, int W, int N, int mt, int* th, int* tw, int* tn) {
+  static int odd = -1;
+  if (odd < 0) {
+    const char* e = getenv("MVAL_BF3_ODD_TILES");
+    odd = e ? atoi(e) : 1;
+  }
+  if (!odd) return;
+  const int64_t wgs2 = (int64_t)((W + *tw - 1) / *tw) * ((H + *th - 1) / *th) * ((N + *tn - 1) / *tn);
+  int64_t best = wgs2;
+  int bth = 0, btw = 0;
+  for (int d = 1; d <= 3; d++) {
+    const int ctw = (W + d - 1) / d;
+    if (ctw < 3 || ctw > mt / 2) continue;
+    int cth = mt / ctw;
+    if (cth > H) cth = H;
+    const int64_t w = (int64_t)((W + ctw - 1) / ctw) * ((H + cth - 1) / cth) * N;
+    if (w < best) {
+      best = w;
+      bth = cth; btw = ctw;
+    }
+  }
+  if (btw && best * 10 <= wgs2 * 9) {
+    *th = bth; *tw = btw; *tn = 1;
+  }
+}
+
 // Tile pixels for a small problem: `px` output pixels x `groups` workgroups per pixel tile (see dispatch_bf3).
 static int bf3_small_tile(int ks, int64_t px, int64_t groups) {
   static int enabled = -1;
@@ -500,35 +529,8 @@ static int dispatch_bf3(const ConvArgs& a, hipStream_t s) {
   const int64_t cgroups = (a.NS_total + wn - 1) / wn, par = (KS == 2 && a.par_w_stride) ? 4 : 1;
   const int mt = bf3_small_tile(KS, px, cgroups * par);
   bf3_pick_tile(a.Hout, a.Wout, mt, &th, &tw, &tn);
-  if constexpr (KS == 3) {
-    // Maps like 24 x 18 or 12 x 9 (HRNet-W48 at 384 x 288) fill power-of-two tiles badly (25 % / 44 % padding):
-    // an odd tile -- tw = W, W / 2 or W / 3 columns by floor(64 / tw) rows, decoded with a magic divide -- is
-    // taken when it needs at least 10 % fewer workgroups.
-    static int odd = -1;
-    if (odd < 0) {
-      const char* e = getenv("MVAL_BF3_ODD_TILES");
-      odd = e ? atoi(e) : 1;
-    }
-    if (odd && mt == 64) {
-      const int64_t wgs2 = (int64_t)((a.Wout + tw - 1) / tw) * ((a.Hout + th - 1) / th) * ((a.N + tn - 1) / tn);
-      int64_t best = wgs2;
-      int bth = 0, btw = 0;
-      for (int d = 1; d <= 3; d++) {
-        const int ctw = (a.Wout + d - 1) / d;
-        if (ctw < 3 || ctw > 32) continue;
-        int cth = 64 / ctw;
-        if (cth > a.Hout) cth = a.Hout;
-        const int64_t w = (int64_t)((a.Wout + ctw - 1) / ctw) * ((a.Hout + cth - 1) / cth) * a.N;
-        if (w < best) {
-          best = w;
-          bth = cth; btw = ctw;
-        }
-      }
-      if (btw && best * 10 <= wgs2 * 9) {
-        th = bth; tw = btw; tn = 1;
-      }
-    }
-  }
+  if constexpr (KS == 3)
+    if (mt == 64) bf3_odd_tile(a.Hout, a.Wout, a.N, 64, &th, &tw, &tn);
   const int nch = (a.Cin + BF_KC - 1) / BF_KC;
   if constexpr (KS == 1) {
     // 1x1: two 32-channel chunks per barrier pair (16 KB of loads in flight per workgroup, twice the MFMAs
@@ -596,6 +598,7 @@ int mval_launch_conv_bf3(const ConvArgs& a, hipStream_t s) {
     int th, tw, tn;
     bf3_pick_tile(a.Hout, a.Wout, 32, &th, &tw, &tn);
     if (a.NS_total <= 2) return launch_bf3<3, 2, 2, 2, 1, 1>(a, th, tw, tn, s);
+    bf3_odd_tile(a.Hout, a.Wout, a.N, 32, &th, &tw, &tn);
     const bool w3 = a.NS_total % 3 == 0 && a.NS_total % 4 != 0;
     if (w3) return launch_bf3<3, 2, 3, 1, 1, 2>(a, th, tw, tn, s);
     return launch_bf3<3, 2, 4, 1, 1, 2>(a, th, tw, tn, s);
