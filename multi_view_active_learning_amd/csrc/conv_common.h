@@ -131,17 +131,26 @@ __device__ __forceinline__ void conv_tile_store(const ConvArgs& a, const float* 
       const int n = n0 + tni;
       if (n >= a.N || y >= a.Hout || x >= a.Wout) continue;
       const conv_f32x4 v = *reinterpret_cast<const conv_f32x4*>(ot + p * LDW + c4 * 4);
-      for (int dy = 0; dy < rep; dy++)
-        for (int dx = 0; dx < rep; dx++) {
-          const int64_t o = (((int64_t)n * Ho + (y << a.up) + dy) * Wo + (x << a.up) + dx) * a.Cout + c;
-          conv_f32x4 r = v;
-          if (a.res1) r += *reinterpret_cast<const conv_f32x4*>(a.res1 + o);
-          if (a.res2) r += *reinterpret_cast<const conv_f32x4*>(a.res2 + o);
+      // four replicas at a time (rep * rep is 4, 16 or 64), their residual loads issued before the first store
+      for (int i0 = 0; i0 < rep * rep; i0 += 4) {
+        int64_t o[4];
+        conv_f32x4 r1[4], r2[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int dy = (i0 + u) >> a.up, dx = (i0 + u) & (rep - 1);
+          o[u] = (((int64_t)n * Ho + (y << a.up) + dy) * Wo + (x << a.up) + dx) * a.Cout + c;
+          r1[u] = a.res1 ? *reinterpret_cast<const conv_f32x4*>(a.res1 + o[u]) : (conv_f32x4){0.f, 0.f, 0.f, 0.f};
+          r2[u] = a.res2 ? *reinterpret_cast<const conv_f32x4*>(a.res2 + o[u]) : (conv_f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          conv_f32x4 r = v + r1[u] + r2[u];
           if (a.relu) {
             r.x = fmaxf(r.x, 0.f); r.y = fmaxf(r.y, 0.f); r.z = fmaxf(r.z, 0.f); r.w = fmaxf(r.w, 0.f);
           }
-          *reinterpret_cast<conv_f32x4*>(a.out + o) = r;
+          *reinterpret_cast<conv_f32x4*>(a.out + o[u]) = r;
         }
+      }
     }
     return;
   }
