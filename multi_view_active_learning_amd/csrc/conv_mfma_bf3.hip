@@ -58,6 +58,8 @@
 // HRNet-W32 forward unchanged within noise, and the extra live values spill in the register-capped 1x1 variant.
 // Dispatching the cout groups of one pixel tile back to back (shared input tile, adjacent stores): +-1 %; an
 // XCD-aware tile order (each XCD a contiguous run of tiles, so halo rows hit its own L2): +-1 % as well.
+// Two sets of LDS planes (80-byte rows, still three workgroups per CU), the next chunk split and stored in the shadow
+// of the current chunk's MFMAs, one barrier per chunk instead of two: 55.8 vs 55.6 us (64 ch), 52.7 vs 50.5 us (128 ch).
 // Phase stripping of the write-heavy 1x1 conv 64 -> 256 on 128 64x64 maps (251 us; HBM streams of that size run at
 // 5.3-6.8 TB/s, tools/micro/hbm_rw.py, i.e. ~120 us): skeleton without loads, MFMAs or stores 55 us (dispatching
 // 16384 empty workgroups takes 4.7 us, tools/micro/dispatch_rate.hip -- the rest is setup, split, LDS traffic and
