@@ -74,6 +74,9 @@ CONV_CASES = [
     (6, 128, 256, 32, 24, 1, 1, True, True, False, 0, False),
     (1, 1024, 256, 16, 12, 1, 1, False, True, False, 0, False),
     (1, 2048, 512, 8, 6, 1, 1, True, False, False, 0, False),
+    # odd (non power-of-two) 7x9 tiles: maps that fill power-of-two tiles badly, at batches large enough for 64-slot tiles
+    (16, 192, 192, 24, 18, 3, 1, True, True, False, 0, False),
+    (32, 384, 384, 12, 9, 3, 1, True, False, False, 0, False),
 ]
 
 
