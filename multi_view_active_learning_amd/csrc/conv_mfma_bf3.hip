@@ -190,7 +190,19 @@ __global__ __launch_bounds__(64 * WN * WM)
       if constexpr (PA) accl[ms][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
 
-  const bf16x8* wq = reinterpret_cast<const bf16x8*>(a.w) + lane;
+  // Weight fragments through a buffer descriptor: uniform base and (tap, chunk) block offset in SGPRs (soffset), a
+  // 32-bit per-lane offset, the plane as immediate -- no 64-bit vector address arithmetic per fragment (it was
+  // three v_mad_u64_u32 per fragment triple; these kernels are bound by vector-instruction issue).
+  const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, 0x7fffffff, 0x00020000);
+  const int blk_bytes = a.NS_total * (192 * 16);
+  int wlane[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; nt++) wlane[nt] = (min(ns0 + nt, a.NS_total - 1) * 192 + lane) * 16;
+  auto bfrag = [&](int blk, int nt, int p) -> bf16x8 {
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wlane[nt] + p * 1024, blk * blk_bytes, 0);
+    return __builtin_bit_cast(bf16x8, v);
+  };
   const int nchunks = (a.Cin + BF_KC - 1) / BF_KC;  // the last chunk may be half empty (cin = 48)
   const int q4 = (tid & 7) * 4;                     // NTH % 8 == 0: a thread always stages the same channel quad
   f32x4 stage[NE];
@@ -231,31 +243,26 @@ __global__ __launch_bounds__(64 * WN * WM)
     if constexpr (RS) {
       if (wave_active) {
         static_assert(!RS || (KS == 3 && S == 1), "row sharing is for 3x3 stride 1");
-        bf16x8 B[3][NT][3], Bn[3][NT][3];
+        bf16x8 B[2][3][NT][3];  // [column parity][row tap][cout sub-tile][plane]: the next column loads into the other half
 #pragma unroll
         for (int ky = 0; ky < 3; ky++)
 #pragma unroll
-          for (int nt = 0; nt < NT; nt++) {
-            const bf16x8* bp = wq + ((int64_t)((ky * 3) * nchunks + ch) * a.NS_total + min(ns0 + nt, a.NS_total - 1)) * 192;
+          for (int nt = 0; nt < NT; nt++)
 #pragma unroll
-            for (int p = 0; p < 3; p++) B[ky][nt][p] = bp[p * 64];
-          }
+            for (int p = 0; p < 3; p++) B[0][ky][nt][p] = bfrag((ky * 3) * nchunks + ch, nt, p);
 #pragma unroll
         for (int kx = 0; kx < 3; kx++) {
 #pragma unroll
           for (int pr = 0; pr < MS + 2; pr++) {
             if (kx + 1 < 3) {
-              // next column's weights, each row tap fetched once the registers of the previous
-              // column's same-or-earlier tap are dead
+              // next column's weights, each row tap fetched once the registers of the column before the
+              // previous one's same-or-earlier tap are dead
               const int kyl = pr == 0 ? 0 : pr == MS ? 1 : pr == MS + 1 ? 2 : -1;
               if (kyl >= 0) {
 #pragma unroll
-                for (int nt = 0; nt < NT; nt++) {
-                  const bf16x8* bp =
-                      wq + ((int64_t)((kyl * 3 + kx + 1) * nchunks + ch) * a.NS_total + min(ns0 + nt, a.NS_total - 1)) * 192;
+                for (int nt = 0; nt < NT; nt++)
 #pragma unroll
-                  for (int p = 0; p < 3; p++) Bn[kyl][nt][p] = bp[p * 64];
-                }
+                  for (int p = 0; p < 3; p++) B[(kx + 1) & 1][kyl][nt][p] = bfrag((kyl * 3 + kx + 1) * nchunks + ch, nt, p);
               }
             }
             const char* ap = planes + abase[0] + (pr * PW + kx) * (BF_ROW * 2);
@@ -275,45 +282,31 @@ __global__ __launch_bounds__(64 * WN * WM)
                   const bf16x8 av = (t == 0) ? al : (t == 2 || t == 3) ? am : ah;
                   const int bi = (t == 0 || t == 3 || t == 5) ? 0 : (t == 1) ? 2 : 1;
                   if (!PA || t == 5)
-                    acc[ms][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, B[ky][nt][bi], acc[ms][nt], 0, 0, 0);
+                    acc[ms][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, B[kx & 1][ky][nt][bi], acc[ms][nt], 0, 0, 0);
                   else
-                    accl[PA ? ms : 0][PA ? nt : 0] =
-                        __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, B[ky][nt][bi], accl[PA ? ms : 0][PA ? nt : 0], 0, 0, 0);
+                    accl[PA ? ms : 0][PA ? nt : 0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                        av, B[kx & 1][ky][nt][bi], accl[PA ? ms : 0][PA ? nt : 0], 0, 0, 0);
                 }
               }
             }
-          }
-          if (kx + 1 < 3) {
-#pragma unroll
-            for (int ky = 0; ky < 3; ky++)
-#pragma unroll
-              for (int nt = 0; nt < NT; nt++)
-#pragma unroll
-                for (int p = 0; p < 3; p++) B[ky][nt][p] = Bn[ky][nt][p];
           }
         }
       }
     } else if (wave_active) {
       // weight fragment blocks: ((tap * G32 + g32) * NS + ns) * 3 planes * 64 lanes (16-byte units)
-      bf16x8 bcur[NT][3], bnxt[NT][3];
+      bf16x8 b[2][NT][3];  // [tap parity][cout sub-tile][plane]
 #pragma unroll
-      for (int nt = 0; nt < NT; nt++) {
-        const int ns = min(ns0 + nt, a.NS_total - 1);
-        const bf16x8* bp = wq + ((int64_t)(ch * G) * a.NS_total + ns) * 192;
+      for (int nt = 0; nt < NT; nt++)
 #pragma unroll
-        for (int p = 0; p < 3; p++) bcur[nt][p] = bp[p * 64];
-      }
+        for (int p = 0; p < 3; p++) b[0][nt][p] = bfrag(ch * G, nt, p);
 #pragma unroll
       for (int tap = 0; tap < TAPS; tap++) {
         if (tap + 1 < TAPS) {
+          const int blk = G > 1 ? ch * G + tap + 1 : (tap + 1) * nchunks + ch;
 #pragma unroll
-          for (int nt = 0; nt < NT; nt++) {
-            const int ns = min(ns0 + nt, a.NS_total - 1);
-            const int blk = G > 1 ? ch * G + tap + 1 : (tap + 1) * nchunks + ch;
-            const bf16x8* bp = wq + ((int64_t)blk * a.NS_total + ns) * 192;
+          for (int nt = 0; nt < NT; nt++)
 #pragma unroll
-            for (int p = 0; p < 3; p++) bnxt[nt][p] = bp[p * 64];
-          }
+            for (int p = 0; p < 3; p++) b[(tap + 1) & 1][nt][p] = bfrag(blk, nt, p);
         }
         const int toff = G > 1 ? tap * sub_bytes : ((tap / KS) * PW + (tap % KS)) * (BF_ROW * 2);
 #pragma unroll
@@ -324,23 +317,20 @@ __global__ __launch_bounds__(64 * WN * WM)
           const bf16x8 al = *reinterpret_cast<const bf16x8*>(ap + 2 * plane_bytes);
 #pragma unroll
           for (int nt = 0; nt < NT; nt++) {
+            const bf16x8* bc = b[tap & 1][nt];
             f32x4 c = PA ? accl[PA ? ms : 0][PA ? nt : 0] : acc[ms][nt];  // corrections, small terms first
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bcur[nt][0], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bcur[nt][2], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bcur[nt][1], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bcur[nt][0], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bcur[nt][1], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bc[0], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bc[2], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bc[1], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bc[0], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bc[1], c, 0, 0, 0);
             if constexpr (PA) {
               accl[ms][nt] = c;
               c = acc[ms][nt];
             }
-            acc[ms][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bcur[nt][0], c, 0, 0, 0);
+            acc[ms][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bc[0], c, 0, 0, 0);
           }
         }
-#pragma unroll
-        for (int nt = 0; nt < NT; nt++)
-#pragma unroll
-          for (int p = 0; p < 3; p++) bcur[nt][p] = bnxt[nt][p];
       }
     }
     __syncthreads();
