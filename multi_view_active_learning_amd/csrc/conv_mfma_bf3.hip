@@ -60,6 +60,11 @@
 // XCD-aware tile order (each XCD a contiguous run of tiles, so halo rows hit its own L2): +-1 % as well.
 // Two sets of LDS planes (80-byte rows, still three workgroups per CU), the next chunk split and stored in the shadow
 // of the current chunk's MFMAs, one barrier per chunk instead of two: 55.8 vs 55.6 us (64 ch), 52.7 vs 50.5 us (128 ch).
+// Occupancy (dynamic LDS inflated): 32 -> 32 takes 122 / 84 / 73.5 us with 1 / 2 / 3 workgroups per CU, 128 -> 128
+// 64.9 / 51.9 / 50.6 us -- a lone 32-channel workgroup lives 7.6 us for 1.8 us of MFMAs, and co-residents overlap only
+// partly.  8-wave workgroups for that layer (128 px x 32 couts, 104 VGPRs): 86 vs 73 us.  A three-times cheaper
+// activation split (timing-only build): 32 -> 32 unchanged, the 64..256-channel layers 5 % faster -- the split is not
+// what bounds the single-chunk layers.
 // Phase stripping of the write-heavy 1x1 conv 64 -> 256 on 128 64x64 maps (251 us; HBM streams of that size run at
 // 5.3-6.8 TB/s, tools/micro/hbm_rw.py, i.e. ~120 us): skeleton without loads, MFMAs or stores 55 us (dispatching
 // 16384 empty workgroups takes 4.7 us, tools/micro/dispatch_rate.hip -- the rest is setup, split, LDS traffic and
