@@ -298,13 +298,13 @@ def main():
         # the process, so this is the committed rocprofv3 measurement of THIS command (separate
         # --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE x2 gfx950 correction; tools/pmc_summary.py)
         try:
-            with open(os.path.join(ROOT, "profiles", "r01", "bench_c2_v8_summary.json")) as f:
+            with open(os.path.join(ROOT, "profiles", "r01", "bench_c2_v9_summary.json")) as f:
                 rows = [r for r in json.load(f)["hbm_traffic_by_instantiation"]
                         if r["kernel"].startswith(roof["kernel"].split(" ...>")[0])]
             if args.workload == "c2" and rows:
                 nl = sum(r["launches"] for r in rows)
                 roof["traffic"] = round(sum(r["launches"] * r["total_bytes"] for r in rows) / nl)
-                roof["traffic_source"] = ("profiles/r01/bench_c2_v8_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, "
+                roof["traffic_source"] = ("profiles/r01/bench_c2_v9_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, "
                                           "launch-weighted mean over this kernel's instantiations)")
         except (OSError, KeyError, ValueError):
             pass
