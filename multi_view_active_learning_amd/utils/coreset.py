@@ -14,6 +14,14 @@ import torch
 from .. import _lib
 
 
+def get_al_dict_for_coreset(labeled_data):
+    """``ActiveLearningDataset.get_al_dict_for_coreset`` (dataset/dataset.py:47-51) as a function of the dataset's
+    ``labeled_data`` list: the labeled-set side of the k-center problem, ``{index: (J, >=3) float64 pose}`` (each
+    record's ``"3d_keypoints"`` is stored (>=3, J)).  Hand the result to ``CoreSet(sal_dict, al_dict, root)`` or
+    ``ActiveLearningStrategy.select_al_guids(..., labeled_dict=...)``."""
+    return {idx: np.array(labeled_data[idx]["3d_keypoints"]).transpose([1, 0]) for idx in range(len(labeled_data))}
+
+
 class CoreSet:
     def __init__(self, sal_dict, al_dict, joint_root_index, metric="euclidean", device=None):
         if metric != "euclidean":

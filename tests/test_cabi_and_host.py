@@ -289,3 +289,14 @@ def test_cluster_file_features(tmp_path):
     assert f.shape == (6, 57)
     kp = np.array(poses["3-4"])
     assert np.array_equal(f[4], (kp[:3] - kp[:3, 2:3]).flatten()) and np.all(f[:, 2] == 0)
+
+
+def test_al_dict_for_coreset_layout():
+    """dataset/dataset.py:47-51: records hold (>=3, J) poses, the core-set wants (J, >=3) rows keyed by index."""
+    from multi_view_active_learning_amd.utils.coreset import get_al_dict_for_coreset
+
+    rng = np.random.default_rng(2)
+    labeled = [{"3d_keypoints": rng.standard_normal((4, 19)).tolist()} for _ in range(3)]
+    d = get_al_dict_for_coreset(labeled)
+    assert list(d) == [0, 1, 2] and d[1].shape == (19, 4) and d[1].dtype == np.float64
+    assert np.array_equal(d[2], np.array(labeled[2]["3d_keypoints"]).T)
