@@ -313,7 +313,7 @@ static int dispatch_k4(const ConvArgs& a, hipStream_t s) {
 int mval_launch_conv_mfma(const ConvArgs& a, hipStream_t s) {
   if (a.in_nchw || a.Cin % 16 != 0) return 1;
   // 32-bit element offsets inside the staging loop
-  if ((int64_t)a.N * a.Hin * a.Win * a.Cin >= (int64_t)1 << 31) return 1;  // TODO(next round): 64-bit path
+  if ((int64_t)a.N * a.Hin * a.Win * a.Cin >= (int64_t)1 << 31) return 1;  // 32-bit element offsets: the engine slices larger batches
   if (a.k == 4 && a.stride == 1 && a.dil == 2 && a.pad == 2) return dispatch_k4<1>(a, s);
   if (a.k == 4 && a.stride == 2 && a.dil == 1 && a.pad == 1) return dispatch_k4<2>(a, s);
   if (a.pad != (a.k - 1) / 2) return 1;

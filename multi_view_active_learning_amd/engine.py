@@ -331,6 +331,23 @@ def _plan_for(model, x):
     return plan
 
 
+def _max_images_per_launch(model, h, w):
+    """The conv kernels index activations with 32-bit element offsets: the largest batch whose biggest activation
+    (input of any op, or its possibly upsampled output) stays below 2^31 elements."""
+    g = model._graph
+    dims = {g.input: (h, w)}
+    biggest = 3 * h * w
+    for op in g.ops:
+        hin, win = dims[op.src]
+        if op.kind == "deconv":
+            hout, wout = (hin - 1) * op.stride - 2 * op.pad + op.k, (win - 1) * op.stride - 2 * op.pad + op.k
+        else:
+            hout, wout = (hin + 2 * op.pad - op.k) // op.stride + 1, (win + 2 * op.pad - op.k) // op.stride + 1
+        dims[op.dst] = (hout << op.up, wout << op.up)
+        biggest = max(biggest, hin * win * op.cin, (hout << op.up) * (wout << op.up) * op.cout)
+    return max(1, (2**31 - 1) // biggest)
+
+
 def run_network(model, x):
     if not torch.is_tensor(x) or not x.is_cuda:
         raise _lib.MvalError("the heat-map network runs on the HIP device only (no CPU path): pass a .cuda() tensor")
@@ -341,6 +358,9 @@ def run_network(model, x):
         from .engine_train import run_network_train
 
         return run_network_train(model, x)
+    cap = _max_images_per_launch(model, x.shape[2], x.shape[3])
+    if x.shape[0] > cap:  # very large batches run as equal slices of one plan size (plus a remainder plan)
+        return torch.cat([_plan_for(model, xs).forward(xs) for xs in x.split(cap)])
     return _plan_for(model, x).forward(x)
 
 

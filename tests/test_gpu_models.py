@@ -283,3 +283,22 @@ def test_c2_full_size_properties(dev):
         assert abs(float(r["metric"][0]) - o["metric"]) <= 1e-9 * abs(o["metric"])
     # every frame triangulated, finite, sane inlier counts
     assert torch.isfinite(r["keypoints_3d"]).all() and int(r["inlier_count"].min()) >= 2
+
+
+@pytest.mark.gpu
+def test_large_batches_run_as_slices(dev, monkeypatch):
+    """Batches above the 32-bit offset limit of the conv kernels are run as slices of one plan size: same heat-maps
+    as the unsliced forward (the limit is patched down so that 7 images already need three slices)."""
+    from multi_view_active_learning_amd import engine
+    from multi_view_active_learning_amd.pose_estimators import PoseResNet
+
+    torch.manual_seed(11)
+    model = PoseResNet(19, 50).to(dev).eval()
+    x = torch.randn(7, 3, 64, 64, device=dev)
+    assert engine._max_images_per_launch(model, 256, 192) == (2**31 - 1) // (64 * 128 * 96)  # the stem output is the largest
+    with torch.no_grad():
+        whole = model(x)
+        monkeypatch.setattr(engine, "_max_images_per_launch", lambda m, h, w: 3)
+        sliced = model(x)
+    assert sliced.shape == whole.shape == (7, 19, 16, 16)
+    assert torch.equal(sliced, whole)
