@@ -21,7 +21,9 @@ Prints ONE JSON line on rank 0 with the driver's contract fields plus
                and the stem: algorithmic bytes / time against HBM); HBM bytes per launch from the
                committed rocprofv3 PMC passes;
   cpu_baseline the CPU oracle (stock torch fp32 HRNet-W32 + numpy RANSAC-DLT restatement,
-               oracle/) timed on the host on a bounded sample of the same workload.
+               oracle/) timed on the host on a bounded sample of the same workload; its "parity_sample" compares
+               the HIP path with the oracle on that sample's first frames (the metric's "MPJPE vs ref": heat-map max
+               error, 2-D keypoint equality, MPJPE and worst-joint delta in mm) -- outside every timed region.
 """
 from __future__ import annotations
 
@@ -98,6 +100,7 @@ def cpu_baseline(wl, sd_np, seconds_target=20.0):
     proj = np.stack([synth.ring_cameras(v, h, w, seed=s) for s in range(frames_per_call)])
     valid = np.ones(j, dtype=bool)
     done, t0 = 0, time.perf_counter()
+    first = None
     with torch.no_grad():
         if wl["arch"] == "resnet50":
             fwd = lambda x: models.pose_resnet_forward(sd, x)
@@ -108,13 +111,16 @@ def cpu_baseline(wl, sd_np, seconds_target=20.0):
         t0 = time.perf_counter()
         while True:
             hm = fwd(imgs).numpy().reshape(frames_per_call, v, j, h // 4, w // 4)
-            for b in range(frames_per_call):
-                geometry.triangulation(hm[b], proj[b], 4, valid)
+            res = [geometry.triangulation(hm[b], proj[b], 4, valid) for b in range(frames_per_call)]
+            if first is None:
+                first = dict(heatmaps=hm, keypoints_3d=np.stack([r["keypoints_3d"] for r in res]),
+                             keypoints_2d=np.stack([r["keypoints_2d"] for r in res]))
             done += frames_per_call
             el = time.perf_counter() - t0
             if el > seconds_target or done >= 64:
                 break
     return dict(
+        _check=dict(images=imgs, proj=proj, **first),
         value=done * v / el, unit="frames*views/s", cores=torch.get_num_threads(), kind="port",
         sample=f"{done} frames x {v} views ({done * v} images) of the same workload, {el:.1f} s, "
                f"stock torch fp32 {wl['arch']} + numpy RANSAC-DLT (oracle/), {torch.get_num_threads()} threads",
@@ -340,7 +346,22 @@ def main():
             "roofline": roof,
         }
         if not args.no_cpu_baseline and not train and world == 1:  # rank 0 at N = 1 only
-            out["cpu_baseline"] = cpu_baseline(wl, sd_np, args.cpu_seconds)
+            cpu = cpu_baseline(wl, sd_np, args.cpu_seconds)
+            # BASELINE.json's "MPJPE vs ref": the HIP path on the oracle's first sample (outside every timed region)
+            chk = cpu.pop("_check")
+            with torch.no_grad():
+                hm = model(chk["images"].to(dev)).reshape(-1, v, j, h // 4, w // 4)
+                got = triangulate_batch(hm, torch.from_numpy(chk["proj"]).to(dev), 4,
+                                        torch.ones(hm.shape[0], j, dtype=torch.uint8, device=dev))
+            delta = np.linalg.norm(got["keypoints_3d"].cpu().numpy() - chk["keypoints_3d"], axis=-1)
+            cpu["parity_sample"] = {
+                "frames": int(hm.shape[0]),
+                "heatmap_max_abs_err": float(np.abs(hm.cpu().numpy() - chk["heatmaps"]).max()),
+                "keypoints_2d_equal": bool(np.array_equal(got["keypoints_2d"].cpu().numpy(), chk["keypoints_2d"])),
+                "mpjpe_vs_oracle_mm": float(delta.mean()),
+                "max_joint_delta_mm": float(delta.max()),
+            }
+            out["cpu_baseline"] = cpu
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
