@@ -363,6 +363,8 @@ def test_batched_weight_pack_equals_single_packs(dev):
             p.copy_(torch.randn_like(p))
     plan = TrainPlan(model, 2, 64, 64, dev)
     plan._refresh()
+    if os.environ.get("MVAL_CONV", "").startswith("f"):
+        pytest.skip("MVAL_CONV=fp32: the plan holds no split-bf16 weights")
     assert plan._pack_jobs is not None and plan._pack_n > 50
     torch.cuda.synchronize()
     batched = plan.params.clone()
