@@ -65,6 +65,10 @@
 // partly.  8-wave workgroups for that layer (128 px x 32 couts, 104 VGPRs): 86 vs 73 us.  A three-times cheaper
 // activation split (timing-only build): 32 -> 32 unchanged, the 64..256-channel layers 5 % faster -- the split is not
 // what bounds the single-chunk layers.
+// 48 input channels with K = taps x channels flattened (9 full steps + 5 steps that pair the channels 32..47 of two
+// taps, 14 MFMA steps instead of 18 with a half-empty second chunk): 22 % fewer MFMAs, 128 -> 123 us on HRNet-W48's
+// 48 -> 48 layers, HRNet-W48 forward unchanged (29.3 ms) -- and the extra path cost every non-row-sharing 3x3 variant
+// 40-80 VGPRs until capped.  Not kept.
 // Phase stripping of the write-heavy 1x1 conv 64 -> 256 on 128 64x64 maps (251 us; HBM streams of that size run at
 // 5.3-6.8 TB/s, tools/micro/hbm_rw.py, i.e. ~120 us): skeleton without loads, MFMAs or stores 55 us (dispatching
 // 16384 empty workgroups takes 4.7 us, tools/micro/dispatch_rate.hip -- the rest is setup, split, LDS traffic and
