@@ -115,7 +115,7 @@ __device__ __forceinline__ void split3(const f32x4 v, bf16x4& h, bf16x4& m, bf16
 // the sub-chunks take the place of the taps in the inner loop.
 template <int KS, int S, int WN, int WM, int NT, int MS, int NE, bool RS = false, bool PA = false, int G = 1>
 __global__ __launch_bounds__(64 * WN * WM)
-    __attribute__((amdgpu_waves_per_eu((KS == 1 && G == 2 && NT == 2) ? (PA ? 3 : 4) : 1, 8))) void conv_bf3_kernel(ConvArgs a) {
+    __attribute__((amdgpu_waves_per_eu((KS == 1 && G == 2 && NT == 2) ? (PA ? 3 : 4) : (PA && KS >= 2 && NE <= 6) ? 3 : 1, 8))) void conv_bf3_kernel(ConvArgs a) {
   static_assert(G == 1 || (KS == 1 && S == 1), "multi-chunk staging is for 1x1 convs");
   constexpr int TAPS = G > 1 ? G : KS * KS;
   constexpr int BF_ROW = BF_ROW_OF(S);
