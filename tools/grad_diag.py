@@ -1,3 +1,5 @@
+"""Per-parameter gradient error of one training step against the torch-CPU oracle (which layers drift, by how
+much): the diagnostic that located the coherent bias of the bf16 MFMA accumulate.  usage: grad_diag.py [arch]"""
 import sys, os
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..")); sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tests", "golden")); sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tests"))
 import numpy as np, torch, cases
