@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
 """Benchmark of the hot path on MI355X: frames x views / s, heat-map -> triangulated 3-D.
 
-    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1 without torchrun's RANK in the environment: this process starts the N ranks itself (as CHILD processes,
+``python -m torch.distributed.run --nproc-per-node N bench.py ...``, before anything here touches the GPU) and relays
+rank 0's line; under torchrun it is one of the ranks.  Fewer than N devices, or WORLD_SIZE != N, is an error.
 
 Workload (BASELINE.json configs[1], "c2"): HRNet-W32, 4 views, 256x256, batch 32 frames
 (128 images per step and per GPU), forward-only heat-maps + hard arg-max decode + pairwise
@@ -42,7 +46,9 @@ import torch.distributed as dist  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, dense fp32-input MFMA
 PEAK_HBM_GBPS = 8000.0  # same guide: HBM3E
-PEAK_BF16_MFMA_TFLOPS = 2500.0  # same guide: dense bf16 MFMA (the 5 PF headline includes 2:1 sparsity)
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # same guide: dense bf16 / fp16 MFMA (the 5 PF headline includes 2:1 sparsity)
+SPLIT_PRODUCTS = {"h2": 3, "bf3": 6}  # MFMA products per algorithmic product of the 16-bit splits
+PARITY_UNPINNED = ["soft_argmax (kornia absent)", "MPE peak_local_max (skimage absent)", "BSB peak_local_max (skimage absent)"]
 FLOP_PER_IMAGE = {"hrnet_w32_256": 20.387e9}  # conv FLOPs (2*MAC) per frame x view
 
 WORKLOADS = {
@@ -95,7 +101,7 @@ def cpu_baseline(wl, sd_np, seconds_target=20.0):
 
     sd = {k: torch.from_numpy(v) for k, v in sd_np.items()}
     v, h, w, j = wl["v"], wl["h"], wl["w"], wl["j"]
-    frames_per_call = 2
+    frames_per_call = max(2, 32 // v)  # >= 32 images per call: small calls starve a many-core host
     imgs = torch.from_numpy(synth.images(123, frames_per_call, v, h, w)).reshape(-1, 3, h, w)
     proj = np.stack([synth.ring_cameras(v, h, w, seed=s) for s in range(frames_per_call)])
     valid = np.ones(j, dtype=bool)
@@ -108,6 +114,17 @@ def cpu_baseline(wl, sd_np, seconds_target=20.0):
             arch = models.HRNET_W48 if wl["arch"] == "hrnet_w48" else models.HRNET_W32
             fwd = lambda x: models.hrnet_forward(sd, x, arch)
         fwd(imgs[:v])  # warm-up (page-in, thread pool)
+        # the fastest thread count for this host (oversubscription made 128 threads slower than 16 in round 1)
+        ncpu = os.cpu_count() or 1
+        tried = {}
+        for nt in sorted({t for t in (16, 32, 64, 128) if t <= ncpu} | {min(ncpu, 8)}):
+            torch.set_num_threads(nt)
+            fwd(imgs[:v])
+            t0 = time.perf_counter()
+            fwd(imgs[: 2 * v])
+            tried[nt] = time.perf_counter() - t0
+        best = min(tried, key=tried.get)
+        torch.set_num_threads(best)
         t0 = time.perf_counter()
         while True:
             hm = fwd(imgs).numpy().reshape(frames_per_call, v, j, h // 4, w // 4)
@@ -123,37 +140,124 @@ def cpu_baseline(wl, sd_np, seconds_target=20.0):
         _check=dict(images=imgs, proj=proj, **first),
         value=done * v / el, unit="frames*views/s", cores=torch.get_num_threads(), kind="port",
         sample=f"{done} frames x {v} views ({done * v} images) of the same workload, {el:.1f} s, "
-               f"stock torch fp32 {wl['arch']} + numpy RANSAC-DLT (oracle/), {torch.get_num_threads()} threads",
+               f"stock torch fp32 {wl['arch']} + numpy RANSAC-DLT (oracle/), {torch.get_num_threads()} threads "
+               f"(best of {sorted(tried)}; {frames_per_call * v} images per call)",
+        threads_tried={str(k): round(2 * v / t, 2) for k, t in tried.items()},
     )
+
+
+def path_kernels(dev, frames, v, j, hh, wh):
+    """The non-conv kernels of the path at this workload's sizes, each against its own bound: events
+    on torch's current stream, which is the stream the wrappers launch on."""
+    from multi_view_active_learning_amd import _lib, synth
+    from multi_view_active_learning_amd.utils.coreset import CoreSet
+
+    def timed(fn, reps=30):
+        for _ in range(3):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        e1.synchronize()
+        return e0.elapsed_time(e1) * 1e-3 / reps
+
+    def hbm(name, t, nbytes, note):
+        return dict(bound="hbm", achieved=round(nbytes / t / 1e9, 1), peak=PEAK_HBM_GBPS, unit="GB/s",
+                    frac=round(nbytes / t / 1e9 / PEAK_HBM_GBPS, 4), traffic=None, kernel=name, peak_note=note,
+                    launches_per_step=1, avg_launch_us=round(t * 1e6, 2), bytes_per_step=nbytes,
+                    seconds_in_kernel_per_step=round(t, 7))
+
+    out = []
+    hm = torch.rand(frames, v, j, hh, wh, device=dev)
+    valid = torch.ones(frames, j, dtype=torch.uint8, device=dev)
+    n_maps, map_bytes = frames * v * j, frames * v * j * hh * wh * 4.0
+    t = timed(lambda: _lib.argmax_decode(hm, valid, frames, v, j, hh, wh, 4, hh))
+    out.append(hbm("argmax_decode_kernel (hard arg-max of every heat-map)", t, map_bytes, "one read of the heat-maps"))
+    for kind, name in ((_lib.SCORE_HP, "HP"), (_lib.SCORE_MPE, "MPE"), (_lib.SCORE_BSB, "BSB")):
+        t = timed(lambda: _lib.score_maps(kind, hm, n_maps, hh, wh))
+        out.append(hbm(f"score_maps_kernel<{name}> (per-map uncertainty statistic)", t, map_bytes, "one read of the heat-maps"))
+    proj = torch.from_numpy(np.stack([synth.ring_cameras(v, hh * 4, wh * 4, seed=s) for s in range(frames)])).to(dev)
+    kp = _lib.argmax_decode(hm, valid, frames, v, j, hh, wh, 4, hh)
+    t = timed(lambda: _lib.triangulate_ransac(kp, proj, valid, frames, v, j, 4.0))
+    out.append(dict(bound="latency", achieved=round(frames * j / t), peak=None, unit="problems/s", frac=None, traffic=None,
+                    kernel="ransac_dlt_kernel (pairwise RANSAC + DLT + reprojection error, float64)",
+                    peak_note=f"{frames * j} (frame, joint) problems x {v * (v - 1) // 2} pairs per launch: "
+                              "a few waves per CU, latency-bound; bytes are negligible",
+                    launches_per_step=1, avg_launch_us=round(t * 1e6, 2), seconds_in_kernel_per_step=round(t, 7)))
+    # core-set k-center at the BASELINE pool size (config.py:43-44: 200 labelled + 50 000 pool, 100 picks; D = 3J)
+    rng = np.random.default_rng(0)
+    pool = torch.from_numpy(rng.standard_normal((50000, j, 3)) * 300.0).to(dev)
+    lab = torch.from_numpy(rng.standard_normal((200, j, 3)) * 300.0).to(dev)
+    cs = CoreSet.from_tensors(pool, lab, 2)
+    t = timed(lambda: cs.select_batch(100), reps=5)
+    step_bytes = 50200 * (3 * j) * 8.0 + 2 * 50200 * 8.0
+    e = hbm("kcenter_step_kernel (greedy k-center, 100 picks over 50 200 x 57 float64 features)", t / 100.0, step_bytes,
+            "per greedy step: features + min-distance read/write; 23.7 MB sits in MALL/L2, so the step is launch-latency bound")
+    e["launches_per_step"] = 103
+    e["select_batch_100_ms"] = round(t * 1e3, 3)
+    out.append(e)
+    return out
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=None, help="default: 150 (c2: ~2.5 s timed), 1 for whole-pool passes")
+    ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--pool", type=int, default=None,
+                    help="c4 / c5: frames of the fixed pool sharded over the ranks (BASELINE: 50000); one step = one whole pass")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     args = ap.parse_args()
+    pool_pass = args.pool is not None or WORKLOADS[args.workload].get("pool") is not None
+    if args.steps is None:
+        args.steps = 1 if (args.pool or 0) > 4096 else 3 if pool_pass else 150 if args.workload == "c2" else 40
+    if args.warmup is None:
+        args.warmup = 1 if pool_pass else 5
+
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # Self-launch: N child ranks, one per GPU, before this process has touched the GPU (device_count() does
+        # not initialise it); the children print, this process only relays their exit code.
+        import socket
+        import subprocess
+
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            sys.exit(f"bench.py --gpus {args.gpus}: needs {args.gpus} devices, this node has {have}")
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.run(cmd).returncode)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.exit(f"bench.py --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus} "
+                 "(or without torchrun: bench.py starts its own ranks)")
+    if torch.cuda.device_count() <= local_rank:
+        sys.exit(f"bench.py: rank {rank} needs device {local_rank}, this node has {torch.cuda.device_count()}")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    if world != args.gpus and rank == 0:
-        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; reporting n_gpus={world}", file=sys.stderr)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
     from multi_view_active_learning_amd import _lib, synth
-    from multi_view_active_learning_amd.engine import ALGO_MFMA, ALGO_MFMA_BF3, _conv_mode, _plan_for
+    from multi_view_active_learning_amd.engine import ALGO_MFMA, ALGO_MFMA_BF3, ALGO_MFMA_H2, _conv_mode, _plan_for
     from multi_view_active_learning_amd.utils.triangulation import triangulate_batch
 
     _lib.lib()  # fail loudly if the HIP extension is missing
-    wl = WORKLOADS[args.workload]
+    wl = dict(WORKLOADS[args.workload])
+    if args.pool is not None:
+        if args.workload not in ("c4", "c5"):
+            sys.exit("--pool applies to the pool passes c4 / c5")
+        wl["pool"] = args.pool
     v, h, w, j, frames = wl["v"], wl["h"], wl["w"], wl["j"], wl["frames"]
     model, sd_np = build_model(wl["arch"], j, dev)
     images = torch.from_numpy(synth.images(1000 + rank, frames, v, h, w)).to(dev).reshape(frames * v, 3, h, w)
@@ -191,7 +295,30 @@ def main():
         picks = cs.select_batch(wl["picks"])
         return {"keypoints_3d": pool, "picks": picks}
 
-    if wl.get("pool"):
+    def scoring_pass():
+        """BASELINE configs[3]: the entropy-scoring pass over the whole fixed pool.  Each rank scores its shard batch
+        by batch (heat-maps, triangulation, MPE -- the per-batch body of _compute_sal_dict), then ONE packed
+        all_gather of the (frames, 6 + 3J) result tables and the nlargest selection on every rank."""
+        from multi_view_active_learning_amd import parallel
+        from multi_view_active_learning_amd.strategy import score_heatmaps_batch
+
+        lo, hi = parallel.shard_range(wl["pool"], rank, world)
+        tables = []
+        for f0 in range(lo, hi, frames):
+            nb = min(frames, hi - f0)
+            hm = model(images[: nb * v]).reshape(nb, v, j, h // 4, w // 4)
+            r = triangulate_batch(hm, proj[:nb], 4, valid[:nb])
+            al = score_heatmaps_batch(wl["score"], "AVG", hm, valid[:nb])[0]
+            fid = torch.arange(f0, f0 + nb, device=dev, dtype=torch.float64)
+            tables.append(torch.cat([torch.zeros_like(fid)[:, None], fid[:, None], al[:, None], r["metric"][:, None],
+                                     r["inlier_count"].to(torch.float64)[:, None], torch.zeros_like(fid)[:, None],
+                                     r["keypoints_3d"].to(torch.float32).to(torch.float64).reshape(nb, 3 * j)], dim=1))
+        local = torch.cat(tables) if tables else torch.zeros((0, 6 + 3 * j), dtype=torch.float64, device=dev)
+        table = parallel.all_gather_cat(local)  # ONE collective for the pass (12.6 MB at 50 k frames)
+        top = torch.topk(table[:, 2], min(100, table.shape[0])).indices  # AL.ITER_AMOUNT = 100 (config.py:44)
+        return {"keypoints_3d": table[:, 6:], "picks": top}
+
+    if wl.get("picks"):
         labeled_pose = torch.from_numpy(np.random.default_rng(5).standard_normal((wl["labeled"], j, 3)) * 300.0).to(dev)
 
     def step():
@@ -202,7 +329,7 @@ def main():
             opt.step()
             return {"keypoints_3d": loss.detach().reshape(1)}
         if wl.get("pool"):
-            return coreset_pass()
+            return coreset_pass() if wl.get("picks") else scoring_pass()
         hm = model(images).reshape(frames, v, j, h // 4, w // 4)
         r = triangulate_batch(hm, proj, 4, valid)
         if wl.get("score"):
@@ -279,42 +406,50 @@ def main():
                         launches_per_step=n, avg_launch_us=round(t / n * 1e6, 2), bytes_per_step=b,
                         seconds_in_kernel_per_step=round(t, 6))
 
-        conv = np.asarray([o.kind == 0 for o in plan.ops])
-        bf3 = np.asarray([o.algo == ALGO_MFMA_BF3 for o in plan.ops]) & conv
+        conv = np.asarray([o.kind != 1 for o in plan.ops])
         f32 = np.asarray([o.algo == ALGO_MFMA for o in plan.ops]) & conv
         k3 = np.asarray([o.k == 3 for o in plan.ops])
         s1 = np.asarray([o.stride == 1 for o in plan.ops])
         stem = np.asarray([o.kind == 0 and o.in_nchw == 1 for o in plan.ops])
-        split_note = "dense bf16 MFMA peak 2500 TFLOP/s / 6 MFMA products per algorithmic product"
-        fams = [
-            family(bf3 & k3 & s1, "conv_bf3_kernel<3, 1, ...> (fused 3x3 stride-1 conv+BN+residual+ReLU; fp32 values as exact "
-                                  "3-way bf16 splits, 6 x v_mfma_f32_16x16x32_bf16 per 32-deep step, fp32 accumulate)",
-                   PEAK_BF16_MFMA_TFLOPS / 6.0, split_note),
-            family(bf3 & k3 & ~s1, "conv_bf3_kernel<3, 2, ...> (same, stride 2)", PEAK_BF16_MFMA_TFLOPS / 6.0, split_note),
-            hbm_family(bf3 & ~k3, "conv_bf3_kernel<1, 1, ...> (fused 1x1 conv+BN+residual+ReLU(+upsample): channel GEMMs of "
-                                  "the bottleneck blocks and fuse up-paths)"),
-            family(f32, "conv_mfma_kernel (exact-fp32 v_mfma_f32_16x16x4_f32: heat-map layer and shapes the split kernel "
-                        "does not cover)", PEAK_FP32_MFMA_TFLOPS, "dense fp32-input MFMA peak"),
+        fams = []
+        split_any = np.zeros(len(plan.ops), dtype=bool)
+        for algo, pl, what in ((ALGO_MFMA_H2, "h2", "fp32 values as scaled 2-way fp16 splits, 3 x v_mfma_f32_16x16x32_f16 per 32-deep step"),
+                               (ALGO_MFMA_BF3, "bf3", "fp32 values as exact 3-way bf16 splits, 6 x v_mfma_f32_16x16x32_bf16 per 32-deep step")):
+            m_ = np.asarray([o.algo == algo for o in plan.ops]) & conv
+            split_any |= m_
+            peak = PEAK_BF16_MFMA_TFLOPS / SPLIT_PRODUCTS[pl]
+            note = f"dense 16-bit MFMA peak 2500 TFLOP/s / {SPLIT_PRODUCTS[pl]} MFMA products per algorithmic product"
+            fams += [
+                family(m_ & k3 & s1, f"conv_split_kernel<{2 if pl == 'h2' else 3}, 3, 1, ...> (fused 3x3 stride-1 conv+BN+residual+ReLU; "
+                                     f"{what}, fp32 accumulate)", peak, note),
+                family(m_ & k3 & ~s1, f"conv_split_kernel<{2 if pl == 'h2' else 3}, 3, 2, ...> (same, stride 2)", peak, note),
+                hbm_family(m_ & ~k3, f"conv_split_kernel<{2 if pl == 'h2' else 3}, 1, 1, ...> (fused 1x1 conv+BN+residual+ReLU(+upsample): "
+                                     "channel GEMMs of the bottleneck blocks and fuse up-paths; 2x2 parity convs of transposed convs)"),
+            ]
+        fams += [
+            family(f32, "conv_mfma_kernel (exact-fp32 v_mfma_f32_16x16x4_f32: heat-map layer and shapes the split kernels "
+                        "do not cover)", PEAK_FP32_MFMA_TFLOPS, "dense fp32-input MFMA peak"),
             hbm_family(stem, "conv_stem_kernel (3-channel NCHW stem conv, VALU)"),
         ]
         fams = sorted([f for f in fams if f], key=lambda f: -f["seconds_in_kernel_per_step"])
         roof = fams[0]
-        roof["other_kernels"] = fams[1:]
+        roof["other_kernels"] = fams[1:] + path_kernels(dev, frames, v, j, h // 4, w // 4)
         # HBM bytes per launch of the dominant kernel: PMC counters cannot be read from inside
         # the process, so this is the committed rocprofv3 measurement of THIS command (separate
         # --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE x2 gfx950 correction; tools/pmc_summary.py)
+        summary = os.path.join("profiles", "r02", f"bench_c2_{_conv_mode()}_summary.json")
         try:
-            with open(os.path.join(ROOT, "profiles", "r01", "bench_c2_v9_summary.json")) as f:
+            with open(os.path.join(ROOT, summary)) as f:
                 rows = [r for r in json.load(f)["hbm_traffic_by_instantiation"]
                         if r["kernel"].startswith(roof["kernel"].split(" ...>")[0])]
             if args.workload == "c2" and rows:
                 nl = sum(r["launches"] for r in rows)
                 roof["traffic"] = round(sum(r["launches"] * r["total_bytes"] for r in rows) / nl)
-                roof["traffic_source"] = ("profiles/r01/bench_c2_v9_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, "
+                roof["traffic_source"] = (summary + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, "
                                           "launch-weighted mean over this kernel's instantiations)")
         except (OSError, KeyError, ValueError):
             pass
-        allc = bf3 | f32
+        allc = split_any | f32
         roof["all_conv_tflops"] = round(float(flops[allc].sum()) / (float(ms[allc].sum()) * 1e-3) / 1e12, 2)
         roof["all_conv_frac_of_fp32_mfma_peak"] = round(roof["all_conv_tflops"] / PEAK_FP32_MFMA_TFLOPS, 4)
         roof["whole_forward_ms"] = round(float(ms.sum()), 3)
@@ -339,11 +474,14 @@ def main():
             "higher_is_better": True,
             "scaling": "strong" if wl.get("pool") else "weak",
             "vs_baseline": None,
-            "dtype": "f32" if _conv_mode() == "fp32" else "f32 (convs: fp32 values as exact 3-way bf16 splits on the bf16 MFMA, fp32 accumulate)",
+            "dtype": {"fp32": "f32", "bf3": "f32 (convs: fp32 values as exact 3-way bf16 splits on the bf16 MFMA, fp32 accumulate)",
+                      "h2": "f32 (convs: fp32 values as scaled 2-way fp16 splits on the fp16 MFMA, fp32 accumulate; "
+                            "measured at the exact-fp32 MFMA chain's error)"}[_conv_mode()],
             "data": "synthetic (random variance-preserving weights, N(0,1) frames, ring cameras)",
             "config": {"workload": wl["desc"], "frames_per_step_per_gpu": frames, "views": v,
                        "images_per_step_per_gpu": frames * v, "parallelism": f"frame-sharded x{world}, no collective"},
             "roofline": roof,
+            "parity_unpinned": PARITY_UNPINNED,
         }
         if not args.no_cpu_baseline and not train and world == 1:  # rank 0 at N = 1 only
             cpu = cpu_baseline(wl, sd_np, args.cpu_seconds)

@@ -174,8 +174,8 @@ int mval_kcenter_select(const double* feat, int64_t n_obs, int D, const int64_t*
  * written by mval_pack_conv_weights; scale/shift are the folded eval-mode BatchNorm
  * (y = x * scale + shift, torch's batch_norm inference formula) or (1, bias). */
 enum { MVAL_OP_CONV = 0, MVAL_OP_MAXPOOL = 1, MVAL_OP_DECONV = 2 };
-enum { MVAL_ALGO_DIRECT = 0, MVAL_ALGO_MFMA = 1, MVAL_ALGO_MFMA_BF3 = 2 };
-enum { MVAL_PACK_HWIO = 0, MVAL_PACK_MFMA16 = 1, MVAL_PACK_MFMA16_BF3 = 2 };
+enum { MVAL_ALGO_DIRECT = 0, MVAL_ALGO_MFMA = 1, MVAL_ALGO_MFMA_BF3 = 2, MVAL_ALGO_MFMA_H2 = 3 };
+enum { MVAL_PACK_HWIO = 0, MVAL_PACK_MFMA16 = 1, MVAL_PACK_MFMA16_BF3 = 2, MVAL_PACK_MFMA16_H2 = 3 };
 
 typedef struct mval_op {
   int32_t kind;      /* MVAL_OP_*: conv, maxpool (k, stride, pad), transposed conv k4 s2 p1 */
@@ -191,6 +191,14 @@ typedef struct mval_op {
   int32_t phase, lane; /* scheduling hints: ops of one phase on different lanes are independent
                           (HRNet branches / fuse outputs) and run on separate HIP streams; all
                           lanes join at a phase change.  0/0 = plain in-order execution. */
+  /* Activation scales of the fp16-split kernels (MVAL_ALGO_MFMA_H2).  Float offsets into the workspace of
+   * n_images rows of MVAL_AMAX_SUB (16) 4-byte slots; the maximum over a row is the bits of max |x| over that image
+   * of an activation tensor (per image, so that a frame's heat-maps do not depend on the rest of the batch; 16
+   * sub-slots so that the producers' atomics spread); 0 = none.  out_amax_off: the op
+   * folds the maxima of what it writes into the slots (any algo); in_amax_off: the slots of the op's input,
+   * required by MVAL_ALGO_MFMA_H2.  mval_net_forward zeroes all slots of a plan before the first op; single-op
+   * callers zero them (or fill the input's with mval_amax) themselves. */
+  int64_t in_amax_off, out_amax_off;
 } mval_op;
 
 /* Weight packing.  MVAL_PACK_HWIO: [k*k][cin][cout] (direct kernels, deconv);
@@ -199,7 +207,11 @@ typedef struct mval_op {
  * cout zero-padded to multiples of 16;
  * MVAL_PACK_MFMA16_BF3: the exact three-way bf16 split of every weight in
  * v_mfma_f32_16x16x32_bf16 B-fragment order [k*k][cin/32][cout/16][plane h,m,l][lane][8 bf16]
- * (conv_mfma_bf3.hip).  `transposed`: 0 = Conv2d weight [cout,cin,k,k]; 1 = ConvTranspose2d
+ * (conv_mfma_split.hip);
+ * MVAL_PACK_MFMA16_H2: the two-way fp16 split of every weight times a power of two chosen so that max |w| lands in
+ * [2^13, 2^14), same fragment order with two planes [k*k][cin/32][cout/16][plane h,l][lane][8 fp16], followed by
+ * a 4-float trailer whose first float is the inverse of that power of two (the conv epilogue multiplies by it).
+ * `transposed`: 0 = Conv2d weight [cout,cin,k,k]; 1 = ConvTranspose2d
  * weight [cin,cout,k,k] as the direct kernel reads it; 2 = a [cin,cout,k,k] tensor with the taps
  * flipped: the data-gradient form of a Conv2d weight (pass cout' = cin, cin' = cout) and the
  * forward form of a ConvTranspose2d weight on the MFMA kernels, which run MVAL_OP_DECONV as a
@@ -222,10 +234,15 @@ int mval_pack_bf3_jobs(const mval_pack_job* jobs_dev, const int* first_block_dev
 int mval_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var, float eps,
                  float* scale, float* shift, int c, void* stream);
 
+/* rows[i][0..15] = max(rows[i][..], bits of max |x|) over image i (per_image consecutive floats each): fills an
+ * activation's max-magnitude rows (see mval_op) for tensors that did not come out of an op of the plan. */
+#define MVAL_AMAX_SUB 16
+int mval_amax(const float* x, int64_t per_image, int n_images, uint32_t* rows, void* stream);
+
 /* 1 when the MFMA kernel family has a configuration for this op geometry (the plan builder
  * asks before choosing MVAL_ALGO_MFMA / MVAL_PACK_MFMA16), else 0. */
 int mval_op_mfma_supported(const mval_op* op, int n_images);
-/* Same question for a given MVAL_ALGO_* (MFMA or MFMA_BF3). */
+/* Same question for a given MVAL_ALGO_* (MFMA, MFMA_BF3 or MFMA_H2). */
 int mval_op_algo_supported(const mval_op* op, int n_images, int algo);
 
 int mval_op_launch(const mval_op* op, int n_images, float* workspace, const float* params,

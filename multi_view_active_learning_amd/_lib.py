@@ -57,6 +57,16 @@ def _stream() -> C.c_void_p:
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+def _same_device(*tensors):
+    """Launches go to the CURRENT device's current stream: every tensor of a call must live there (a tensor on
+    another GPU would be addressed from the wrong device's stream)."""
+    cur = torch.cuda.current_device()
+    for t in tensors:
+        if t is not None and torch.is_tensor(t) and t.is_cuda and t.device.index != cur:
+            raise MvalError(f"tensor on cuda:{t.device.index} but the current device is cuda:{cur}: "
+                            "call torch.cuda.set_device() (one process per GPU) or wrap the call in torch.cuda.device()")
+
+
 def _p(t):
     """Device pointer of a contiguous HIP tensor (None -> NULL)."""
     if t is None:
@@ -65,6 +75,7 @@ def _p(t):
         raise MvalError("hot-path tensors must live on the HIP device (no CPU path)")
     if not t.is_contiguous():
         raise MvalError("hot-path tensors must be contiguous")
+    _same_device(t)
     return C.c_void_p(t.data_ptr())
 
 

@@ -25,6 +25,20 @@ struct ConvArgs {
   // sets org_dy/dx and ooy/oox and advances w by parity * par_w_stride floats)
   int par_w_stride;
   int precise;  // split-bf16 kernel: separate accumulator for the correction products (training plans)
+  // 16-bit split kernels (conv_mfma_split.hip): planes = 3 bf16x3 (six products), 2 fp16x2 (three products).  The
+  // fp16 split needs the power-of-two scales: in_amax[n][MVAL_AMAX_SUB] = bits of max |x| over image n of the input
+  // tensor (kept by its producer; PER IMAGE, so a frame's result does not depend on what else is in the batch; the
+  // maximum of the image's sub-slots is the value), w_unscale = the factor that undoes the weight scale (trailer of
+  // the packed weights).
+  int planes;
+  const unsigned* in_amax;
+  const float* w_unscale;
+  // != nullptr: every kernel that writes `out` folds max |value| of what it stored for image n into one of the
+  // sub-slots out_amax[n][0..MVAL_AMAX_SUB) (bits of a non-negative float, so an unsigned atomicMax orders them; the
+  // slots are zeroed once per forward).  Sub-slots: atomics on one cache line serialise at ~20 ns each, so a
+  // workgroup issues ONE (after an LDS reduction over its waves, and only when it would raise the slot) and the
+  // workgroups of an image spread over the 16 sub-slots of its 64-byte row.
+  unsigned* out_amax;
   // MFMA tiling (filled by the launcher)
   int th, tw, tn, tw_log2, thw_log2;
   int tiles_x, tiles_y;
@@ -53,6 +67,40 @@ __device__ __forceinline__ void conv_store(const ConvArgs& a, int n, int y, int 
   }
 }
 
+#define MVAL_AMAX_SUB 16  // sub-slots per (activation, image): one 64-byte row
+
+// sub-slot of this workgroup within its image's row
+__device__ __forceinline__ int conv_amax_sub() { return (blockIdx.x + blockIdx.y * 5 + blockIdx.z * 3) & (MVAL_AMAX_SUB - 1); }
+
+// one thread's value (>= 0) into a slot; the atomic is issued only when it would raise the slot (a stale read only
+// costs a redundant atomic; the result is order-independent, hence deterministic)
+__device__ __forceinline__ void conv_amax_one(unsigned* slot, float m) {
+  const unsigned b = __float_as_uint(m);
+  if (b > __builtin_nontemporal_load(slot)) atomicMax(slot, b);
+}
+// Fold the threads' running max |value| (>= 0) into image row `row` ([MVAL_AMAX_SUB] slots): wave maxima through
+// `lds` (>= blockDim.x / 64 floats that nobody else touches), then ONE conditional atomic per workgroup.  Every
+// thread of the workgroup must call it (it holds a barrier).
+__device__ __forceinline__ void conv_amax_commit(unsigned* row, float m, float* lds) {
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < (int)(blockDim.x >> 6); w++) m = fmaxf(m, lds[w]);
+    conv_amax_one(row + conv_amax_sub(), m);
+  }
+}
+// max over the sub-slots of an image row
+__device__ __forceinline__ unsigned conv_amax_read(const unsigned* row) {
+  unsigned m = 0;
+#pragma unroll
+  for (int i = 0; i < MVAL_AMAX_SUB; i++) m = max(m, row[i]);
+  return m;
+}
+__device__ __forceinline__ float conv_amax4(float m, const float x, const float y, const float z, const float w) {
+  return fmaxf(fmaxf(m, fmaxf(fabsf(x), fabsf(y))), fmaxf(fabsf(z), fabsf(w)));
+}
+
 // floor(v / d) for v < 4096 and d < 256 with magic = ceil(2^20 / d) (exact: v * (d - 1) < 2^20)
 __device__ __forceinline__ int conv_div20(int v, unsigned magic) { return (int)(((unsigned)v * magic) >> 20); }
 
@@ -74,7 +122,8 @@ __device__ __forceinline__ bool conv_tile_decode(const ConvArgs& a, int p, int& 
 }
 
 // Second half of the MFMA kernels' epilogue: the BN'd output tile sits in LDS as
-// ot[pixel][NTILE + 4]; add the residual(s), ReLU and store with float4 lanes along channels.
+// ot[pixel][NTILE + 4] (followed by 8 floats of scratch for the max |x| reduction: the launchers size the LDS for
+// it); add the residual(s), ReLU and store with float4 lanes along channels.
 // All residual loads of a thread are issued before the first store (MT*NTILE/1024 float4 loads
 // in flight per thread) -- with one load per iteration the memory-bound layers (1x1 convs,
 // 32-channel 3x3) sat at 2.8 TB/s, latency- rather than bandwidth-bound.
@@ -107,6 +156,7 @@ __device__ __forceinline__ void conv_tile_store(const ConvArgs& a, const float* 
         r1[i] = (ok && a.res1) ? *reinterpret_cast<const conv_f32x4*>(a.res1 + off[i]) : (conv_f32x4){0.f, 0.f, 0.f, 0.f};
         r2[i] = (ok && a.res2) ? *reinterpret_cast<const conv_f32x4*>(a.res2 + off[i]) : (conv_f32x4){0.f, 0.f, 0.f, 0.f};
       }
+      float amax = 0.f;
 #pragma unroll
       for (int i = 0; i < IT; i++) {
         if (off[i] < 0) continue;
@@ -118,9 +168,16 @@ __device__ __forceinline__ void conv_tile_store(const ConvArgs& a, const float* 
           r.x = fmaxf(r.x, 0.f); r.y = fmaxf(r.y, 0.f); r.z = fmaxf(r.z, 0.f); r.w = fmaxf(r.w, 0.f);
         }
         *reinterpret_cast<conv_f32x4*>(a.out + off[i]) = r;
+        amax = conv_amax4(amax, r.x, r.y, r.z, r.w);
+        if (a.out_amax && a.tn != 1) {  // several images per tile (maps under 8 rows): per value
+          conv_amax_one(a.out_amax + (n0 + ((e / Q) >> a.thw_log2)) * MVAL_AMAX_SUB + (tid & (MVAL_AMAX_SUB - 1)), amax);
+          amax = 0.f;
+        }
       }
+      if (a.out_amax && a.tn == 1) conv_amax_commit(a.out_amax + n0 * MVAL_AMAX_SUB, amax, const_cast<float*>(ot) + MT * LDW);
       return;
     }
+    float amax = 0.f;
     for (int e = tid; e < MT * Q; e += NTH) {  // fused nearest upsample: 2^up x 2^up replicas
       const int p = e / Q, c4 = e % Q;
       const int c = cbase + c4 * 4;
@@ -149,9 +206,15 @@ __device__ __forceinline__ void conv_tile_store(const ConvArgs& a, const float* 
             r.x = fmaxf(r.x, 0.f); r.y = fmaxf(r.y, 0.f); r.z = fmaxf(r.z, 0.f); r.w = fmaxf(r.w, 0.f);
           }
           *reinterpret_cast<conv_f32x4*>(a.out + o[u]) = r;
+          amax = conv_amax4(amax, r.x, r.y, r.z, r.w);
         }
       }
+      if (a.out_amax && a.tn != 1) {
+        conv_amax_one(a.out_amax + n * MVAL_AMAX_SUB + (tid & (MVAL_AMAX_SUB - 1)), amax);
+        amax = 0.f;
+      }
     }
+    if (a.out_amax && a.tn == 1) conv_amax_commit(a.out_amax + n0 * MVAL_AMAX_SUB, amax, const_cast<float*>(ot) + MT * LDW);
     return;
   }
   // scalar path (NCHW heat-map output, odd channel counts): pixel-fastest so that NCHW rows are
@@ -171,9 +234,12 @@ __device__ __forceinline__ void conv_tile_store(const ConvArgs& a, const float* 
 
 int mval_launch_conv_mfma(const ConvArgs& a, hipStream_t s);  // conv_mfma.hip; returns 1 if unsupported
 int mval_conv_mfma_supported(const ConvArgs& a);            // same selection logic, no launch
-int mval_launch_conv_bf3(const ConvArgs& a, hipStream_t s);   // conv_mfma_bf3.hip; returns 1 if unsupported
-int mval_conv_bf3_supported(const ConvArgs& a);
+int mval_launch_conv_split(const ConvArgs& a, hipStream_t s);  // conv_mfma_split.hip (a.planes); returns 1 if unsupported
+int mval_conv_split_supported(const ConvArgs& a);
 int mval_pack_bf3(int mode, const float* w, float* packed, int cout, int cin, int k, hipStream_t s);
+int mval_pack_h2(int mode, const float* w, float* packed, int cout, int cin, int k, hipStream_t s);
+// net.hip: rows[i][*] = max(rows[i][*], max |x| over image i) for n_images images of per_image floats each
+int mval_launch_amax(const float* x, int64_t per_image, int n_images, unsigned* rows, hipStream_t s);
 int mval_pack_bf3_batch(const void* jobs_dev, const int* first_block_dev, int n_jobs, int total_blocks, hipStream_t s);
 int mval_launch_conv_direct(const ConvArgs& a, int kind, hipStream_t s);
 int mval_launch_conv_stem(const ConvArgs& a, hipStream_t s);  // conv_stem.hip; returns 1 if unsupported

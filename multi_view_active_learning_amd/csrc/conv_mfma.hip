@@ -244,7 +244,7 @@ static int launch_cfg(ConvArgs a, int th, int tw, int tn, hipStream_t s) {
   const int ne = (tn * PH * PW * (KC / 4) + 255) / 256;
   const int nbuf = (a.Cin / KC > 1 && ne <= 10) ? 2 : 1;  // the generic staging path is single-buffered
   size_t smem = (size_t)patch_floats * nbuf * sizeof(float);
-  const size_t otile = (size_t)MT * (NTILE + OPAD) * sizeof(float);
+  const size_t otile = (size_t)(MT * (NTILE + OPAD) + 8) * sizeof(float);  // + the max |x| reduction scratch
   if (otile > smem) smem = otile;
   if (smem > 128 * 1024) return 1;  // LDS is 160 KiB per CU on gfx950
   if (g_dry_run) return 0;

@@ -1,82 +1,36 @@
-// fp32-accurate 3x3 conv on the bf16 matrix cores: "bf16x3 split, 6 products".
+// fp32-accurate conv on the 16-bit matrix cores: every fp32 value is split EXACTLY into a few 16-bit planes and
+// the fp32 product is rebuilt from the plane products (exact in the MFMA, fp32 accumulate, small terms first).
 //
-// The exact-fp32 MFMA (v_mfma_f32_16x16x4_f32, conv_mfma.hip) runs at 1/16 of the bf16 MFMA
-// rate.  Every fp32 value splits EXACTLY into three bf16 values  x = xh + xm + xl  (3 x 8
-// significand bits), so
-//     a*b = ah*bh + (ah*bm + am*bh) + (ah*bl + al*bh + am*bm) + O(2^-24 |a||b|)
-// i.e. six v_mfma_f32_16x16x32_bf16 (exact products, fp32 accumulate) reproduce the fp32 product
-// to fp32 rounding level (the three dropped cross terms am*bl, al*bm, al*bl are <= 2^-24
-// relative) at 6 x 16 cycles per 32-deep k-step instead of 8 x 32 cycles: 2.67x the fp32-MFMA
-// rate.  Small terms are accumulated first.
+// The exact-fp32 MFMA (v_mfma_f32_16x16x4_f32, conv_mfma.hip) runs at 1/16 of the 16-bit MFMA rate.  Two splits:
 //
-// Same dataflow as conv_mfma.hip (patch with halo in LDS, taps = LDS offsets, weights
-// pre-packed in fragment order and streamed straight to VGPRs one step ahead, BN / residual /
-// ReLU epilogue through LDS) with these differences:
-//   * the activation split happens ONCE per element while staging: three bf16 planes
-//     [plane][pixel][32 ch + pad] in LDS (row stride 96 B: a 16-lane ds_read_b128 group covers
-//     all 64 banks);
-//   * weights are split at pack time (mval_pack_conv_weights, MVAL_PACK_MFMA16_BF3):
-//     [tap][cin/32][cout/16][plane][lane][8 bf16];
+//   PL = 2 ("h2", inference default): x * 2^s = xh + xl with xh, xl fp16 (11 + 11 significand bits; the
+//     power-of-two scale 2^s puts the tensor's largest magnitude in [2^14, 2^15), so nothing overflows and the
+//     low parts of every value that matters stay normal numbers):
+//         a*b = ah*bh + (ah*bl + al*bh) + O(2^-22 |a||b|)
+//     THREE v_mfma_f32_16x16x32_f16 per 32-deep k-step: 5.3x the fp32-MFMA rate.  The split residual is
+//     <= 2^-22 |x| worst case / ~2^-24 rms -- the size of ONE fp32 rounding -- and there are half as many fp32
+//     accumulate roundings per k-step as with six products, so the measured error against float64 is the same
+//     as (or below) the exact-fp32 MFMA chain's (tests/test_gpu_models.py::test_fused_conv_vs_torch_cpu).
+//     The activation scale comes from the producer: every kernel that writes an activation keeps max|x| of
+//     the tensor in a 4-byte slot (wave maximum, then one conditional atomicMax per wave; order-independent,
+//     so deterministic) and the consumer turns its exponent into 2^s while staging.  Weights are scaled by
+//     their own maximum at pack time; both scales are powers of two and are undone exactly by the epilogue
+//     (folded into the BatchNorm scale factor: acc * (2^-s * scale) rounds like (acc * 2^-s) * scale).
+//   PL = 3 ("bf3", training plans and MVAL_CONV=bf3): x = xh + xm + xl with three bf16 values (3 x 8 bits, no
+//     scaling needed: bf16 has the fp32 exponent range):
+//         a*b = ah*bh + (ah*bm + am*bh) + (ah*bl + al*bh + am*bm) + O(2^-24 |a||b|)
+//     SIX v_mfma_f32_16x16x32_bf16: 2.67x the fp32-MFMA rate.
+//
+// Same dataflow as conv_mfma.hip (patch with halo in LDS, taps = LDS offsets, weights pre-packed in fragment
+// order and streamed straight to VGPRs one step ahead, BN / residual / ReLU epilogue through LDS) with these
+// differences:
+//   * the activation split happens ONCE per element while staging: PL 16-bit planes
+//     [plane][pixel][32 ch + pad] in LDS (row stride 96 B: a 16-lane ds_read_b128 group covers all 64 banks);
+//   * weights are split at pack time (mval_pack_conv_weights): [tap][cin/32][cout/16][plane][lane][8 x 16 bit];
 //   * one LDS buffer + register prefetch of the next chunk (two barriers per 32-channel chunk).
-// Measured dead ends (interleaved A/B in one process with per-launch variant knobs; 128 images): fetching A
-// fragments one sub-tile ahead: +-1 % (64+ channels), -16 % (32 channels); an 8-wave
-// producer/consumer split (4 staging waves, 4 MFMA waves, double-buffered LDS): -15..-20 %;
-// 128 px x 32 cout tiles (half the weight stream): -3..-15 %; 8 sub-tiles per wave: 220 VGPRs;
-// persistent workgroups that fetch the next tile's patch during the MFMA loop (32-channel layers):
-// 78 vs 76 us -- those layers are not exposed-latency-bound (dropping the residual read changes
-// 76 -> 74 us) but LDS-read / issue-bound.
-// a pixel-major LDS layout [pixel][h|m|l|pad] (one address register + immediate offsets per fragment
-// triple, 28 % less LDS): the compiler then sinks the weight prefetch loads next to their uses
-// (vmcnt(0..1) waits inside the MFMA loop, 50 -> 66 us at 128 channels) and neither
-// sched_barrier masks nor an SGPR-pinned block address bring the early issue back.  Instruction
-// mix of the chunk loop (ISA): ~0.9 vector instructions per MFMA, i.e. under the 2-per-MFMA issue
-// budget; LDS fragment reads are conflict-free for the hardware's b128 lane groups on 16-wide
-// stride-1 tiles (2-way on 8-wide and stride-2 tiles, <= 3 ms of launches together).
-// 8-wave workgroups (128 px x 64 couts, the two wave rows re-reading each weight block through L1, i.e.
-// half the L2 weight stream, which PMC puts at ~10 TB/s of the ~17-19 TB/s L2 can deliver): -6..-15 %.
-// weight fragments issued as asm loads a whole tap column (72 MFMAs) ahead instead of the ~18 MFMAs the
-// compiler leaves after sinking them: -7 % (168 VGPRs, small spills) -- L2 latency is already hidden by the
-// three waves per SIMD.
-// a weight-stationary persistent kernel for the 32 -> 32 layers (8 waves, the wave's 27 weight fragments
-// held in 108 VGPRs for all tiles, double-buffered patch planes, one barrier per tile, no weight stream at
-// all): 75.4 vs 73.5 us -- the same time from a completely different structure; fetching the tile's residual
-// before its MFMA loop as well: 74.4 vs 75.2 us.
-// Phase stripping (same kernel with its MFMA loop and / or its store epilogue skipped) shows where the time is:
-// 32 -> 32 on 128 64x64 maps: staging 22 us + MFMA loop 35 us + epilogue 17 us = the measured 74 us;
-// 128 -> 128 on 16x16 maps: 10.7 + 33.6 + 4.4 = 48.7 us -- the phases of the workgroups sharing a CU simply
-// add up, and the MFMA loop alone runs at 287 TFLOP/s (69 % of the split peak, ~86 % of what the clock under
-// MFMA load allows).  Staggering the co-resident workgroups (s_sleep offsets) only adds the sleep; per tile the
-// vector work (split, addressing, epilogue: 1.4-2.3 instructions per MFMA) needs about as many issue cycles as
-// the MFMAs themselves (an MFMA holds the SIMD's vector issue for 8 of its 16 cycles), so what remains to be
-// gained is in removing vector instructions, not in overlapping phases.
-// A 16-deep tail step for the 48-channel layers (v_mfma_f32_16x16x16_bf16 on the half-empty second chunk)
-// cannot pay: tools/micro/mfma_rate.hip measures 8.2 ns per MFMA per SIMD for the 16-deep form against 8.4 ns
-// for the 32-deep one (1019 vs 1998 TFLOP/s chip-wide) -- same issue slot, half the work.
-// The weight fragment as the MFMA's first operand (a lane then holds four consecutive output channels of one pixel)
-// with BN / residual / ReLU finished in registers and float4 stores straight from the accumulators -- no LDS round
-// trip, no barrier, but 64-byte instead of 256-byte store runs: 32 -> 32 78.8 vs 73.4 us, 128 -> 128 50.2 vs 55.6 us,
-// HRNet-W32 forward unchanged within noise, and the extra live values spill in the register-capped 1x1 variant.
-// Dispatching the cout groups of one pixel tile back to back (shared input tile, adjacent stores): +-1 %; an
-// XCD-aware tile order (each XCD a contiguous run of tiles, so halo rows hit its own L2): +-1 % as well.
-// Two sets of LDS planes (80-byte rows, still three workgroups per CU), the next chunk split and stored in the shadow
-// of the current chunk's MFMAs, one barrier per chunk instead of two: 55.8 vs 55.6 us (64 ch), 52.7 vs 50.5 us (128 ch).
-// Occupancy (dynamic LDS inflated): 32 -> 32 takes 122 / 84 / 73.5 us with 1 / 2 / 3 workgroups per CU, 128 -> 128
-// 64.9 / 51.9 / 50.6 us -- a lone 32-channel workgroup lives 7.6 us for 1.8 us of MFMAs, and co-residents overlap only
-// partly.  8-wave workgroups for that layer (128 px x 32 couts, 104 VGPRs): 86 vs 73 us.  A three-times cheaper
-// activation split (timing-only build): 32 -> 32 unchanged, the 64..256-channel layers 5 % faster -- the split is not
-// what bounds the single-chunk layers.
-// 48 input channels with K = taps x channels flattened (9 full steps + 5 steps that pair the channels 32..47 of two
-// taps, 14 MFMA steps instead of 18 with a half-empty second chunk): 22 % fewer MFMAs, 128 -> 123 us on HRNet-W48's
-// 48 -> 48 layers, HRNet-W48 forward unchanged (29.3 ms) -- and the extra path cost every non-row-sharing 3x3 variant
-// 40-80 VGPRs until capped.  Not kept.
-// Phase stripping of the write-heavy 1x1 conv 64 -> 256 on 128 64x64 maps (251 us; HBM streams of that size run at
-// 5.3-6.8 TB/s, tools/micro/hbm_rw.py, i.e. ~120 us): skeleton without loads, MFMAs or stores 55 us (dispatching
-// 16384 empty workgroups takes 4.7 us, tools/micro/dispatch_rate.hip -- the rest is setup, split, LDS traffic and
-// barriers), + loads 9, + MFMA loop 43, + stores 75 = 182 us; the remaining 70 us are phases of co-resident
-// workgroups that do not overlap.
-// All variants sit at ~50 us / 190 TFLOP/s on the 64..256-channel layers (46 % of the split peak;
-// the guide's tuned 8-phase bf16 GEMM reaches 53-59 % of peak on random data).
-// Used for 3x3 convs with cin % 32 == 0 (or cin = 48) when the plan selects MVAL_ALGO_MFMA_BF3.
+// The measurement log of the variants that were tried and dropped is DESIGN.md appendix A.
+// Used for 3x3 / 1x1 / 2x2-parity convs with cin % 32 == 0 (or cin = 48) when the plan selects
+// MVAL_ALGO_MFMA_H2 / MVAL_ALGO_MFMA_BF3.
 #include <stdlib.h>
 
 #include "conv_common.h"
@@ -84,6 +38,9 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 #define BF_KC 32
 // bf16 elements per LDS pixel row: 32 + 16 pad = 96 bytes, or 32 + 8 pad = 80 bytes for the stride-2 kernels (both
@@ -91,6 +48,41 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 // stride-2 workgroup -- 40 KB of planes -- fit a CU: 10-16 % on those layers)
 #define BF_ROW_OF(S) ((S) == 2 ? 40 : 48)
 #define OPAD 4
+
+// One MFMA of the split product; fragments travel as untyped 128-bit registers (8 x 16 bit).
+template <int PL>
+__device__ __forceinline__ f32x4 mfma_split(const u32x4 a, const u32x4 b, const f32x4 c) {
+  if constexpr (PL == 3)
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+// Products of a k-step in accumulation order (small terms first; the last one is the leading h x h product).
+// Planes: 0 = h, 1 = m (PL = 3) / l (PL = 2), 2 = l (PL = 3).
+template <int PL> __device__ __forceinline__ constexpr int split_np() { return PL == 3 ? 6 : 3; }
+template <int PL> __device__ __forceinline__ constexpr int split_pa(int t) {  // activation plane of product t
+  return PL == 3 ? (t == 0 ? 2 : (t == 2 || t == 3) ? 1 : 0) : (t == 0 ? 1 : 0);
+}
+template <int PL> __device__ __forceinline__ constexpr int split_pb(int t) {  // weight plane of product t
+  return PL == 3 ? ((t == 0 || t == 3 || t == 5) ? 0 : t == 1 ? 2 : 1) : (t == 1 ? 1 : 0);
+}
+
+// fp16 two-way split of an already scaled value: h = RNE(v), l = RNE(v - h) (the subtraction is exact)
+__device__ __forceinline__ void split2(const f32x4 v, f16x4& h, f16x4& l) {
+  h = __builtin_convertvector(v, f16x4);
+  const f32x4 r = v - __builtin_convertvector(h, f32x4);
+  l = __builtin_convertvector(r, f16x4);
+}
+
+// 2^s as a float for the activation scale: the tensor's largest magnitude (its bits in *amax) lands in [2^14, 2^15);
+// returns the factor and its exact inverse.  An all-zero tensor, or one that holds inf / NaN, is left unscaled.
+__device__ __forceinline__ void split_act_scale(const unsigned* amax_row, float& mul, float& inv) {
+  const int e = (int)((conv_amax_read(amax_row) >> 23) & 0xff);  // biased exponent of max |x| (denormal maxima: 0 -> unscaled)
+  int s = (e == 0 || e == 255) ? 0 : 14 - (e - 127);
+  s = max(-110, min(110, s));
+  mul = __uint_as_float((unsigned)(127 + s) << 23);
+  inv = __uint_as_float((unsigned)(127 - s) << 23);
+}
 
 __device__ __forceinline__ void split3(const f32x4 v, bf16x4& h, bf16x4& m, bf16x4& l) {
 #pragma unroll
@@ -113,10 +105,12 @@ __device__ __forceinline__ void split3(const f32x4 v, bf16x4& h, bf16x4& m, bf16
 // G > 1 (1x1 convs only): G 32-channel chunks are staged per barrier pair instead of one -- a 1x1 conv has a single
 // tap per chunk, i.e. only MS * NT * 6 MFMAs (~0.2 us) between barriers and 8 KB of loads in flight per workgroup;
 // the sub-chunks take the place of the taps in the inner loop.
-template <int KS, int S, int WN, int WM, int NT, int MS, int NE, bool RS = false, bool PA = false, int G = 1>
+template <int PL, int KS, int S, int WN, int WM, int NT, int MS, int NE, bool RS = false, bool PA = false, int G = 1>
 __global__ __launch_bounds__(64 * WN * WM)
-    __attribute__((amdgpu_waves_per_eu((KS == 1 && G == 2 && NT == 2) ? (PA ? 3 : 4) : (PA && KS >= 2 && NE <= 6) ? 3 : 1, 8))) void conv_bf3_kernel(ConvArgs a) {
+    __attribute__((amdgpu_waves_per_eu((KS == 1 && G == 2 && NT == 2) ? (PA ? 3 : 4) : (PA && KS >= 2 && NE <= 6) ? 3 : (PL == 2 && NE <= 6) ? 4 : 1, 8))) void conv_split_kernel(ConvArgs a) {
   static_assert(G == 1 || (KS == 1 && S == 1), "multi-chunk staging is for 1x1 convs");
+  static_assert(PL == 3 || !PA, "the separate correction accumulator belongs to the bf16x3 training kernels");
+  constexpr int NP = split_np<PL>();
   constexpr int TAPS = G > 1 ? G : KS * KS;
   constexpr int BF_ROW = BF_ROW_OF(S);
   constexpr int NTH = 64 * WN * WM;  // 256 threads, or 192 for the 48-channel-granular (HRNet-W48) tiles
@@ -152,7 +146,12 @@ __global__ __launch_bounds__(64 * WN * WM)
   const int patch_e = patch_px * (BF_KC / 4);
   const int sub_bytes = patch_px * BF_ROW * 2;
   const int plane_bytes = sub_bytes * G;
-  char* planes = smem_raw;  // [3][G][patch_px][BF_ROW] bf16
+  char* planes = smem_raw;  // [PL][G][patch_px][BF_ROW] 16-bit
+  float in_mul = 1.f, unscale = 1.f;
+  if constexpr (PL == 2) {  // one image per tile (the launcher refuses tn > 1): the image's own scale
+    split_act_scale(a.in_amax + n0 * MVAL_AMAX_SUB, in_mul, unscale);
+    unscale *= *a.w_unscale;
+  }
 
   int abase[MS];  // byte offset inside a plane: pixel row + k quarter
 #pragma unroll
@@ -203,14 +202,12 @@ __global__ __launch_bounds__(64 * WN * WM)
   // 32-bit per-lane offset, the plane as immediate -- no 64-bit vector address arithmetic per fragment (it was
   // three v_mad_u64_u32 per fragment triple; these kernels are bound by vector-instruction issue).
   const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, 0x7fffffff, 0x00020000);
-  const int blk_bytes = a.NS_total * (192 * 16);
+  const int blk_bytes = a.NS_total * (PL * 64 * 16);
   int wlane[NT];
 #pragma unroll
-  for (int nt = 0; nt < NT; nt++) wlane[nt] = (min(ns0 + nt, a.NS_total - 1) * 192 + lane) * 16;
-  auto bfrag = [&](int blk, int nt, int p) -> bf16x8 {
-    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wlane[nt] + p * 1024, blk * blk_bytes, 0);
-    return __builtin_bit_cast(bf16x8, v);
+  for (int nt = 0; nt < NT; nt++) wlane[nt] = (min(ns0 + nt, a.NS_total - 1) * (PL * 64) + lane) * 16;
+  auto bfrag = [&](int blk, int nt, int p) -> u32x4 {
+    return __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wlane[nt] + p * 1024, blk * blk_bytes, 0);
   };
   const int nchunks = (a.Cin + BF_KC - 1) / BF_KC;  // the last chunk may be half empty (cin = 48)
   const int q4 = (tid & 7) * 4;                     // NTH % 8 == 0: a thread always stages the same channel quad
@@ -231,12 +228,19 @@ __global__ __launch_bounds__(64 * WN * WM)
       const int g = G > 1 ? e0 / (MT * 8) : 0;
       const int e = e0 - g * (MT * 8);
       if (e < patch_e && g < G) {
-        bf16x4 h, m, l;
-        split3(stage[i], h, m, l);
         const int off = g * sub_bytes + (e >> 3) * (BF_ROW * 2) + (e & 7) * 8;
-        *reinterpret_cast<bf16x4*>(planes + off) = h;
-        *reinterpret_cast<bf16x4*>(planes + plane_bytes + off) = m;
-        *reinterpret_cast<bf16x4*>(planes + 2 * plane_bytes + off) = l;
+        if constexpr (PL == 3) {
+          bf16x4 h, m, l;
+          split3(stage[i], h, m, l);
+          *reinterpret_cast<bf16x4*>(planes + off) = h;
+          *reinterpret_cast<bf16x4*>(planes + plane_bytes + off) = m;
+          *reinterpret_cast<bf16x4*>(planes + 2 * plane_bytes + off) = l;
+        } else {
+          f16x4 h, l;
+          split2(stage[i] * in_mul, h, l);
+          *reinterpret_cast<f16x4*>(planes + off) = h;
+          *reinterpret_cast<f16x4*>(planes + plane_bytes + off) = l;
+        }
       }
     }
   };
@@ -252,13 +256,13 @@ __global__ __launch_bounds__(64 * WN * WM)
     if constexpr (RS) {
       if (wave_active) {
         static_assert(!RS || (KS == 3 && S == 1), "row sharing is for 3x3 stride 1");
-        bf16x8 B[2][3][NT][3];  // [column parity][row tap][cout sub-tile][plane]: the next column loads into the other half
+        u32x4 B[2][3][NT][PL];  // [column parity][row tap][cout sub-tile][plane]: the next column loads into the other half
 #pragma unroll
         for (int ky = 0; ky < 3; ky++)
 #pragma unroll
           for (int nt = 0; nt < NT; nt++)
 #pragma unroll
-            for (int p = 0; p < 3; p++) B[0][ky][nt][p] = bfrag((ky * 3) * nchunks + ch, nt, p);
+            for (int p = 0; p < PL; p++) B[0][ky][nt][p] = bfrag((ky * 3) * nchunks + ch, nt, p);
 #pragma unroll
         for (int kx = 0; kx < 3; kx++) {
 #pragma unroll
@@ -271,30 +275,28 @@ __global__ __launch_bounds__(64 * WN * WM)
 #pragma unroll
                 for (int nt = 0; nt < NT; nt++)
 #pragma unroll
-                  for (int p = 0; p < 3; p++) B[(kx + 1) & 1][kyl][nt][p] = bfrag((kyl * 3 + kx + 1) * nchunks + ch, nt, p);
+                  for (int p = 0; p < PL; p++) B[(kx + 1) & 1][kyl][nt][p] = bfrag((kyl * 3 + kx + 1) * nchunks + ch, nt, p);
               }
             }
             const char* ap = planes + abase[0] + (pr * PW + kx) * (BF_ROW * 2);
-            const bf16x8 ah = *reinterpret_cast<const bf16x8*>(ap);
-            const bf16x8 am = *reinterpret_cast<const bf16x8*>(ap + plane_bytes);
-            const bf16x8 al = *reinterpret_cast<const bf16x8*>(ap + 2 * plane_bytes);
+            u32x4 av[PL];
+#pragma unroll
+            for (int p = 0; p < PL; p++) av[p] = *reinterpret_cast<const u32x4*>(ap + p * plane_bytes);
 #pragma unroll
             for (int nt = 0; nt < NT; nt++) {
-              // the six products in small-to-large order, interleaved over the (up to three)
+              // the products in small-to-large order, interleaved over the (up to three)
               // independent accumulators this fragment feeds
 #pragma unroll
-              for (int t = 0; t < 6; t++) {
+              for (int t = 0; t < NP; t++) {
 #pragma unroll
                 for (int ky = 0; ky < 3; ky++) {
                   const int ms = pr - ky;
                   if (ms < 0 || ms >= MS) continue;
-                  const bf16x8 av = (t == 0) ? al : (t == 2 || t == 3) ? am : ah;
-                  const int bi = (t == 0 || t == 3 || t == 5) ? 0 : (t == 1) ? 2 : 1;
-                  if (!PA || t == 5)
-                    acc[ms][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, B[kx & 1][ky][nt][bi], acc[ms][nt], 0, 0, 0);
+                  const int ai = split_pa<PL>(t), bi = split_pb<PL>(t);
+                  if (!PA || t == NP - 1)
+                    acc[ms][nt] = mfma_split<PL>(av[ai], B[kx & 1][ky][nt][bi], acc[ms][nt]);
                   else
-                    accl[PA ? ms : 0][PA ? nt : 0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                        av, B[kx & 1][ky][nt][bi], accl[PA ? ms : 0][PA ? nt : 0], 0, 0, 0);
+                    accl[PA ? ms : 0][PA ? nt : 0] = mfma_split<PL>(av[ai], B[kx & 1][ky][nt][bi], accl[PA ? ms : 0][PA ? nt : 0]);
                 }
               }
             }
@@ -303,11 +305,11 @@ __global__ __launch_bounds__(64 * WN * WM)
       }
     } else if (wave_active) {
       // weight fragment blocks: ((tap * G32 + g32) * NS + ns) * 3 planes * 64 lanes (16-byte units)
-      bf16x8 b[2][NT][3];  // [tap parity][cout sub-tile][plane]
+      u32x4 b[2][NT][PL];  // [tap parity][cout sub-tile][plane]
 #pragma unroll
       for (int nt = 0; nt < NT; nt++)
 #pragma unroll
-        for (int p = 0; p < 3; p++) b[0][nt][p] = bfrag(ch * G, nt, p);
+        for (int p = 0; p < PL; p++) b[0][nt][p] = bfrag(ch * G, nt, p);
 #pragma unroll
       for (int tap = 0; tap < TAPS; tap++) {
         if (tap + 1 < TAPS) {
@@ -315,29 +317,26 @@ __global__ __launch_bounds__(64 * WN * WM)
 #pragma unroll
           for (int nt = 0; nt < NT; nt++)
 #pragma unroll
-            for (int p = 0; p < 3; p++) b[(tap + 1) & 1][nt][p] = bfrag(blk, nt, p);
+            for (int p = 0; p < PL; p++) b[(tap + 1) & 1][nt][p] = bfrag(blk, nt, p);
         }
         const int toff = G > 1 ? tap * sub_bytes : ((tap / KS) * PW + (tap % KS)) * (BF_ROW * 2);
 #pragma unroll
         for (int ms = 0; ms < MS; ms++) {
           const char* ap = planes + abase[ms] + toff;
-          const bf16x8 ah = *reinterpret_cast<const bf16x8*>(ap);
-          const bf16x8 am = *reinterpret_cast<const bf16x8*>(ap + plane_bytes);
-          const bf16x8 al = *reinterpret_cast<const bf16x8*>(ap + 2 * plane_bytes);
+          u32x4 av[PL];
+#pragma unroll
+          for (int p = 0; p < PL; p++) av[p] = *reinterpret_cast<const u32x4*>(ap + p * plane_bytes);
 #pragma unroll
           for (int nt = 0; nt < NT; nt++) {
-            const bf16x8* bc = b[tap & 1][nt];
+            const u32x4* bc = b[tap & 1][nt];
             f32x4 c = PA ? accl[PA ? ms : 0][PA ? nt : 0] : acc[ms][nt];  // corrections, small terms first
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bc[0], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bc[2], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bc[1], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bc[0], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bc[1], c, 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < NP - 1; t++) c = mfma_split<PL>(av[split_pa<PL>(t)], bc[split_pb<PL>(t)], c);
             if constexpr (PA) {
               accl[ms][nt] = c;
               c = acc[ms][nt];
             }
-            acc[ms][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bc[0], c, 0, 0, 0);
+            acc[ms][nt] = mfma_split<PL>(av[0], bc[0], c);
           }
         }
       }
@@ -356,7 +355,8 @@ __global__ __launch_bounds__(64 * WN * WM)
     for (int nt = 0; nt < NT; nt++) {
       const int cl = (wn * NT + nt) * 16 + (lane & 15);
       const int c = blockIdx.y * NTILE + cl;
-      const float sc = c < a.Cout ? a.scale[c] : 0.f, sh = c < a.Cout ? a.shift[c] : 0.f;
+      // the power-of-two scales of the fp16 split are undone here: acc * (scale * 2^-s) rounds like (acc * 2^-s) * scale
+      const float sc = c < a.Cout ? a.scale[c] * unscale : 0.f, sh = c < a.Cout ? a.shift[c] : 0.f;
 #pragma unroll
       for (int ms = 0; ms < MS; ms++)
 #pragma unroll
@@ -372,17 +372,8 @@ __global__ __launch_bounds__(64 * WN * WM)
 
 static thread_local int g_bf3_dry = 0;
 
-static int bf3_row_sharing() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("MVAL_BF3_RS");
-    v = e ? atoi(e) : 1;
-  }
-  return v;
-}
-
-template <int KS, int S, int WN, int WM, int NT, int MS, int G = 1>
-static int launch_bf3(ConvArgs a, int th, int tw, int tn, hipStream_t s) {
+template <int PL, int KS, int S, int WN, int WM, int NT, int MS, int G = 1>
+static int launch_split(ConvArgs a, int th, int tw, int tn, hipStream_t s) {
   a.th = th; a.tw = tw; a.tn = tn;
   a.tw_log2 = __builtin_ctz(tw);
   a.thw_log2 = __builtin_ctz(th * tw);
@@ -400,8 +391,8 @@ static int launch_bf3(ConvArgs a, int th, int tw, int tn, hipStream_t s) {
   constexpr int MT = 16 * MS * WM, NTILE = 16 * NT * WN;
   const int patch_px = tn * PH * PW;
   constexpr int BF_ROW = BF_ROW_OF(S);
-  size_t smem = (size_t)3 * G * patch_px * BF_ROW * 2;
-  const size_t otile = (size_t)MT * (NTILE + OPAD) * sizeof(float);
+  size_t smem = (size_t)PL * G * patch_px * BF_ROW * 2;
+  const size_t otile = (size_t)(MT * (NTILE + OPAD) + 8) * sizeof(float);  // + the max |x| reduction scratch
   if (otile > smem) smem = otile;
   if (smem > 128 * 1024) return 1;
   constexpr int NTH = 64 * WN * WM;
@@ -410,51 +401,54 @@ static int launch_bf3(ConvArgs a, int th, int tw, int tn, hipStream_t s) {
   constexpr bool NE10 = MT >= 64 || S == 2;  // the small-problem tiles only exist with 6 staging slots
   if (!NE10 && ne > 6) return 1;
   if (G > 1 && (patch_px != MT || ((a.Cin + BF_KC - 1) / BF_KC) % G != 0)) return 1;
+  if (PL == 2 && tn != 1) return 1;  // the fp16 split scales per image: one image per tile (maps under 8 rows use bf16x3)
   if (g_bf3_dry) return 0;
+  constexpr bool PAOK = PL == 3;  // the separate correction accumulator exists for the bf16x3 split only
+  if (a.precise && !PAOK) return 1;
   dim3 grid((unsigned)(a.tiles_x * a.tiles_y * ngroups), (unsigned)((a.NS_total + WN * NT - 1) / (WN * NT)),
             (KS == 2 && a.par_w_stride) ? 4u : 1u);
   if constexpr (G > 1) {
     constexpr int NEG = (G * MT * 8 + NTH - 1) / NTH;
-    if (a.precise)
-      hipLaunchKernelGGL((conv_bf3_kernel<KS, S, WN, WM, NT, MS, NEG, false, true, G>), grid, dim3(NTH), smem, s, a);
-    else
-      hipLaunchKernelGGL((conv_bf3_kernel<KS, S, WN, WM, NT, MS, NEG, false, false, G>), grid, dim3(NTH), smem, s, a);
+    if constexpr (PAOK)
+      if (a.precise) {
+        hipLaunchKernelGGL((conv_split_kernel<PL, KS, S, WN, WM, NT, MS, NEG, false, true, G>), grid, dim3(NTH), smem, s, a);
+        return 0;
+      }
+    hipLaunchKernelGGL((conv_split_kernel<PL, KS, S, WN, WM, NT, MS, NEG, false, false, G>), grid, dim3(NTH), smem, s, a);
     return 0;
   }
   if constexpr (KS == 3 && S == 1) {
-    if (tw == 16 && tn == 1 && ne <= 6 && bf3_row_sharing()) {
-      if (a.precise)
-        hipLaunchKernelGGL((conv_bf3_kernel<KS, S, WN, WM, NT, MS, 6, true, true>), grid, dim3(NTH), smem, s, a);
-      else
-        hipLaunchKernelGGL((conv_bf3_kernel<KS, S, WN, WM, NT, MS, 6, true>), grid, dim3(NTH), smem, s, a);
+    if (tw == 16 && tn == 1 && ne <= 6) {  // row sharing
+      if constexpr (PAOK)
+        if (a.precise) {
+          hipLaunchKernelGGL((conv_split_kernel<PL, KS, S, WN, WM, NT, MS, 6, true, true>), grid, dim3(NTH), smem, s, a);
+          return 0;
+        }
+      hipLaunchKernelGGL((conv_split_kernel<PL, KS, S, WN, WM, NT, MS, 6, true>), grid, dim3(NTH), smem, s, a);
       return 0;
     }
   }
-  if (a.precise) {
-    if (ne <= 6)
-      hipLaunchKernelGGL((conv_bf3_kernel<KS, S, WN, WM, NT, MS, 6, false, true>), grid, dim3(NTH), smem, s, a);
-    else if constexpr (NE10)
-      hipLaunchKernelGGL((conv_bf3_kernel<KS, S, WN, WM, NT, MS, 10, false, true>), grid, dim3(NTH), smem, s, a);
-    return 0;
-  }
+  if constexpr (PAOK)
+    if (a.precise) {
+      if (ne <= 6)
+        hipLaunchKernelGGL((conv_split_kernel<PL, KS, S, WN, WM, NT, MS, 6, false, true>), grid, dim3(NTH), smem, s, a);
+      else if constexpr (NE10)
+        hipLaunchKernelGGL((conv_split_kernel<PL, KS, S, WN, WM, NT, MS, 10, false, true>), grid, dim3(NTH), smem, s, a);
+      return 0;
+    }
   if (ne <= 6)
-    hipLaunchKernelGGL((conv_bf3_kernel<KS, S, WN, WM, NT, MS, 6>), grid, dim3(NTH), smem, s, a);
+    hipLaunchKernelGGL((conv_split_kernel<PL, KS, S, WN, WM, NT, MS, 6>), grid, dim3(NTH), smem, s, a);
   else if constexpr (NE10)
-    hipLaunchKernelGGL((conv_bf3_kernel<KS, S, WN, WM, NT, MS, 10>), grid, dim3(NTH), smem, s, a);
+    hipLaunchKernelGGL((conv_split_kernel<PL, KS, S, WN, WM, NT, MS, 10>), grid, dim3(NTH), smem, s, a);
   return 0;
 }
 
-static void bf3_pick_tile(int H, int W, int mt, int* th, int* tw, int* tn) {
+static void split_pick_tile(int H, int W, int mt, int* th, int* tw, int* tn) {
   int w = (W > 8) ? 16 : 8;
   // widths that are no multiple of 16 (72 / 36 / 18 for HRNet-W48 at 384 x 288, 24 for PoseResNet at 256 x 192):
   // 8-wide tiles waste fewer columns than 16-wide ones, which outweighs the row-sharing kernel they give up
   // (HRNet-W48 forward 36.4 -> 32.0 ms on 64 images)
-  static int tw8 = -1;
-  if (tw8 < 0) {
-    const char* e = getenv("MVAL_BF3_TW8");
-    tw8 = e ? atoi(e) : 1;
-  }
-  if (tw8 && W > 8 && mt >= 32 && ((W + 7) / 8) * 8 < ((W + 15) / 16) * 16) w = 8;
+  if (W > 8 && mt >= 32 && ((W + 7) / 8) * 8 < ((W + 15) / 16) * 16) w = 8;
   int h = mt / w, n = 1;
   int hh = 1;
   while (hh < H) hh <<= 1;
@@ -468,13 +462,7 @@ static void bf3_pick_tile(int H, int W, int mt, int* th, int* tw, int* tn) {
 // Maps like 24 x 18 or 12 x 9 (HRNet-W48 at 384 x 288) fill power-of-two tiles badly (25 % / 44 % padding): an odd
 // tile -- tw = W, W / 2 or W / 3 columns by floor(mt / tw) rows, decoded with a magic divide -- replaces the
 // power-of-two one in (th, tw, tn) when it needs at least 10 % fewer workgroups.
-static void bf3_odd_tile(int H, int W, int N, int mt, int* th, int* tw, int* tn) {
-  static int odd = -1;
-  if (odd < 0) {
-    const char* e = getenv("MVAL_BF3_ODD_TILES");
-    odd = e ? atoi(e) : 1;
-  }
-  if (!odd) return;
+static void split_odd_tile(int H, int W, int N, int mt, int* th, int* tw, int* tn) {
   const int64_t wgs2 = (int64_t)((W + *tw - 1) / *tw) * ((H + *th - 1) / *th) * ((N + *tn - 1) / *tn);
   int64_t best = wgs2;
   int bth = 0, btw = 0;
@@ -494,14 +482,8 @@ static void bf3_odd_tile(int H, int W, int N, int mt, int* th, int* tw, int* tn)
   }
 }
 
-// Tile pixels for a small problem: `px` output pixels x `groups` workgroups per pixel tile (see dispatch_bf3).
-static int bf3_small_tile(int ks, int64_t px, int64_t groups) {
-  static int enabled = -1;
-  if (enabled < 0) {
-    const char* e = getenv("MVAL_BF3_SMALL_TILES");
-    enabled = e ? atoi(e) : 1;
-  }
-  if (!enabled) return 64;
+// Tile pixels for a small problem: `px` output pixels x `groups` workgroups per pixel tile (see dispatch_split).
+static int split_small_tile(int ks, int64_t px, int64_t groups) {
   const int64_t wgs64 = ((px + 63) / 64) * groups;
   if (ks == 3) return wgs64 <= 64 ? 16 : 64;
   int mt = 64;
@@ -509,16 +491,16 @@ static int bf3_small_tile(int ks, int64_t px, int64_t groups) {
   return mt;
 }
 
-template <int KS, int S>
-static int dispatch_bf3(const ConvArgs& a, hipStream_t s) {
+template <int PL, int KS, int S>
+static int dispatch_split(const ConvArgs& a, hipStream_t s) {
   int th, tw, tn;
   const int64_t px = (int64_t)a.N * a.Hout * a.Wout;
   // 4 sub-tiles per wave: 8 would need 220 VGPRs (one wave per SIMD) and measured slower
   if (a.NS_total <= 2) {
     const bool small = px < (int64_t)128 * 1024;
-    bf3_pick_tile(a.Hout, a.Wout, small ? 64 : 128, &th, &tw, &tn);
-    if (small) return launch_bf3<KS, S, 2, 2, 1, 2>(a, th, tw, tn, s);
-    return launch_bf3<KS, S, 2, 2, 1, 4>(a, th, tw, tn, s);
+    split_pick_tile(a.Hout, a.Wout, small ? 64 : 128, &th, &tw, &tn);
+    if (small) return launch_split<PL, KS, S, 2, 2, 1, 2>(a, th, tw, tn, s);
+    return launch_split<PL, KS, S, 2, 2, 1, 4>(a, th, tw, tn, s);
   }
   // Small problems (a few images, or the deep low-resolution layers): with 64-pixel tiles fewer workgroups than
   // CUs exist while each walks all of cin serially.  1x1 convs and the 2x2 parity convs of a transposed conv go
@@ -528,95 +510,111 @@ static int dispatch_bf3(const ConvArgs& a, hipStream_t s) {
   // the CUs had work (512 -> 512 on 8x6: 78 -> 64 us; 32-pixel tiles measured 1.5x SLOWER than 64-pixel ones).
   const int wn = (a.NS_total % 3 == 0 && a.NS_total % 4 != 0) ? 3 : 4;  // 48 / 96 output channels: three cout waves
   const int64_t cgroups = (a.NS_total + wn - 1) / wn, par = (KS == 2 && a.par_w_stride) ? 4 : 1;
-  const int mt = bf3_small_tile(KS, px, cgroups * par);
-  bf3_pick_tile(a.Hout, a.Wout, mt, &th, &tw, &tn);
+  const int mt = split_small_tile(KS, px, cgroups * par);
+  split_pick_tile(a.Hout, a.Wout, mt, &th, &tw, &tn);
   if constexpr (KS == 3)
-    if (mt == 64) bf3_odd_tile(a.Hout, a.Wout, a.N, 64, &th, &tw, &tn);
+    if (mt == 64) split_odd_tile(a.Hout, a.Wout, a.N, 64, &th, &tw, &tn);
   const int nch = (a.Cin + BF_KC - 1) / BF_KC;
   if constexpr (KS == 1) {
     // 1x1: two 32-channel chunks per barrier pair (16 KB of loads in flight per workgroup, twice the MFMAs
     // between barriers) and, from 128 output channels on, 128-cout tiles (half the staging redundancy):
     // 5-19 % on the bottleneck shapes of HRNet's layer1 / PoseResNet-50 (tools/conv1x1_sweep.py; four chunks
     // per stage cost a workgroup per CU in LDS and measured 20-30 % slower)
-    static int k1 = -1;
-    if (k1 < 0) {
-      const char* e = getenv("MVAL_BF3_K1");
-      k1 = e ? atoi(e) : 1;
-    }
-    if (k1 && wn == 4 && a.NS_total % 4 == 0 && nch % 2 == 0) {
+    if (wn == 4 && a.NS_total % 4 == 0 && nch % 2 == 0) {
       // 128-cout tiles only while they still give every CU a few workgroups
       const int64_t wgs128 = ((px + 63) / 64) * (a.NS_total / 8);
-      if (a.NS_total % 8 == 0 && wgs128 >= 1024) return launch_bf3<KS, S, 4, 1, 2, 4, 2>(a, th, tw, tn, s);
-      if (mt == 16) return launch_bf3<KS, S, 4, 1, 1, 1, 2>(a, th, tw, tn, s);
-      if (mt == 32) return launch_bf3<KS, S, 4, 1, 1, 2, 2>(a, th, tw, tn, s);
-      return launch_bf3<KS, S, 4, 1, 1, 4, 2>(a, th, tw, tn, s);
+      if (a.NS_total % 8 == 0 && wgs128 >= 1024) return launch_split<PL, KS, S, 4, 1, 2, 4, 2>(a, th, tw, tn, s);
+      if (mt == 16) return launch_split<PL, KS, S, 4, 1, 1, 1, 2>(a, th, tw, tn, s);
+      if (mt == 32) return launch_split<PL, KS, S, 4, 1, 1, 2, 2>(a, th, tw, tn, s);
+      return launch_split<PL, KS, S, 4, 1, 1, 4, 2>(a, th, tw, tn, s);
     }
   }
   if (wn == 3) {
-    if (mt == 16) return launch_bf3<KS, S, 3, 1, 1, 1>(a, th, tw, tn, s);
+    if (mt == 16) return launch_split<PL, KS, S, 3, 1, 1, 1>(a, th, tw, tn, s);
     if constexpr (KS != 3)
-      if (mt == 32) return launch_bf3<KS, S, 3, 1, 1, 2>(a, th, tw, tn, s);
-    return launch_bf3<KS, S, 3, 1, 1, 4>(a, th, tw, tn, s);
+      if (mt == 32) return launch_split<PL, KS, S, 3, 1, 1, 2>(a, th, tw, tn, s);
+    return launch_split<PL, KS, S, 3, 1, 1, 4>(a, th, tw, tn, s);
   }
-  if (mt == 16) return launch_bf3<KS, S, 4, 1, 1, 1>(a, th, tw, tn, s);
+  if (mt == 16) return launch_split<PL, KS, S, 4, 1, 1, 1>(a, th, tw, tn, s);
   if constexpr (KS != 3)
-    if (mt == 32) return launch_bf3<KS, S, 4, 1, 1, 2>(a, th, tw, tn, s);
-  return launch_bf3<KS, S, 4, 1, 1, 4>(a, th, tw, tn, s);
+    if (mt == 32) return launch_split<PL, KS, S, 4, 1, 1, 2>(a, th, tw, tn, s);
+  return launch_split<PL, KS, S, 4, 1, 1, 4>(a, th, tw, tn, s);
 }
 
-int mval_launch_conv_bf3(const ConvArgs& a, hipStream_t s) {
+template <int PL>
+static int launch_conv_split(const ConvArgs& a, hipStream_t s) {
   // cin a multiple of 32, or 48 (HRNet-W48's first branch: second chunk half empty, 25 % padding)
   if (a.in_nchw || (a.Cin % BF_KC != 0 && a.Cin != 48)) return 1;
   if ((int64_t)a.N * a.Hin * a.Win * a.Cin >= (int64_t)1 << 31) return 1;
+  if (PL == 2 && !g_bf3_dry && (!a.in_amax || !a.w_unscale)) return 1;  // the fp16 split needs both scales
   // 1x1 channel GEMMs (bottleneck blocks, fuse up-paths): at the fp32-MFMA rate they are as
   // MFMA-bound as HBM-bound; here only HBM is left (202 vs 242 us for 256->64 on 128 64x64 maps, 3.3 TB/s;
   // keeping two chunks in flight instead of one measured slower, 226 us)
   if (a.k == 1 && a.pad == 0 && a.stride == 1 && a.dil == 1 && !a.out_nchw && (a.Cout & 15) == 0)
-    return dispatch_bf3<1, 1>(a, s);
+    return dispatch_split<PL, 1, 1>(a, s);
   // stride-2 1x1 conv (ResNet downsample paths) = stride-1 1x1 conv on the even pixels
   if (a.k == 1 && a.pad == 0 && a.stride == 2 && a.dil == 1 && !a.out_nchw && (a.Cout & 15) == 0 && a.in_sub_log2 == 0) {
     ConvArgs b = a;
     b.stride = 1;
     b.in_sub_log2 = 1;
-    return dispatch_bf3<1, 1>(b, s);
+    return dispatch_split<PL, 1, 1>(b, s);
   }
   // 2x2 parity kernel of a transposed conv (weights packed with mode 3, one parity's 4 taps at a.w)
   if (a.k == 2 && a.pad == 1 && a.stride == 1 && a.dil == 1 && !a.out_nchw && a.up == 0 && (a.Cout & 3) == 0)
-    return dispatch_bf3<2, 1>(a, s);
+    return dispatch_split<PL, 2, 1>(a, s);
   if (a.k != 3 || a.pad != 1) return 1;
   // dil == 2: data gradient of a stride-2 conv (dz read as a zero-dilated input: 3 of 4 staged values
   // are zeros, still ~2x the exact-fp32 MFMA kernel)
-  if (a.stride == 1 && (a.dil == 1 || a.dil == 2)) return dispatch_bf3<3, 1>(a, s);
+  if (a.stride == 1 && (a.dil == 1 || (a.dil == 2 && PL == 3))) return dispatch_split<PL, 3, 1>(a, s);
   // stride 2: the patch is ~4x larger per output pixel, so 32-pixel tiles (44 KB of LDS planes);
   // 64-pixel tiles (87 KB, 196 VGPRs) measured slower than the exact-fp32 kernel
   if (a.stride == 2 && a.dil == 1) {
-    static int s2 = -1;
-    if (s2 < 0) {
-      const char* e = getenv("MVAL_BF3_S2");
-      s2 = e ? atoi(e) : 1;
-    }
-    if (!s2) return 1;
     int th, tw, tn;
-    bf3_pick_tile(a.Hout, a.Wout, 32, &th, &tw, &tn);
-    if (a.NS_total <= 2) return launch_bf3<3, 2, 2, 2, 1, 1>(a, th, tw, tn, s);
-    bf3_odd_tile(a.Hout, a.Wout, a.N, 32, &th, &tw, &tn);
+    split_pick_tile(a.Hout, a.Wout, 32, &th, &tw, &tn);
+    if (a.NS_total <= 2) return launch_split<PL, 3, 2, 2, 2, 1, 1>(a, th, tw, tn, s);
+    split_odd_tile(a.Hout, a.Wout, a.N, 32, &th, &tw, &tn);
     const bool w3 = a.NS_total % 3 == 0 && a.NS_total % 4 != 0;
-    if (w3) return launch_bf3<3, 2, 3, 1, 1, 2>(a, th, tw, tn, s);
-    return launch_bf3<3, 2, 4, 1, 1, 2>(a, th, tw, tn, s);
+    if (w3) return launch_split<PL, 3, 2, 3, 1, 1, 2>(a, th, tw, tn, s);
+    return launch_split<PL, 3, 2, 4, 1, 1, 2>(a, th, tw, tn, s);
   }
   return 1;
 }
 
-int mval_conv_bf3_supported(const ConvArgs& a) {
+// a.planes: 3 = bf16x3 (six products), 2 = fp16x2 (three products; needs a.in_amax and a.w_unscale)
+int mval_launch_conv_split(const ConvArgs& a, hipStream_t s) {
+  if (a.planes == 2) return a.precise ? 1 : launch_conv_split<2>(a, s);
+  if (a.planes == 3) return launch_conv_split<3>(a, s);
+  return 1;
+}
+
+int mval_conv_split_supported(const ConvArgs& a) {
   g_bf3_dry = 1;
-  int rc = mval_launch_conv_bf3(a, nullptr);
+  int rc = mval_launch_conv_split(a, nullptr);
   g_bf3_dry = 0;
   return rc == 0;
 }
 
-// ---- weight packing: [tap][cin/32][cout/16][plane][lane][8 bf16] ---------------------------
-__device__ __forceinline__ void pack_bf3_element(const float* __restrict__ w, unsigned short* __restrict__ p, int mode,
-                                                 int cout, int cin, int k, int64_t i) {
+// ---- weight packing: [tap][cin/32][cout/16][plane][lane][8 x 16 bit] --------------------------
+// Source element of packed position (tap t, cin ci, cout co) for the `mode`s of mval_pack_conv_weights.
+__device__ __forceinline__ float split_w_at(const float* __restrict__ w, int mode, int cout, int cin, int k, int t, int ci, int co) {
+  const int T = k * k;
+  if (mode == 3) {
+    // ConvTranspose2d(k4, s2, p1) as four 2x2 stride-1 convs, one per output parity (py, px):
+    // t = parity * 4 + (dy * 2 + dx); window row dy of parity py reads kernel row 3 - 2 dy (py = 0:
+    // input rows a - 1, a) or 2 - 2 dy (py = 1: rows a, a + 1); columns alike
+    const int pp = t >> 2, dy = (t >> 1) & 1, dx = t & 1;
+    const int ky = (pp >> 1) ? 2 - 2 * dy : 3 - 2 * dy, kx = (pp & 1) ? 2 - 2 * dx : 3 - 2 * dx;
+    return w[((int64_t)ci * cout + co) * 16 + ky * 4 + kx];
+  }
+  if (mode == 2) return w[((int64_t)ci * cout + co) * T + (T - 1 - t)];  // data-gradient form
+  if (mode == 1) return w[((int64_t)ci * cout + co) * T + t];            // ConvTranspose2d layout
+  return w[((int64_t)co * cin + ci) * T + t];
+}
+
+// wmul: power-of-two weight scale of the fp16 split (unused for PL = 3)
+template <int PL>
+__device__ __forceinline__ void pack_split_element(const float* __restrict__ w, unsigned short* __restrict__ p, int mode,
+                                                   int cout, int cin, int k, int64_t i, float wmul) {
   const int G = (cin + 31) / 32, NS = (cout + 15) / 16;
   const int64_t total = (int64_t)k * k * G * NS * 512;  // (lane, j) pairs per block
   if (i >= total) return;
@@ -628,33 +626,55 @@ __device__ __forceinline__ void pack_bf3_element(const float* __restrict__ w, un
   const int t = (int)(r / ((int64_t)NS * G));
   const int co = ns * 16 + (lane & 15);
   const int ci = g * 32 + (lane >> 4) * 8 + j;
-  float v = 0.f;
-  if (co < cout && ci < cin) {
-    const int T = k * k;
-    if (mode == 3) {
-      // ConvTranspose2d(k4, s2, p1) as four 2x2 stride-1 convs, one per output parity (py, px):
-      // t = parity * 4 + (dy * 2 + dx); window row dy of parity py reads kernel row 3 - 2 dy (py = 0:
-      // input rows a - 1, a) or 2 - 2 dy (py = 1: rows a, a + 1); columns alike
-      const int pp = t >> 2, dy = (t >> 1) & 1, dx = t & 1;
-      const int ky = (pp >> 1) ? 2 - 2 * dy : 3 - 2 * dy, kx = (pp & 1) ? 2 - 2 * dx : 3 - 2 * dx;
-      v = w[((int64_t)ci * cout + co) * 16 + ky * 4 + kx];
-    } else if (mode == 2) v = w[((int64_t)ci * cout + co) * T + (T - 1 - t)];       // data-gradient form
-    else if (mode == 1) v = w[((int64_t)ci * cout + co) * T + t];           // ConvTranspose2d layout
-    else v = w[((int64_t)co * cin + ci) * T + t];
+  const float v = (co < cout && ci < cin) ? split_w_at(w, mode, cout, cin, k, t, ci, co) : 0.f;
+  const int64_t base = r * (PL * 512) + lane * 8 + j;  // PL planes x 512 values per block
+  if constexpr (PL == 3) {
+    const __bf16 h = (__bf16)v;
+    const float r1 = v - (float)h;
+    const __bf16 m = (__bf16)r1;
+    const __bf16 l = (__bf16)(r1 - (float)m);
+    p[base] = __builtin_bit_cast(unsigned short, h);
+    p[base + 512] = __builtin_bit_cast(unsigned short, m);
+    p[base + 1024] = __builtin_bit_cast(unsigned short, l);
+  } else {
+    const float vs = v * wmul;
+    const _Float16 h = (_Float16)vs;
+    const _Float16 l = (_Float16)(vs - (float)h);
+    p[base] = __builtin_bit_cast(unsigned short, h);
+    p[base + 512] = __builtin_bit_cast(unsigned short, l);
   }
-  const __bf16 h = (__bf16)v;
-  const float r1 = v - (float)h;
-  const __bf16 m = (__bf16)r1;
-  const __bf16 l = (__bf16)(r1 - (float)m);
-  const int64_t base = r * 1536 + lane * 8 + j;  // 3 planes x 512 bf16 per block
-  p[base] = __builtin_bit_cast(unsigned short, h);
-  p[base + 512] = __builtin_bit_cast(unsigned short, m);
-  p[base + 1024] = __builtin_bit_cast(unsigned short, l);
 }
 
 __global__ void pack_bf3_kernel(const float* __restrict__ w, unsigned short* __restrict__ p, int mode, int cout, int cin,
                                 int k) {
-  pack_bf3_element(w, p, mode, cout, cin, k, (int64_t)blockIdx.x * blockDim.x + threadIdx.x);
+  pack_split_element<3>(w, p, mode, cout, cin, k, (int64_t)blockIdx.x * blockDim.x + threadIdx.x, 1.f);
+}
+
+// fp16 split: max |w| first (into trailer[1], zeroed by the launcher), then the pack scales every weight by the
+// power of two that puts that maximum in [2^13, 2^14) and leaves the exact inverse in trailer[0] for the conv epilogue.
+__global__ void weight_amax_kernel(const float* __restrict__ w, int64_t n, unsigned* __restrict__ slot) {
+  float m = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    m = fmaxf(m, fabsf(w[i]));
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) atomicMax(slot, __float_as_uint(m));
+}
+
+__device__ __forceinline__ void split_weight_scale(unsigned amax_bits, float& mul, float& inv) {
+  const int e = (int)((amax_bits >> 23) & 0xff);
+  int s = (e == 0 || e == 255) ? 0 : 13 - (e - 127);
+  s = max(-110, min(110, s));
+  mul = __uint_as_float((unsigned)(127 + s) << 23);
+  inv = __uint_as_float((unsigned)(127 - s) << 23);
+}
+
+__global__ void pack_h2_kernel(const float* __restrict__ w, unsigned short* __restrict__ p, int mode, int cout, int cin,
+                               int k, float* __restrict__ trailer) {
+  float mul, inv;
+  split_weight_scale(reinterpret_cast<const unsigned*>(trailer)[1], mul, inv);
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0) trailer[0] = inv;
+  pack_split_element<2>(w, p, mode, cout, cin, k, i, mul);
 }
 
 // All weight tensors of a training plan in ONE launch (they are re-packed after every optimizer step: ~580 tiny
@@ -675,7 +695,7 @@ __global__ void pack_bf3_batch_kernel(const PackBf3Job* __restrict__ jobs, const
     else hi = mid - 1;
   }
   const PackBf3Job jb = jobs[lo];
-  pack_bf3_element(jb.w, jb.p, jb.mode, jb.cout, jb.cin, jb.k, (int64_t)(blockIdx.x - first_block[lo]) * blockDim.x + threadIdx.x);
+  pack_split_element<3>(jb.w, jb.p, jb.mode, jb.cout, jb.cin, jb.k, (int64_t)(blockIdx.x - first_block[lo]) * blockDim.x + threadIdx.x, 1.f);
 }
 
 int mval_pack_bf3_batch(const void* jobs_dev, const int* first_block_dev, int n_jobs, int total_blocks, hipStream_t s) {
@@ -689,5 +709,20 @@ int mval_pack_bf3(int mode, const float* w, float* packed, int cout, int cin, in
   const int64_t total = (int64_t)k * k * G * NS * 512;
   hipLaunchKernelGGL(pack_bf3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w,
                      reinterpret_cast<unsigned short*>(packed), mode, cout, cin, k);
+  return 0;
+}
+
+// fp16-split packing: `packed` holds k*k*G*NS*512 floats of fragments followed by a 4-float trailer
+// [2^-s (the epilogue's factor), bits of max |w|, 0, 0].
+int mval_pack_h2(int mode, const float* w, float* packed, int cout, int cin, int k, hipStream_t s) {
+  const int G = (cin + 31) / 32, NS = (cout + 15) / 16;
+  const int64_t total = (int64_t)k * k * G * NS * 512;
+  float* trailer = packed + total;  // 2 planes x 512 halves = 512 floats per block
+  (void)hipMemsetAsync(trailer, 0, 4 * sizeof(float), s);
+  const int64_t nw = (int64_t)cout * cin * k * k;
+  hipLaunchKernelGGL(weight_amax_kernel, dim3((unsigned)((nw + 1023) / 1024 > 256 ? 256 : (nw + 1023) / 1024)), dim3(256), 0, s, w, nw,
+                     reinterpret_cast<unsigned*>(trailer) + 1);
+  hipLaunchKernelGGL(pack_h2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w,
+                     reinterpret_cast<unsigned short*>(packed), mode, cout, cin, k, trailer);
   return 0;
 }

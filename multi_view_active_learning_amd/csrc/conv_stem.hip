@@ -53,6 +53,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
   const int cq = tid & 15;        // cout quad within a pass
   const int grp = tid >> 4;       // 16 groups: row = grp >> 1, x half = grp & 1
   const int ty = grp >> 1, tx0 = (grp & 1) * ST_P;
+  float amax = 0.f;  // max |stored value| (the fp16-split consumer's activation scale, conv_common.h)
   for (int cbase = 0; cbase < cq_n; cbase += 16) {
     const int q = cbase + cq;
     if (q >= cq_n) continue;
@@ -91,9 +92,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
           r.x = fmaxf(r.x, 0.f); r.y = fmaxf(r.y, 0.f); r.z = fmaxf(r.z, 0.f); r.w = fmaxf(r.w, 0.f);
         }
         *reinterpret_cast<f32x4*>(a.out + (((int64_t)n * a.Hout + y) * a.Wout + x) * a.Cout + q * 4) = r;
+        amax = conv_amax4(amax, r.x, r.y, r.z, r.w);
       }
     }
   }
+  if (a.out_amax) conv_amax_commit(a.out_amax + n * MVAL_AMAX_SUB, amax, patch + 3 * PH * PWP);
 }
 
 // returns 1 when the op is not a stem of the supported shape
@@ -102,7 +105,7 @@ int mval_launch_conv_stem(const ConvArgs& a, hipStream_t s) {
   if (a.k != 3 && a.k != 7) return 1;
   if (a.pad != a.k / 2) return 1;
   const int PH = (ST_TH - 1) * 2 + a.k, PW = ((ST_TW - 1) * 2 + a.k) | 1;
-  size_t smem = (size_t)(a.k * a.k * 3 * a.Cout + 3 * PH * PW) * sizeof(float);
+  size_t smem = (size_t)(a.k * a.k * 3 * a.Cout + 3 * PH * PW + 8) * sizeof(float);  // + the max |x| reduction scratch
   if (smem > 64 * 1024) return 1;
   const int tiles = ((a.Wout + ST_TW - 1) / ST_TW) * ((a.Hout + ST_TH - 1) / ST_TH) * a.N;
   if (a.k == 3)

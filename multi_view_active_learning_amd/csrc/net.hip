@@ -14,6 +14,8 @@
 extern "C" size_t mval_packed_weight_floats(int pack, int cout, int cin, int k) {
   if (pack == MVAL_PACK_HWIO) return (size_t)k * k * cin * cout;
   if (pack == MVAL_PACK_MFMA16_BF3) return (size_t)k * k * ((cin + 31) / 32) * ((cout + 15) / 16) * 768;
+  // two fp16 planes per block + the 4-float trailer [2^-s, bits of max |w|, 0, 0] (conv_mfma_split.hip)
+  if (pack == MVAL_PACK_MFMA16_H2) return (size_t)k * k * ((cin + 31) / 32) * ((cout + 15) / 16) * 512 + 4;
   size_t g = (cin + 15) / 16, ns = (cout + 15) / 16;
   return (size_t)k * k * g * ns * 256;
 }
@@ -68,6 +70,11 @@ extern "C" int mval_pack_conv_weights(int pack, int transposed, const float* w, 
   if (pack == MVAL_PACK_MFMA16_BF3) {
     mval_pack_bf3(transposed, w, packed, cout, cin, k, mval_stream(stream));
     MVAL_CHECK_LAUNCH("mval_pack_conv_weights/bf3");
+    return 0;
+  }
+  if (pack == MVAL_PACK_MFMA16_H2) {
+    mval_pack_h2(transposed, w, packed, cout, cin, k, mval_stream(stream));
+    MVAL_CHECK_LAUNCH("mval_pack_conv_weights/h2");
     return 0;
   }
   int64_t total = (int64_t)mval_packed_weight_floats(pack, cout, cin, k);
@@ -207,6 +214,39 @@ __global__ __launch_bounds__(256) void maxpool_kernel(ConvArgs a) {
   a.out[t] = m;
 }
 
+// slots[i] = max(slots[i], max |x| over image i): the per-image activation scale of the fp16-split convs for tensors
+// whose producer does not keep it itself (max-pool, the generic direct kernels) and for single-op launches.
+__global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, int64_t per_image, int vec, unsigned* slots) {
+  const float* xi = x + (int64_t)blockIdx.y * per_image;
+  float m = 0.f;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t n4 = vec ? per_image / 4 : 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const conv_f32x4 v = reinterpret_cast<const conv_f32x4*>(xi)[i];
+    m = conv_amax4(m, v.x, v.y, v.z, v.w);
+  }
+  for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < per_image; i += stride) m = fmaxf(m, fabsf(xi[i]));
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0)
+    conv_amax_one(slots + blockIdx.y * MVAL_AMAX_SUB + ((blockIdx.x * 4 + (threadIdx.x >> 6)) & (MVAL_AMAX_SUB - 1)), m);
+}
+
+int mval_launch_amax(const float* x, int64_t per_image, int n_images, unsigned* slots, hipStream_t s) {
+  const int vec = (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (per_image & 3) == 0;
+  int64_t blocks = (per_image / 4 + 255) / 256;
+  if (blocks > 64) blocks = 64;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(amax_kernel, dim3((unsigned)blocks, (unsigned)n_images), dim3(256), 0, s, x, per_image, vec, slots);
+  return 0;
+}
+
+extern "C" int mval_amax(const float* x, int64_t per_image, int n_images, uint32_t* slots, void* stream) {
+  MVAL_REQUIRE(x && slots && per_image > 0 && n_images > 0, "mval_amax: bad arguments");
+  mval_launch_amax(x, per_image, n_images, slots, mval_stream(stream));
+  MVAL_CHECK_LAUNCH("mval_amax");
+  return 0;
+}
+
 int mval_launch_conv_direct(const ConvArgs& a, int kind, hipStream_t s) {
   if (kind == MVAL_OP_MAXPOOL) {
     int64_t total = (int64_t)a.N * a.Hout * a.Wout * a.Cout;
@@ -266,25 +306,30 @@ extern "C" int mval_op_mfma_supported(const mval_op* op, int n_images) {
 // ConvTranspose2d(k4, s2, p1) on the split-bf16 kernel: four 2x2 stride-1 convs, one per output parity
 // (py, px), each over the (hin, win) grid and scattered to rows 2a + py, columns 2b + px.  Weights:
 // pack mode 3 ([parity][2x2 taps]...), one parity = a quarter of the k = 4 packed buffer.
+static size_t deconv_parity_floats(const mval_op* op) {  // one parity's 2x2 taps in the packed k4 buffer
+  const int pack = op->algo == MVAL_ALGO_MFMA_H2 ? MVAL_PACK_MFMA16_H2 : MVAL_PACK_MFMA16_BF3;
+  return (mval_packed_weight_floats(pack, op->cout, op->cin, 4) & ~(size_t)7) / 4;  // (the h2 trailer is not a parity's)
+}
 static void deconv_parity(ConvArgs& a, const mval_op* op, int parity, const float* w_packed) {
   a.k = 2; a.stride = 1; a.pad = 1; a.dil = 1;
   a.Hout = op->hin; a.Wout = op->win;
   a.org_dy = parity >> 1; a.org_dx = parity & 1;
   a.os_log2 = 1; a.ooy = parity >> 1; a.oox = parity & 1;
-  if (w_packed) a.w = w_packed + (size_t)parity * (mval_packed_weight_floats(MVAL_PACK_MFMA16_BF3, op->cout, op->cin, 4) / 4);
+  if (w_packed) a.w = w_packed + (size_t)parity * deconv_parity_floats(op);
 }
 
 extern "C" int mval_op_algo_supported(const mval_op* op, int n_images, int algo) {
   if (algo == MVAL_ALGO_MFMA) return mval_op_mfma_supported(op, n_images);
-  if (algo != MVAL_ALGO_MFMA_BF3 || !op || n_images <= 0) return 0;
+  if ((algo != MVAL_ALGO_MFMA_BF3 && algo != MVAL_ALGO_MFMA_H2) || !op || n_images <= 0) return 0;
   if (op->kind != MVAL_OP_CONV && op->kind != MVAL_OP_DECONV) return 0;
   ConvArgs a = {};
   fill_geometry(a, op, n_images);
+  a.planes = algo == MVAL_ALGO_MFMA_H2 ? 2 : 3;
   if (op->kind == MVAL_OP_DECONV) {
     if (op->k != 4 || op->stride != 2 || op->pad != 1 || op->up || op->out_nchw) return 0;
     deconv_parity(a, op, 0, nullptr);
   }
-  return mval_conv_bf3_supported(a);
+  return mval_conv_split_supported(a);
 }
 
 extern "C" int mval_op_launch(const mval_op* op, int n_images, float* workspace, const float* params,
@@ -301,15 +346,29 @@ extern "C" int mval_op_launch(const mval_op* op, int n_images, float* workspace,
   fill_geometry(a, op, n_images);
   MVAL_REQUIRE(a.in && a.out, "mval_op_launch: missing input/output buffer");
   hipStream_t s = mval_stream(stream);
-  if (op->kind == MVAL_OP_DECONV && op->algo == MVAL_ALGO_MFMA_BF3) {
+  const bool split = op->algo == MVAL_ALGO_MFMA_BF3 || op->algo == MVAL_ALGO_MFMA_H2;
+  a.out_amax = op->out_amax_off > 0 ? reinterpret_cast<unsigned*>(workspace + op->out_amax_off) : nullptr;
+  bool amax_kept = false;  // does the kernel that runs keep out_amax itself?
+  if (split) {
+    a.planes = op->algo == MVAL_ALGO_MFMA_H2 ? 2 : 3;
+    if (a.planes == 2) {
+      MVAL_REQUIRE(op->in_amax_off > 0 && a.w, "mval_op_launch: the fp16-split conv needs in_amax_off (max |x| of its input)");
+      a.in_amax = reinterpret_cast<const unsigned*>(workspace + op->in_amax_off);
+      const int kk = op->kind == MVAL_OP_DECONV ? 4 : op->k;
+      a.w_unscale = a.w + mval_packed_weight_floats(MVAL_PACK_MFMA16_H2, op->cout, op->cin, kk) - 4;
+    }
+    amax_kept = !op->out_nchw && (op->cout & 3) == 0;
+  }
+  if (op->kind == MVAL_OP_DECONV && split) {
     // the four parity convs in one launch (blockIdx.z): on a few images one parity alone leaves most CUs idle
-    deconv_parity(a, op, 0, a.w);
-    a.par_w_stride = (int)(mval_packed_weight_floats(MVAL_PACK_MFMA16_BF3, op->cout, op->cin, 4) / 4);
-    int rc = mval_launch_conv_bf3(a, s);
-    MVAL_REQUIRE(rc == 0, "mval_op_launch: no bf16x3 MFMA kernel for the transposed conv cin%d cout%d", op->cin, op->cout);
-  } else if (op->kind == MVAL_OP_CONV && op->algo == MVAL_ALGO_MFMA_BF3) {
-    int rc = mval_launch_conv_bf3(a, s);
-    MVAL_REQUIRE(rc == 0, "mval_op_launch: no bf16x3 MFMA kernel for conv k%d s%d cin%d cout%d", op->k, op->stride, op->cin,
+    const float* w0 = a.w;
+    deconv_parity(a, op, 0, w0);
+    a.par_w_stride = (int)deconv_parity_floats(op);
+    int rc = mval_launch_conv_split(a, s);
+    MVAL_REQUIRE(rc == 0, "mval_op_launch: no split MFMA kernel for the transposed conv cin%d cout%d", op->cin, op->cout);
+  } else if (op->kind == MVAL_OP_CONV && split) {
+    int rc = mval_launch_conv_split(a, s);
+    MVAL_REQUIRE(rc == 0, "mval_op_launch: no split MFMA kernel for conv k%d s%d cin%d cout%d", op->k, op->stride, op->cin,
                  op->cout);
   } else if ((op->kind == MVAL_OP_CONV || op->kind == MVAL_OP_DECONV) && op->algo == MVAL_ALGO_MFMA) {
     MVAL_REQUIRE(!force_direct(), "MVAL_FORCE_DIRECT=1 but the plan was packed for the MFMA kernels");
@@ -317,12 +376,17 @@ extern "C" int mval_op_launch(const mval_op* op, int n_images, float* workspace,
     int rc = mval_launch_conv_mfma(a, s);
     MVAL_REQUIRE(rc == 0, "mval_op_launch: no MFMA kernel for conv k%d s%d cin%d cout%d", op->k, op->stride, op->cin,
                  op->cout);
+    amax_kept = !op->out_nchw && (op->cout & 3) == 0;
   } else {
     MVAL_REQUIRE(op->kind == MVAL_OP_MAXPOOL || (a.w && a.scale && a.shift), "mval_op_launch: missing parameters");
     // 3-channel NCHW stems have their own store-shaped kernel; everything else is generic
     if (op->kind != MVAL_OP_CONV || force_direct() || mval_launch_conv_stem(a, s))
       mval_launch_conv_direct(a, op->kind, s);
+    else
+      amax_kept = true;  // the stem kernel keeps it
   }
+  if (a.out_amax && !amax_kept)  // max-pool / generic direct kernels: one extra read of the output
+    mval_launch_amax(a.out, (int64_t)(op->hout << op->up) * (op->wout << op->up) * op->cout, n_images, a.out_amax, s);
   MVAL_CHECK_LAUNCH("mval_op_launch");
   return 0;
 }
@@ -334,6 +398,8 @@ extern "C" int mval_op_launch(const mval_op* op, int n_images, float* workspace,
 
 struct MvalNet {
   std::vector<mval_op> ops;
+  // workspace floats [amax_lo, amax_hi + n_images): the per-image max |x| slots of the plan, zeroed per forward
+  int64_t amax_lo = 0, amax_hi = 0;
   hipStream_t side[MVAL_MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t fork_ev = nullptr;
   hipEvent_t join_ev[MVAL_MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};
@@ -357,8 +423,14 @@ extern "C" void* mval_net_create(const mval_op* ops, int n_ops) {
   }
   MvalNet* n = new MvalNet();
   n->ops.assign(ops, ops + n_ops);
-  for (const auto& o : n->ops)
+  for (const auto& o : n->ops) {
     if (o.lane + 1 > n->n_lanes) n->n_lanes = o.lane + 1;
+    for (int64_t off : {o.in_amax_off, o.out_amax_off})
+      if (off > 0) {
+        if (n->amax_hi == 0 || off < n->amax_lo) n->amax_lo = off;
+        if (off > n->amax_hi) n->amax_hi = off;
+      }
+  }
   if (n->n_lanes > MVAL_MAX_LANES) n->n_lanes = MVAL_MAX_LANES;
   return n;
 }
@@ -397,6 +469,8 @@ extern "C" int mval_net_forward(void* net, int n_images, float* workspace, const
   hipStream_t main_s = mval_stream(stream);
   const bool multi = n->n_lanes > 1 && (n->lanes_override < 0 ? multi_stream_enabled() : n->lanes_override != 0);
   if (multi) MVAL_REQUIRE(ensure_streams(n) == 0, "mval_net_forward: could not create side streams");
+  if (n->amax_hi)
+    (void)hipMemsetAsync(workspace + n->amax_lo, 0, (size_t)(n->amax_hi + (int64_t)n_images * MVAL_AMAX_SUB - n->amax_lo) * sizeof(float), main_s);
   bool used[MVAL_MAX_LANES] = {false, false, false, false};
   int phase = n->ops.empty() ? 0 : n->ops[0].phase;
   auto join = [&]() {  // side streams -> main
@@ -417,12 +491,14 @@ extern "C" int mval_net_forward(void* net, int n_images, float* workspace, const
         phase = op.phase;
         forked = false;
       }
+      if (!forked) {
+        // recorded at the START of the phase, before its lane-0 ops are enqueued: the side lanes then wait for the
+        // previous phases only, not for this phase's (longest) lane-0 chain as well
+        (void)hipEventRecord(n->fork_ev, main_s);
+        forked = true;
+      }
       int lane = op.lane < n->n_lanes ? op.lane : 0;
       if (lane > 0) {
-        if (!forked) {  // everything enqueued on main so far precedes this phase's side work
-          (void)hipEventRecord(n->fork_ev, main_s);
-          forked = true;
-        }
         if (!used[lane]) {
           (void)hipStreamWaitEvent(n->side[lane], n->fork_ev, 0);
           used[lane] = true;
@@ -457,6 +533,8 @@ extern "C" int mval_net_forward_timed(void* net, int n_images, float* workspace,
     }
   }
   int rc = 0;
+  if (n->amax_hi)
+    (void)hipMemsetAsync(workspace + n->amax_lo, 0, (size_t)(n->amax_hi + (int64_t)n_images * MVAL_AMAX_SUB - n->amax_lo) * sizeof(float), s);
   (void)hipEventRecord(ev[0], s);
   for (size_t i = 0; i < n->ops.size() && !rc; i++) {
     rc = mval_op_launch(&n->ops[i], n_images, workspace, params, input_nchw, output_nchw, stream);

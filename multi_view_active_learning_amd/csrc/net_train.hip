@@ -32,7 +32,7 @@ static void geometry(ConvArgs& a, const mval_op& op, int n_images) {
   a.G_total = (op.cin + 15) / 16;
   a.NS_total = (op.cout + 15) / 16;
   a.res1 = a.res2 = nullptr;
-  a.precise = 1;  // bias-free accumulation: training gradients amplify a coherent -1 ulp (conv_mfma_bf3.hip)
+  a.precise = 1;  // bias-free accumulation: training gradients amplify a coherent -1 ulp (conv_mfma_split.hip)
 }
 
 // ConvTranspose2d forward on the matrix cores: stride-1 conv over the zero-dilated input (net.hip)
@@ -42,9 +42,11 @@ static void deconv_as_conv(ConvArgs& a, const mval_op& op) {
   a.pad = op.k - 1 - op.pad;
 }
 
-static int run_conv(const ConvArgs& a, int algo, hipStream_t s, const char* what) {
+static int run_conv(const ConvArgs& a0, int algo, hipStream_t s, const char* what) {
+  ConvArgs a = a0;
   if (algo == MVAL_ALGO_MFMA_BF3) {
-    if (mval_launch_conv_bf3(a, s)) {
+    a.planes = 3;  // training keeps the bf16x3 split (scale-free, and its bias-free accumulate mode)
+    if (mval_launch_conv_split(a, s)) {
       mval_set_error("%s: no bf16x3 MFMA configuration (k%d cin%d cout%d dil%d)", what, a.k, a.Cin, a.Cout, a.dil);
       return -1;
     }

@@ -26,9 +26,10 @@ from . import _lib
 from .pose_estimators import params as _params
 
 OP_CONV, OP_MAXPOOL, OP_DECONV = 0, 1, 2
-ALGO_DIRECT, ALGO_MFMA, ALGO_MFMA_BF3 = 0, 1, 2
-PACK_HWIO, PACK_MFMA16, PACK_MFMA16_BF3 = 0, 1, 2
-_PACK_OF = {ALGO_DIRECT: PACK_HWIO, ALGO_MFMA: PACK_MFMA16, ALGO_MFMA_BF3: PACK_MFMA16_BF3}
+ALGO_DIRECT, ALGO_MFMA, ALGO_MFMA_BF3, ALGO_MFMA_H2 = 0, 1, 2, 3
+PACK_HWIO, PACK_MFMA16, PACK_MFMA16_BF3, PACK_MFMA16_H2 = 0, 1, 2, 3
+AMAX_SUB = 16
+_PACK_OF = {ALGO_DIRECT: PACK_HWIO, ALGO_MFMA: PACK_MFMA16, ALGO_MFMA_BF3: PACK_MFMA16_BF3, ALGO_MFMA_H2: PACK_MFMA16_H2}
 
 
 class MvalOp(C.Structure):
@@ -43,6 +44,7 @@ class MvalOp(C.Structure):
         ("in_off", C.c_int64), ("out_off", C.c_int64), ("res1_off", C.c_int64), ("res2_off", C.c_int64),
         ("w_off", C.c_int64), ("scale_off", C.c_int64), ("shift_off", C.c_int64),
         ("phase", C.c_int32), ("lane", C.c_int32),
+        ("in_amax_off", C.c_int64), ("out_amax_off", C.c_int64),
     ]
 
 
@@ -54,11 +56,16 @@ def _align(n, a=64):
 
 
 def _conv_mode():
-    """MVAL_CONV selects the 3x3-conv kernel family of inference plans:
-    bf3 (default) -- fp32 values as exact 3-way bf16 splits on the bf16 matrix cores (6 MFMA
-                     products, fp32 accumulate; measured as accurate as the fp32-MFMA chain, 1.6x faster);
-    fp32          -- exact fp32-input MFMA (v_mfma_f32_16x16x4_f32) everywhere."""
-    return os.environ.get("MVAL_CONV", "bf3")
+    """MVAL_CONV selects the conv kernel family of inference plans:
+    h2 (default) -- fp32 values as scaled two-way fp16 splits on the fp16 matrix cores (3 MFMA products per
+                    32-deep step, fp32 accumulate; the per-tensor power-of-two scales come from max |x| slots the
+                    producers keep; measured as accurate as the fp32-MFMA chain);
+    bf3          -- exact three-way bf16 splits (6 MFMA products; what training plans always use);
+    fp32         -- exact fp32-input MFMA (v_mfma_f32_16x16x4_f32) everywhere."""
+    mode = os.environ.get("MVAL_CONV", "h2")
+    if mode not in ("h2", "bf3", "fp32"):
+        raise ValueError("MVAL_CONV must be h2, bf3 or fp32")
+    return mode
 
 
 def _mfma_ok(op, in_nchw):
@@ -78,7 +85,7 @@ def _pack_mode(op, pack):
         return 0
     # direct kernel: as stored (1); exact-fp32 MFMA: tap-flipped conv over the zero-dilated input (2);
     # split-bf16 MFMA: four 2x2 parity kernels (3)
-    return {PACK_HWIO: 1, PACK_MFMA16: 2, PACK_MFMA16_BF3: 3}[pack]
+    return {PACK_HWIO: 1, PACK_MFMA16: 2, PACK_MFMA16_BF3: 3, PACK_MFMA16_H2: 3}[pack]
 
 
 class InferencePlan:
@@ -144,7 +151,11 @@ class InferencePlan:
                 else:
                     merged.append((o, s))
             free = merged
-        self.arena_floats = max(top, 64)
+        # max |x| slots (one float each) behind the activations: what the fp16-split convs scale their input by
+        self.amax_base = _align(max(top, 64))
+        # (n images x AMAX_SUB sub-slots per activation, include/mval_hip.h: MVAL_AMAX_SUB)
+        amax_slot = {a.id: self.amax_base + k * n * AMAX_SUB for k, a in enumerate(g.acts)}
+        self.arena_floats = self.amax_base + _align(len(g.acts) * n * AMAX_SUB)
         # ---- parameter buffer layout -------------------------------------------------------------
         lib = _lib.lib()
         self.ops = (MvalOp * len(g.ops))()
@@ -162,16 +173,20 @@ class InferencePlan:
             m.algo = ALGO_DIRECT
             if _mfma_ok(op, in_nchw) and lib.mval_op_mfma_supported(C.byref(m), C.c_int(n)):
                 m.algo = ALGO_MFMA
-                # 3x3 convs: fp32-accurate bf16x3 split on the bf16 matrix cores (2.67x MFMA rate)
-                if (_conv_mode() == "bf3" and (op.k in (1, 3) or op.kind == "deconv") and (op.cin % 32 == 0 or op.cin == 48)
-                        and lib.mval_op_algo_supported(C.byref(m), C.c_int(n), C.c_int(ALGO_MFMA_BF3))):
-                    m.algo = ALGO_MFMA_BF3
+                # fp32-accurate 16-bit splits on the matrix cores (fp16x2: 5.3x, bf16x3: 2.67x the fp32-MFMA rate)
+                # (the fp16 split wants one image per tile; maps under 8 rows fall back to bf16x3)
+                if (op.k in (1, 3) or op.kind == "deconv") and (op.cin % 32 == 0 or op.cin == 48) and op.src != g.input:
+                    for split in {"h2": (ALGO_MFMA_H2, ALGO_MFMA_BF3), "bf3": (ALGO_MFMA_BF3,)}.get(_conv_mode(), ()):
+                        if lib.mval_op_algo_supported(C.byref(m), C.c_int(n), C.c_int(split)):
+                            m.algo = split
+                            break
             m.in_off = -1 if op.src == g.input else offset[op.src]
             m.out_off = -1 if op.dst == g.output else offset[op.dst]
             m.res1_off = -1 if op.res1 is None else offset[op.res1]
             m.res2_off = -1 if op.res2 is None else offset[op.res2]
             m.w_off = m.scale_off = m.shift_off = -1
             m.phase, m.lane = op.phase, op.lane
+            m.in_amax_off = amax_slot[op.src] if m.algo == ALGO_MFMA_H2 else 0
             if op.kind in ("conv", "deconv"):
                 pack = _PACK_OF[m.algo]
                 nw = int(lib.mval_packed_weight_floats(C.c_int(pack), C.c_int(op.cout), C.c_int(op.cin), C.c_int(op.k)))
@@ -182,6 +197,12 @@ class InferencePlan:
                 m.shift_off = ptop
                 ptop += _align(op.cout)
                 self.param_jobs.append((i, pack, m.w_off, m.scale_off, m.shift_off))
+        # producers keep max |x| only for tensors an fp16-split conv reads
+        need = {g.ops[i].src for i in range(len(g.ops)) if self.ops[i].algo == ALGO_MFMA_H2}
+        if g.input in need:
+            raise _lib.MvalError("the network input cannot feed an fp16-split conv (no producer to keep its max |x|)")
+        for i, op in enumerate(g.ops):
+            self.ops[i].out_amax_off = amax_slot[op.dst] if op.dst in need else 0
         self.param_floats = max(ptop, 64)
         self.arena = torch.empty(self.arena_floats, dtype=torch.float32, device=device)
         self.params = torch.zeros(self.param_floats, dtype=torch.float32, device=device)
@@ -353,6 +374,7 @@ def run_network(model, x):
         raise _lib.MvalError("the heat-map network runs on the HIP device only (no CPU path): pass a .cuda() tensor")
     if x.dtype != torch.float32:
         raise TypeError("expected float32 images")
+    _lib._same_device(x, next(iter(model.parameters()), None))
     x = x.contiguous()
     if model.training:
         from .engine_train import run_network_train
@@ -362,26 +384,3 @@ def run_network(model, x):
     if x.shape[0] > cap:  # very large batches run as equal slices of one plan size (plus a remainder plan)
         return torch.cat([_plan_for(model, xs).forward(xs) for xs in x.split(cap)])
     return _plan_for(model, x).forward(x)
-
-
-def smoke(dev):
-    """Tiny HRNet-W32 forward on the device checked against the CPU oracle (used by
-    __graft_entry__.smoke())."""
-    import numpy as np
-
-    from oracle import models as omodels
-
-    from . import synth
-    from .pose_estimators import PoseHighResolutionNet
-
-    m = PoseHighResolutionNet(5)
-    sd = {k: torch.from_numpy(v) for k, v in synth.synthetic_state_dict(m._graph.param_shapes(), 1).items()}
-    m.load_state_dict(sd, strict=True)
-    m = m.to(dev).eval()
-    x = torch.from_numpy(synth.images(1, 2, 1, 64, 64).reshape(2, 3, 64, 64))
-    with torch.no_grad():
-        y = m(x.to(dev)).cpu()
-        want = omodels.hrnet_forward(sd, x, omodels.HRNET_W32)
-    err = (y - want).abs().max().item()
-    assert err < 2e-4 * max(1.0, want.abs().max().item()), err
-    print(f"smoke: HRNet-W32 forward parity OK (max abs err {err:.2e})")

@@ -104,7 +104,7 @@ class TrainPlan:
             m.hin, m.win, m.hout, m.wout = hin, win, hout, wout
             m.up, m.relu, m.in_nchw, m.out_nchw = op.up, int(op.relu), int(in_nchw), int(out_nchw)
             m.algo = ALGO_DIRECT
-            bf3 = _conv_mode() == "bf3"
+            bf3 = _conv_mode() in ("bf3", "h2")  # training always uses the scale-free bf16x3 split
             if _mfma_ok(op, in_nchw) and lib.mval_op_mfma_supported(C.byref(m), C.c_int(n)):
                 m.algo = ALGO_MFMA
                 if (bf3 and op.kind == "conv" and op.k in (1, 3) and (op.cin % 32 == 0 or op.cin == 48)
@@ -310,6 +310,9 @@ class TrainPlan:
 
     def forward(self, x):
         self._refresh()
+        # the arena, z buffers and batch statistics of THIS forward are what backward reads: a second train-mode
+        # forward of the same plan overwrites them, so backward checks that it pairs with the latest forward
+        self.generation = getattr(self, "generation", 0) + 1
         out = torch.empty((self.n, self.out_channels) + tuple(self.out_hw), dtype=torch.float32, device=self.device)
         _lib._check(
             _lib.lib().mval_train_forward(
@@ -365,11 +368,19 @@ class _NetTrainFn(torch.autograd.Function):
     def forward(ctx, x, plan, *params):
         ctx.plan = plan
         ctx.save_for_backward(x)
-        return plan.forward(x)
+        out = plan.forward(x)
+        ctx.generation = plan.generation
+        return out
 
     @staticmethod
     def backward(ctx, gout):
         (x,) = ctx.saved_tensors
+        if ctx.generation != ctx.plan.generation:
+            raise _lib.MvalError(
+                "backward() of a train-mode forward whose saved activations were overwritten by a later train-mode "
+                "forward of the same model and input shape (the training plan keeps ONE set of activations): call "
+                "backward() before the next forward, as the reference's loop does (strategy.py:470-484), or run the "
+                "extra forward under model.eval()")
         grads = ctx.plan.backward(x, gout.contiguous())
         return (None, None, *grads)
 

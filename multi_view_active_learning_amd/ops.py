@@ -8,8 +8,8 @@ import ctypes as C
 import torch
 
 from . import _lib
-from .engine import (ALGO_DIRECT, ALGO_MFMA, ALGO_MFMA_BF3, OP_CONV, OP_DECONV, OP_MAXPOOL, PACK_HWIO, PACK_MFMA16,
-                     PACK_MFMA16_BF3, _PACK_OF, MvalOp, _align)
+from .engine import (ALGO_DIRECT, ALGO_MFMA, ALGO_MFMA_BF3, ALGO_MFMA_H2, OP_CONV, OP_DECONV, OP_MAXPOOL, PACK_HWIO,
+                     PACK_MFMA16, PACK_MFMA16_BF3, AMAX_SUB, _PACK_OF, MvalOp, _align)
 
 
 def pack_weights(weight, algo, transposed=False):
@@ -22,7 +22,7 @@ def pack_weights(weight, algo, transposed=False):
     pack = _PACK_OF[algo]
     # ConvTranspose2d: as stored for the direct kernel (1), tap-flipped for the MFMA kernels (2), which
     # run it as a stride-1 conv over the zero-dilated input
-    mode = 0 if not transposed else {ALGO_DIRECT: 1, ALGO_MFMA: 2, ALGO_MFMA_BF3: 3}[algo]
+    mode = 0 if not transposed else {ALGO_DIRECT: 1, ALGO_MFMA: 2, ALGO_MFMA_BF3: 3, ALGO_MFMA_H2: 3}[algo]
     n = int(lib.mval_packed_weight_floats(C.c_int(pack), C.c_int(cout), C.c_int(cin), C.c_int(k)))
     out = torch.empty(n, dtype=torch.float32, device=weight.device)
     w = weight.detach().contiguous()
@@ -64,7 +64,8 @@ def fused_conv(x, weight, scale, shift, stride=1, pad=None, relu=False, res1=Non
             offs.append(_align(offs[-1] + tensors[-1].numel()))
             tensors.append(t.contiguous().reshape(-1))
     out_off = _align(offs[-1] + tensors[-1].numel())
-    arena = torch.zeros(out_off + n * ho * wo * cout, dtype=torch.float32, device=dev)
+    amax_off = _align(out_off + n * ho * wo * cout)  # per-image max |x| slots: n for the input, n for the output
+    arena = torch.zeros(amax_off + _align(2 * n * AMAX_SUB), dtype=torch.float32, device=dev)
     for o, t in zip(offs, tensors):
         arena[o : o + t.numel()] = t
     if kind == OP_MAXPOOL:
@@ -89,11 +90,18 @@ def fused_conv(x, weight, scale, shift, stride=1, pad=None, relu=False, res1=Non
     m.res1_off = next(it) if res1 is not None else -1
     m.res2_off = next(it) if res2 is not None else -1
     m.w_off, m.scale_off, m.shift_off = w_off, s_off, b_off
+    m.out_amax_off = amax_off + n * AMAX_SUB
+    if algo == ALGO_MFMA_H2:  # the fp16 split scales every image of its input by that image's max |x|
+        m.in_amax_off = amax_off
+        _lib._check(_lib.lib().mval_amax(_lib._p(arena), C.c_int64(tensors[0].numel() // n), C.c_int(n),
+                                         C.c_void_p(arena.data_ptr() + 4 * amax_off), _lib._stream()), "mval_amax")
     _lib._check(
         _lib.lib().mval_op_launch(C.byref(m), C.c_int(n), _lib._p(arena), _lib._p(params), C.c_void_p(0), C.c_void_p(0),
                                   _lib._stream()),
         "mval_op_launch")
-    out = arena[out_off:]
+    # (tests: the per-image max |x| the kernel kept = the maximum over each image's sub-slots)
+    fused_conv.last_out_amax = arena[amax_off + n * AMAX_SUB : amax_off + 2 * n * AMAX_SUB].view(torch.int32).reshape(n, AMAX_SUB).amax(1)
+    out = arena[out_off : out_off + n * ho * wo * cout]
     return out.reshape(n, cout, ho, wo) if out_nchw else out.reshape(n, ho, wo, cout)
 
 

@@ -53,24 +53,33 @@ def score_heatmaps_batch(kind: str, config: str, heatmaps, joint_valid):
 def tables_to_sal_dict(per_rank, batch_sizes, sal_dict=None):
     """Packed per-rank tables [pose, frame_id, al_metric, sal_metric, inlier_count, mkpe,
     keypoints_3d(3J)] -> the reference's five dicts, inserted in its gather order
-    (for batch: for sample: for rank; strategy.py:1024,1036,1115-1145)."""
+    (for batch: for sample: for rank; strategy.py:1024,1036,1115-1145).
+
+    ``batch_sizes``: one list of batch sizes PER RANK (a single flat list = every rank has that
+    structure, the DistributedSampler case).  Ranks may be ragged (a short last shard, a short
+    last batch): the walk covers the longest structure and skips what a rank does not have, so
+    every rank builds the identical dict from the identical gathered inputs."""
     if sal_dict is None:
         sal_dict = {k: OrderedDict() for k in ("al_metric", "sal_metric", "inlier_count", "pred_3d_keypoints", "mkpe")}
     j = (per_rank[0].shape[1] - 6) // 3
-    offsets = np.concatenate([[0], np.cumsum(batch_sizes)]).astype(np.int64)
-    for bi in range(len(batch_sizes)):
-        for si in range(int(batch_sizes[bi])):
-            row = int(offsets[bi]) + si
-            for tab in per_rank:
-                if row >= tab.shape[0]:
-                    continue
-                e = tab[row]
-                guid = "%s-%s" % (int(e[0]), int(e[1]))
-                sal_dict["sal_metric"][guid] = float(e[3])
-                sal_dict["inlier_count"][guid] = float(e[4])
-                sal_dict["pred_3d_keypoints"][guid] = e[6:].reshape(j, 3).tolist()
-                sal_dict["al_metric"][guid] = float(e[2])
-                sal_dict["mkpe"][guid] = float(e[5])
+    if len(batch_sizes) == 0 or np.isscalar(batch_sizes[0]):
+        batch_sizes = [list(batch_sizes)] * len(per_rank)
+    if len(batch_sizes) != len(per_rank):
+        raise ValueError("tables_to_sal_dict: one batch-size list per rank expected")
+    sizes = [[int(x) for x in b] for b in batch_sizes]
+    for r, (tab, b) in enumerate(zip(per_rank, sizes)):
+        if sum(b) != tab.shape[0]:
+            raise ValueError("tables_to_sal_dict: rank %d has %d rows but batch sizes sum to %d" % (r, tab.shape[0], sum(b)))
+    from .parallel import reference_gather_order
+
+    for r, row in reference_gather_order(sizes):
+        e = per_rank[r][row]
+        guid = "%s-%s" % (int(e[0]), int(e[1]))
+        sal_dict["sal_metric"][guid] = float(e[3])
+        sal_dict["inlier_count"][guid] = float(e[4])
+        sal_dict["pred_3d_keypoints"][guid] = e[6:].reshape(j, 3).tolist()
+        sal_dict["al_metric"][guid] = float(e[2])
+        sal_dict["mkpe"][guid] = float(e[5])
     return sal_dict
 
 
@@ -208,14 +217,21 @@ class ActiveLearningStrategy:
                 t = self.score_batch(heatmaps, dp)
                 tables.append(t)
                 sizes.append(t.shape[0])
+        from .parallel import world
+
         if not tables:
-            return sal_dict
+            if world()[1] == 1:
+                return sal_dict
+            # an empty shard still takes part in the pass's collective (the other ranks would hang otherwise)
+            j = self.num_joints
+            dev = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+            tables = [torch.zeros((0, 6 + 3 * j), dtype=torch.float64, device=dev)]
         self._raise_deferred_errors()
         local = torch.cat(tables, dim=0)
         from .parallel import gather_tables
 
-        per_rank = gather_tables(local)  # list over ranks of (n_r, 6+3J) host arrays
-        return tables_to_sal_dict(per_rank, sizes, sal_dict)
+        per_rank, per_rank_sizes = gather_tables(local, sizes)  # (n_r, 6+3J) host arrays + each rank's batch sizes
+        return tables_to_sal_dict(per_rank, per_rank_sizes, sal_dict)
 
     def _raise_deferred_errors(self):
         """Error behaviour of the reference's per-sample loop, checked once per pass."""
@@ -284,7 +300,7 @@ class ActiveLearningStrategy:
     def evaluate_mkpe(self, data_loader, pose_estimator):
         """_evaluate_all's MKPE path: heat-maps -> hard arg-max triangulation -> MPJPE over the
         whole loader (one packed gather instead of 3 all_gathers per sample)."""
-        preds, gts, valids = [], [], []
+        preds, gts, valids, sizes = [], [], [], []
         with torch.no_grad():
             for dp in data_loader:
                 hm = self._compute_batch_heatmap(pose_estimator, dp)
@@ -296,10 +312,23 @@ class ActiveLearningStrategy:
                 preds.append(r["keypoints_3d"].to(torch.float32))
                 gts.append(torch.as_tensor(dp["3d_keypoints"]).to(hm.device, torch.float32))
                 valids.append(jv.to(hm.device, torch.float32))
-        pred, gt, valid = torch.cat(preds), torch.cat(gts), torch.cat(valids)
-        from .parallel import all_gather_cat
+                sizes.append(b)
+        from .parallel import all_gather_reference_order as gather
 
-        pred, gt, valid = all_gather_cat(pred), all_gather_cat(gt), all_gather_cat(valid)
+        j = self.num_joints if not preds else preds[0].shape[1]
+        rows = 3 if not gts else gts[0].shape[1]
+        if preds:
+            # ONE packed table per pass: [pred 3J | gt rows*J | valid J] per sample
+            local = torch.cat([torch.cat(preds).reshape(-1, 3 * j), torch.cat(gts).reshape(-1, rows * j),
+                               torch.cat(valids).reshape(-1, j)], dim=1)
+        else:  # an empty shard still takes part in the collective
+            local = torch.zeros((0, (4 + rows) * j), dtype=torch.float32, device=torch.device("cuda", torch.cuda.current_device()))
+        # the reference appends its per-sample all_gathers batch by batch, sample by sample, rank by rank
+        # (strategy.py:600-636): same row order here, so the float32 sample-order sums of compute_mkpe match
+        table = gather(local, sizes)
+        pred = table[:, : 3 * j].reshape(-1, j, 3)
+        gt = table[:, 3 * j : (3 + rows) * j].reshape(-1, rows, j)
+        valid = table[:, (3 + rows) * j :]
         out, _ = _lib.mkpe(pred.contiguous(), gt.contiguous(), valid.contiguous(), pred.shape[0], pred.shape[1], gt.shape[1])
         self._eval_tables = (pred, gt, valid)
         return out

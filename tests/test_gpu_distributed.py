@@ -1,0 +1,98 @@
+"""World size 2 through the REAL device path: two processes share cuda:0 and talk over gloo (RCCL refuses two
+ranks on one device; the collectives' payloads are the same tensors either way).  Pool scoring
+(``_compute_sal_dict`` for an entropy strategy and for CORESET), selection (``select_al_guids``: nlargest /
+k-center on device) and evaluation (``evaluate_all``) on DistributedSampler-style strided shards must give
+EXACTLY what one rank computes over the whole loader: per-frame results do not depend on the batch they sit
+in, and the gathers restore the reference's (batch, sample, rank) order (strategy.py:1106-1145, 600-636)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import cases
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FIELDS = ("al_metric", "sal_metric", "inlier_count", "pred_3d_keypoints", "mkpe")
+
+
+def _frames(c):
+    """The case's loader flattened to per-frame records (dict of arrays without the batch axis, heat-maps (V,J,h,w))."""
+    loader, hms = cases.build_sal_loader(c)
+    out = []
+    for dp, hm in zip(loader, hms):
+        b = dp["pose"].shape[0]
+        hm = hm.reshape((b, -1) + hm.shape[1:])
+        for i in range(b):
+            out.append(({k: v[i] for k, v in dp.items()}, hm[i]))
+    return out
+
+
+def _batches(frames, b):
+    loader, hms = [], []
+    for i in range(0, len(frames), b):
+        chunk = frames[i:i + b]
+        loader.append({k: torch.from_numpy(np.stack([f[0][k] for f in chunk])) for k in chunk[0][0]})
+        hms.append(np.concatenate([f[1] for f in chunk]))
+    return loader, hms
+
+
+def _passes(c, frames, labeled):
+    """sal_dict, picks and evaluation of one rank's loader (collectives inside when torch.distributed is up)."""
+    from multi_view_active_learning_amd.config import get_default_configs
+    from multi_view_active_learning_amd.strategy import ActiveLearningStrategy
+
+    dev = torch.device("cuda:0")
+    cfg = get_default_configs()
+    cfg.AL.STRATEGY = c["strategy"]
+    cfg.POSE_ESTIMATOR.STRIDE = c["stride"]
+    st = ActiveLearningStrategy(cfg)
+    out = {}
+    loader, hms = _batches(frames, c["b"])
+    it = iter(hms)
+    out["sal"] = st._compute_sal_dict(loader, lambda images: torch.from_numpy(next(it)).to(dev))
+    out["picks"] = st.select_al_guids(out["sal"], c["select"], labeled)
+    it = iter(hms)
+    out["eval"] = st.evaluate_all(loader, lambda images: torch.from_numpy(next(it)).to(dev))
+    return out
+
+
+def _labeled(c):
+    """A labelled set for the core-set pass: {guid: {"3d_keypoints": (rows, J)}} as get_al_dict_for_coreset builds it."""
+    rng = np.random.default_rng(9)
+    return {"L-%d" % i: (rng.standard_normal((c["j"], 3)) * 250.0).tolist() for i in range(5)}
+
+
+def _worker(rank, world, path, out, c):
+    import sys
+
+    for p in (REPO, os.path.join(REPO, "tests", "golden")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world, init_method="file://" + path)
+    frames = _frames(c)[rank::world]  # DistributedSampler: indices[rank::world]
+    res = _passes(c, frames, _labeled(c) if c["strategy"] == "CORESET" else None)
+    torch.save(res, out + ".%d" % rank)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("strategy", ["MPE", "CORESET"])
+def test_two_ranks_one_gpu_equal_one_rank(tmp_path, strategy):
+    assert torch.cuda.is_available()
+    c = dict(cases.sal_cases()["mpe"], strategy=strategy, nbatch=4, select=3)
+    sync, out = str(tmp_path / "sync"), str(tmp_path / "out")
+    mp.spawn(_worker, args=(2, sync, out, c), nprocs=2, join=True)
+    got = [torch.load(out + ".%d" % r, weights_only=False) for r in range(2)]
+    want = _passes(c, _frames(c), _labeled(c) if strategy == "CORESET" else None)
+    assert len(want["sal"]["al_metric"]) == 8
+    for g in got:
+        for k in FIELDS:
+            assert list(g["sal"][k].items()) == list(want["sal"][k].items()), k  # values AND key order, exactly
+        assert g["picks"] == want["picks"]
+        assert g["eval"] == want["eval"]  # float32 MKPE summed in the same sample order; PCK counts

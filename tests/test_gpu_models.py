@@ -80,14 +80,17 @@ CONV_CASES = [
 ]
 
 
-@pytest.mark.parametrize("algo", ["mfma", "direct", "bf3"])
+_ALGO = {"mfma": "ALGO_MFMA", "direct": "ALGO_DIRECT", "bf3": "ALGO_MFMA_BF3", "h2": "ALGO_MFMA_H2"}
+
+
+@pytest.mark.parametrize("algo", ["mfma", "direct", "bf3", "h2"])
 @pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "n%d_c%d-%d_%dx%d_k%ds%d_r%d%d%d_u%d_o%d" % tuple(int(v) for v in c))
 def test_fused_conv_vs_torch_cpu(dev, algo, case):
     from multi_view_active_learning_amd import ops
 
     n, cin, cout, h, w, k, stride, relu, r1, r2, up, out_nchw = case
-    if algo == "bf3" and ((cin % 32 and cin != 48) or (k == 1 and (cout % 16 or out_nchw))):
-        pytest.skip("the bf16x3-split kernel covers 3x3 and 1x1 convs with cin % 32 == 0 (or 48)")
+    if algo in ("bf3", "h2") and ((cin % 32 and cin != 48) or (k == 1 and (cout % 16 or out_nchw))):
+        pytest.skip("the split kernels cover 3x3 and 1x1 convs with cin % 32 == 0 (or 48)")
     rng = np.random.default_rng(hash(case) % 2**31)
     x = torch.from_numpy(rng.standard_normal((n, cin, h, w)).astype(np.float32))
     wt = torch.from_numpy((rng.standard_normal((cout, cin, k, k)) * np.sqrt(2.0 / (cin * k * k))).astype(np.float32))
@@ -99,24 +102,35 @@ def test_fused_conv_vs_torch_cpu(dev, algo, case):
     res2 = torch.from_numpy(rng.standard_normal((n, cout, ho, wo)).astype(np.float32)) if r2 else None
     want = _ref_conv(x, wt, scale, shift, stride, relu, res1, res2, up)
     nhwc = lambda t: None if t is None else t.permute(0, 2, 3, 1).contiguous().to(dev)
-    got = ops.fused_conv(nhwc(x), wt.to(dev), scale.to(dev), shift.to(dev), stride=stride, relu=relu,
-                         res1=nhwc(res1), res2=nhwc(res2), up=up,
-                         algo={"mfma": ops.ALGO_MFMA, "direct": ops.ALGO_DIRECT, "bf3": ops.ALGO_MFMA_BF3}[algo],
-                         out_nchw=out_nchw)
-    got = got.cpu() if out_nchw else got.permute(0, 3, 1, 2).cpu()
+    def run(which):
+        y = ops.fused_conv(nhwc(x), wt.to(dev), scale.to(dev), shift.to(dev), stride=stride, relu=relu,
+                           res1=nhwc(res1), res2=nhwc(res2), up=up, algo=getattr(ops, _ALGO[which]), out_nchw=out_nchw)
+        return y.cpu() if out_nchw else y.permute(0, 3, 1, 2).cpu()
+
+    got = run(algo)
+    if not out_nchw and cout % 4 == 0:
+        # every producer keeps max |x| per image of what it stores (the fp16 split's activation scale): exact
+        kept = ops.fused_conv.last_out_amax.cpu().view(torch.float32)  # (non-negative floats order like their bits)
+        assert torch.equal(kept, got.abs().amax(dim=(1, 2, 3))), "per-image max |x| slots"
     # fp32 with a different summation order: K = cin*k*k products of O(1/sqrt(K)) magnitude
     np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=1e-4, atol=2e-5)
-    if algo in ("mfma", "bf3"):
+    if algo in ("mfma", "bf3", "h2"):
         # against a float64 reference the kernel must sit at fp32 rounding level, like torch-CPU fp32
-        # does (this is what makes the bf16x3 split a legitimate fp32 path)
+        # does (this is what makes the 16-bit splits legitimate fp32 paths)
         want64 = _ref_conv(x.double(), wt.double(), scale.double(), shift.double(), stride, relu,
                            None if res1 is None else res1.double(), None if res2 is None else res2.double(), up)
-        err_gpu = (got.double() - want64).abs().max().item()
-        err_cpu = (want.double() - want64).abs().max().item()
-        # measured: both MFMA paths are 4-9x torch-CPU's error (one long k-ordered accumulation
-        # chain per output vs oneDNN's blocked sums); the bf16x3 split is NOT less accurate than
-        # the exact-fp32 MFMA chain (1.2e-5 vs 0.8-1.8e-5 max abs on O(1) outputs at K = 1152-4608)
+        err = lambda y: ((y.double() - want64).abs().max().item(), (y.double() - want64).pow(2).mean().sqrt().item())
+        err_gpu, rms_gpu = err(got)
+        err_cpu, _ = err(want)
+        # measured: the MFMA paths are 4-9x torch-CPU's MAX error (one long k-ordered accumulation
+        # chain per output vs oneDNN's blocked sums)
         assert err_gpu <= 12.0 * err_cpu + 1e-6, (algo, err_gpu, err_cpu)
+        if algo != "mfma":
+            # ... and the split kernels may not be less accurate than the EXACT-fp32 MFMA chain
+            # (v_mfma_f32_16x16x4_f32) on the same problem: that is the bound that matters
+            err_f32, rms_f32 = err(run("mfma"))
+            # (rms is the statistic with power; the max over ~1e5 outputs is noisy: bf16x3 1.8x at K = 64 with a BETTER rms)
+            assert rms_gpu <= 1.25 * rms_f32 + 1e-8 and err_gpu <= 2.5 * err_f32 + 1e-7, (algo, err_gpu, err_f32, rms_gpu, rms_f32)
 
 
 def test_stem_maxpool_deconv_direct(dev):
@@ -151,7 +165,7 @@ def test_stem_maxpool_deconv_direct(dev):
 
 @pytest.mark.parametrize("shape", [(2, 64, 32, 8, 6), (3, 256, 256, 16, 12), (1, 2048, 256, 8, 6), (2, 32, 48, 5, 7)],
                          ids=lambda s: "n%d_c%d-%d_%dx%d" % s)
-@pytest.mark.parametrize("algo", ["mfma", "bf3"])
+@pytest.mark.parametrize("algo", ["mfma", "bf3", "h2"])
 def test_deconv_mfma_vs_torch_cpu(dev, shape, algo):
     """ConvTranspose2d(k4, s2, p1) + BN + ReLU (PoseResNet head) on the matrix cores: exact-fp32 MFMA as a
     stride-1 conv over the zero-dilated input with tap-flipped weights; split-bf16 MFMA as four 2x2
@@ -166,7 +180,7 @@ def test_deconv_mfma_vs_torch_cpu(dev, shape, algo):
     sh = torch.from_numpy(rng.standard_normal(cout).astype(np.float32))
     want = _ref_conv(x, wt, sc, sh, 2, True, None, None, 0, transposed=True)
     got = ops.fused_conv(x.permute(0, 2, 3, 1).contiguous().to(dev), wt.to(dev), sc.to(dev), sh.to(dev), stride=2, pad=1,
-                         relu=True, kind=ops.OP_DECONV, algo=ops.ALGO_MFMA if algo == "mfma" else ops.ALGO_MFMA_BF3)
+                         relu=True, kind=ops.OP_DECONV, algo=getattr(ops, _ALGO[algo]))
     assert tuple(got.shape) == (n, 2 * h, 2 * w, cout)
     np.testing.assert_allclose(got.permute(0, 3, 1, 2).cpu().numpy(), want.numpy(), rtol=1e-4, atol=3e-5)
 
@@ -178,11 +192,14 @@ def _load(c, dev):
     return m.to(dev).eval(), sd
 
 
+@pytest.mark.parametrize("mode", ["h2", "bf3", "fp32"])
 @pytest.mark.parametrize("name", list(cases.model_cases()))
-def test_network_vs_reference_golden(dev, name):
-    """Whole-network heat-maps against the real reference's output (tests/golden/models.npz).
+def test_network_vs_reference_golden(dev, name, mode, monkeypatch):
+    """Whole-network heat-maps against the real reference's output (tests/golden/models.npz), for every conv
+    kernel family (MVAL_CONV: fp16x2 split = default, bf16x3 split, exact-fp32 MFMA).
     Tolerance: fp32 with a different summation order through ~60 layers: 2e-4 of the heat-map
     range; arg-max positions must agree wherever the reference's top-2 margin exceeds it."""
+    monkeypatch.setenv("MVAL_CONV", mode)
     c = cases.model_cases()[name]
     z = np.load(os.path.join(G, "models.npz"))
     m, _ = _load(c, dev)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Time the HRNet-W32 3x3 layer shapes through the C-ABI in one process (kernel-variant A/B runs:
-set the variant knob in the environment, run once per setting).
-usage: conv_sweep.py [algo=bf3] [n_images=128] [reps=100]"""
+one run per kernel family).
+usage: conv_sweep.py [algo=bf3|h2|mfma] [n_images=128] [reps=100]"""
 import ctypes as C
 import os
 import sys
@@ -14,7 +14,7 @@ from multi_view_active_learning_amd import _lib, ops
 from multi_view_active_learning_amd.engine import MvalOp, _align
 
 algo_name = sys.argv[1] if len(sys.argv) > 1 else "bf3"
-algo = {"mfma": ops.ALGO_MFMA, "bf3": ops.ALGO_MFMA_BF3}[algo_name]
+algo = {"mfma": ops.ALGO_MFMA, "bf3": ops.ALGO_MFMA_BF3, "h2": ops.ALGO_MFMA_H2}[algo_name]
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 128
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 100
 dev = torch.device("cuda:0")
@@ -32,7 +32,8 @@ def bench(cin, cout, h, w, stride, k=3):
     pw = ops.pack_weights(wt, algo)
     res_off = _align(x.numel())
     out_off = res_off + _align(n * ho * wo * cout)
-    arena = torch.zeros(out_off + n * ho * wo * cout, device=dev)
+    amax_off = _align(out_off + n * ho * wo * cout)  # per-image max |x| slots (input, output)
+    arena = torch.zeros(amax_off + _align(2 * n * 16), device=dev)
     arena[: x.numel()] = x.reshape(-1)
     arena[res_off : res_off + n * ho * wo * cout] = torch.randn(n * ho * wo * cout, device=dev)
     s_off = _align(pw.numel())
@@ -46,8 +47,12 @@ def bench(cin, cout, h, w, stride, k=3):
     m.up, m.relu, m.in_nchw, m.out_nchw = 0, 1, 0, 0
     m.in_off, m.out_off, m.res1_off, m.res2_off = 0, out_off, res_off, -1
     m.w_off, m.scale_off, m.shift_off = 0, s_off, s_off + _align(cout)
+    m.in_amax_off, m.out_amax_off = amax_off, amax_off + n * 16
+    _lib._check(lib.mval_amax(_lib._p(arena), C.c_int64(h * w * cin), C.c_int(n), C.c_void_p(arena.data_ptr() + 4 * amax_off),
+                              _lib._stream()), "mval_amax")
 
     def run():
+        arena[amax_off + n * 16 :].zero_()  # as mval_net_forward does: the producers' atomics all happen
         _lib._check(lib.mval_op_launch(C.byref(m), C.c_int(n), _lib._p(arena), _lib._p(params), C.c_void_p(0),
                                        C.c_void_p(0), _lib._stream()), "launch")
 
