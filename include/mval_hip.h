@@ -192,12 +192,12 @@ typedef struct mval_op {
                           (HRNet branches / fuse outputs) and run on separate HIP streams; all
                           lanes join at a phase change.  0/0 = plain in-order execution. */
   /* Activation scales of the fp16-split kernels (MVAL_ALGO_MFMA_H2).  Float offsets into the workspace of
-   * n_images rows of MVAL_AMAX_SUB (16) 4-byte slots; the maximum over a row is the bits of max |x| over that image
-   * of an activation tensor (per image, so that a frame's heat-maps do not depend on the rest of the batch; 16
-   * sub-slots so that the producers' atomics spread); 0 = none.  out_amax_off: the op
-   * folds the maxima of what it writes into the slots (any algo); in_amax_off: the slots of the op's input,
-   * required by MVAL_ALGO_MFMA_H2.  mval_net_forward zeroes all slots of a plan before the first op; single-op
-   * callers zero them (or fill the input's with mval_amax) themselves. */
+   * n_images rows of MVAL_AMAX_ROW dwords, one row per image of an activation tensor (per image, so that a frame's
+   * heat-maps do not depend on the rest of the batch): row[0] = number of partial maxima that follow, row[1..] =
+   * bits of max |x| over the part of the image each producing wave wrote (plain stores, no atomics, nothing to
+   * zero between forwards); the maximum of the partials is the image's max |x|.  0 = none.  out_amax_off: the op
+   * writes the rows of its output (any algo); in_amax_off: the rows of the op's input, required by
+   * MVAL_ALGO_MFMA_H2 (single-op callers fill them with mval_amax). */
   int64_t in_amax_off, out_amax_off;
 } mval_op;
 
@@ -234,9 +234,9 @@ int mval_pack_bf3_jobs(const mval_pack_job* jobs_dev, const int* first_block_dev
 int mval_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var, float eps,
                  float* scale, float* shift, int c, void* stream);
 
-/* rows[i][0..15] = max(rows[i][..], bits of max |x|) over image i (per_image consecutive floats each): fills an
- * activation's max-magnitude rows (see mval_op) for tensors that did not come out of an op of the plan. */
-#define MVAL_AMAX_SUB 16
+/* Writes the max-magnitude rows (see mval_op; [n_images][MVAL_AMAX_ROW] dwords) of a tensor of n_images images of
+ * per_image consecutive floats each: for tensors that did not come out of an op of the plan. */
+#define MVAL_AMAX_ROW 1024
 int mval_amax(const float* x, int64_t per_image, int n_images, uint32_t* rows, void* stream);
 
 /* 1 when the MFMA kernel family has a configuration for this op geometry (the plan builder

@@ -26,19 +26,18 @@ struct ConvArgs {
   int par_w_stride;
   int precise;  // split-bf16 kernel: separate accumulator for the correction products (training plans)
   // 16-bit split kernels (conv_mfma_split.hip): planes = 3 bf16x3 (six products), 2 fp16x2 (three products).  The
-  // fp16 split needs the power-of-two scales: in_amax[n][MVAL_AMAX_SUB] = bits of max |x| over image n of the input
-  // tensor (kept by its producer; PER IMAGE, so a frame's result does not depend on what else is in the batch; the
-  // maximum of the image's sub-slots is the value), w_unscale = the factor that undoes the weight scale (trailer of
-  // the packed weights).
+  // fp16 split needs the power-of-two scales: in_amax[n][MVAL_AMAX_ROW] = the max |x| row of image n of the input
+  // tensor (kept by its producer; PER IMAGE, so a frame's result does not depend on what else is in the batch;
+  // conv_amax_read gives the value), w_unscale = the factor that undoes the weight scale (trailer of the packed
+  // weights).
   int planes;
   const unsigned* in_amax;
   const float* w_unscale;
-  // != nullptr: every kernel that writes `out` folds max |value| of what it stored for image n into one of the
-  // sub-slots out_amax[n][0..MVAL_AMAX_SUB) (bits of a non-negative float, so an unsigned atomicMax orders them; the
-  // slots are zeroed once per forward).  Sub-slots: atomics on one cache line serialise at ~20 ns each, so a
-  // workgroup issues ONE (after an LDS reduction over its waves, and only when it would raise the slot) and the
-  // workgroups of an image spread over the 16 sub-slots of its 64-byte row.
+  // != nullptr: every workgroup that writes part of image n of `out` leaves max |value| of what it stored in its
+  // slot of the row out_amax[n][MVAL_AMAX_ROW] (see conv_amax_put).  amax_tiles: workgroups per image and cout
+  // group (filled by the launcher)
   unsigned* out_amax;
+  int amax_tiles;
   // MFMA tiling (filled by the launcher)
   int th, tw, tn, tw_log2, thw_log2;
   int tiles_x, tiles_y;
@@ -67,34 +66,37 @@ __device__ __forceinline__ void conv_store(const ConvArgs& a, int n, int y, int 
   }
 }
 
-#define MVAL_AMAX_SUB 16  // sub-slots per (activation, image): one 64-byte row
-
-// sub-slot of this workgroup within its image's row
-__device__ __forceinline__ int conv_amax_sub() { return (blockIdx.x + blockIdx.y * 5 + blockIdx.z * 3) & (MVAL_AMAX_SUB - 1); }
-
-// one thread's value (>= 0) into a slot; the atomic is issued only when it would raise the slot (a stale read only
-// costs a redundant atomic; the result is order-independent, hence deterministic)
-__device__ __forceinline__ void conv_amax_one(unsigned* slot, float m) {
-  const unsigned b = __float_as_uint(m);
-  if (b > __builtin_nontemporal_load(slot)) atomicMax(slot, b);
-}
-// Fold the threads' running max |value| (>= 0) into image row `row` ([MVAL_AMAX_SUB] slots): wave maxima through
-// `lds` (>= blockDim.x / 64 floats that nobody else touches), then ONE conditional atomic per workgroup.  Every
-// thread of the workgroup must call it (it holds a barrier).
-__device__ __forceinline__ void conv_amax_commit(unsigned* row, float m, float* lds) {
-  m = wave_max(m);
-  if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = m;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    for (int w = 1; w < (int)(blockDim.x >> 6); w++) m = fmaxf(m, lds[w]);
-    conv_amax_one(row + conv_amax_sub(), m);
+// Row of one (activation, image): [count, partial maxima ...] (MVAL_AMAX_ROW dwords, include/mval_hip.h).  Every
+// WAVE that writes part of the image stores the maximum of what it wrote (bits of a non-negative float) in its own
+// slot and the number of such waves in the header -- plain stores, fire and forget: no atomics (device-scope
+// atomics on one cache line cost ~300 ns each: 20 us on a 60 us conv), no workgroup barrier at the end of the kernel
+// (a reduction over the waves first: 12 us on the same conv, the workgroup keeps its LDS / registers while it
+// waits), nothing to zero between forwards; the consumer takes the maximum of the first `count` slots.  More than
+// MVAL_AMAX_ROW - 1 partials per image (inputs above ~512 x 512): the launcher zeroes the rows and the waves fold
+// into slot % (MVAL_AMAX_ROW - 1) with atomicMax.
+__device__ __forceinline__ void conv_amax_put(unsigned* row, int slot, int count, unsigned bits) {
+  if (count <= MVAL_AMAX_ROW - 1) {
+    row[0] = (unsigned)count;
+    row[1 + slot] = bits;
+  } else {
+    row[0] = MVAL_AMAX_ROW - 1;
+    atomicMax(row + 1 + slot % (MVAL_AMAX_ROW - 1), bits);
   }
 }
-// max over the sub-slots of an image row
+// One image per workgroup: every wave leaves its own partial (workgroup slot `slot` of `count`).  All lanes of the
+// wave must call it.
+__device__ __forceinline__ void conv_amax_commit(unsigned* row, int slot, int count, float m) {
+  m = wave_max(m);
+  const int nw = (int)(blockDim.x >> 6);
+  if ((threadIdx.x & 63) == 0) conv_amax_put(row, slot * nw + (int)(threadIdx.x >> 6), count * nw, __float_as_uint(m));
+}
+// Consumer side: max |x| bits of an image.  Lanes read the partial slots, one wave reduction (uniform result).
 __device__ __forceinline__ unsigned conv_amax_read(const unsigned* row) {
+  const int count = (int)row[0];
   unsigned m = 0;
+  for (int i = (int)(threadIdx.x & 63); i < count; i += 64) m = max(m, row[1 + i]);
 #pragma unroll
-  for (int i = 0; i < MVAL_AMAX_SUB; i++) m = max(m, row[i]);
+  for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
   return m;
 }
 __device__ __forceinline__ float conv_amax4(float m, const float x, const float y, const float z, const float w) {
@@ -122,17 +124,40 @@ __device__ __forceinline__ bool conv_tile_decode(const ConvArgs& a, int p, int& 
 }
 
 // Second half of the MFMA kernels' epilogue: the BN'd output tile sits in LDS as
-// ot[pixel][NTILE + 4] (followed by 8 floats of scratch for the max |x| reduction: the launchers size the LDS for
-// it); add the residual(s), ReLU and store with float4 lanes along channels.
+// ot[pixel][NTILE + 4] (followed by MT + 8 dwords of scratch for the max |x| reduction: the launchers size the LDS
+// for it, CONV_OTILE_FLOATS); add the residual(s), ReLU and store with float4 lanes along channels.
 // All residual loads of a thread are issued before the first store (MT*NTILE/1024 float4 loads
 // in flight per thread) -- with one load per iteration the memory-bound layers (1x1 convs,
 // 32-channel 3x3) sat at 2.8 TB/s, latency- rather than bandwidth-bound.
 typedef float conv_f32x4 __attribute__((ext_vector_type(4)));
 
+#define CONV_OTILE_FLOATS(MT, NTILE) ((MT) * ((NTILE) + 4) + (MT) + 8)
+
+// Leave the workgroup's max |stored value| in the rows of its image(s).  tn == 1: `amax` holds every thread's
+// running maximum; tn > 1: the threads already folded theirs into scratch[image of the tile] (LDS atomics).
+template <int MT>
+__device__ __forceinline__ void conv_tile_amax(const ConvArgs& a, unsigned* scratch, float amax, int n0) {
+  if (!a.out_amax) return;
+  const int slot = (int)(blockIdx.x % (unsigned)a.amax_tiles) + a.amax_tiles * (int)(blockIdx.y + gridDim.y * blockIdx.z);
+  const int count = a.amax_tiles * (int)(gridDim.y * gridDim.z);
+  if (a.tn == 1) {
+    conv_amax_commit(a.out_amax + (int64_t)n0 * MVAL_AMAX_ROW, slot, count, amax);
+    return;
+  }
+  __syncthreads();
+  const int t = threadIdx.x;
+  if (t < a.tn && n0 + t < a.N) conv_amax_put(a.out_amax + (int64_t)(n0 + t) * MVAL_AMAX_ROW, slot, count, scratch[t]);
+}
+
 template <int MT, int NTILE, int NTH = 256>
 __device__ __forceinline__ void conv_tile_store(const ConvArgs& a, const float* ot, int tid, int n0, int oy0, int ox0,
                                                 int cbase) {
   constexpr int LDW = NTILE + 4;
+  unsigned* scratch = reinterpret_cast<unsigned*>(const_cast<float*>(ot)) + MT * LDW;
+  if (a.out_amax && a.tn != 1) {  // rare (maps under 8 rows): per-image maxima of the tile, zeroed here
+    for (int i = tid; i < a.tn; i += NTH) scratch[i] = 0u;
+    __syncthreads();
+  }
   const int Ho = a.Hout << a.up, Wo = a.Wout << a.up, rep = 1 << a.up;
   if (!a.out_nchw && (a.Cout & 3) == 0) {
     constexpr int Q = NTILE / 4;
@@ -169,12 +194,12 @@ __device__ __forceinline__ void conv_tile_store(const ConvArgs& a, const float* 
         }
         *reinterpret_cast<conv_f32x4*>(a.out + off[i]) = r;
         amax = conv_amax4(amax, r.x, r.y, r.z, r.w);
-        if (a.out_amax && a.tn != 1) {  // several images per tile (maps under 8 rows): per value
-          conv_amax_one(a.out_amax + (n0 + ((e / Q) >> a.thw_log2)) * MVAL_AMAX_SUB + (tid & (MVAL_AMAX_SUB - 1)), amax);
+        if (a.out_amax && a.tn != 1) {  // several images per tile (maps under 8 rows): per image through LDS
+          atomicMax(scratch + ((e / Q) >> a.thw_log2), __float_as_uint(amax));
           amax = 0.f;
         }
       }
-      if (a.out_amax && a.tn == 1) conv_amax_commit(a.out_amax + n0 * MVAL_AMAX_SUB, amax, const_cast<float*>(ot) + MT * LDW);
+      conv_tile_amax<MT>(a, scratch, amax, n0);
       return;
     }
     float amax = 0.f;
@@ -210,11 +235,11 @@ __device__ __forceinline__ void conv_tile_store(const ConvArgs& a, const float* 
         }
       }
       if (a.out_amax && a.tn != 1) {
-        conv_amax_one(a.out_amax + n * MVAL_AMAX_SUB + (tid & (MVAL_AMAX_SUB - 1)), amax);
+        atomicMax(scratch + tni, __float_as_uint(amax));
         amax = 0.f;
       }
     }
-    if (a.out_amax && a.tn == 1) conv_amax_commit(a.out_amax + n0 * MVAL_AMAX_SUB, amax, const_cast<float*>(ot) + MT * LDW);
+    conv_tile_amax<MT>(a, scratch, amax, n0);
     return;
   }
   // scalar path (NCHW heat-map output, odd channel counts): pixel-fastest so that NCHW rows are
@@ -230,6 +255,14 @@ __device__ __forceinline__ void conv_tile_store(const ConvArgs& a, const float* 
     if (n >= a.N || y >= a.Hout || x >= a.Wout) continue;
     conv_store(a, n, y, x, c, ot[p * LDW + cl]);
   }
+}
+
+// Launcher side of the max |x| rows: sets a.amax_tiles; more workgroups per image than a row has slots -> the rows are
+// zeroed here and the kernel folds with atomics (conv_amax_put).
+static inline void conv_amax_prepare(ConvArgs& a, int tiles_per_image, int groups, hipStream_t s) {
+  a.amax_tiles = tiles_per_image;
+  if (a.out_amax && (int64_t)tiles_per_image * groups * 4 > MVAL_AMAX_ROW - 1)  // (up to 4 waves per workgroup)
+    (void)hipMemsetAsync(a.out_amax, 0, (size_t)a.N * MVAL_AMAX_ROW * sizeof(unsigned), s);
 }
 
 int mval_launch_conv_mfma(const ConvArgs& a, hipStream_t s);  // conv_mfma.hip; returns 1 if unsupported

@@ -244,11 +244,12 @@ static int launch_cfg(ConvArgs a, int th, int tw, int tn, hipStream_t s) {
   const int ne = (tn * PH * PW * (KC / 4) + 255) / 256;
   const int nbuf = (a.Cin / KC > 1 && ne <= 10) ? 2 : 1;  // the generic staging path is single-buffered
   size_t smem = (size_t)patch_floats * nbuf * sizeof(float);
-  const size_t otile = (size_t)(MT * (NTILE + OPAD) + 8) * sizeof(float);  // + the max |x| reduction scratch
+  const size_t otile = (size_t)CONV_OTILE_FLOATS(MT, NTILE) * sizeof(float);  // (with the max |x| reduction scratch)
   if (otile > smem) smem = otile;
   if (smem > 128 * 1024) return 1;  // LDS is 160 KiB per CU on gfx950
   if (g_dry_run) return 0;
   dim3 grid((unsigned)(a.tiles_x * a.tiles_y * ngroups), (unsigned)((a.NS_total + WN * NT - 1) / (WN * NT)));
+  conv_amax_prepare(a, a.tiles_x * a.tiles_y, (int)grid.y, s);
   // staging registers are sized at compile time (runtime-indexed arrays would go to scratch)
   if (ne <= 4)
     hipLaunchKernelGGL((conv_mfma_kernel<KS, S, KC, WN, WM, NT, MS, 4>), grid, dim3(256), smem, s, a);

@@ -148,10 +148,6 @@ __global__ __launch_bounds__(64 * WN * WM)
   const int plane_bytes = sub_bytes * G;
   char* planes = smem_raw;  // [PL][G][patch_px][BF_ROW] 16-bit
   float in_mul = 1.f, unscale = 1.f;
-  if constexpr (PL == 2) {  // one image per tile (the launcher refuses tn > 1): the image's own scale
-    split_act_scale(a.in_amax + n0 * MVAL_AMAX_SUB, in_mul, unscale);
-    unscale *= *a.w_unscale;
-  }
 
   int abase[MS];  // byte offset inside a plane: pixel row + k quarter
 #pragma unroll
@@ -246,6 +242,13 @@ __global__ __launch_bounds__(64 * WN * WM)
   };
 
   load_chunk(0);
+  if constexpr (PL == 2) {
+    // one image per tile (the launcher refuses tn > 1): the image's own scale.  Read AFTER the first chunk's loads
+    // are in flight: the two dependent L2 round trips (header, partials) then hide behind them (issued first they
+    // cost 10 us on the 32-channel layers)
+    split_act_scale(a.in_amax + (int64_t)n0 * MVAL_AMAX_ROW, in_mul, unscale);
+    unscale *= *a.w_unscale;
+  }
   store_chunk();
   __syncthreads();
 
@@ -392,7 +395,7 @@ static int launch_split(ConvArgs a, int th, int tw, int tn, hipStream_t s) {
   const int patch_px = tn * PH * PW;
   constexpr int BF_ROW = BF_ROW_OF(S);
   size_t smem = (size_t)PL * G * patch_px * BF_ROW * 2;
-  const size_t otile = (size_t)(MT * (NTILE + OPAD) + 8) * sizeof(float);  // + the max |x| reduction scratch
+  const size_t otile = (size_t)CONV_OTILE_FLOATS(MT, NTILE) * sizeof(float);  // (with the max |x| reduction scratch)
   if (otile > smem) smem = otile;
   if (smem > 128 * 1024) return 1;
   constexpr int NTH = 64 * WN * WM;
@@ -407,6 +410,7 @@ static int launch_split(ConvArgs a, int th, int tw, int tn, hipStream_t s) {
   if (a.precise && !PAOK) return 1;
   dim3 grid((unsigned)(a.tiles_x * a.tiles_y * ngroups), (unsigned)((a.NS_total + WN * NT - 1) / (WN * NT)),
             (KS == 2 && a.par_w_stride) ? 4u : 1u);
+  conv_amax_prepare(a, a.tiles_x * a.tiles_y, (int)(grid.y * grid.z), s);
   if constexpr (G > 1) {
     constexpr int NEG = (G * MT * 8 + NTH - 1) / NTH;
     if constexpr (PAOK)

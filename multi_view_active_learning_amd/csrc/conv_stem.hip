@@ -96,18 +96,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
       }
     }
   }
-  if (a.out_amax) conv_amax_commit(a.out_amax + n * MVAL_AMAX_SUB, amax, patch + 3 * PH * PWP);
+  if (a.out_amax) conv_amax_commit(a.out_amax + (int64_t)n * MVAL_AMAX_ROW, (int)(blockIdx.x % (unsigned)a.amax_tiles), a.amax_tiles, amax);
 }
 
 // returns 1 when the op is not a stem of the supported shape
-int mval_launch_conv_stem(const ConvArgs& a, hipStream_t s) {
+int mval_launch_conv_stem(const ConvArgs& a0, hipStream_t s) {
+  ConvArgs a = a0;
   if (!a.in_nchw || a.Cin != 3 || a.stride != 2 || a.up || a.res1 || a.res2 || a.out_nchw || (a.Cout & 3)) return 1;
   if (a.k != 3 && a.k != 7) return 1;
   if (a.pad != a.k / 2) return 1;
   const int PH = (ST_TH - 1) * 2 + a.k, PW = ((ST_TW - 1) * 2 + a.k) | 1;
-  size_t smem = (size_t)(a.k * a.k * 3 * a.Cout + 3 * PH * PW + 8) * sizeof(float);  // + the max |x| reduction scratch
+  size_t smem = (size_t)(a.k * a.k * 3 * a.Cout + 3 * PH * PW) * sizeof(float);
   if (smem > 64 * 1024) return 1;
   const int tiles = ((a.Wout + ST_TW - 1) / ST_TW) * ((a.Hout + ST_TH - 1) / ST_TH) * a.N;
+  conv_amax_prepare(a, tiles / a.N, 1, s);
   if (a.k == 3)
     hipLaunchKernelGGL(conv_stem_kernel<3>, dim3(tiles), dim3(256), smem, s, a);
   else

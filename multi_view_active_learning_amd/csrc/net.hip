@@ -217,6 +217,7 @@ __global__ __launch_bounds__(256) void maxpool_kernel(ConvArgs a) {
 // slots[i] = max(slots[i], max |x| over image i): the per-image activation scale of the fp16-split convs for tensors
 // whose producer does not keep it itself (max-pool, the generic direct kernels) and for single-op launches.
 __global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, int64_t per_image, int vec, unsigned* slots) {
+
   const float* xi = x + (int64_t)blockIdx.y * per_image;
   float m = 0.f;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -226,9 +227,7 @@ __global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, 
     m = conv_amax4(m, v.x, v.y, v.z, v.w);
   }
   for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < per_image; i += stride) m = fmaxf(m, fabsf(xi[i]));
-  m = wave_max(m);
-  if ((threadIdx.x & 63) == 0)
-    conv_amax_one(slots + blockIdx.y * MVAL_AMAX_SUB + ((blockIdx.x * 4 + (threadIdx.x >> 6)) & (MVAL_AMAX_SUB - 1)), m);
+  conv_amax_commit(slots + (int64_t)blockIdx.y * MVAL_AMAX_ROW, (int)blockIdx.x, (int)gridDim.x, m);
 }
 
 int mval_launch_amax(const float* x, int64_t per_image, int n_images, unsigned* slots, hipStream_t s) {
@@ -398,8 +397,7 @@ extern "C" int mval_op_launch(const mval_op* op, int n_images, float* workspace,
 
 struct MvalNet {
   std::vector<mval_op> ops;
-  // workspace floats [amax_lo, amax_hi + n_images): the per-image max |x| slots of the plan, zeroed per forward
-  int64_t amax_lo = 0, amax_hi = 0;
+
   hipStream_t side[MVAL_MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t fork_ev = nullptr;
   hipEvent_t join_ev[MVAL_MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};
@@ -423,14 +421,8 @@ extern "C" void* mval_net_create(const mval_op* ops, int n_ops) {
   }
   MvalNet* n = new MvalNet();
   n->ops.assign(ops, ops + n_ops);
-  for (const auto& o : n->ops) {
+  for (const auto& o : n->ops)
     if (o.lane + 1 > n->n_lanes) n->n_lanes = o.lane + 1;
-    for (int64_t off : {o.in_amax_off, o.out_amax_off})
-      if (off > 0) {
-        if (n->amax_hi == 0 || off < n->amax_lo) n->amax_lo = off;
-        if (off > n->amax_hi) n->amax_hi = off;
-      }
-  }
   if (n->n_lanes > MVAL_MAX_LANES) n->n_lanes = MVAL_MAX_LANES;
   return n;
 }
@@ -469,8 +461,6 @@ extern "C" int mval_net_forward(void* net, int n_images, float* workspace, const
   hipStream_t main_s = mval_stream(stream);
   const bool multi = n->n_lanes > 1 && (n->lanes_override < 0 ? multi_stream_enabled() : n->lanes_override != 0);
   if (multi) MVAL_REQUIRE(ensure_streams(n) == 0, "mval_net_forward: could not create side streams");
-  if (n->amax_hi)
-    (void)hipMemsetAsync(workspace + n->amax_lo, 0, (size_t)(n->amax_hi + (int64_t)n_images * MVAL_AMAX_SUB - n->amax_lo) * sizeof(float), main_s);
   bool used[MVAL_MAX_LANES] = {false, false, false, false};
   int phase = n->ops.empty() ? 0 : n->ops[0].phase;
   auto join = [&]() {  // side streams -> main
@@ -533,8 +523,6 @@ extern "C" int mval_net_forward_timed(void* net, int n_images, float* workspace,
     }
   }
   int rc = 0;
-  if (n->amax_hi)
-    (void)hipMemsetAsync(workspace + n->amax_lo, 0, (size_t)(n->amax_hi + (int64_t)n_images * MVAL_AMAX_SUB - n->amax_lo) * sizeof(float), s);
   (void)hipEventRecord(ev[0], s);
   for (size_t i = 0; i < n->ops.size() && !rc; i++) {
     rc = mval_op_launch(&n->ops[i], n_images, workspace, params, input_nchw, output_nchw, stream);

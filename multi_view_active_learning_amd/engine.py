@@ -28,7 +28,7 @@ from .pose_estimators import params as _params
 OP_CONV, OP_MAXPOOL, OP_DECONV = 0, 1, 2
 ALGO_DIRECT, ALGO_MFMA, ALGO_MFMA_BF3, ALGO_MFMA_H2 = 0, 1, 2, 3
 PACK_HWIO, PACK_MFMA16, PACK_MFMA16_BF3, PACK_MFMA16_H2 = 0, 1, 2, 3
-AMAX_SUB = 16
+AMAX_ROW = 1024
 _PACK_OF = {ALGO_DIRECT: PACK_HWIO, ALGO_MFMA: PACK_MFMA16, ALGO_MFMA_BF3: PACK_MFMA16_BF3, ALGO_MFMA_H2: PACK_MFMA16_H2}
 
 
@@ -153,9 +153,9 @@ class InferencePlan:
             free = merged
         # max |x| slots (one float each) behind the activations: what the fp16-split convs scale their input by
         self.amax_base = _align(max(top, 64))
-        # (n images x AMAX_SUB sub-slots per activation, include/mval_hip.h: MVAL_AMAX_SUB)
-        amax_slot = {a.id: self.amax_base + k * n * AMAX_SUB for k, a in enumerate(g.acts)}
-        self.arena_floats = self.amax_base + _align(len(g.acts) * n * AMAX_SUB)
+        # (n rows of AMAX_ROW dwords per activation that an fp16-split conv reads; include/mval_hip.h: MVAL_AMAX_ROW)
+        self._amax_top = self.amax_base
+        amax_slot = {}
         # ---- parameter buffer layout -------------------------------------------------------------
         lib = _lib.lib()
         self.ops = (MvalOp * len(g.ops))()
@@ -186,7 +186,11 @@ class InferencePlan:
             m.res2_off = -1 if op.res2 is None else offset[op.res2]
             m.w_off = m.scale_off = m.shift_off = -1
             m.phase, m.lane = op.phase, op.lane
-            m.in_amax_off = amax_slot[op.src] if m.algo == ALGO_MFMA_H2 else 0
+            if m.algo == ALGO_MFMA_H2:
+                if op.src not in amax_slot:
+                    amax_slot[op.src] = self._amax_top
+                    self._amax_top += n * AMAX_ROW
+                m.in_amax_off = amax_slot[op.src]
             if op.kind in ("conv", "deconv"):
                 pack = _PACK_OF[m.algo]
                 nw = int(lib.mval_packed_weight_floats(C.c_int(pack), C.c_int(op.cout), C.c_int(op.cin), C.c_int(op.k)))
@@ -198,11 +202,11 @@ class InferencePlan:
                 ptop += _align(op.cout)
                 self.param_jobs.append((i, pack, m.w_off, m.scale_off, m.shift_off))
         # producers keep max |x| only for tensors an fp16-split conv reads
-        need = {g.ops[i].src for i in range(len(g.ops)) if self.ops[i].algo == ALGO_MFMA_H2}
-        if g.input in need:
+        if g.input in amax_slot:
             raise _lib.MvalError("the network input cannot feed an fp16-split conv (no producer to keep its max |x|)")
         for i, op in enumerate(g.ops):
-            self.ops[i].out_amax_off = amax_slot[op.dst] if op.dst in need else 0
+            self.ops[i].out_amax_off = amax_slot.get(op.dst, 0)
+        self.arena_floats = _align(self._amax_top)
         self.param_floats = max(ptop, 64)
         self.arena = torch.empty(self.arena_floats, dtype=torch.float32, device=device)
         self.params = torch.zeros(self.param_floats, dtype=torch.float32, device=device)

@@ -9,7 +9,7 @@ import torch
 
 from . import _lib
 from .engine import (ALGO_DIRECT, ALGO_MFMA, ALGO_MFMA_BF3, ALGO_MFMA_H2, OP_CONV, OP_DECONV, OP_MAXPOOL, PACK_HWIO,
-                     PACK_MFMA16, PACK_MFMA16_BF3, AMAX_SUB, _PACK_OF, MvalOp, _align)
+                     PACK_MFMA16, PACK_MFMA16_BF3, AMAX_ROW, _PACK_OF, MvalOp, _align)
 
 
 def pack_weights(weight, algo, transposed=False):
@@ -65,7 +65,7 @@ def fused_conv(x, weight, scale, shift, stride=1, pad=None, relu=False, res1=Non
             tensors.append(t.contiguous().reshape(-1))
     out_off = _align(offs[-1] + tensors[-1].numel())
     amax_off = _align(out_off + n * ho * wo * cout)  # per-image max |x| slots: n for the input, n for the output
-    arena = torch.zeros(amax_off + _align(2 * n * AMAX_SUB), dtype=torch.float32, device=dev)
+    arena = torch.zeros(amax_off + _align(2 * n * AMAX_ROW), dtype=torch.float32, device=dev)
     for o, t in zip(offs, tensors):
         arena[o : o + t.numel()] = t
     if kind == OP_MAXPOOL:
@@ -90,7 +90,7 @@ def fused_conv(x, weight, scale, shift, stride=1, pad=None, relu=False, res1=Non
     m.res1_off = next(it) if res1 is not None else -1
     m.res2_off = next(it) if res2 is not None else -1
     m.w_off, m.scale_off, m.shift_off = w_off, s_off, b_off
-    m.out_amax_off = amax_off + n * AMAX_SUB
+    m.out_amax_off = amax_off + n * AMAX_ROW
     if algo == ALGO_MFMA_H2:  # the fp16 split scales every image of its input by that image's max |x|
         m.in_amax_off = amax_off
         _lib._check(_lib.lib().mval_amax(_lib._p(arena), C.c_int64(tensors[0].numel() // n), C.c_int(n),
@@ -99,8 +99,10 @@ def fused_conv(x, weight, scale, shift, stride=1, pad=None, relu=False, res1=Non
         _lib.lib().mval_op_launch(C.byref(m), C.c_int(n), _lib._p(arena), _lib._p(params), C.c_void_p(0), C.c_void_p(0),
                                   _lib._stream()),
         "mval_op_launch")
-    # (tests: the per-image max |x| the kernel kept = the maximum over each image's sub-slots)
-    fused_conv.last_out_amax = arena[amax_off + n * AMAX_SUB : amax_off + 2 * n * AMAX_SUB].view(torch.int32).reshape(n, AMAX_SUB).amax(1)
+    # (tests: the per-image max |x| the kernel kept = the maximum over the first row[0] partials of each image's row)
+    rows = arena[amax_off + n * AMAX_ROW : amax_off + 2 * n * AMAX_ROW].view(torch.int32).reshape(n, AMAX_ROW)
+    live = torch.arange(AMAX_ROW - 1, device=dev)[None, :] < rows[:, :1]
+    fused_conv.last_out_amax = torch.where(live, rows[:, 1:], torch.zeros_like(rows[:, 1:])).amax(1)
     out = arena[out_off : out_off + n * ho * wo * cout]
     return out.reshape(n, cout, ho, wo) if out_nchw else out.reshape(n, ho, wo, cout)
 

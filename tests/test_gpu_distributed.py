@@ -93,6 +93,8 @@ def test_two_ranks_one_gpu_equal_one_rank(tmp_path, strategy):
     assert len(want["sal"]["al_metric"]) == 8
     for g in got:
         for k in FIELDS:
-            assert list(g["sal"][k].items()) == list(want["sal"][k].items()), k  # values AND key order, exactly
+            assert list(g["sal"][k]) == list(want["sal"][k]), k  # key order
+            for guid, val in want["sal"][k].items():  # values exactly (mkpe is NaN where a joint is invalid, as in the reference)
+                assert g["sal"][k][guid] == val or (val != val and g["sal"][k][guid] != g["sal"][k][guid]), (k, guid)
         assert g["picks"] == want["picks"]
         assert g["eval"] == want["eval"]  # float32 MKPE summed in the same sample order; PCK counts
