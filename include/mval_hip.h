@@ -173,7 +173,7 @@ int mval_kcenter_select(const double* feat, int64_t n_obs, int D, const int64_t*
  * floats from the workspace base; -1 = absent.  Weights are in the packed fragment order
  * written by mval_pack_conv_weights; scale/shift are the folded eval-mode BatchNorm
  * (y = x * scale + shift, torch's batch_norm inference formula) or (1, bias). */
-enum { MVAL_OP_CONV = 0, MVAL_OP_MAXPOOL = 1, MVAL_OP_DECONV = 2 };
+enum { MVAL_OP_CONV = 0, MVAL_OP_MAXPOOL = 1, MVAL_OP_DECONV = 2, MVAL_OP_BLOCK = 3 };
 enum { MVAL_ALGO_DIRECT = 0, MVAL_ALGO_MFMA = 1, MVAL_ALGO_MFMA_BF3 = 2, MVAL_ALGO_MFMA_H2 = 3 };
 enum { MVAL_PACK_HWIO = 0, MVAL_PACK_MFMA16 = 1, MVAL_PACK_MFMA16_BF3 = 2, MVAL_PACK_MFMA16_H2 = 3 };
 
@@ -199,6 +199,11 @@ typedef struct mval_op {
    * writes the rows of its output (any algo); in_amax_off: the rows of the op's input, required by
    * MVAL_ALGO_MFMA_H2 (single-op callers fill them with mval_amax). */
   int64_t in_amax_off, out_amax_off;
+  /* MVAL_OP_BLOCK (hrnet.py:19-52, a whole BasicBlock in one launch, csrc/conv_block.hip):
+   *   out = relu(bn2(conv3x3(relu(bn1(conv3x3(in))))) + in),  cin = cout in {32, 64}, k 3, stride 1, pad 1,
+   * algo MVAL_ALGO_MFMA_H2.  w_off / scale_off / shift_off are conv1 + bn1, these three conv2 + bn2 (both
+   * weights packed MVAL_PACK_MFMA16_H2); res1_off must equal in_off (or be -1). */
+  int64_t w2_off, scale2_off, shift2_off;
 } mval_op;
 
 /* Weight packing.  MVAL_PACK_HWIO: [k*k][cin][cout] (direct kernels, deconv);
@@ -236,7 +241,7 @@ int mval_bn_fold(const float* gamma, const float* beta, const float* mean, const
 
 /* Writes the max-magnitude rows (see mval_op; [n_images][MVAL_AMAX_ROW] dwords) of a tensor of n_images images of
  * per_image consecutive floats each: for tensors that did not come out of an op of the plan. */
-#define MVAL_AMAX_ROW 1024
+#define MVAL_AMAX_ROW 4096
 int mval_amax(const float* x, int64_t per_image, int n_images, uint32_t* rows, void* stream);
 
 /* 1 when the MFMA kernel family has a configuration for this op geometry (the plan builder

@@ -1,0 +1,328 @@
+// Fused BasicBlock on the fp16 matrix cores (hrnet.py:19-52 in eval mode):
+//
+//     out = relu( bn2(conv3x3(relu(bn1(conv3x3(x))))) + x )          x, out: NHWC fp32, C = 32 or 64 channels
+//
+// ONE launch instead of two conv launches, and the intermediate activation never leaves the CU.  These are the
+// high-resolution branches of HRNet (32 channels on 64x64 maps, 64 on 32x32 at 256x256 input): 128 of HRNet-W32's 293
+// launches, and as two separate convs they are bound by their HBM traffic and by per-workgroup latency, not by the
+// matrix cores (the MFMA pipe is ~20 % busy on the 32-channel layer).  Per block the unfused pair moves
+// x + mid + mid + x + out = 5 tensors through HBM; this kernel moves x + out (the residual re-read of x hits L2).
+//
+// Arithmetic = the fp16x2 split of conv_mfma_split.hip (PL = 2: three exact fp16 products per fp32 product, fp32
+// accumulate, power-of-two scales undone exactly in the epilogues):
+//   * x is scaled by its image's max |x| (the row its producer kept, conv_common.h);
+//   * the intermediate tile is scaled by ITS OWN maximum (a workgroup-local reduction): the tile decomposition
+//     depends on the image geometry only, so results stay deterministic and independent of the batch.
+//
+// Workgroup = 4 waves, output tile 8 x 16 pixels:
+//   1. stage the 12 x 20 input patch (2-pixel halo), split, into LDS planes X[plane][chunk][pixel][32 ch + pad];
+//   2. conv1 over the 10 x 18 intermediate pixels (1-pixel halo for conv2; 12 sub-tiles of 16 pixel slots, 3 per
+//      wave, every wave all C output channels).  The WEIGHT fragment is the MFMA's first operand, so a lane ends up
+//      with 4 consecutive channels of one pixel: BN1 + ReLU (+ zero outside the image = conv2's zero padding) in
+//      registers, tile maximum through LDS, split, 8-byte LDS stores into M[plane][chunk][pixel][32 ch + pad],
+//      which overlays X (conv1 is done with it);
+//   3. conv2 over the 8 x 16 output pixels from M (2 sub-tile rows per wave); BN2 + residual + ReLU in registers,
+//      float4 stores straight from the accumulators (64-byte runs per pixel; no LDS round trip, no barrier).
+// Halo recompute: conv1 does 12 / 8 = 1.5x the MFMAs of a plain conv; at 3 MFMAs per product that is cheaper than
+// the two staging passes, two epilogues and 3 tensor round trips it replaces.
+#include "conv_common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+#define BK_TH 8
+#define BK_TW 16
+#define BK_XH (BK_TH + 4)  // 12
+#define BK_XW (BK_TW + 4)  // 20
+#define BK_MH (BK_TH + 2)  // 10
+#define BK_MW (BK_TW + 2)  // 18
+#define BK_XPX (BK_XH * BK_XW)  // 240
+#define BK_MPX (BK_MH * BK_MW)  // 180
+#define BK_MSLOTS 192           // 12 sub-tiles of 16
+#define BK_ROWB 80              // bytes per LDS pixel row: 32 fp16 + 8 pad (16 consecutive pixels cover all banks)
+
+__device__ __forceinline__ f32x4 bk_mfma(const u32x4 a, const u32x4 b, const f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ void bk_split(const f32x4 v, f16x4& h, f16x4& l) {
+  h = __builtin_convertvector(v, f16x4);
+  l = __builtin_convertvector(v - __builtin_convertvector(h, f32x4), f16x4);
+}
+// 2^s that puts a maximum with these float bits into [2^14, 2^15), and its inverse (zero / inf / NaN: unscaled)
+__device__ __forceinline__ void bk_scale(unsigned amax_bits, float& mul, float& inv) {
+  const int e = (int)((amax_bits >> 23) & 0xff);
+  int s = (e == 0 || e == 255) ? 0 : 14 - (e - 127);
+  s = max(-110, min(110, s));
+  mul = __uint_as_float((unsigned)(127 + s) << 23);
+  inv = __uint_as_float((unsigned)(127 - s) << 23);
+}
+
+struct BlockArgs {
+  const float* in;
+  float* out;
+  const float *w1, *scale1, *shift1, *w1_unscale;
+  const float *w2, *scale2, *shift2, *w2_unscale;
+  const unsigned* in_amax;
+  unsigned* out_amax;
+  int N, H, W;
+  int tiles_x, tiles_y;
+};
+
+template <int C>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C == 32 ? 4 : 2, 8))) void conv_block_kernel(BlockArgs a) {
+  constexpr int NCH = C / 32;   // 32-channel chunks
+  constexpr int NS = C / 16;    // 16-cout sub-tiles: every wave computes all of them
+  constexpr int Q = C / 4;      // float4 per pixel
+  constexpr int NE = (BK_XPX * Q + 255) / 256;
+  constexpr int XCHUNK = BK_XPX * BK_ROWB, XPLANE = NCH * XCHUNK;
+  constexpr int MCHUNK = BK_MSLOTS * BK_ROWB, MPLANE = NCH * MCHUNK;
+  static_assert(2 * MPLANE <= 2 * XPLANE, "M overlays X");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ float tile_max[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+  int t = blockIdx.x;
+  const int txi = t % a.tiles_x;
+  t /= a.tiles_x;
+  const int tyi = t % a.tiles_y;
+  const int n = t / a.tiles_y;
+  const int oy0 = tyi * BK_TH, ox0 = txi * BK_TW;
+  const float* xin = a.in + (int64_t)n * a.H * a.W * C;
+
+  // ---- 1. input patch: global -> registers -> (scale, split) -> LDS ------------------------------------------
+  f32x4 stage[NE];
+#pragma unroll
+  for (int i = 0; i < NE; i++) {
+    const int e = tid + 256 * i;
+    const int px = e / Q, q = e % Q;
+    const int py = px / BK_XW, pxx = px - py * BK_XW;
+    const int iy = oy0 - 2 + py, ix = ox0 - 2 + pxx;
+    const bool ok = e < BK_XPX * Q && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+    stage[i] = ok ? *reinterpret_cast<const f32x4*>(xin + ((int64_t)iy * a.W + ix) * C + q * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  float in_mul, in_inv;
+  bk_scale(conv_amax_read(a.in_amax + (int64_t)n * MVAL_AMAX_ROW), in_mul, in_inv);
+#pragma unroll
+  for (int i = 0; i < NE; i++) {
+    const int e = tid + 256 * i;
+    if (e < BK_XPX * Q) {
+      const int px = e / Q, q = e % Q;
+      f16x4 h, l;
+      bk_split(stage[i] * in_mul, h, l);
+      const int off = (q >> 3) * XCHUNK + px * BK_ROWB + (q & 7) * 8;
+      *reinterpret_cast<f16x4*>(smem + off) = h;
+      *reinterpret_cast<f16x4*>(smem + XPLANE + off) = l;
+    }
+  }
+  __syncthreads();
+
+  // Weight fragments ([tap][chunk][cout/16][plane h,l][lane][8 fp16], mval_pack_conv_weights) through buffer
+  // descriptors: block offset in SGPRs, a per-lane 32-bit offset, the plane as immediate.
+  const __amdgpu_buffer_rsrc_t w1r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w1), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t w2r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w2), 0, 0x7fffffff, 0x00020000);
+  constexpr int BLK = NS * 2048;  // bytes per (tap, chunk): NS sub-tiles x 2 planes x 1 KiB
+  auto wfrag = [&](const __amdgpu_buffer_rsrc_t& r, int blk, int ns, int p) -> u32x4 {
+    return __builtin_amdgcn_raw_buffer_load_b128(r, (ns * 128 + p * 64 + lane) * 16, blk * BLK, 0);
+  };
+
+  // ---- 2. conv1 over the intermediate pixels: sub-tiles wave * 3 + {0, 1, 2} --------------------------------------
+  constexpr int MS1 = 3;
+  int xb[MS1];  // LDS byte offset of the lane's pixel (tap (0,0)) + its k octet
+  int mpix[MS1];
+#pragma unroll
+  for (int ms = 0; ms < MS1; ms++) {
+    const int p = (wave * MS1 + ms) * 16 + (lane & 15);
+    mpix[ms] = p;
+    const int pc = p < BK_MPX ? p : 0;
+    const int my = pc / BK_MW, mx = pc - my * BK_MW;
+    xb[ms] = (my * BK_XW + mx) * BK_ROWB + (lane >> 4) * 16;
+  }
+  f32x4 acc1[MS1][NS];
+#pragma unroll
+  for (int ms = 0; ms < MS1; ms++)
+#pragma unroll
+    for (int ns = 0; ns < NS; ns++) acc1[ms][ns] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  {
+    u32x4 wf[2][NS][2];
+#pragma unroll
+    for (int ns = 0; ns < NS; ns++)
+#pragma unroll
+      for (int p = 0; p < 2; p++) wf[0][ns][p] = wfrag(w1r, 0, ns, p);
+#pragma unroll
+    for (int ch = 0; ch < NCH; ch++) {
+#pragma unroll
+      for (int tap = 0; tap < 9; tap++) {
+        const int step = ch * 9 + tap;
+        if (step + 1 < NCH * 9) {
+          const int nt = (step + 1) % 9, nc = (step + 1) / 9;
+#pragma unroll
+          for (int ns = 0; ns < NS; ns++)
+#pragma unroll
+            for (int p = 0; p < 2; p++) wf[(step + 1) & 1][ns][p] = wfrag(w1r, nt * NCH + nc, ns, p);
+        }
+        const int toff = ch * XCHUNK + ((tap / 3) * BK_XW + (tap % 3)) * BK_ROWB;
+#pragma unroll
+        for (int ms = 0; ms < MS1; ms++) {
+          const u32x4 xh = *reinterpret_cast<const u32x4*>(smem + xb[ms] + toff);
+          const u32x4 xl = *reinterpret_cast<const u32x4*>(smem + XPLANE + xb[ms] + toff);
+#pragma unroll
+          for (int ns = 0; ns < NS; ns++) {
+            f32x4 c = acc1[ms][ns];
+            c = bk_mfma(wf[step & 1][ns][1], xh, c);  // wl * xh
+            c = bk_mfma(wf[step & 1][ns][0], xl, c);  // wh * xl
+            acc1[ms][ns] = bk_mfma(wf[step & 1][ns][0], xh, c);
+          }
+        }
+      }
+    }
+  }
+  // BN1 + ReLU; zero outside the image (conv2's padding).  Lane = (pixel lane & 15, channels (lane >> 4) * 4 .. + 3).
+  const float u1 = in_inv * *a.w1_unscale;
+  float tmax = 0.f;
+#pragma unroll
+  for (int ms = 0; ms < MS1; ms++) {
+    const int p = mpix[ms];
+    const int my = p / BK_MW, mx = p - my * BK_MW;
+    const int gy = oy0 - 1 + my, gx = ox0 - 1 + mx;
+    const bool inside = p < BK_MPX && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+#pragma unroll
+    for (int ns = 0; ns < NS; ns++) {
+      const int c0 = ns * 16 + (lane >> 4) * 4;
+      const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale1 + c0) * u1;
+      const f32x4 sh = *reinterpret_cast<const f32x4*>(a.shift1 + c0);
+      f32x4 v = acc1[ms][ns] * sc + sh;
+      v.x = inside ? fmaxf(v.x, 0.f) : 0.f;
+      v.y = inside ? fmaxf(v.y, 0.f) : 0.f;
+      v.z = inside ? fmaxf(v.z, 0.f) : 0.f;
+      v.w = inside ? fmaxf(v.w, 0.f) : 0.f;
+      acc1[ms][ns] = v;
+      tmax = fmaxf(fmaxf(tmax, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
+    }
+  }
+  tmax = wave_max(tmax);
+  if (lane == 0) tile_max[wave] = tmax;
+  __syncthreads();  // every wave is done reading X; the tile maximum is complete
+  float m_mul, m_inv;
+  bk_scale(__float_as_uint(fmaxf(fmaxf(tile_max[0], tile_max[1]), fmaxf(tile_max[2], tile_max[3]))), m_mul, m_inv);
+#pragma unroll
+  for (int ms = 0; ms < MS1; ms++) {
+#pragma unroll
+    for (int ns = 0; ns < NS; ns++) {
+      f16x4 h, l;
+      bk_split(acc1[ms][ns] * m_mul, h, l);
+      const int off = (ns >> 1) * MCHUNK + mpix[ms] * BK_ROWB + ((ns & 1) * 16 + (lane >> 4) * 4) * 2;
+      *reinterpret_cast<f16x4*>(smem + off) = h;
+      *reinterpret_cast<f16x4*>(smem + MPLANE + off) = l;
+    }
+  }
+
+  // ---- 3. conv2 over the output rows wave * 2 + {0, 1}; the residual loads travel during its MFMA loop ----------
+  constexpr int MS2 = 2;
+  const int ox = ox0 + (lane & 15);
+  f32x4 res[MS2][NS];
+  int64_t ooff[MS2];
+#pragma unroll
+  for (int ms = 0; ms < MS2; ms++) {
+    const int oy = oy0 + wave * MS2 + ms;
+    const bool ok = oy < a.H && ox < a.W;
+    ooff[ms] = ok ? (((int64_t)n * a.H + oy) * a.W + ox) * C + (lane >> 4) * 4 : -1;
+#pragma unroll
+    for (int ns = 0; ns < NS; ns++)
+      res[ms][ns] = ok ? *reinterpret_cast<const f32x4*>(a.in + ooff[ms] + ns * 16) : (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  f32x4 acc2[MS2][NS];
+#pragma unroll
+  for (int ms = 0; ms < MS2; ms++)
+#pragma unroll
+    for (int ns = 0; ns < NS; ns++) acc2[ms][ns] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  __syncthreads();  // M is complete
+  {
+    u32x4 wf[2][NS][2];
+#pragma unroll
+    for (int ns = 0; ns < NS; ns++)
+#pragma unroll
+      for (int p = 0; p < 2; p++) wf[0][ns][p] = wfrag(w2r, 0, ns, p);
+    const int mb = ((wave * MS2) * BK_MW + (lane & 15)) * BK_ROWB + (lane >> 4) * 16;
+#pragma unroll
+    for (int ch = 0; ch < NCH; ch++) {
+#pragma unroll
+      for (int tap = 0; tap < 9; tap++) {
+        const int step = ch * 9 + tap;
+        if (step + 1 < NCH * 9) {
+          const int nt = (step + 1) % 9, nc = (step + 1) / 9;
+#pragma unroll
+          for (int ns = 0; ns < NS; ns++)
+#pragma unroll
+            for (int p = 0; p < 2; p++) wf[(step + 1) & 1][ns][p] = wfrag(w2r, nt * NCH + nc, ns, p);
+        }
+        const int toff = ch * MCHUNK + ((tap / 3) * BK_MW + (tap % 3)) * BK_ROWB;
+#pragma unroll
+        for (int ms = 0; ms < MS2; ms++) {
+          const u32x4 mh = *reinterpret_cast<const u32x4*>(smem + mb + ms * (BK_MW * BK_ROWB) + toff);
+          const u32x4 ml = *reinterpret_cast<const u32x4*>(smem + MPLANE + mb + ms * (BK_MW * BK_ROWB) + toff);
+#pragma unroll
+          for (int ns = 0; ns < NS; ns++) {
+            f32x4 c = acc2[ms][ns];
+            c = bk_mfma(wf[step & 1][ns][1], mh, c);
+            c = bk_mfma(wf[step & 1][ns][0], ml, c);
+            acc2[ms][ns] = bk_mfma(wf[step & 1][ns][0], mh, c);
+          }
+        }
+      }
+    }
+  }
+  const float u2 = m_inv * *a.w2_unscale;
+  float amax = 0.f;
+#pragma unroll
+  for (int ms = 0; ms < MS2; ms++) {
+    if (ooff[ms] < 0) continue;
+#pragma unroll
+    for (int ns = 0; ns < NS; ns++) {
+      const int c0 = ns * 16 + (lane >> 4) * 4;
+      const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale2 + c0) * u2;
+      const f32x4 sh = *reinterpret_cast<const f32x4*>(a.shift2 + c0);
+      f32x4 v = acc2[ms][ns] * sc + sh;
+      v += res[ms][ns];
+      v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+      *reinterpret_cast<f32x4*>(a.out + ooff[ms] + ns * 16) = v;
+      amax = fmaxf(fmaxf(amax, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
+    }
+  }
+  if (a.out_amax)
+    conv_amax_commit(a.out_amax + (int64_t)n * MVAL_AMAX_ROW, (int)(blockIdx.x % (unsigned)(a.tiles_x * a.tiles_y)), a.tiles_x * a.tiles_y, amax);
+}
+
+// 1 when the fused kernel covers this geometry
+int mval_conv_block_supported(int C, int N, int H, int W) {
+  if (C != 32 && C != 64) return 0;
+  if (H < 8 || W < 16) return 0;  // small maps: the unfused kernels pack several images into a tile instead
+  if ((int64_t)N * H * W * C >= (int64_t)1 << 31) return 0;
+  return 1;
+}
+
+int mval_launch_conv_block(int C, const float* in, float* out, const float* w1, const float* scale1, const float* shift1,
+                           const float* w1_unscale, const float* w2, const float* scale2, const float* shift2,
+                           const float* w2_unscale, const unsigned* in_amax, unsigned* out_amax, int N, int H, int W,
+                           hipStream_t s) {
+  if (!mval_conv_block_supported(C, N, H, W) || !in_amax) return 1;
+  BlockArgs a;
+  a.in = in; a.out = out;
+  a.w1 = w1; a.scale1 = scale1; a.shift1 = shift1; a.w1_unscale = w1_unscale;
+  a.w2 = w2; a.scale2 = scale2; a.shift2 = shift2; a.w2_unscale = w2_unscale;
+  a.in_amax = in_amax; a.out_amax = out_amax;
+  a.N = N; a.H = H; a.W = W;
+  a.tiles_x = (W + BK_TW - 1) / BK_TW;
+  a.tiles_y = (H + BK_TH - 1) / BK_TH;
+  const int tiles = a.tiles_x * a.tiles_y;
+  if (out_amax && (int64_t)tiles * 4 > MVAL_AMAX_ROW - 1)
+    mval_launch_zero_rows(out_amax, (int64_t)N * MVAL_AMAX_ROW, s);
+  const size_t smem = (size_t)2 * (C / 32) * BK_XPX * BK_ROWB;
+  dim3 grid((unsigned)(tiles * N));
+  if (C == 32)
+    hipLaunchKernelGGL(conv_block_kernel<32>, grid, dim3(256), smem, s, a);
+  else
+    hipLaunchKernelGGL(conv_block_kernel<64>, grid, dim3(256), smem, s, a);
+  return 0;
+}

@@ -259,10 +259,11 @@ __device__ __forceinline__ void conv_tile_store(const ConvArgs& a, const float* 
 
 // Launcher side of the max |x| rows: sets a.amax_tiles; more workgroups per image than a row has slots -> the rows are
 // zeroed here and the kernel folds with atomics (conv_amax_put).
+void mval_launch_zero_rows(unsigned* rows, int64_t n_dwords, hipStream_t s);  // net.hip (a kernel: graph-capturable anywhere)
 static inline void conv_amax_prepare(ConvArgs& a, int tiles_per_image, int groups, hipStream_t s) {
   a.amax_tiles = tiles_per_image;
   if (a.out_amax && (int64_t)tiles_per_image * groups * 4 > MVAL_AMAX_ROW - 1)  // (up to 4 waves per workgroup)
-    (void)hipMemsetAsync(a.out_amax, 0, (size_t)a.N * MVAL_AMAX_ROW * sizeof(unsigned), s);
+    mval_launch_zero_rows(a.out_amax, (int64_t)a.N * MVAL_AMAX_ROW, s);
 }
 
 int mval_launch_conv_mfma(const ConvArgs& a, hipStream_t s);  // conv_mfma.hip; returns 1 if unsupported
@@ -272,6 +273,12 @@ int mval_conv_split_supported(const ConvArgs& a);
 int mval_pack_bf3(int mode, const float* w, float* packed, int cout, int cin, int k, hipStream_t s);
 int mval_pack_h2(int mode, const float* w, float* packed, int cout, int cin, int k, hipStream_t s);
 // net.hip: rows[i][*] = max(rows[i][*], max |x| over image i) for n_images images of per_image floats each
+// conv_block.hip: a whole BasicBlock (two 3x3 convs + BNs + residual + ReLUs) in one launch; returns 1 if unsupported
+int mval_conv_block_supported(int C, int N, int H, int W);
+int mval_launch_conv_block(int C, const float* in, float* out, const float* w1, const float* scale1, const float* shift1,
+                           const float* w1_unscale, const float* w2, const float* scale2, const float* shift2,
+                           const float* w2_unscale, const unsigned* in_amax, unsigned* out_amax, int N, int H, int W,
+                           hipStream_t s);
 int mval_launch_amax(const float* x, int64_t per_image, int n_images, unsigned* rows, hipStream_t s);
 int mval_pack_bf3_batch(const void* jobs_dev, const int* first_block_dev, int n_jobs, int total_blocks, hipStream_t s);
 int mval_launch_conv_direct(const ConvArgs& a, int kind, hipStream_t s);

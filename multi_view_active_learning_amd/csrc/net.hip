@@ -230,6 +230,15 @@ __global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, 
   conv_amax_commit(slots + (int64_t)blockIdx.y * MVAL_AMAX_ROW, (int)blockIdx.x, (int)gridDim.x, m);
 }
 
+__global__ void zero_rows_kernel(unsigned* rows, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) rows[i] = 0u;
+}
+void mval_launch_zero_rows(unsigned* rows, int64_t n_dwords, hipStream_t s) {
+  int64_t blocks = (n_dwords + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(zero_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, s, rows, n_dwords);
+}
+
 int mval_launch_amax(const float* x, int64_t per_image, int n_images, unsigned* slots, hipStream_t s) {
   const int vec = (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (per_image & 3) == 0;
   int64_t blocks = (per_image / 4 + 255) / 256;
@@ -318,6 +327,10 @@ static void deconv_parity(ConvArgs& a, const mval_op* op, int parity, const floa
 }
 
 extern "C" int mval_op_algo_supported(const mval_op* op, int n_images, int algo) {
+  if (op && op->kind == MVAL_OP_BLOCK)
+    return algo == MVAL_ALGO_MFMA_H2 && n_images > 0 && op->cin == op->cout && op->k == 3 && op->stride == 1 && op->pad == 1 &&
+           !op->up && !op->in_nchw && !op->out_nchw && op->hin == op->hout && op->win == op->wout &&
+           mval_conv_block_supported(op->cin, n_images, op->hin, op->win);
   if (algo == MVAL_ALGO_MFMA) return mval_op_mfma_supported(op, n_images);
   if ((algo != MVAL_ALGO_MFMA_BF3 && algo != MVAL_ALGO_MFMA_H2) || !op || n_images <= 0) return 0;
   if (op->kind != MVAL_OP_CONV && op->kind != MVAL_OP_DECONV) return 0;
@@ -345,6 +358,22 @@ extern "C" int mval_op_launch(const mval_op* op, int n_images, float* workspace,
   fill_geometry(a, op, n_images);
   MVAL_REQUIRE(a.in && a.out, "mval_op_launch: missing input/output buffer");
   hipStream_t s = mval_stream(stream);
+  if (op->kind == MVAL_OP_BLOCK) {
+    MVAL_REQUIRE(op->algo == MVAL_ALGO_MFMA_H2 && op->in_amax_off > 0 && a.w && a.scale && a.shift && op->w2_off >= 0 &&
+                     op->scale2_off >= 0 && op->shift2_off >= 0 && (op->res1_off < 0 || op->res1_off == op->in_off) &&
+                     op->res2_off < 0 && op->relu,
+                 "mval_op_launch: malformed MVAL_OP_BLOCK");
+    const size_t nw = mval_packed_weight_floats(MVAL_PACK_MFMA16_H2, op->cout, op->cin, 3);
+    const float* w2 = params + op->w2_off;
+    int rc = mval_launch_conv_block(op->cin, a.in, a.out, a.w, a.scale, a.shift, a.w + nw - 4, w2, params + op->scale2_off,
+                                    params + op->shift2_off, w2 + nw - 4,
+                                    reinterpret_cast<const unsigned*>(workspace + op->in_amax_off),
+                                    op->out_amax_off > 0 ? reinterpret_cast<unsigned*>(workspace + op->out_amax_off) : nullptr,
+                                    n_images, op->hin, op->win, s);
+    MVAL_REQUIRE(rc == 0, "mval_op_launch: no fused BasicBlock kernel for c%d %dx%d", op->cin, op->hin, op->win);
+    MVAL_CHECK_LAUNCH("mval_op_launch/block");
+    return 0;
+  }
   const bool split = op->algo == MVAL_ALGO_MFMA_BF3 || op->algo == MVAL_ALGO_MFMA_H2;
   a.out_amax = op->out_amax_off > 0 ? reinterpret_cast<unsigned*>(workspace + op->out_amax_off) : nullptr;
   bool amax_kept = false;  // does the kernel that runs keep out_amax itself?
@@ -395,12 +424,22 @@ extern "C" int mval_op_launch(const mval_op* op, int n_images, float* workspace,
 // kernel overlaps the head of another's instead of leaving CUs idle at ~300 kernel boundaries.
 #define MVAL_MAX_LANES 4
 
-struct MvalNet {
-  std::vector<mval_op> ops;
-
+// The side streams and the fork / join events are per DEVICE, created on first use and never destroyed: nets come
+// and go with their plans (every (N, H, W) of every model has one), and creating / destroying streams around
+// hipGraph captures made a later capture's replay crash inside the HIP runtime (round 2: five plans' worth of
+// stream churn before a capture).  Forwards of different nets on one device therefore share the lanes; stream order
+// keeps that correct.
+struct MvalLanes {
   hipStream_t side[MVAL_MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t fork_ev = nullptr;
   hipEvent_t join_ev[MVAL_MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};
+  bool ready = false;
+};
+#define MVAL_MAX_DEVICES 16
+static MvalLanes g_lanes[MVAL_MAX_DEVICES];
+
+struct MvalNet {
+  std::vector<mval_op> ops;
   int n_lanes = 1;
   int lanes_override = -1;  // -1: MVAL_STREAMS decides; 0 / 1: forced off / on (mval_net_set_multi_stream)
 };
@@ -434,24 +473,21 @@ extern "C" int mval_net_set_multi_stream(void* net, int mode) {
 }
 
 extern "C" void mval_net_destroy(void* net) {
-  MvalNet* n = reinterpret_cast<MvalNet*>(net);
-  if (!n) return;
-  for (int l = 1; l < MVAL_MAX_LANES; l++) {
-    if (n->side[l]) (void)hipStreamDestroy(n->side[l]);
-    if (n->join_ev[l]) (void)hipEventDestroy(n->join_ev[l]);
-  }
-  if (n->fork_ev) (void)hipEventDestroy(n->fork_ev);
-  delete n;
+  delete reinterpret_cast<MvalNet*>(net);
 }
 
-static int ensure_streams(MvalNet* n) {
-  if (n->fork_ev) return 0;
-  if (hipEventCreateWithFlags(&n->fork_ev, hipEventDisableTiming) != hipSuccess) return -1;
-  for (int l = 1; l < n->n_lanes; l++) {
-    if (hipStreamCreateWithFlags(&n->side[l], hipStreamNonBlocking) != hipSuccess) return -1;
-    if (hipEventCreateWithFlags(&n->join_ev[l], hipEventDisableTiming) != hipSuccess) return -1;
+static MvalLanes* device_lanes() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MVAL_MAX_DEVICES) return nullptr;
+  MvalLanes* L = &g_lanes[dev];
+  if (L->ready) return L;
+  if (hipEventCreateWithFlags(&L->fork_ev, hipEventDisableTiming) != hipSuccess) return nullptr;
+  for (int l = 1; l < MVAL_MAX_LANES; l++) {
+    if (hipStreamCreateWithFlags(&L->side[l], hipStreamNonBlocking) != hipSuccess) return nullptr;
+    if (hipEventCreateWithFlags(&L->join_ev[l], hipEventDisableTiming) != hipSuccess) return nullptr;
   }
-  return 0;
+  L->ready = true;
+  return L;
 }
 
 extern "C" int mval_net_forward(void* net, int n_images, float* workspace, const float* params,
@@ -460,14 +496,15 @@ extern "C" int mval_net_forward(void* net, int n_images, float* workspace, const
   MvalNet* n = reinterpret_cast<MvalNet*>(net);
   hipStream_t main_s = mval_stream(stream);
   const bool multi = n->n_lanes > 1 && (n->lanes_override < 0 ? multi_stream_enabled() : n->lanes_override != 0);
-  if (multi) MVAL_REQUIRE(ensure_streams(n) == 0, "mval_net_forward: could not create side streams");
+  MvalLanes* L = multi ? device_lanes() : nullptr;
+  if (multi) MVAL_REQUIRE(L != nullptr, "mval_net_forward: could not create the side streams");
   bool used[MVAL_MAX_LANES] = {false, false, false, false};
   int phase = n->ops.empty() ? 0 : n->ops[0].phase;
   auto join = [&]() {  // side streams -> main
     for (int l = 1; l < n->n_lanes; l++)
       if (used[l]) {
-        (void)hipEventRecord(n->join_ev[l], n->side[l]);
-        (void)hipStreamWaitEvent(main_s, n->join_ev[l], 0);
+        (void)hipEventRecord(L->join_ev[l], L->side[l]);
+        (void)hipStreamWaitEvent(main_s, L->join_ev[l], 0);
         used[l] = false;
       }
   };
@@ -484,16 +521,16 @@ extern "C" int mval_net_forward(void* net, int n_images, float* workspace, const
       if (!forked) {
         // recorded at the START of the phase, before its lane-0 ops are enqueued: the side lanes then wait for the
         // previous phases only, not for this phase's (longest) lane-0 chain as well
-        (void)hipEventRecord(n->fork_ev, main_s);
+        (void)hipEventRecord(L->fork_ev, main_s);
         forked = true;
       }
       int lane = op.lane < n->n_lanes ? op.lane : 0;
       if (lane > 0) {
         if (!used[lane]) {
-          (void)hipStreamWaitEvent(n->side[lane], n->fork_ev, 0);
+          (void)hipStreamWaitEvent(L->side[lane], L->fork_ev, 0);
           used[lane] = true;
         }
-        s = n->side[lane];
+        s = L->side[lane];
       }
     }
     int rc = mval_op_launch(&n->ops[i], n_images, workspace, params, input_nchw, output_nchw, s);
@@ -505,6 +542,8 @@ extern "C" int mval_net_forward(void* net, int n_images, float* workspace, const
 
 extern "C" double mval_op_flops(const mval_op* op, int n_images) {
   if (!op || op->kind == MVAL_OP_MAXPOOL) return 0.0;
+  if (op->kind == MVAL_OP_BLOCK)  // algorithmic work of the two convs (the halo recompute is not counted)
+    return 2.0 * 2.0 * n_images * op->hout * op->wout * (double)op->cin * op->cout * 9;
   if (op->kind == MVAL_OP_DECONV)  // every input pixel meets every tap once
     return 2.0 * n_images * op->hin * op->win * (double)op->cin * op->cout * op->k * op->k;
   return 2.0 * n_images * op->hout * op->wout * (double)op->cin * op->cout * op->k * op->k;

@@ -25,10 +25,10 @@ import torch
 from . import _lib
 from .pose_estimators import params as _params
 
-OP_CONV, OP_MAXPOOL, OP_DECONV = 0, 1, 2
+OP_CONV, OP_MAXPOOL, OP_DECONV, OP_BLOCK = 0, 1, 2, 3
 ALGO_DIRECT, ALGO_MFMA, ALGO_MFMA_BF3, ALGO_MFMA_H2 = 0, 1, 2, 3
 PACK_HWIO, PACK_MFMA16, PACK_MFMA16_BF3, PACK_MFMA16_H2 = 0, 1, 2, 3
-AMAX_ROW = 1024
+AMAX_ROW = 4096
 _PACK_OF = {ALGO_DIRECT: PACK_HWIO, ALGO_MFMA: PACK_MFMA16, ALGO_MFMA_BF3: PACK_MFMA16_BF3, ALGO_MFMA_H2: PACK_MFMA16_H2}
 
 
@@ -45,6 +45,7 @@ class MvalOp(C.Structure):
         ("w_off", C.c_int64), ("scale_off", C.c_int64), ("shift_off", C.c_int64),
         ("phase", C.c_int32), ("lane", C.c_int32),
         ("in_amax_off", C.c_int64), ("out_amax_off", C.c_int64),
+        ("w2_off", C.c_int64), ("scale2_off", C.c_int64), ("shift2_off", C.c_int64),
     ]
 
 
@@ -207,14 +208,56 @@ class InferencePlan:
         for i, op in enumerate(g.ops):
             self.ops[i].out_amax_off = amax_slot.get(op.dst, 0)
         self.arena_floats = _align(self._amax_top)
+        self.graph_ops = self.ops  # one per graph op (what param_jobs index); self.ops becomes the launch list
+        self.ops = self._fuse_blocks(lib, g, n)
         self.param_floats = max(ptop, 64)
         self.arena = torch.empty(self.arena_floats, dtype=torch.float32, device=device)
         self.params = torch.zeros(self.param_floats, dtype=torch.float32, device=device)
         self.param_sig = None
         self._graph, self._graph_failed = None, False
-        self.net = lib.mval_net_create(self.ops, C.c_int(len(g.ops)))
+        self.net = lib.mval_net_create(self.ops, C.c_int(len(self.ops)))
         if not self.net:
             raise _lib.MvalError("mval_net_create failed: " + lib.mval_last_error().decode())
+
+    def _fuse_blocks(self, lib, g, n):
+        """Launch list: every BasicBlock of the 32- / 64-channel branches (conv3x3+BN+ReLU -> conv3x3+BN+residual+ReLU,
+        hrnet.py:36-52) whose two convs run on the fp16-split kernels becomes ONE MVAL_OP_BLOCK launch
+        (csrc/conv_block.hip); everything else is launched op by op.  MVAL_FUSE_BLOCKS=0 keeps the unfused pair (the
+        on-device cross-check of the fused kernel, tests/test_gpu_models.py)."""
+        fuse = os.environ.get("MVAL_FUSE_BLOCKS", "1") != "0"
+        uses = {}
+        for op in g.ops:
+            for a in (op.src, op.res1, op.res2):
+                if a is not None:
+                    uses[a] = uses.get(a, 0) + 1
+        launch, i = [], 0
+        while i < len(g.ops):
+            a = g.ops[i]
+            b = g.ops[i + 1] if i + 1 < len(g.ops) else None
+            ma = self.graph_ops[i]
+            if (fuse and b is not None and a.kind == b.kind == "conv" and a.k == b.k == 3 and a.stride == b.stride == 1
+                    and a.pad == b.pad == 1 and a.cin == a.cout == b.cin == b.cout and a.cin in (32, 64) and a.bn and b.bn
+                    and a.relu and b.relu and a.res1 is None and a.res2 is None and a.up == b.up == 0 and b.src == a.dst
+                    and b.res1 == a.src and b.res2 is None and uses.get(a.dst, 0) == 1 and a.dst != g.output
+                    and (a.phase, a.lane) == (b.phase, b.lane)
+                    and ma.algo == self.graph_ops[i + 1].algo == ALGO_MFMA_H2):
+                mb = self.graph_ops[i + 1]
+                blk = MvalOp()
+                C.memmove(C.byref(blk), C.byref(ma), C.sizeof(MvalOp))
+                blk.kind = OP_BLOCK
+                blk.out_off, blk.res1_off, blk.res2_off = mb.out_off, ma.in_off, -1
+                blk.out_amax_off = mb.out_amax_off
+                blk.w2_off, blk.scale2_off, blk.shift2_off = mb.w_off, mb.scale_off, mb.shift_off
+                if lib.mval_op_algo_supported(C.byref(blk), C.c_int(n), C.c_int(ALGO_MFMA_H2)):
+                    launch.append(blk)
+                    i += 2
+                    continue
+            launch.append(ma)
+            i += 1
+        arr = (MvalOp * len(launch))()
+        for k, m in enumerate(launch):
+            C.memmove(C.byref(arr[k]), C.byref(m), C.sizeof(MvalOp))
+        return arr
 
     def __del__(self):
         try:
@@ -333,10 +376,10 @@ class InferencePlan:
         return out, np.asarray(list(ms), dtype=np.float64), np.asarray(flops)
 
     def run_op(self, i, x, out):
-        """Launch a single op (debug / layer-wise tests)."""
+        """Launch a single GRAPH op, unfused (debug / layer-wise tests)."""
         _lib._check(
             _lib.lib().mval_op_launch(
-                C.byref(self.ops[i]), C.c_int(self.n), C.c_void_p(self.arena.data_ptr()),
+                C.byref(self.graph_ops[i]), C.c_int(self.n), C.c_void_p(self.arena.data_ptr()),
                 C.c_void_p(self.params.data_ptr()), C.c_void_p(x.data_ptr()), C.c_void_p(out.data_ptr()),
                 _lib._stream()),
             "mval_op_launch")
@@ -347,7 +390,7 @@ def _plan_for(model, x):
     if c != 3:
         raise ValueError("expected (N, 3, H, W) images")
     cache = model.__dict__.setdefault("_plans", {})
-    key = (n, h, w, x.device.index, os.environ.get("MVAL_FORCE_DIRECT") == "1", _conv_mode())
+    key = (n, h, w, x.device.index, os.environ.get("MVAL_FORCE_DIRECT") == "1", _conv_mode(), os.environ.get("MVAL_FUSE_BLOCKS", "1"))
     plan = cache.get(key)
     if plan is None:
         if len(cache) >= 4:  # keep the arena footprint bounded

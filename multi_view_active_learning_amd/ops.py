@@ -8,7 +8,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from .engine import (ALGO_DIRECT, ALGO_MFMA, ALGO_MFMA_BF3, ALGO_MFMA_H2, OP_CONV, OP_DECONV, OP_MAXPOOL, PACK_HWIO,
+from .engine import (ALGO_DIRECT, ALGO_MFMA, ALGO_MFMA_BF3, ALGO_MFMA_H2, OP_BLOCK, OP_CONV, OP_DECONV, OP_MAXPOOL, PACK_HWIO,
                      PACK_MFMA16, PACK_MFMA16_BF3, AMAX_ROW, _PACK_OF, MvalOp, _align)
 
 
@@ -105,6 +105,44 @@ def fused_conv(x, weight, scale, shift, stride=1, pad=None, relu=False, res1=Non
     fused_conv.last_out_amax = torch.where(live, rows[:, 1:], torch.zeros_like(rows[:, 1:])).amax(1)
     out = arena[out_off : out_off + n * ho * wo * cout]
     return out.reshape(n, cout, ho, wo) if out_nchw else out.reshape(n, ho, wo, cout)
+
+
+def fused_basic_block(x, w1, scale1, shift1, w2, scale2, shift2):
+    """relu(bn2(conv3x3(relu(bn1(conv3x3(x))))) + x) in ONE launch (MVAL_OP_BLOCK, csrc/conv_block.hip): x NHWC
+    (N,H,W,C) with C in {32, 64}, w1 / w2 (C,C,3,3), folded BatchNorms as (scale, shift).  Returns NHWC."""
+    dev = x.device
+    n, h, w, c = x.shape
+    lib = _lib.lib()
+    pw1, pw2 = pack_weights(w1, ALGO_MFMA_H2), pack_weights(w2, ALGO_MFMA_H2)
+    out_off = _align(x.numel())
+    amax_off = _align(out_off + x.numel())
+    arena = torch.zeros(amax_off + _align(2 * n * AMAX_ROW), dtype=torch.float32, device=dev)
+    arena[: x.numel()] = x.contiguous().reshape(-1)
+    offs, top = [], 0
+    chunks = []
+    for t in (pw1, scale1, shift1, pw2, scale2, shift2):
+        offs.append(top)
+        chunks.append(t.to(dev, torch.float32).reshape(-1))
+        top += _align(chunks[-1].numel())
+    params = torch.zeros(top, dtype=torch.float32, device=dev)
+    for o, t in zip(offs, chunks):
+        params[o : o + t.numel()] = t
+    m = MvalOp()
+    m.kind, m.algo = OP_BLOCK, ALGO_MFMA_H2
+    m.k, m.stride, m.pad, m.cin, m.cout = 3, 1, 1, c, c
+    m.hin, m.win, m.hout, m.wout = h, w, h, w
+    m.up, m.relu, m.in_nchw, m.out_nchw = 0, 1, 0, 0
+    m.in_off, m.out_off, m.res1_off, m.res2_off = 0, out_off, 0, -1
+    m.w_off, m.scale_off, m.shift_off, m.w2_off, m.scale2_off, m.shift2_off = offs
+    m.in_amax_off, m.out_amax_off = amax_off, amax_off + n * AMAX_ROW
+    _lib._check(lib.mval_amax(_lib._p(arena), C.c_int64(h * w * c), C.c_int(n), C.c_void_p(arena.data_ptr() + 4 * amax_off),
+                              _lib._stream()), "mval_amax")
+    _lib._check(lib.mval_op_launch(C.byref(m), C.c_int(n), _lib._p(arena), _lib._p(params), C.c_void_p(0), C.c_void_p(0),
+                                   _lib._stream()), "mval_op_launch")
+    rows = arena[amax_off + n * AMAX_ROW : amax_off + 2 * n * AMAX_ROW].view(torch.int32).reshape(n, AMAX_ROW)
+    live = torch.arange(AMAX_ROW - 1, device=dev)[None, :] < rows[:, :1]
+    fused_basic_block.last_out_amax = torch.where(live, rows[:, 1:], torch.zeros_like(rows[:, 1:])).amax(1)
+    return arena[out_off : out_off + x.numel()].reshape(n, h, w, c)
 
 
 def conv_dgrad(dz, weight, in_hw, stride=1, algo=ALGO_MFMA, accumulate_into=None):

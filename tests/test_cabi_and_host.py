@@ -74,7 +74,7 @@ def test_plan_geometry_and_arena(lib, name):
     # no op may read and write overlapping arena ranges
     g = m._graph
     for i, op in enumerate(g.ops):
-        o = p.ops[i]
+        o = p.graph_ops[i]
         if o.out_off < 0:
             continue
         out_n = 4 * (o.hout << o.up) * (o.wout << o.up) * o.cout

@@ -133,6 +133,41 @@ def test_fused_conv_vs_torch_cpu(dev, algo, case):
             assert rms_gpu <= 1.25 * rms_f32 + 1e-8 and err_gpu <= 2.5 * err_f32 + 1e-7, (algo, err_gpu, err_f32, rms_gpu, rms_f32)
 
 
+@pytest.mark.parametrize("shape", [(3, 32, 64, 64), (2, 64, 32, 32), (2, 32, 21, 37), (1, 64, 9, 16), (5, 32, 8, 16)],
+                         ids=lambda s: "n%d_c%d_%dx%d" % s)
+def test_fused_basic_block_vs_torch_cpu(dev, shape):
+    """MVAL_OP_BLOCK (a whole hrnet.py:19-52 BasicBlock in one launch) against torch-CPU fp32 and float64, and
+    against the same block as two fused-conv launches of the fp16-split kernel (it must not be less accurate)."""
+    from multi_view_active_learning_amd import ops
+
+    n, c, h, w = shape
+    rng = np.random.default_rng(7 + h)
+    x = torch.from_numpy(np.maximum(rng.standard_normal((n, c, h, w)), 0).astype(np.float32) * 1.5)  # post-ReLU input
+    ws = [torch.from_numpy((rng.standard_normal((c, c, 3, 3)) * np.sqrt(2.0 / (c * 9))).astype(np.float32)) for _ in range(2)]
+    sc = [torch.from_numpy(rng.uniform(0.5, 1.5, c).astype(np.float32)) for _ in range(2)]
+    sh = [torch.from_numpy(rng.standard_normal(c).astype(np.float32) * 0.1) for _ in range(2)]
+
+    def ref(dt):
+        mid = _ref_conv(x.to(dt), ws[0].to(dt), sc[0].to(dt), sh[0].to(dt), 1, True, None, None, 0)
+        return _ref_conv(mid, ws[1].to(dt), sc[1].to(dt), sh[1].to(dt), 1, True, x.to(dt), None, 0)
+
+    want, want64 = ref(torch.float32), ref(torch.float64)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    got = ops.fused_basic_block(xd, ws[0].to(dev), sc[0].to(dev), sh[0].to(dev), ws[1].to(dev), sc[1].to(dev), sh[1].to(dev))
+    kept = ops.fused_basic_block.last_out_amax.cpu().view(torch.float32)
+    got = got.permute(0, 3, 1, 2).cpu()
+    assert torch.equal(kept, got.abs().amax(dim=(1, 2, 3))), "per-image max |x| rows"
+    np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=1e-4, atol=2e-5)
+    mid = ops.fused_conv(xd, ws[0].to(dev), sc[0].to(dev), sh[0].to(dev), relu=True, algo=ops.ALGO_MFMA_H2)
+    two = ops.fused_conv(mid, ws[1].to(dev), sc[1].to(dev), sh[1].to(dev), relu=True, res1=xd, algo=ops.ALGO_MFMA_H2).permute(0, 3, 1, 2).cpu()
+    rms = lambda y: (y.double() - want64).pow(2).mean().sqrt().item()
+    assert rms(got) <= 1.25 * rms(two) + 1e-8, (rms(got), rms(two), rms(want))
+    # batch independence: image 0 alone gives the same bits
+    alone = ops.fused_basic_block(xd[:1].contiguous(), ws[0].to(dev), sc[0].to(dev), sh[0].to(dev), ws[1].to(dev), sc[1].to(dev),
+                                  sh[1].to(dev)).permute(0, 3, 1, 2).cpu()
+    assert torch.equal(alone[0], got[0])
+
+
 def test_stem_maxpool_deconv_direct(dev):
     from multi_view_active_learning_amd import ops
 
@@ -218,6 +253,28 @@ def test_network_vs_reference_golden(dev, name, mode, monkeypatch):
     assert np.all(same | risky), "arg-max moved on a map whose top-2 margin is above the tolerance"
     np.testing.assert_allclose(flat.max(-1), z[name + "/max"], rtol=0, atol=tol)
     np.testing.assert_allclose(flat.mean(-1), z[name + "/mean"], rtol=0, atol=tol)
+
+
+def test_network_fused_blocks_vs_unfused(dev, monkeypatch):
+    """HRNet-W32 at 256 x 256 (the 32- and 64-channel BasicBlocks run as MVAL_OP_BLOCK launches) against the
+    same plan with MVAL_FUSE_BLOCKS=0 and against the reference golden."""
+    c = cases.model_cases()["w32"]
+    z = np.load(os.path.join(G, "models.npz"))
+    m, _ = _load(c, dev)
+    x = torch.from_numpy(cases.model_input(c)).to(dev)
+    from multi_view_active_learning_amd import engine
+
+    with torch.no_grad():
+        y1 = m(x).cpu()
+        kinds = [o.kind for o in engine._plan_for(m, x).ops]
+        assert kinds.count(engine.OP_BLOCK) == 64, "32 + 32 BasicBlocks of the two high-resolution branches"
+        monkeypatch.setenv("MVAL_FUSE_BLOCKS", "0")
+        y2 = m(x).cpu()
+        assert engine.OP_BLOCK not in [o.kind for o in engine._plan_for(m, x).ops]
+    want0 = torch.from_numpy(z["w32/heatmaps0"])
+    tol = 2e-4 * float(want0.abs().max())
+    assert float((y1[0] - want0).abs().max()) <= tol and float((y2[0] - want0).abs().max()) <= tol
+    assert float((y1 - y2).abs().max()) <= tol
 
 
 def test_network_mfma_vs_direct_kernels(dev, monkeypatch):

@@ -33,7 +33,7 @@ def bench(cin, cout, h, w, stride, k=3):
     res_off = _align(x.numel())
     out_off = res_off + _align(n * ho * wo * cout)
     amax_off = _align(out_off + n * ho * wo * cout)  # per-image max |x| slots (input, output)
-    arena = torch.zeros(amax_off + _align(2 * n * 1024), device=dev)
+    arena = torch.zeros(amax_off + _align(2 * n * 4096), device=dev)
     arena[: x.numel()] = x.reshape(-1)
     arena[res_off : res_off + n * ho * wo * cout] = torch.randn(n * ho * wo * cout, device=dev)
     s_off = _align(pw.numel())
@@ -47,7 +47,7 @@ def bench(cin, cout, h, w, stride, k=3):
     m.up, m.relu, m.in_nchw, m.out_nchw = 0, 1, 0, 0
     m.in_off, m.out_off, m.res1_off, m.res2_off = 0, out_off, res_off, -1
     m.w_off, m.scale_off, m.shift_off = 0, s_off, s_off + _align(cout)
-    m.in_amax_off, m.out_amax_off = amax_off, amax_off + n * 1024
+    m.in_amax_off, m.out_amax_off = amax_off, amax_off + n * 4096
     _lib._check(lib.mval_amax(_lib._p(arena), C.c_int64(h * w * cin), C.c_int(n), C.c_void_p(arena.data_ptr() + 4 * amax_off),
                               _lib._stream()), "mval_amax")
 
@@ -69,3 +69,60 @@ def bench(cin, cout, h, w, stride, k=3):
 
 for layer in LAYERS:
     bench(*layer)
+
+
+def bench_block(c, h, w):
+    """A whole BasicBlock (MVAL_OP_BLOCK) on n images of c x h x w, next to the same block as two h2 launches."""
+    x = torch.relu(torch.randn(n, h, w, c, device=dev))
+    ws = [torch.randn(c, c, 3, 3, device=dev) * (2.0 / (c * 9)) ** 0.5 for _ in range(2)]
+    one, zero = torch.ones(c, device=dev), torch.zeros(c, device=dev)
+
+    def run():
+        return ops.fused_basic_block(x, ws[0], one, zero, ws[1], one, zero)
+
+    # ops.fused_basic_block re-packs weights and re-builds its arena per call: time the launch alone through events
+    for _ in range(3):
+        run()
+    # build once, launch many
+    pw = [ops.pack_weights(wt, ops.ALGO_MFMA_H2) for wt in ws]
+    out_off = _align(x.numel())
+    amax_off = _align(out_off + x.numel())
+    arena = torch.zeros(amax_off + _align(2 * n * 4096), device=dev)
+    arena[: x.numel()] = x.reshape(-1)
+    offs, top = [], 0
+    for t in (pw[0], one, zero, pw[1], one, zero):
+        offs.append(top)
+        top += _align(t.numel())
+    params = torch.zeros(top, device=dev)
+    for o, t in zip(offs, (pw[0], one, zero, pw[1], one, zero)):
+        params[o : o + t.numel()] = t
+    m = MvalOp()
+    m.kind, m.algo = 3, ops.ALGO_MFMA_H2
+    m.k, m.stride, m.pad, m.cin, m.cout = 3, 1, 1, c, c
+    m.hin, m.win, m.hout, m.wout = h, w, h, w
+    m.up, m.relu = 0, 1
+    m.in_off, m.out_off, m.res1_off, m.res2_off = 0, out_off, 0, -1
+    m.w_off, m.scale_off, m.shift_off, m.w2_off, m.scale2_off, m.shift2_off = offs
+    m.in_amax_off, m.out_amax_off = amax_off, amax_off + n * 4096
+    _lib._check(lib.mval_amax(_lib._p(arena), C.c_int64(h * w * c), C.c_int(n), C.c_void_p(arena.data_ptr() + 4 * amax_off),
+                              _lib._stream()), "mval_amax")
+
+    def launch():
+        _lib._check(lib.mval_op_launch(C.byref(m), C.c_int(n), _lib._p(arena), _lib._p(params), C.c_void_p(0),
+                                       C.c_void_p(0), _lib._stream()), "launch")
+
+    for _ in range(5):
+        launch()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        launch()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    fl = 2 * 2.0 * n * h * w * c * c * 9
+    print(f"block {c}ch {h}x{w} n={n}: {dt * 1e6:7.1f} us  {fl / dt / 1e12:6.1f} TFLOP/s (two convs)", flush=True)
+
+
+if algo_name == "h2":
+    bench_block(32, 64, 64)
+    bench_block(64, 32, 32)

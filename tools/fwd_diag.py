@@ -22,7 +22,7 @@ for mode in ("fp32", "bf3"):
     plan = InferencePlan(model, n, h, w, dev)
     plan.refresh_params()
     res = []
-    for i, op in enumerate(plan.ops):
+    for i, op in enumerate(plan.graph_ops):
         # run op by op; copy every output out of the (re-used) arena right away
         out = torch.empty((n, plan.out_channels) + tuple(plan.out_hw), device=dev)
         plan.run_op(i, x, out)
@@ -37,7 +37,7 @@ worst = []
 for i, (a, b) in enumerate(zip(res32, res3)):
     d = (a - b).abs().max().item()
     s = a.abs().max().item() + 1e-30
-    op = plan.ops[i]
+    op = plan.graph_ops[i]
     worst.append((d / s, i, op.algo, op.k, op.stride, op.cin, op.cout, op.hout, op.wout, op.up, g.ops[i].conv))
 for r in worst:
     if r[0] > 1e-4:
