@@ -89,6 +89,13 @@ enum { MVAL_REDUCE_AVG_F64 = 0, MVAL_REDUCE_AVG_F32 = 1, MVAL_REDUCE_STD_F64 = 2
 int mval_score_maps(int kind, const float* heatmaps, float* stat, int32_t* n_peaks,
                     int64_t n_maps, int hh, int wh, void* stream);
 
+/* The same statistic AND the hard arg-max key-point of every map (utils/evaluation.py:13-30, as mval_argmax_decode)
+ * from ONE staged read of each heat-map: what a scoring pass of strategy.py:1027-1090 needs per map.
+ *   heatmaps [B,V,J,hh,wh] f32 ; valid [B,J] u8 or NULL (invalid joints -> key-point (0, 0); their statistic is
+ *   still written, mval_score_reduce skips it) ; stat, n_peaks [B*V*J] ; kp2d [B,V,J,2] i64 (x, y). */
+int mval_score_decode_maps(int kind, const float* heatmaps, const uint8_t* valid, float* stat, int32_t* n_peaks,
+                           int64_t* kp2d, int B, int V, int J, int hh, int wh, int stride, int split_width, void* stream);
+
 /* AVG / STD over the valid (view, joint) maps of each frame in the reference's python /
  * numpy evaluation order and precision (strategy.py:1151-1155,1188-1193,1210-1215;
  * SURVEY A.8).  per_map [B,V,J] f32 ; valid [B,J] u8 or NULL ; out [B] f64. */

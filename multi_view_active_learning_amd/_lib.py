@@ -169,6 +169,22 @@ def score_maps(kind, hm, n_maps, hh, wh):
     return out, cnt
 
 
+def score_decode_maps(kind, hm, valid, b, v, j, hh, wh, stride, split_width):
+    """Per-map statistic + peak count + hard arg-max key-points (B,V,J,2) int64 from ONE read of the heat-maps."""
+    n_maps = b * v * j
+    out = torch.empty((n_maps,), dtype=torch.float32, device=hm.device)
+    cnt = torch.empty((n_maps,), dtype=torch.int32, device=hm.device)
+    kp = torch.empty((b, v, j, 2), dtype=torch.int64, device=hm.device)
+    _check(
+        lib().mval_score_decode_maps(
+            C.c_int(kind), _p(_req(hm, torch.float32, "heatmaps")), _p(valid), _p(out), _p(cnt), _p(kp),
+            C.c_int(b), C.c_int(v), C.c_int(j), C.c_int(hh), C.c_int(wh), C.c_int(stride), C.c_int(split_width), _stream(),
+        ),
+        "mval_score_decode_maps",
+    )
+    return out, cnt, kp
+
+
 def score_reduce(per_map, valid, b, v, j, mode):
     out = torch.empty((b,), dtype=torch.float64, device=per_map.device)
     _check(

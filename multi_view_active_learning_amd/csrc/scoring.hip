@@ -46,40 +46,112 @@ __device__ __forceinline__ bool cand_before(float va, int ia, float vb, int ib) 
   return (va > vb) || (va == vb && ia < ib);
 }
 
-template <int KIND>
+// order of torch.argmax: NaN is the maximum; ties -> lowest flat index (as csrc/decode.hip)
+__device__ __forceinline__ bool sc_better(float v, int i, float bv, int bi) {
+  const bool vn = v != v, bn = bv != bv;
+  if (vn != bn) return vn;
+  if (vn) return i < bi;
+  return (v > bv) || (v == bv && i < bi);
+}
+
+// DECODE: the same staged copy also yields the hard arg-max key-point of the map (utils/evaluation.py:13-30, what
+// mval_argmax_decode computes from a second read of the heat-maps): one pass over each map per scoring pass.
+struct ScoreDecodeArgs {
+  const uint8_t* valid;  // [B,J] or null
+  int64_t* kp2d;         // [n_maps,2] (x, y)
+  int V, J, stride, split_width;
+};
+
+template <int KIND, bool DECODE>
 __global__ __launch_bounds__(SC_THREADS) void score_maps_kernel(const float* __restrict__ hm, float* __restrict__ stat,
-                                                                int32_t* __restrict__ n_peaks, int hh, int wh) {
+                                                                int32_t* __restrict__ n_peaks, int hh, int wh,
+                                                                ScoreDecodeArgs d) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const int ld = wh + 1;
   float* tile = reinterpret_cast<float*>(smem_raw);                      // hh * ld
+  // (the HP kernel has no candidate list: its workgroups need only the tile, so twice as many fit a CU)
   float* cval = tile + (((hh * ld) + 3) & ~3);                           // SC_MAX_PEAKS
-  int* cidx = reinterpret_cast<int*>(cval + SC_MAX_PEAKS);               // SC_MAX_PEAKS
-  ScoreSmem* sm = reinterpret_cast<ScoreSmem*>(cidx + SC_MAX_PEAKS);
+  int* cidx = reinterpret_cast<int*>(cval + (KIND == MVAL_SCORE_HP ? 0 : SC_MAX_PEAKS));  // SC_MAX_PEAKS
+  ScoreSmem* sm = reinterpret_cast<ScoreSmem*>(cidx + (KIND == MVAL_SCORE_HP ? 0 : SC_MAX_PEAKS));
   const int tid = threadIdx.x;
   const int64_t map = blockIdx.x;
   const float* p = hm + map * (int64_t)hh * wh;
   const int npix = hh * wh;
 
-  for (int i = tid; i < npix; i += SC_THREADS) {
-    int y = i / wh, x = i - y * wh;
-    tile[y * ld + x] = p[i];
+  float bv = -INFINITY;
+  int bi = 0x7fffffff;
+  if ((npix & 3) == 0 && (wh & 3) == 0) {  // float4 loads (maps are 16-byte aligned then); a quad never straddles rows
+    const float4* p4 = reinterpret_cast<const float4*>(p);
+    for (int i = tid; i < (npix >> 2); i += SC_THREADS) {
+      const float4 q = p4[i];
+      const int base = i << 2;
+      const int y = base / wh, x = base - y * wh;
+      float* t = tile + y * ld + x;
+      t[0] = q.x; t[1] = q.y; t[2] = q.z; t[3] = q.w;
+      if (DECODE) {
+        if (sc_better(q.x, base, bv, bi)) { bv = q.x; bi = base; }
+        if (sc_better(q.y, base + 1, bv, bi)) { bv = q.y; bi = base + 1; }
+        if (sc_better(q.z, base + 2, bv, bi)) { bv = q.z; bi = base + 2; }
+        if (sc_better(q.w, base + 3, bv, bi)) { bv = q.w; bi = base + 3; }
+      }
+    }
+  } else {
+    for (int i = tid; i < npix; i += SC_THREADS) {
+      const int y = i / wh, x = i - y * wh;
+      const float q = p[i];
+      tile[y * ld + x] = q;
+      if (DECODE && sc_better(q, i, bv, bi)) { bv = q; bi = i; }
+    }
   }
   if (tid == 0) { sm->n_cand = 0; sm->overflow = 0; }
+  if (DECODE) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(bv, o, 64);
+      const int oi = __shfl_xor(bi, o, 64);
+      if (sc_better(ov, oi, bv, bi)) { bv = ov; bi = oi; }
+    }
+    if ((tid & 63) == 0) { sm->red[tid >> 6] = bv; sm->red[4 + (tid >> 6)] = __int_as_float(bi); }
+  }
   __syncthreads();
+  if (DECODE && tid == 0) {
+    for (int w = 1; w < SC_THREADS / 64; w++) {
+      const float ov = sm->red[w];
+      const int oi = __float_as_int(sm->red[4 + w]);
+      if (sc_better(ov, oi, bv, bi)) { bv = ov; bi = oi; }
+    }
+    if (bi == 0x7fffffff) bi = 0;  // all -inf: first element
+    const int j = (int)(map % d.J);
+    const int64_t b = map / ((int64_t)d.V * d.J);
+    const bool ok = !d.valid || d.valid[b * d.J + j];
+    d.kp2d[map * 2] = ok ? (int64_t)(bi % d.split_width) * d.stride : 0;
+    d.kp2d[map * 2 + 1] = ok ? (int64_t)(bi / d.split_width) * d.stride : 0;
+  }
+  if (DECODE) __syncthreads();  // red[] is reused below
 
-  // ---- row-wise softmax statistics (HP, BSB) ------------------------------------------
+  // ---- row-wise softmax statistics (HP, BSB): T lanes per row ---------------------------------
   if (KIND == MVAL_SCORE_HP || KIND == MVAL_SCORE_BSB) {
+    int T = 1;
+    while (T < 16 && T * 2 * hh <= SC_THREADS) T <<= 1;  // 4 lanes per row on 64-row maps, 2 on 96-row maps
+    const int sub = tid & (T - 1);
     float best = 0.f;
-    for (int r = tid; r < hh; r += SC_THREADS) {
-      float* row = tile + r * ld;
+    const int rows_per_pass = SC_THREADS / T;
+    for (int r0 = 0; r0 < hh; r0 += rows_per_pass) {  // every thread makes every pass: the shuffles need whole lane groups
+      const int r = r0 + tid / T;
+      const bool live = r < hh;
+      float* row = tile + (live ? r : 0) * ld;
       float m = -INFINITY;
-      for (int c = 0; c < wh; c++) m = fmaxf(m, row[c]);
+      for (int c = sub; c < wh; c += T) m = fmaxf(m, row[c]);
+      for (int o = T >> 1; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+      // the reference sums exp(x - m) over a row left to right in float32 (torch softmax on CPU vectorises, so the
+      // last bits differ anyway: tests allow 3e-6 relative); partial sums over interleaved columns here
       float s = 0.f;
-      for (int c = 0; c < wh; c++) s += expf(row[c] - m);
-      if (KIND == MVAL_SCORE_BSB) {
-        for (int c = 0; c < wh; c++) row[c] = expf(row[c] - m) / s;
+      for (int c = sub; c < wh; c += T) s += expf(row[c] - m);
+      for (int o = T >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+      if (KIND == MVAL_SCORE_BSB && live) {
+        for (int c = sub; c < wh; c += T) row[c] = expf(row[c] - m) / s;
       }
-      best = fmaxf(best, 1.0f / s);
+      if (live) best = fmaxf(best, 1.0f / s);
     }
     if (KIND == MVAL_SCORE_HP) {
       best = block_reduce_max(best, sm->red);
@@ -199,22 +271,44 @@ __global__ __launch_bounds__(SC_THREADS) void score_maps_kernel(const float* __r
   }
 }
 
+template <bool DECODE>
+static int launch_score(int kind, const float* heatmaps, float* stat, int32_t* n_peaks, int64_t n_maps, int hh, int wh,
+                        const ScoreDecodeArgs& d, hipStream_t s) {
+  size_t smem = (size_t)((hh * (wh + 1) + 3) & ~3) * 4 + (kind == MVAL_SCORE_HP ? 0 : SC_MAX_PEAKS * 8) + sizeof(ScoreSmem) + 16;
+  if (smem > 160 * 1024) return 1;
+  dim3 grid((unsigned)n_maps), block(SC_THREADS);
+  if (kind == MVAL_SCORE_HP)
+    hipLaunchKernelGGL((score_maps_kernel<MVAL_SCORE_HP, DECODE>), grid, block, smem, s, heatmaps, stat, n_peaks, hh, wh, d);
+  else if (kind == MVAL_SCORE_MPE)
+    hipLaunchKernelGGL((score_maps_kernel<MVAL_SCORE_MPE, DECODE>), grid, block, smem, s, heatmaps, stat, n_peaks, hh, wh, d);
+  else
+    hipLaunchKernelGGL((score_maps_kernel<MVAL_SCORE_BSB, DECODE>), grid, block, smem, s, heatmaps, stat, n_peaks, hh, wh, d);
+  return 0;
+}
+
 extern "C" int mval_score_maps(int kind, const float* heatmaps, float* stat, int32_t* n_peaks, int64_t n_maps, int hh,
                                int wh, void* stream) {
   MVAL_REQUIRE(n_maps >= 0 && hh > 0 && wh > 0, "mval_score_maps: bad dims");
   MVAL_REQUIRE(kind >= 0 && kind <= 2, "mval_score_maps: unknown kind %d", kind);
   if (n_maps == 0) return 0;
-  size_t smem = (size_t)((hh * (wh + 1) + 3) & ~3) * 4 + SC_MAX_PEAKS * 8 + sizeof(ScoreSmem) + 16;
-  MVAL_REQUIRE(smem <= 160 * 1024, "mval_score_maps: heat-map %dx%d does not fit LDS", hh, wh);
-  dim3 grid((unsigned)n_maps), block(SC_THREADS);
-  hipStream_t s = mval_stream(stream);
-  if (kind == MVAL_SCORE_HP)
-    hipLaunchKernelGGL(score_maps_kernel<MVAL_SCORE_HP>, grid, block, smem, s, heatmaps, stat, n_peaks, hh, wh);
-  else if (kind == MVAL_SCORE_MPE)
-    hipLaunchKernelGGL(score_maps_kernel<MVAL_SCORE_MPE>, grid, block, smem, s, heatmaps, stat, n_peaks, hh, wh);
-  else
-    hipLaunchKernelGGL(score_maps_kernel<MVAL_SCORE_BSB>, grid, block, smem, s, heatmaps, stat, n_peaks, hh, wh);
+  ScoreDecodeArgs d = {};
+  MVAL_REQUIRE(launch_score<false>(kind, heatmaps, stat, n_peaks, n_maps, hh, wh, d, mval_stream(stream)) == 0,
+               "mval_score_maps: heat-map %dx%d does not fit LDS", hh, wh);
   MVAL_CHECK_LAUNCH("mval_score_maps");
+  return 0;
+}
+
+extern "C" int mval_score_decode_maps(int kind, const float* heatmaps, const uint8_t* valid, float* stat, int32_t* n_peaks,
+                                      int64_t* kp2d, int B, int V, int J, int hh, int wh, int stride, int split_width,
+                                      void* stream) {
+  MVAL_REQUIRE(B >= 0 && V > 0 && J > 0 && hh > 0 && wh > 0 && split_width > 0 && kp2d, "mval_score_decode_maps: bad arguments");
+  MVAL_REQUIRE(kind >= 0 && kind <= 2, "mval_score_decode_maps: unknown kind %d", kind);
+  const int64_t n_maps = (int64_t)B * V * J;
+  if (n_maps == 0) return 0;
+  ScoreDecodeArgs d = {valid, kp2d, V, J, stride, split_width};
+  MVAL_REQUIRE(launch_score<true>(kind, heatmaps, stat, n_peaks, n_maps, hh, wh, d, mval_stream(stream)) == 0,
+               "mval_score_decode_maps: heat-map %dx%d does not fit LDS", hh, wh);
+  MVAL_CHECK_LAUNCH("mval_score_decode_maps");
   return 0;
 }
 

@@ -50,6 +50,19 @@ def score_heatmaps_batch(kind: str, config: str, heatmaps, joint_valid):
     return out, per_map.reshape(b, v, j), n_peaks.reshape(b, v, j), valid
 
 
+def score_decode_heatmaps_batch(kind: str, config: str, heatmaps, joint_valid, stride, mirror_nonsquare_quirk=True):
+    """``score_heatmaps_batch`` + the hard arg-max decode of ``triangulate_batch`` from ONE read of the heat-maps
+    (csrc/scoring.hip, DECODE): what a pool-scoring pass needs per map (strategy.py:1027-1090 reads every heat-map in
+    get_scaled_pred_corrdinates AND in _compute_{hp,mpe,bsb}).  Returns (out, per_map, n_peaks, valid, keypoints_2d)."""
+    b, v, j, hh, wh = heatmaps.shape
+    hm = heatmaps.to(torch.float32).contiguous()
+    valid = (torch.as_tensor(joint_valid) != 0).to(torch.uint8).reshape(b, j).to(hm.device).contiguous()
+    per_map, n_peaks, kp2d = _lib.score_decode_maps(_KIND[kind], hm, valid, b, v, j, hh, wh, int(stride),
+                                                    hh if mirror_nonsquare_quirk else wh)
+    out = _lib.score_reduce(per_map, valid, b, v, j, _reduce_mode(kind, config))
+    return out, per_map.reshape(b, v, j), n_peaks.reshape(b, v, j), valid, kp2d
+
+
 def tables_to_sal_dict(per_rank, batch_sizes, sal_dict=None):
     """Packed per-rank tables [pose, frame_id, al_metric, sal_metric, inlier_count, mkpe,
     keypoints_3d(3J)] -> the reference's five dicts, inserted in its gather order
@@ -160,20 +173,25 @@ class ActiveLearningStrategy:
         _, j, hh, wh = heatmaps.shape
         hm = heatmaps.reshape(b, -1, j, hh, wh)
         joint_valid = torch.as_tensor(dp["joint_valid"]).reshape(b, j)
+        strat = cfg.AL.STRATEGY
+        scored = None
+        if strat in ("MPE", "HP", "BSB") and not cfg.AL.USE_SOFTARGMAX:
+            # one read of every heat-map for both the uncertainty statistic and the key-point decode
+            scored = score_decode_heatmaps_batch(strat, getattr(cfg.AL, strat + "_CONFIG"), hm, joint_valid, cfg.POSE_ESTIMATOR.STRIDE)
         r = triangulation.triangulate_batch(
             hm, dp["proj_matrices"], cfg.POSE_ESTIMATOR.STRIDE, joint_valid,
             cfg.AL.USE_SOFTARGMAX, cfg.AL.USE_REPROJECTION_XE, cfg.AL.REPROJECTION_SIGMA,
+            keypoints_2d=None if scored is None else scored[4],
         )
         pred32 = r["keypoints_3d"].to(torch.float32)  # torch.Tensor(results["keypoints_3d"]) (:1046)
         sal_metric = r["metric"].to(torch.float32).to(torch.float64)  # torch.Tensor([metric]) (:1061)
-        strat = cfg.AL.STRATEGY
         if strat == "RANDOM":
             al = torch.cat([torch.rand(1) for _ in range(b)]).to(torch.float64).to(dev)
         elif strat == "TRIANGULATION":
             al = r["metric"].to(torch.float64)  # torch.tensor([np.float64]) keeps float64 (:1075)
         elif strat in ("MPE", "HP", "BSB"):
             conf = getattr(cfg.AL, strat + "_CONFIG")
-            al, _, n_peaks, valid = score_heatmaps_batch(strat, conf, hm, joint_valid)
+            al, _, n_peaks, valid = scored[:4] if scored is not None else score_heatmaps_batch(strat, conf, hm, joint_valid)
             self._pending_checks.append((strat, n_peaks, valid))
             if conf == "AVG" or strat != "HP":
                 al = al.to(torch.float32).to(torch.float64)  # torch.tensor(python float) is float32

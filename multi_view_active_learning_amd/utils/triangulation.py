@@ -40,6 +40,7 @@ def triangulate_batch(
     n_iters=64,
     reprojection_error_epsilon=5,
     mirror_nonsquare_quirk=True,
+    keypoints_2d=None,
 ):
     """heatmaps (B,V,J,Hh,Wh) f32 HIP tensor, proj (B,V,3,4), valid (B,J) ->
     dict of HIP tensors: keypoints_3d (B,J,3) f64, keypoints_2d (B,V,J,2) i64|f32,
@@ -48,7 +49,10 @@ def triangulate_batch(
 
     ``mirror_nonsquare_quirk``: the reference splits the flat arg-max index with
     ``shape[2]`` (the map HEIGHT) for both x and y (utils/evaluation.py:25-26).
-    True reproduces that bit for bit; False uses the geometrically correct width."""
+    True reproduces that bit for bit; False uses the geometrically correct width.
+
+    ``keypoints_2d``: key-points already decoded from these heat-maps (the fused scoring pass,
+    ``_lib.score_decode_maps``): the decode launch, i.e. a second read of the heat-maps, is skipped."""
     dev = _device_of(heatmaps)
     if heatmaps.dim() != 5:
         raise ValueError("heatmaps must be (B, V, J, Hh, Wh)")
@@ -62,7 +66,9 @@ def triangulate_batch(
     hm = heatmaps.to(torch.float32).contiguous()
     proj = torch.as_tensor(proj_matricies).to(device=dev, dtype=torch.float64).reshape(b, v, 3, 4).contiguous()
     valid = _as_valid_u8(valid_joints, (b, j), dev)
-    if use_soft_argmax:
+    if keypoints_2d is not None:
+        kp2d = keypoints_2d
+    elif use_soft_argmax:
         kp2d = _lib.soft_argmax(hm, b * v * j, hh, wh, float(stride)).reshape(b, v, j, 2)
     else:
         kp2d = _lib.argmax_decode(hm, valid, b, v, j, hh, wh, int(stride), hh if mirror_nonsquare_quirk else wh)

@@ -403,3 +403,31 @@ def test_sal_filter_vs_reference_golden(dev, name):
     random.seed(c["seed"])
     got = st.select_sal_guids(sal, al, done, c["pseudo_num"], want["centers"] if c["use_clusters"] else None, device=dev)
     assert got == want["sal_guids"]
+
+
+@pytest.mark.parametrize("shape", [(2, 4, 19, 64, 64), (1, 8, 19, 96, 72), (3, 2, 5, 17, 23)], ids=lambda s: "x".join(map(str, s)))
+def test_fused_score_decode_equals_separate_passes(dev, shape):
+    """mval_score_decode_maps (ONE staged read per heat-map: statistic + hard arg-max) against mval_score_maps and
+    mval_argmax_decode (two reads): identical bits, including ties, NaN maps, invalid joints and the reference's
+    non-square index split."""
+    from multi_view_active_learning_amd import _lib
+
+    b, v, j, hh, wh = shape
+    rng = np.random.default_rng(hh * 7 + wh)
+    hm = rng.standard_normal(shape).astype(np.float32) * 0.3
+    hm[0, 0, 0] = 0.25                      # a constant map: all ties -> index 0, no peak above the minimum
+    hm[0, 1, 1, 3, 4] = np.nan              # NaN is the arg-max
+    hm[-1, -1, 2, 5:7, 6:8] = 9.0           # a 2 x 2 plateau: first index wins, plateau spacing in the peak list
+    valid = np.ones((b, j), dtype=np.uint8)
+    valid[0, 3] = 0
+    t = torch.from_numpy(hm).to(dev)
+    vd = torch.from_numpy(valid).to(dev)
+    for kind in (_lib.SCORE_HP, _lib.SCORE_MPE, _lib.SCORE_BSB):
+        for split in (hh, wh):
+            stat, cnt, kp = _lib.score_decode_maps(kind, t, vd, b, v, j, hh, wh, 4, split)
+            stat0, cnt0 = _lib.score_maps(kind, t, b * v * j, hh, wh)
+            kp0 = _lib.argmax_decode(t, vd, b, v, j, hh, wh, 4, split)
+            assert torch.equal(kp, kp0)
+            assert torch.equal(cnt, cnt0)
+            np.testing.assert_array_equal(stat.cpu().numpy(), stat0.cpu().numpy())  # (NaN == NaN here)
+    assert kp[0, :, 3].abs().sum().item() == 0  # invalid joint -> (0, 0)
