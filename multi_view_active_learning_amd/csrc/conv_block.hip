@@ -14,14 +14,16 @@
 //   * the intermediate tile is scaled by ITS OWN maximum (a workgroup-local reduction): the tile decomposition
 //     depends on the image geometry only, so results stay deterministic and independent of the batch.
 //
-// Workgroup = 4 waves, output tile 8 x 16 pixels:
+// Workgroup = 2 waves, output tile 8 x 16 pixels (every wave streams ALL weight fragments of both convs from L2, so
+// weight traffic through the CU's L1 goes with the number of waves per pixel: four waves per tile measured 98 us
+// per 32-channel block, of which ~30 us of L1 time for weights alone):
 //   1. stage the 12 x 20 input patch (2-pixel halo), split, into LDS planes X[plane][chunk][pixel][32 ch + pad];
-//   2. conv1 over the 10 x 18 intermediate pixels (1-pixel halo for conv2; 12 sub-tiles of 16 pixel slots, 3 per
+//   2. conv1 over the 10 x 18 intermediate pixels (1-pixel halo for conv2; 12 sub-tiles of 16 pixel slots, 6 per
 //      wave, every wave all C output channels).  The WEIGHT fragment is the MFMA's first operand, so a lane ends up
 //      with 4 consecutive channels of one pixel: BN1 + ReLU (+ zero outside the image = conv2's zero padding) in
 //      registers, tile maximum through LDS, split, 8-byte LDS stores into M[plane][chunk][pixel][32 ch + pad],
 //      which overlays X (conv1 is done with it);
-//   3. conv2 over the 8 x 16 output pixels from M (2 sub-tile rows per wave); BN2 + residual + ReLU in registers,
+//   3. conv2 over the 8 x 16 output pixels from M (4 sub-tile rows per wave); BN2 + residual + ReLU in registers,
 //      float4 stores straight from the accumulators (64-byte runs per pixel; no LDS round trip, no barrier).
 // Halo recompute: conv1 does 12 / 8 = 1.5x the MFMAs of a plain conv; at 3 MFMAs per product that is cheaper than
 // the two staging passes, two epilogues and 3 tensor round trips it replaces.
@@ -42,6 +44,8 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #define BK_MPX (BK_MH * BK_MW)  // 180
 #define BK_MSLOTS 192           // 12 sub-tiles of 16
 #define BK_ROWB 80              // bytes per LDS pixel row: 32 fp16 + 8 pad (16 consecutive pixels cover all banks)
+#define BK_WAVES 4
+#define BK_NTH (64 * BK_WAVES)
 
 __device__ __forceinline__ f32x4 bk_mfma(const u32x4 a, const u32x4 b, const f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
@@ -71,16 +75,19 @@ struct BlockArgs {
 };
 
 template <int C>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C == 32 ? 4 : 2, 8))) void conv_block_kernel(BlockArgs a) {
+__global__ __launch_bounds__(BK_NTH) __attribute__((amdgpu_waves_per_eu(C == 32 ? 2 : 1, 8))) void conv_block_kernel(BlockArgs a) {
   constexpr int NCH = C / 32;   // 32-channel chunks
   constexpr int NS = C / 16;    // 16-cout sub-tiles: every wave computes all of them
   constexpr int Q = C / 4;      // float4 per pixel
-  constexpr int NE = (BK_XPX * Q + 255) / 256;
+  constexpr int NE = (BK_XPX * Q + BK_NTH - 1) / BK_NTH;
+  // weight fragments in flight: one (tap, chunk) step is ~0.1 us of MFMAs per wave, an L2 hit several times that; two
+  // steps ahead where the registers allow it (64 channels: 96 registers would cost the second wave per SIMD)
+  constexpr int WD = C == 32 ? 3 : 2;
   constexpr int XCHUNK = BK_XPX * BK_ROWB, XPLANE = NCH * XCHUNK;
   constexpr int MCHUNK = BK_MSLOTS * BK_ROWB, MPLANE = NCH * MCHUNK;
   static_assert(2 * MPLANE <= 2 * XPLANE, "M overlays X");
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  __shared__ float tile_max[4];
+  __shared__ float tile_max[BK_WAVES];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
   int t = blockIdx.x;
@@ -89,24 +96,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C == 32 ? 4
   const int tyi = t % a.tiles_y;
   const int n = t / a.tiles_y;
   const int oy0 = tyi * BK_TH, ox0 = txi * BK_TW;
-  const float* xin = a.in + (int64_t)n * a.H * a.W * C;
+  // the image through a buffer descriptor: out-of-image lanes get an out-of-range offset and read zeros, without
+  // a branch per staged element
+  const __amdgpu_buffer_rsrc_t xr =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in + (int64_t)n * a.H * a.W * C), 0, a.H * a.W * C * 4, 0x00020000);
 
   // ---- 1. input patch: global -> registers -> (scale, split) -> LDS ------------------------------------------
   f32x4 stage[NE];
 #pragma unroll
   for (int i = 0; i < NE; i++) {
-    const int e = tid + 256 * i;
+    const int e = tid + BK_NTH * i;
     const int px = e / Q, q = e % Q;
     const int py = px / BK_XW, pxx = px - py * BK_XW;
     const int iy = oy0 - 2 + py, ix = ox0 - 2 + pxx;
     const bool ok = e < BK_XPX * Q && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-    stage[i] = ok ? *reinterpret_cast<const f32x4*>(xin + ((int64_t)iy * a.W + ix) * C + q * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    stage[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, ok ? ((iy * a.W + ix) * C + q * 4) * 4 : -1, 0, 0));
   }
   float in_mul, in_inv;
   bk_scale(conv_amax_read(a.in_amax + (int64_t)n * MVAL_AMAX_ROW), in_mul, in_inv);
 #pragma unroll
   for (int i = 0; i < NE; i++) {
-    const int e = tid + 256 * i;
+    const int e = tid + BK_NTH * i;
     if (e < BK_XPX * Q) {
       const int px = e / Q, q = e % Q;
       f16x4 h, l;
@@ -127,8 +137,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C == 32 ? 4
     return __builtin_amdgcn_raw_buffer_load_b128(r, (ns * 128 + p * 64 + lane) * 16, blk * BLK, 0);
   };
 
-  // ---- 2. conv1 over the intermediate pixels: sub-tiles wave * 3 + {0, 1, 2} --------------------------------------
-  constexpr int MS1 = 3;
+  // ---- 2. conv1 over the intermediate pixels: sub-tiles wave * MS1 + {0 .. MS1 - 1} -------------------------------
+  constexpr int MS1 = 12 / BK_WAVES;
   int xb[MS1];  // LDS byte offset of the lane's pixel (tap (0,0)) + its k octet
   int mpix[MS1];
 #pragma unroll
@@ -139,28 +149,42 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C == 32 ? 4
     const int my = pc / BK_MW, mx = pc - my * BK_MW;
     xb[ms] = (my * BK_XW + mx) * BK_ROWB + (lane >> 4) * 16;
   }
+  // BN factors of the lane's 4 channels per sub-tile: with 32 channels they are fetched BEFORE the MFMA loop that
+  // precedes their use (16 registers); with 64 channels those 32 registers would cost the second wave per SIMD
+  constexpr bool PRE = C == 32;
+  f32x4 bn_sc[NS], bn_sh[NS];
+  auto load_bn = [&](const float* sc, const float* sh) {
+#pragma unroll
+    for (int ns = 0; ns < NS; ns++) {
+      bn_sc[ns] = *reinterpret_cast<const f32x4*>(sc + ns * 16 + (lane >> 4) * 4);
+      bn_sh[ns] = *reinterpret_cast<const f32x4*>(sh + ns * 16 + (lane >> 4) * 4);
+    }
+  };
+  if constexpr (PRE) load_bn(a.scale1, a.shift1);
   f32x4 acc1[MS1][NS];
 #pragma unroll
   for (int ms = 0; ms < MS1; ms++)
 #pragma unroll
     for (int ns = 0; ns < NS; ns++) acc1[ms][ns] = (f32x4){0.f, 0.f, 0.f, 0.f};
   {
-    u32x4 wf[2][NS][2];
+    u32x4 wf[WD][NS][2];  // fetched WD - 1 (tap, chunk) steps ahead
 #pragma unroll
-    for (int ns = 0; ns < NS; ns++)
+    for (int st = 0; st < WD - 1; st++)
 #pragma unroll
-      for (int p = 0; p < 2; p++) wf[0][ns][p] = wfrag(w1r, 0, ns, p);
+      for (int ns = 0; ns < NS; ns++)
+#pragma unroll
+        for (int p = 0; p < 2; p++) wf[st][ns][p] = wfrag(w1r, (st % 9) * NCH + st / 9, ns, p);
 #pragma unroll
     for (int ch = 0; ch < NCH; ch++) {
 #pragma unroll
       for (int tap = 0; tap < 9; tap++) {
         const int step = ch * 9 + tap;
-        if (step + 1 < NCH * 9) {
-          const int nt = (step + 1) % 9, nc = (step + 1) / 9;
+        if (step + WD - 1 < NCH * 9) {
+          const int nt = (step + WD - 1) % 9, nc = (step + WD - 1) / 9;
 #pragma unroll
           for (int ns = 0; ns < NS; ns++)
 #pragma unroll
-            for (int p = 0; p < 2; p++) wf[(step + 1) & 1][ns][p] = wfrag(w1r, nt * NCH + nc, ns, p);
+            for (int p = 0; p < 2; p++) wf[(step + WD - 1) % WD][ns][p] = wfrag(w1r, nt * NCH + nc, ns, p);
         }
         const int toff = ch * XCHUNK + ((tap / 3) * BK_XW + (tap % 3)) * BK_ROWB;
 #pragma unroll
@@ -170,15 +194,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C == 32 ? 4
 #pragma unroll
           for (int ns = 0; ns < NS; ns++) {
             f32x4 c = acc1[ms][ns];
-            c = bk_mfma(wf[step & 1][ns][1], xh, c);  // wl * xh
-            c = bk_mfma(wf[step & 1][ns][0], xl, c);  // wh * xl
-            acc1[ms][ns] = bk_mfma(wf[step & 1][ns][0], xh, c);
+            c = bk_mfma(wf[step % WD][ns][1], xh, c);  // wl * xh
+            c = bk_mfma(wf[step % WD][ns][0], xl, c);  // wh * xl
+            acc1[ms][ns] = bk_mfma(wf[step % WD][ns][0], xh, c);
           }
         }
       }
     }
   }
   // BN1 + ReLU; zero outside the image (conv2's padding).  Lane = (pixel lane & 15, channels (lane >> 4) * 4 .. + 3).
+  if constexpr (!PRE) load_bn(a.scale1, a.shift1);
   const float u1 = in_inv * *a.w1_unscale;
   float tmax = 0.f;
 #pragma unroll
@@ -189,10 +214,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C == 32 ? 4
     const bool inside = p < BK_MPX && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
 #pragma unroll
     for (int ns = 0; ns < NS; ns++) {
-      const int c0 = ns * 16 + (lane >> 4) * 4;
-      const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale1 + c0) * u1;
-      const f32x4 sh = *reinterpret_cast<const f32x4*>(a.shift1 + c0);
-      f32x4 v = acc1[ms][ns] * sc + sh;
+      f32x4 v = acc1[ms][ns] * (bn_sc[ns] * u1) + bn_sh[ns];
       v.x = inside ? fmaxf(v.x, 0.f) : 0.f;
       v.y = inside ? fmaxf(v.y, 0.f) : 0.f;
       v.z = inside ? fmaxf(v.z, 0.f) : 0.f;
@@ -205,7 +227,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C == 32 ? 4
   if (lane == 0) tile_max[wave] = tmax;
   __syncthreads();  // every wave is done reading X; the tile maximum is complete
   float m_mul, m_inv;
-  bk_scale(__float_as_uint(fmaxf(fmaxf(tile_max[0], tile_max[1]), fmaxf(tile_max[2], tile_max[3]))), m_mul, m_inv);
+  float tm = tile_max[0];
+#pragma unroll
+  for (int w = 1; w < BK_WAVES; w++) tm = fmaxf(tm, tile_max[w]);
+  bk_scale(__float_as_uint(tm), m_mul, m_inv);
 #pragma unroll
   for (int ms = 0; ms < MS1; ms++) {
 #pragma unroll
@@ -218,8 +243,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C == 32 ? 4
     }
   }
 
-  // ---- 3. conv2 over the output rows wave * 2 + {0, 1}; the residual loads travel during its MFMA loop ----------
-  constexpr int MS2 = 2;
+  // ---- 3. conv2 over the output rows wave * MS2 + {0 .. MS2 - 1}; the residual loads travel during its MFMA loop --
+  constexpr int MS2 = BK_TH / BK_WAVES;
   const int ox = ox0 + (lane & 15);
   f32x4 res[MS2][NS];
   int64_t ooff[MS2];
@@ -230,8 +255,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C == 32 ? 4
     ooff[ms] = ok ? (((int64_t)n * a.H + oy) * a.W + ox) * C + (lane >> 4) * 4 : -1;
 #pragma unroll
     for (int ns = 0; ns < NS; ns++)
-      res[ms][ns] = ok ? *reinterpret_cast<const f32x4*>(a.in + ooff[ms] + ns * 16) : (f32x4){0.f, 0.f, 0.f, 0.f};
+      res[ms][ns] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                  xr, ok ? ((oy * a.W + ox) * C + (lane >> 4) * 4 + ns * 16) * 4 : -1, 0, 0));
   }
+  if constexpr (PRE) load_bn(a.scale2, a.shift2);
   f32x4 acc2[MS2][NS];
 #pragma unroll
   for (int ms = 0; ms < MS2; ms++)
@@ -239,23 +266,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C == 32 ? 4
     for (int ns = 0; ns < NS; ns++) acc2[ms][ns] = (f32x4){0.f, 0.f, 0.f, 0.f};
   __syncthreads();  // M is complete
   {
-    u32x4 wf[2][NS][2];
+    u32x4 wf[WD][NS][2];  // fetched WD - 1 (tap, chunk) steps ahead
 #pragma unroll
-    for (int ns = 0; ns < NS; ns++)
+    for (int st = 0; st < WD - 1; st++)
 #pragma unroll
-      for (int p = 0; p < 2; p++) wf[0][ns][p] = wfrag(w2r, 0, ns, p);
+      for (int ns = 0; ns < NS; ns++)
+#pragma unroll
+        for (int p = 0; p < 2; p++) wf[st][ns][p] = wfrag(w2r, (st % 9) * NCH + st / 9, ns, p);
     const int mb = ((wave * MS2) * BK_MW + (lane & 15)) * BK_ROWB + (lane >> 4) * 16;
 #pragma unroll
     for (int ch = 0; ch < NCH; ch++) {
 #pragma unroll
       for (int tap = 0; tap < 9; tap++) {
         const int step = ch * 9 + tap;
-        if (step + 1 < NCH * 9) {
-          const int nt = (step + 1) % 9, nc = (step + 1) / 9;
+        if (step + WD - 1 < NCH * 9) {
+          const int nt = (step + WD - 1) % 9, nc = (step + WD - 1) / 9;
 #pragma unroll
           for (int ns = 0; ns < NS; ns++)
 #pragma unroll
-            for (int p = 0; p < 2; p++) wf[(step + 1) & 1][ns][p] = wfrag(w2r, nt * NCH + nc, ns, p);
+            for (int p = 0; p < 2; p++) wf[(step + WD - 1) % WD][ns][p] = wfrag(w2r, nt * NCH + nc, ns, p);
         }
         const int toff = ch * MCHUNK + ((tap / 3) * BK_MW + (tap % 3)) * BK_ROWB;
 #pragma unroll
@@ -265,14 +294,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C == 32 ? 4
 #pragma unroll
           for (int ns = 0; ns < NS; ns++) {
             f32x4 c = acc2[ms][ns];
-            c = bk_mfma(wf[step & 1][ns][1], mh, c);
-            c = bk_mfma(wf[step & 1][ns][0], ml, c);
-            acc2[ms][ns] = bk_mfma(wf[step & 1][ns][0], mh, c);
+            c = bk_mfma(wf[step % WD][ns][1], mh, c);
+            c = bk_mfma(wf[step % WD][ns][0], ml, c);
+            acc2[ms][ns] = bk_mfma(wf[step % WD][ns][0], mh, c);
           }
         }
       }
     }
   }
+  if constexpr (!PRE) load_bn(a.scale2, a.shift2);
   const float u2 = m_inv * *a.w2_unscale;
   float amax = 0.f;
 #pragma unroll
@@ -280,10 +310,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C == 32 ? 4
     if (ooff[ms] < 0) continue;
 #pragma unroll
     for (int ns = 0; ns < NS; ns++) {
-      const int c0 = ns * 16 + (lane >> 4) * 4;
-      const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale2 + c0) * u2;
-      const f32x4 sh = *reinterpret_cast<const f32x4*>(a.shift2 + c0);
-      f32x4 v = acc2[ms][ns] * sc + sh;
+      f32x4 v = acc2[ms][ns] * (bn_sc[ns] * u2) + bn_sh[ns];
       v += res[ms][ns];
       v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
       *reinterpret_cast<f32x4*>(a.out + ooff[ms] + ns * 16) = v;
@@ -316,13 +343,13 @@ int mval_launch_conv_block(int C, const float* in, float* out, const float* w1, 
   a.tiles_x = (W + BK_TW - 1) / BK_TW;
   a.tiles_y = (H + BK_TH - 1) / BK_TH;
   const int tiles = a.tiles_x * a.tiles_y;
-  if (out_amax && (int64_t)tiles * 4 > MVAL_AMAX_ROW - 1)
+  if (out_amax && (int64_t)tiles * BK_WAVES > MVAL_AMAX_ROW - 1)
     mval_launch_zero_rows(out_amax, (int64_t)N * MVAL_AMAX_ROW, s);
   const size_t smem = (size_t)2 * (C / 32) * BK_XPX * BK_ROWB;
   dim3 grid((unsigned)(tiles * N));
   if (C == 32)
-    hipLaunchKernelGGL(conv_block_kernel<32>, grid, dim3(256), smem, s, a);
+    hipLaunchKernelGGL(conv_block_kernel<32>, grid, dim3(BK_NTH), smem, s, a);
   else
-    hipLaunchKernelGGL(conv_block_kernel<64>, grid, dim3(256), smem, s, a);
+    hipLaunchKernelGGL(conv_block_kernel<64>, grid, dim3(BK_NTH), smem, s, a);
   return 0;
 }
