@@ -3,7 +3,12 @@
 of the conv kernels from the FETCH_SIZE / WRITE_SIZE passes (separate --pmc runs, as the
 MI355X guide prescribes; gfx950 correction: FETCH_SIZE x2 for wide coalesced reads; unit KB).
 
-usage: pmc_summary.py <kernel_stats.csv> <fetch counter_collection.csv> <write counter_collection.csv>"""
+usage: pmc_summary.py <kernel_stats.csv> <fetch counter_collection.csv> <write counter_collection.csv> [sq counter_collection.csv]
+
+The optional fourth file is an SQ pass (GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY
+SQ_WAIT_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU / _LDS): per conv instantiation, matrix-core busy cycles
+as a fraction of the kernel's GPU-active cycles x CUs x 4 SIMDs -> "mfma_util", and how the waves' cycles split between issuing,
+waiting on memory / barriers and issue stalls."""
 import collections
 import csv
 import json
@@ -11,7 +16,8 @@ import sys
 
 
 def fam(n):
-    return ("conv_bf3_kernel" if "conv_bf3" in n else "conv_mfma_kernel" if "conv_mfma" in n else
+    return ("conv_block_kernel" if "conv_block" in n else "conv_split_kernel" if "conv_split" in n else
+            "conv_bf3_kernel" if "conv_bf3" in n else "conv_mfma_kernel" if "conv_mfma" in n else
             "conv_stem_kernel" if "conv_stem" in n else n.split("(")[0][:48])
 
 
@@ -34,6 +40,7 @@ def agg(path, counter, key=fam):
 
 
 stats, fetch, write = sys.argv[1:4]
+sq = sys.argv[4] if len(sys.argv) > 4 else None
 rows = list(csv.DictReader(open(stats)))
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
 k = {}
@@ -45,7 +52,7 @@ out = {"kernel_stats": [dict(kernel=n, calls=c, avg_us=round(t / c / 1e3, 2), to
                              pct=round(100 * t / tot, 2)) for n, (c, t) in sorted(k.items(), key=lambda kv: -kv[1][1])[:10]]}
 f, w = agg(fetch, "FETCH_SIZE"), agg(write, "WRITE_SIZE")
 out["hbm_traffic_per_launch"] = []
-for n in ("conv_bf3_kernel", "conv_mfma_kernel", "conv_stem_kernel"):
+for n in ("conv_split_kernel", "conv_block_kernel", "conv_bf3_kernel", "conv_mfma_kernel", "conv_stem_kernel"):
     if n in f and n in w:
         nf, fs, tf = f[n]
         nw, ws, _ = w[n]
@@ -66,4 +73,32 @@ for n in sorted(fi, key=lambda n: -fi[n][2]):
     out["hbm_traffic_by_instantiation"].append(dict(kernel=n, launches=nf, avg_us_under_pmc=round(tf / nf / 1e3, 2),
                                                     fetch_bytes_corrected=round(rd), write_bytes=round(wr),
                                                     total_bytes=round(rd + wr), GBps=round((rd + wr) / (tf / nf), 1)))
+if sq:
+    # SQ pass: one row per (dispatch, counter); sums over the XCDs / SEs are already folded by rocprofv3
+    per = collections.defaultdict(lambda: collections.defaultdict(float))
+    cnt = collections.Counter()
+    for r in csv.DictReader(open(sq)):
+        k_ = inst(r["Kernel_Name"])
+        if "conv_" not in k_:
+            continue
+        per[k_][r["Counter_Name"]] += float(r["Counter_Value"])
+        if r["Counter_Name"] == "GRBM_GUI_ACTIVE":
+            cnt[k_] += 1
+            per[k_]["_ns"] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+    out["sq_by_instantiation"] = []
+    for k_, c in sorted(per.items(), key=lambda kv: -kv[1]["_ns"]):
+        n_ = max(cnt[k_], 1)
+        gui = c.get("GRBM_GUI_ACTIVE", 0.0)
+        wave = c.get("SQ_WAVE_CYCLES", 0.0)
+        row = dict(kernel=k_, launches=n_, avg_us_under_pmc=round(c["_ns"] / n_ / 1e3, 2))
+        if gui:
+            # SQ_VALU_MFMA_BUSY_CYCLES counts cycles summed over the SIMDs (256 CUs x 4 can be busy at once);
+            # GRBM_GUI_ACTIVE comes back summed over the 8 XCDs (937 786 "cycles" for a 52.6 us kernel = 8 x 2.23 GHz)
+            row["mfma_util"] = round(c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (gui / 8.0 * 256 * 4), 4)
+        if wave:
+            for name, key in (("issuing", "SQ_ACTIVE_INST_ANY"), ("waiting_mem_or_barrier", "SQ_WAIT_ANY"),
+                              ("issue_stalled", "SQ_WAIT_INST_ANY"), ("valu", "SQ_ACTIVE_INST_VALU"), ("lds", "SQ_ACTIVE_INST_LDS")):
+                if key in c:
+                    row["wave_cycles_" + name] = round(c[key] / wave, 4)
+        out["sq_by_instantiation"].append(row)
 print(json.dumps(out, indent=1))
