@@ -176,8 +176,11 @@ def path_kernels(dev, frames, v, j, hh, wh):
     t = timed(lambda: _lib.argmax_decode(hm, valid, frames, v, j, hh, wh, 4, hh))
     out.append(hbm("argmax_decode_kernel (hard arg-max of every heat-map)", t, map_bytes, "one read of the heat-maps"))
     for kind, name in ((_lib.SCORE_HP, "HP"), (_lib.SCORE_MPE, "MPE"), (_lib.SCORE_BSB, "BSB")):
-        t = timed(lambda: _lib.score_maps(kind, hm, n_maps, hh, wh))
-        out.append(hbm(f"score_maps_kernel<{name}> (per-map uncertainty statistic)", t, map_bytes, "one read of the heat-maps"))
+        t = timed(lambda: _lib.score_decode_maps(kind, hm, valid, frames, v, j, hh, wh, 4, hh))
+        out.append(hbm(f"score_maps_kernel<{name}, decode> (per-map uncertainty statistic AND hard arg-max key-point from one "
+                       "staged read: the scoring pass's only pass over the heat-maps)", t, map_bytes,
+                       "one read of the heat-maps (uniform-noise maps: ~160 local maxima each to sort for MPE / BSB; "
+                       "trained heat-maps have a handful)"))
     proj = torch.from_numpy(np.stack([synth.ring_cameras(v, hh * 4, wh * 4, seed=s) for s in range(frames)])).to(dev)
     kp = _lib.argmax_decode(hm, valid, frames, v, j, hh, wh, 4, hh)
     t = timed(lambda: _lib.triangulate_ransac(kp, proj, valid, frames, v, j, 4.0))
