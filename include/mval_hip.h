@@ -242,6 +242,10 @@ typedef struct mval_pack_job {
   int mode, cout, cin, k;
 } mval_pack_job;
 int mval_pack_bf3_jobs(const mval_pack_job* jobs_dev, const int* first_block_dev, int n_jobs, int total_blocks, void* stream);
+/* The same for a mix of both splits: a job with bit 8 of `mode` set (mode | 0x100) is packed MVAL_PACK_MFMA16_H2
+ * (its max |w| is taken first, in the same call: two launches in all), the others MVAL_PACK_MFMA16_BF3; a job's block
+ * count is the same for both. */
+int mval_pack_split_jobs(const mval_pack_job* jobs_dev, const int* first_block_dev, int n_jobs, int total_blocks, void* stream);
 /* scale = gamma / sqrt(var + eps) ; shift = beta - mean * scale  (all [c] f32). */
 int mval_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var, float eps,
                  float* scale, float* shift, int c, void* stream);
@@ -290,6 +294,11 @@ int mval_bn_batch_stats(const float* z, int64_t M, int C, float eps, float momen
 int mval_bn_apply_fwd(const float* z, const float* mean, const float* invstd, const float* gamma, const float* beta,
                       const float* res1, const float* res2, float* out, int N, int H, int W, int C, int up, int relu,
                       void* stream);
+/* The same, and the max |out| of the tensor left in amax_row ([count, partial maxima ...], >= 513 dwords; NULL = as
+ * above): the activation scale of the fp16-split convs that read `out` in training (ONE row per tensor there). */
+int mval_bn_apply_fwd_amax(const float* z, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                           const float* res1, const float* res2, float* out, int N, int H, int W, int C, int up, int relu,
+                           uint32_t* amax_row, void* stream);
 /* Backward of the above: masks gout by (out > 0) when relu, adds it into gres1/gres2 (stores it
  * instead where `overwrite` bit 0 / bit 1 is set: the first writer of a gradient slot), window-sums
  * it to the conv resolution, then (has_bn) dgamma/dbeta and dz = gamma*invstd*(g - dbeta/M -
@@ -298,6 +307,11 @@ int mval_bn_apply_fwd(const float* z, const float* mean, const float* invstd, co
 int mval_bn_bwd(const float* gout, const float* out, const float* z, const float* mean, const float* invstd,
                 const float* gamma, float* gres1, float* gres2, float* gz, float* dgamma, float* dbeta, double* ws,
                 float* sums, int N, int H, int W, int C, int up, int relu, int has_bn, int overwrite, void* stream);
+/* The same, and max |gz| left in gz_amax_row (has_bn only; the scale of the fp16-split data-gradient conv). */
+int mval_bn_bwd_amax(const float* gout, const float* out, const float* z, const float* mean, const float* invstd,
+                     const float* gamma, float* gres1, float* gres2, float* gz, float* dgamma, float* dbeta, double* ws,
+                     float* sums, int N, int H, int W, int C, int up, int relu, int has_bn, int overwrite,
+                     uint32_t* gz_amax_row, void* stream);
 /* Weight gradient dw [cout][cin][k][k] of a conv: x NHWC (NCHW when x_nchw), dz NHWC.
  * ws >= mval_conv_wgrad_workspace_floats(cin, cout, k) floats. */
 size_t mval_conv_wgrad_workspace_floats(int cin, int cout, int k);
@@ -317,6 +331,11 @@ int mval_maxpool_bwd(const float* gout, const float* x, float* gin, int N, int H
 int mval_conv_dgrad(const float* dz, const float* w_packed, const float* ones, const float* zeros, float* dx,
                     int accumulate, int N, int hin, int win, int cin, int hout, int wout, int cout, int k,
                     int stride, int pad, int algo, void* stream);
+/* The same with algo = MVAL_ALGO_MFMA_H2 allowed (stride 1): dz_amax_row = the magnitude row of dz (one row for the
+ * tensor), w_packed in MVAL_PACK_MFMA16_H2 form (with its trailer). */
+int mval_conv_dgrad_scaled(const float* dz, const float* w_packed, const float* ones, const float* zeros, float* dx,
+                           int accumulate, int N, int hin, int win, int cin, int hout, int wout, int cout, int k,
+                           int stride, int pad, int algo, const uint32_t* dz_amax_row, void* stream);
 
 /* One operator of the training graph: the forward geometry / arena offsets (`op`, as in
  * inference, weights packed for the forward kernel at op.w_off; op.shift_off = bias for a conv
@@ -336,6 +355,12 @@ typedef struct mval_train_op {
   float* gamma; float* beta; float* running_mean; float* running_var; /* device pointers */
   float* mean; float* invstd;            /* saved batch statistics [cout] */
   float* dweight; float* dgamma; float* dbeta; /* gradient outputs (dbeta = bias grad w/o BN) */
+  /* fp16-split kernels in training (op.algo / dgrad_algo == MVAL_ALGO_MFMA_H2): magnitude rows ([count, partials],
+   * ONE row per tensor, >= 513 dwords each, float offsets into `arena`; 0 = none).  op.in_amax_off = the row of the
+   * op's INPUT activation (written by its producer's out_amax_off); out_amax_off = where this op's BatchNorm apply
+   * leaves max |out|; gz_amax_off = the row of the op's dz scratch (written by its BatchNorm backward, read by its
+   * data-gradient conv). */
+  int64_t out_amax_off, gz_amax_off;
 } mval_train_op;
 
 /* ones_off / zeros_off: params offsets of >= max(cout) floats of 1.0 / 0.0.

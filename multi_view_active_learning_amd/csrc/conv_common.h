@@ -31,6 +31,7 @@ struct ConvArgs {
   // conv_amax_read gives the value), w_unscale = the factor that undoes the weight scale (trailer of the packed
   // weights).
   int planes;
+  int in_amax_stride;  // dwords between the rows of consecutive images (MVAL_AMAX_ROW); 0 = ONE row for the whole tensor
   const unsigned* in_amax;
   const float* w_unscale;
   // != nullptr: every workgroup that writes part of image n of `out` leaves max |value| of what it stored in its
@@ -281,5 +282,6 @@ int mval_launch_conv_block(int C, const float* in, float* out, const float* w1, 
                            hipStream_t s);
 int mval_launch_amax(const float* x, int64_t per_image, int n_images, unsigned* rows, hipStream_t s);
 int mval_pack_bf3_batch(const void* jobs_dev, const int* first_block_dev, int n_jobs, int total_blocks, hipStream_t s);
+int mval_pack_split_batch(const void* jobs_dev, const int* first_block_dev, int n_jobs, int total_blocks, hipStream_t s);
 int mval_launch_conv_direct(const ConvArgs& a, int kind, hipStream_t s);
 int mval_launch_conv_stem(const ConvArgs& a, hipStream_t s);  // conv_stem.hip; returns 1 if unsupported

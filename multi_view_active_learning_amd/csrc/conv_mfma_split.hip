@@ -107,9 +107,8 @@ __device__ __forceinline__ void split3(const f32x4 v, bf16x4& h, bf16x4& m, bf16
 // the sub-chunks take the place of the taps in the inner loop.
 template <int PL, int KS, int S, int WN, int WM, int NT, int MS, int NE, bool RS = false, bool PA = false, int G = 1>
 __global__ __launch_bounds__(64 * WN * WM)
-    __attribute__((amdgpu_waves_per_eu((KS == 1 && G == 2 && NT == 2) ? (PA ? 3 : 4) : (PA && KS >= 2 && NE <= 6) ? 3 : (PL == 2 && NE <= 6) ? 4 : 1, 8))) void conv_split_kernel(ConvArgs a) {
+    __attribute__((amdgpu_waves_per_eu((KS == 1 && G == 2 && NT == 2) ? (PA ? 3 : 4) : (PA && KS >= 2 && NE <= 6) ? 3 : (PL == 2 && NE <= 6 && !PA) ? 4 : 1, 8))) void conv_split_kernel(ConvArgs a) {
   static_assert(G == 1 || (KS == 1 && S == 1), "multi-chunk staging is for 1x1 convs");
-  static_assert(PL == 3 || !PA, "the separate correction accumulator belongs to the bf16x3 training kernels");
   constexpr int NP = split_np<PL>();
   constexpr int TAPS = G > 1 ? G : KS * KS;
   constexpr int BF_ROW = BF_ROW_OF(S);
@@ -246,7 +245,7 @@ __global__ __launch_bounds__(64 * WN * WM)
     // one image per tile (the launcher refuses tn > 1): the image's own scale.  Read AFTER the first chunk's loads
     // are in flight: the two dependent L2 round trips (header, partials) then hide behind them (issued first they
     // cost 10 us on the 32-channel layers)
-    split_act_scale(a.in_amax + (int64_t)n0 * MVAL_AMAX_ROW, in_mul, unscale);
+    split_act_scale(a.in_amax + (int64_t)n0 * a.in_amax_stride, in_mul, unscale);
     unscale *= *a.w_unscale;
   }
   store_chunk();
@@ -406,8 +405,7 @@ static int launch_split(ConvArgs a, int th, int tw, int tn, hipStream_t s) {
   if (G > 1 && (patch_px != MT || ((a.Cin + BF_KC - 1) / BF_KC) % G != 0)) return 1;
   if (PL == 2 && tn != 1) return 1;  // the fp16 split scales per image: one image per tile (maps under 8 rows use bf16x3)
   if (g_bf3_dry) return 0;
-  constexpr bool PAOK = PL == 3;  // the separate correction accumulator exists for the bf16x3 split only
-  if (a.precise && !PAOK) return 1;
+  constexpr bool PAOK = true;  // (both splits have the separate-correction-accumulator form)
   dim3 grid((unsigned)(a.tiles_x * a.tiles_y * ngroups), (unsigned)((a.NS_total + WN * NT - 1) / (WN * NT)),
             (KS == 2 && a.par_w_stride) ? 4u : 1u);
   conv_amax_prepare(a, a.tiles_x * a.tiles_y, (int)(grid.y * grid.z), s);
@@ -586,7 +584,7 @@ static int launch_conv_split(const ConvArgs& a, hipStream_t s) {
 
 // a.planes: 3 = bf16x3 (six products), 2 = fp16x2 (three products; needs a.in_amax and a.w_unscale)
 int mval_launch_conv_split(const ConvArgs& a, hipStream_t s) {
-  if (a.planes == 2) return a.precise ? 1 : launch_conv_split<2>(a, s);
+  if (a.planes == 2) return launch_conv_split<2>(a, s);
   if (a.planes == 3) return launch_conv_split<3>(a, s);
   return 1;
 }
@@ -700,6 +698,57 @@ __global__ void pack_bf3_batch_kernel(const PackBf3Job* __restrict__ jobs, const
   }
   const PackBf3Job jb = jobs[lo];
   pack_split_element<3>(jb.w, jb.p, jb.mode, jb.cout, jb.cin, jb.k, (int64_t)(blockIdx.x - first_block[lo]) * blockDim.x + threadIdx.x, 1.f);
+}
+
+// Mixed batch: jobs with bit 8 of `mode` are fp16-split packings (trailer after the fragments; max |w| by
+// pack_amax_batch_kernel first, one workgroup per job).
+__global__ __launch_bounds__(256) void pack_amax_batch_kernel(const PackBf3Job* __restrict__ jobs) {
+  const PackBf3Job jb = jobs[blockIdx.x];
+  if (!(jb.mode & 0x100)) return;
+  __shared__ float red[4];
+  const int64_t n = (int64_t)jb.cout * jb.cin * jb.k * jb.k;
+  float m = 0.f;
+  for (int64_t i = threadIdx.x; i < n; i += 256) m = fmaxf(m, fabsf(jb.w[i]));
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    const int G = (jb.cin + 31) / 32, NS = (jb.cout + 15) / 16;
+    float* trailer = reinterpret_cast<float*>(jb.p) + (int64_t)jb.k * jb.k * G * NS * 512;
+    float mul, inv;
+    split_weight_scale(__float_as_uint(m), mul, inv);
+    trailer[0] = inv;
+    reinterpret_cast<unsigned*>(trailer)[1] = __float_as_uint(m);
+    trailer[2] = trailer[3] = 0.f;
+  }
+}
+
+__global__ void pack_split_batch_kernel(const PackBf3Job* __restrict__ jobs, const int* __restrict__ first_block, int n_jobs) {
+  int lo = 0, hi = n_jobs - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (first_block[mid] <= (int)blockIdx.x) lo = mid;
+    else hi = mid - 1;
+  }
+  const PackBf3Job jb = jobs[lo];
+  const int64_t i = (int64_t)(blockIdx.x - first_block[lo]) * blockDim.x + threadIdx.x;
+  if (jb.mode & 0x100) {
+    const int G = (jb.cin + 31) / 32, NS = (jb.cout + 15) / 16;
+    const float* trailer = reinterpret_cast<const float*>(jb.p) + (int64_t)jb.k * jb.k * G * NS * 512;
+    float mul, inv;
+    split_weight_scale(reinterpret_cast<const unsigned*>(trailer)[1], mul, inv);
+    pack_split_element<2>(jb.w, jb.p, jb.mode & 0xff, jb.cout, jb.cin, jb.k, i, mul);
+  } else {
+    pack_split_element<3>(jb.w, jb.p, jb.mode, jb.cout, jb.cin, jb.k, i, 1.f);
+  }
+}
+
+int mval_pack_split_batch(const void* jobs_dev, const int* first_block_dev, int n_jobs, int total_blocks, hipStream_t s) {
+  hipLaunchKernelGGL(pack_amax_batch_kernel, dim3((unsigned)n_jobs), dim3(256), 0, s, reinterpret_cast<const PackBf3Job*>(jobs_dev));
+  hipLaunchKernelGGL(pack_split_batch_kernel, dim3((unsigned)total_blocks), dim3(256), 0, s,
+                     reinterpret_cast<const PackBf3Job*>(jobs_dev), first_block_dev, n_jobs);
+  return 0;
 }
 
 int mval_pack_bf3_batch(const void* jobs_dev, const int* first_block_dev, int n_jobs, int total_blocks, hipStream_t s) {

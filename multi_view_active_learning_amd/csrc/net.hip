@@ -64,6 +64,14 @@ extern "C" int mval_pack_bf3_jobs(const mval_pack_job* jobs_dev, const int* firs
   return 0;
 }
 
+extern "C" int mval_pack_split_jobs(const mval_pack_job* jobs_dev, const int* first_block_dev, int n_jobs, int total_blocks,
+                                   void* stream) {
+  MVAL_REQUIRE(jobs_dev && first_block_dev && n_jobs > 0 && total_blocks > 0, "mval_pack_split_jobs: bad arguments");
+  mval_pack_split_batch(jobs_dev, first_block_dev, n_jobs, total_blocks, mval_stream(stream));
+  MVAL_CHECK_LAUNCH("mval_pack_split_jobs");
+  return 0;
+}
+
 extern "C" int mval_pack_conv_weights(int pack, int transposed, const float* w, float* packed, int cout, int cin, int k,
                                       void* stream) {
   MVAL_REQUIRE(cout > 0 && cin > 0 && k > 0, "mval_pack_conv_weights: bad dims");
@@ -382,6 +390,7 @@ extern "C" int mval_op_launch(const mval_op* op, int n_images, float* workspace,
     if (a.planes == 2) {
       MVAL_REQUIRE(op->in_amax_off > 0 && a.w, "mval_op_launch: the fp16-split conv needs in_amax_off (max |x| of its input)");
       a.in_amax = reinterpret_cast<const unsigned*>(workspace + op->in_amax_off);
+      a.in_amax_stride = MVAL_AMAX_ROW;
       const int kk = op->kind == MVAL_OP_DECONV ? 4 : op->k;
       a.w_unscale = a.w + mval_packed_weight_floats(MVAL_PACK_MFMA16_H2, op->cout, op->cin, kk) - 4;
     }

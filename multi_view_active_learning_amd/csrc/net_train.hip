@@ -44,8 +44,14 @@ static void deconv_as_conv(ConvArgs& a, const mval_op& op) {
 
 static int run_conv(const ConvArgs& a0, int algo, hipStream_t s, const char* what) {
   ConvArgs a = a0;
-  if (algo == MVAL_ALGO_MFMA_BF3) {
-    a.planes = 3;  // training keeps the bf16x3 split (scale-free, and its bias-free accumulate mode)
+  if (algo == MVAL_ALGO_MFMA_BF3 || algo == MVAL_ALGO_MFMA_H2) {
+    // bf16x3: scale-free; fp16x2: the caller set a.in_amax (ONE magnitude row for the tensor: in_amax_stride 0) and
+    // a.w_unscale.  Both have the bias-free accumulate mode (a.precise) the training forward needs.
+    a.planes = algo == MVAL_ALGO_MFMA_H2 ? 2 : 3;
+    if (a.planes == 2 && (!a.in_amax || !a.w_unscale)) {
+      mval_set_error("%s: the fp16-split conv needs its input's magnitude row and the packed weights' trailer", what);
+      return -1;
+    }
     if (mval_launch_conv_split(a, s)) {
       mval_set_error("%s: no bf16x3 MFMA configuration (k%d cin%d cout%d dil%d)", what, a.k, a.Cin, a.Cout, a.dil);
       return -1;
@@ -82,6 +88,8 @@ extern "C" int mval_train_forward(const mval_train_op* ops, int n_ops, int n_ima
       a.w = a.scale = a.shift = nullptr;
       a.out = arena + op.out_off;
       mval_launch_conv_direct(a, MVAL_OP_MAXPOOL, s);
+      if (t.out_amax_off > 0)  // (one row for the tensor: "one image" of the whole size)
+        mval_launch_amax(a.out, (int64_t)n_images * op.hout * op.wout * op.cout, 1, reinterpret_cast<unsigned*>(arena + t.out_amax_off), s);
       continue;
     }
     if (op.kind == MVAL_OP_DECONV) {
@@ -89,6 +97,11 @@ extern "C" int mval_train_forward(const mval_train_op* ops, int n_ops, int n_ima
       deconv_as_conv(a, op);
     }
     a.w = params + op.w_off;
+    if (op.algo == MVAL_ALGO_MFMA_H2) {
+      MVAL_REQUIRE(op.in_amax_off > 0, "mval_train_forward: op %d: fp16-split conv without its input's magnitude row", i);
+      a.in_amax = reinterpret_cast<const unsigned*>(arena + op.in_amax_off);
+      a.w_unscale = a.w + mval_packed_weight_floats(MVAL_PACK_MFMA16_H2, op.cout, op.cin, op.k) - 4;
+    }
     float* out = op.out_off >= 0 ? arena + op.out_off : output_nchw;
     if (t.has_bn) {
       a.out = arena + t.z_off;
@@ -100,9 +113,10 @@ extern "C" int mval_train_forward(const mval_train_op* ops, int n_ops, int n_ima
       rc = mval_bn_batch_stats(a.out, M, op.cout, eps, momentum, t.mean, t.invstd, t.running_mean, t.running_var, ws,
                                stream);
       if (rc) return rc;
-      rc = mval_bn_apply_fwd(a.out, t.mean, t.invstd, t.gamma, t.beta, op.res1_off >= 0 ? arena + op.res1_off : nullptr,
-                             op.res2_off >= 0 ? arena + op.res2_off : nullptr, out, n_images, op.hout, op.wout, op.cout,
-                             op.up, op.relu, stream);
+      rc = mval_bn_apply_fwd_amax(a.out, t.mean, t.invstd, t.gamma, t.beta, op.res1_off >= 0 ? arena + op.res1_off : nullptr,
+                                  op.res2_off >= 0 ? arena + op.res2_off : nullptr, out, n_images, op.hout, op.wout, op.cout,
+                                  op.up, op.relu, t.out_amax_off > 0 ? reinterpret_cast<uint32_t*>(arena + t.out_amax_off) : nullptr,
+                                  stream);
       if (rc) return rc;
     } else {
       MVAL_REQUIRE(op.up == 0, "mval_train_forward: op %d: upsample without BatchNorm is not part of any graph", i);
@@ -141,10 +155,11 @@ extern "C" int mval_train_backward(const mval_train_op* ops, int n_ops, int n_im
     // the output activation is only needed for the ReLU mask; NCHW outputs (final layer) have none
     const float* outp = op.out_off >= 0 ? arena + op.out_off : nullptr;
     MVAL_REQUIRE(!(op.relu && !outp), "mval_train_backward: op %d: ReLU on an external output", i);
-    int rc = mval_bn_bwd(garena + t.gout_off, outp, t.has_bn ? arena + t.z_off : nullptr, t.mean, t.invstd, t.gamma,
-                         t.gres1_off >= 0 ? garena + t.gres1_off : nullptr,
-                         t.gres2_off >= 0 ? garena + t.gres2_off : nullptr, gz, t.dgamma, t.dbeta, ws, sums, n_images,
-                         op.hout, op.wout, op.cout, op.up, op.relu, t.has_bn, t.first_touch >> 1, stream);
+    uint32_t* gz_row = (t.has_bn && t.gz_amax_off > 0) ? reinterpret_cast<uint32_t*>(arena + t.gz_amax_off) : nullptr;
+    int rc = mval_bn_bwd_amax(garena + t.gout_off, outp, t.has_bn ? arena + t.z_off : nullptr, t.mean, t.invstd, t.gamma,
+                              t.gres1_off >= 0 ? garena + t.gres1_off : nullptr,
+                              t.gres2_off >= 0 ? garena + t.gres2_off : nullptr, gz, t.dgamma, t.dbeta, ws, sums, n_images,
+                              op.hout, op.wout, op.cout, op.up, op.relu, t.has_bn, t.first_touch >> 1, gz_row, stream);
     if (rc) return rc;
     const float* x = op.in_off >= 0 ? arena + op.in_off : input_nchw;
     if (op.kind == MVAL_OP_DECONV) {
@@ -182,10 +197,11 @@ extern "C" int mval_train_backward(const mval_train_op* ops, int n_ops, int n_im
                          op.stride, op.pad, op.in_nchw, stream);
     if (rc) return rc;
     if (t.gin_off >= 0) {
-      rc = mval_conv_dgrad(gz, params + t.wd_off, params + ones_off, params + zeros_off, garena + t.gin_off,
-                           !(t.first_touch & 1), n_images,
-                           op.hin, op.win, op.cin, op.hout, op.wout, op.cout, op.k, op.stride, op.pad, t.dgrad_algo,
-                           stream);
+      MVAL_REQUIRE(t.dgrad_algo != MVAL_ALGO_MFMA_H2 || gz_row, "mval_train_backward: op %d: fp16-split data gradient without dz's magnitude row", i);
+      rc = mval_conv_dgrad_scaled(gz, params + t.wd_off, params + ones_off, params + zeros_off, garena + t.gin_off,
+                                  !(t.first_touch & 1), n_images,
+                                  op.hin, op.win, op.cin, op.hout, op.wout, op.cout, op.k, op.stride, op.pad, t.dgrad_algo,
+                                  gz_row, stream);
       if (rc) return rc;
     }
   }
@@ -197,9 +213,18 @@ extern "C" int mval_train_backward(const mval_train_op* ops, int n_ops, int n_im
 extern "C" int mval_conv_dgrad(const float* dz, const float* w_packed, const float* ones, const float* zeros, float* dx,
                                int accumulate, int N, int hin, int win, int cin, int hout, int wout, int cout, int k,
                                int stride, int pad, int algo, void* stream) {
+  MVAL_REQUIRE(algo != MVAL_ALGO_MFMA_H2, "mval_conv_dgrad: the fp16-split form needs dz's magnitude row (mval_conv_dgrad_scaled)");
+  return mval_conv_dgrad_scaled(dz, w_packed, ones, zeros, dx, accumulate, N, hin, win, cin, hout, wout, cout, k, stride, pad,
+                                algo, nullptr, stream);
+}
+
+extern "C" int mval_conv_dgrad_scaled(const float* dz, const float* w_packed, const float* ones, const float* zeros, float* dx,
+                                      int accumulate, int N, int hin, int win, int cin, int hout, int wout, int cout, int k,
+                                      int stride, int pad, int algo, const uint32_t* dz_amax_row, void* stream) {
   MVAL_REQUIRE(dz && w_packed && ones && zeros && dx && N > 0, "mval_conv_dgrad: bad arguments");
   MVAL_REQUIRE(algo == MVAL_ALGO_MFMA || algo == MVAL_ALGO_MFMA_BF3 || stride == 1,
                "mval_conv_dgrad: strided data gradient needs an MFMA kernel");
+  MVAL_REQUIRE(algo != MVAL_ALGO_MFMA_H2 || (stride == 1 && dz_amax_row), "mval_conv_dgrad: fp16-split form: stride 1 with dz's magnitude row");
   ConvArgs a = {};
   a.N = N;
   a.Hin = hout; a.Win = wout; a.Cin = cout;
@@ -213,6 +238,10 @@ extern "C" int mval_conv_dgrad(const float* dz, const float* w_packed, const flo
   a.precise = 0;  // measured: only the FORWARD needs bias-free accumulation (its outputs enter batch statistics)
   a.in = dz;
   a.w = w_packed;
+  if (algo == MVAL_ALGO_MFMA_H2) {  // the data-gradient conv has cin' = cout, cout' = cin
+    a.in_amax = dz_amax_row;
+    a.w_unscale = w_packed + mval_packed_weight_floats(MVAL_PACK_MFMA16_H2, cin, cout, k) - 4;
+  }
   a.scale = ones;
   a.shift = zeros;
   a.out = dx;

@@ -10,6 +10,26 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define TR_BLOCKS 512
+// The two elementwise BatchNorm streams run 1024-thread workgroups, at most two per CU: every workgroup leaves ONE
+// partial maximum, and every workgroup of the consuming conv reads them all -- 2048 partials (256-thread workgroups)
+// cost the 32-channel convs 10-14 us each (134 MB of L2 reads per launch), 512 cost ~2.
+#define TR_APPLY_THREADS 1024
+#define TR_APPLY_BLOCKS 512
+
+// max |value| of what this workgroup wrote -> its slot of the tensor's magnitude row ([count, partials ...], the
+// activation scale of the fp16-split convs, conv_common.h; ONE row per tensor in training: BatchNorm couples the
+// batch anyway).  Every thread of the workgroup calls it.
+__device__ __forceinline__ void tr_amax_store(unsigned* row, float m) {
+  __shared__ float red[TR_APPLY_THREADS / 64];
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < (int)(blockDim.x >> 6); w++) m = fmaxf(m, red[w]);
+    row[0] = gridDim.x;
+    row[1 + blockIdx.x] = __float_as_uint(m);
+  }
+}
 #define TR_UNROLL 8
 #define TR_EW 4  // pixels per thread and pass in the backward reduction
 
@@ -114,17 +134,19 @@ extern "C" int mval_bn_batch_stats(const float* z, int64_t M, int C, float eps, 
 }
 
 // ---- forward apply: out = act(((z*alpha + beta') up) + res1 + res2) ------------------------
-__global__ __launch_bounds__(256) void bn_apply_fwd_kernel(const float* __restrict__ z, const float* __restrict__ mean,
+__global__ __launch_bounds__(TR_APPLY_THREADS) void bn_apply_fwd_kernel(const float* __restrict__ z, const float* __restrict__ mean,
                                                            const float* __restrict__ invstd,
                                                            const float* __restrict__ gamma,
                                                            const float* __restrict__ beta,
                                                            const float* __restrict__ res1,
                                                            const float* __restrict__ res2, float* __restrict__ out,
-                                                           int N, int H, int W, int C, int up, int relu) {
+                                                           int N, int H, int W, int C, int up, int relu,
+                                                           unsigned* __restrict__ amax_row) {
   const int c4n = C >> 2;
   const int Ho = H << up, Wo = W << up;
   const int64_t total = (int64_t)N * Ho * Wo * c4n;
-  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+  float amax = 0.f;
+  for (int64_t t = (int64_t)blockIdx.x * TR_APPLY_THREADS + threadIdx.x; t < total; t += (int64_t)gridDim.x * TR_APPLY_THREADS) {
     const int q = (int)(t % c4n);
     int64_t p = t / c4n;
     const int X = (int)(p % Wo);
@@ -145,20 +167,27 @@ __global__ __launch_bounds__(256) void bn_apply_fwd_kernel(const float* __restri
       r.x = fmaxf(r.x, 0.f); r.y = fmaxf(r.y, 0.f); r.z = fmaxf(r.z, 0.f); r.w = fmaxf(r.w, 0.f);
     }
     *reinterpret_cast<f32x4*>(out + o) = r;
+    amax = fmaxf(fmaxf(amax, fmaxf(fabsf(r.x), fabsf(r.y))), fmaxf(fabsf(r.z), fabsf(r.w)));
   }
+  if (amax_row) tr_amax_store(amax_row, amax);
 }
 
+extern "C" int mval_bn_apply_fwd_amax(const float* z, const float* mean, const float* invstd, const float* gamma,
+                                      const float* beta, const float* res1, const float* res2, float* out, int N, int H,
+                                      int W, int C, int up, int relu, uint32_t* amax_row, void* stream) {
+  MVAL_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && (C & 3) == 0 && up >= 0, "mval_bn_apply_fwd: bad dims");
+  int64_t total = (int64_t)N * (H << up) * (W << up) * (C >> 2);
+  int nb = (int)((total + TR_APPLY_THREADS - 1) / TR_APPLY_THREADS);
+  if (nb > TR_APPLY_BLOCKS) nb = TR_APPLY_BLOCKS;
+  hipLaunchKernelGGL(bn_apply_fwd_kernel, dim3(nb), dim3(TR_APPLY_THREADS), 0, mval_stream(stream), z, mean, invstd, gamma, beta,
+                     res1, res2, out, N, H, W, C, up, relu, amax_row);
+  MVAL_CHECK_LAUNCH("mval_bn_apply_fwd");
+  return 0;
+}
 extern "C" int mval_bn_apply_fwd(const float* z, const float* mean, const float* invstd, const float* gamma,
                                  const float* beta, const float* res1, const float* res2, float* out, int N, int H,
                                  int W, int C, int up, int relu, void* stream) {
-  MVAL_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && (C & 3) == 0 && up >= 0, "mval_bn_apply_fwd: bad dims");
-  int64_t total = (int64_t)N * (H << up) * (W << up) * (C >> 2);
-  int nb = (int)((total + 255) / 256);
-  if (nb > 8192) nb = 8192;
-  hipLaunchKernelGGL(bn_apply_fwd_kernel, dim3(nb), dim3(256), 0, mval_stream(stream), z, mean, invstd, gamma, beta,
-                     res1, res2, out, N, H, W, C, up, relu);
-  MVAL_CHECK_LAUNCH("mval_bn_apply_fwd");
-  return 0;
+  return mval_bn_apply_fwd_amax(z, mean, invstd, gamma, beta, res1, res2, out, N, H, W, C, up, relu, nullptr, stream);
 }
 
 // ---- backward, stage 1 ------------------------------------------------------------------
@@ -309,15 +338,17 @@ __global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(const double* __res
 }
 
 // stage 2 (in place on gz): dz = gamma * invstd * (gz - dbeta / M - xhat * dgamma / M)
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(float* __restrict__ gz, const float* __restrict__ z,
+__global__ __launch_bounds__(TR_APPLY_THREADS) void bn_bwd_apply_kernel(float* __restrict__ gz, const float* __restrict__ z,
                                                            const float* __restrict__ mean,
                                                            const float* __restrict__ invstd,
                                                            const float* __restrict__ gamma,
-                                                           const float* __restrict__ sums, int64_t M, int C) {
+                                                           const float* __restrict__ sums, int64_t M, int C,
+                                                           unsigned* __restrict__ amax_row) {
   const int c4n = C >> 2;
   const int64_t total = M * c4n;
   const float invM = 1.0f / (float)M;
-  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+  float amax = 0.f;
+  for (int64_t t = (int64_t)blockIdx.x * TR_APPLY_THREADS + threadIdx.x; t < total; t += (int64_t)gridDim.x * TR_APPLY_THREADS) {
     const int q = (int)(t % c4n);
     const int64_t i = (t / c4n) * C + q * 4;
     const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + q * 4);
@@ -327,8 +358,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(float* __restrict__ g
     const f32x4 dg = *reinterpret_cast<const f32x4*>(sums + C + q * 4);
     const f32x4 xh = (*reinterpret_cast<const f32x4*>(z + i) - mu) * is;
     const f32x4 gv = *reinterpret_cast<const f32x4*>(gz + i);
-    *reinterpret_cast<f32x4*>(gz + i) = (g * is) * (gv - db * invM - xh * (dg * invM));
+    const f32x4 r = (g * is) * (gv - db * invM - xh * (dg * invM));
+    *reinterpret_cast<f32x4*>(gz + i) = r;
+    amax = fmaxf(fmaxf(amax, fmaxf(fabsf(r.x), fabsf(r.y))), fmaxf(fabsf(r.z), fabsf(r.w)));
   }
+  if (amax_row) tr_amax_store(amax_row, amax);
 }
 
 // channel counts that are not a multiple of 4 (the 19-joint heat-map layer): plain conv with
@@ -363,6 +397,14 @@ extern "C" int mval_bn_bwd(const float* gout, const float* out, const float* z, 
                            const float* gamma, float* gres1, float* gres2, float* gz, float* dgamma, float* dbeta,
                            double* ws, float* sums, int N, int H, int W, int C, int up, int relu, int has_bn,
                            int overwrite, void* stream) {
+  return mval_bn_bwd_amax(gout, out, z, mean, invstd, gamma, gres1, gres2, gz, dgamma, dbeta, ws, sums, N, H, W, C, up, relu,
+                          has_bn, overwrite, nullptr, stream);
+}
+
+extern "C" int mval_bn_bwd_amax(const float* gout, const float* out, const float* z, const float* mean, const float* invstd,
+                                const float* gamma, float* gres1, float* gres2, float* gz, float* dgamma, float* dbeta,
+                                double* ws, float* sums, int N, int H, int W, int C, int up, int relu, int has_bn,
+                                int overwrite, uint32_t* gz_amax_row, void* stream) {
   MVAL_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && up >= 0, "mval_bn_bwd: bad dims");
   MVAL_REQUIRE((int64_t)N * (H << up) * (W << up) * C < ((int64_t)1 << 33), "mval_bn_bwd: more than 2^31 float4 elements");
   MVAL_REQUIRE(!gres1 || gres1 != gres2, "mval_bn_bwd: the two residual gradients must be distinct buffers");
@@ -394,9 +436,9 @@ extern "C" int mval_bn_bwd(const float* gout, const float* out, const float* z, 
   MVAL_CHECK_LAUNCH("mval_bn_bwd/finalize");
   if (has_bn) {
     int64_t total = M * c4n;
-    int nb2 = (int)((total + 255) / 256);
-    if (nb2 > 8192) nb2 = 8192;
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(nb2), dim3(256), 0, s, gz, z, mean, invstd, gamma, sums, M, C);
+    int nb2 = (int)((total + TR_APPLY_THREADS - 1) / TR_APPLY_THREADS);
+    if (nb2 > TR_APPLY_BLOCKS) nb2 = TR_APPLY_BLOCKS;
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(nb2), dim3(TR_APPLY_THREADS), 0, s, gz, z, mean, invstd, gamma, sums, M, C, gz_amax_row);
     MVAL_CHECK_LAUNCH("mval_bn_bwd/apply");
   }
   return 0;

@@ -23,8 +23,10 @@ import os
 import torch
 
 from . import _lib
-from .engine import (ALGO_DIRECT, ALGO_MFMA, ALGO_MFMA_BF3, PACK_HWIO, PACK_MFMA16, PACK_MFMA16_BF3, _KIND, _PACK_OF, MvalOp,
-                     _align, _conv_mode, _mfma_ok)
+from .engine import (ALGO_DIRECT, ALGO_MFMA, ALGO_MFMA_BF3, ALGO_MFMA_H2, PACK_HWIO, PACK_MFMA16, PACK_MFMA16_BF3,
+                     PACK_MFMA16_H2, _KIND, _PACK_OF, MvalOp, _align, _conv_mode, _mfma_ok)
+
+TRAIN_AMAX_ROW = 576  # dwords per magnitude row in training: [count, <= 512 partial maxima], one row per tensor
 
 BN_MOMENTUM = 0.1
 BN_EPS = 1e-5
@@ -43,6 +45,7 @@ class MvalTrainOp(C.Structure):
         ("gamma", C.c_void_p), ("beta", C.c_void_p), ("running_mean", C.c_void_p), ("running_var", C.c_void_p),
         ("mean", C.c_void_p), ("invstd", C.c_void_p),
         ("dweight", C.c_void_p), ("dgamma", C.c_void_p), ("dbeta", C.c_void_p),
+        ("out_amax_off", C.c_int64), ("gz_amax_off", C.c_int64),
     ]
 
 
@@ -83,7 +86,12 @@ class TrainPlan:
                 top += _align(n * geo[i][2] * geo[i][3] * op.cout)
             else:
                 z_off.append(-1)
-        self.arena_floats = top
+        # magnitude rows of the fp16-split convs (MVAL_CONV=h2, the default): one per activation a split conv reads,
+        # one for the dz scratch
+        amax_row = {}
+        self.gz_amax_off = top
+        top += TRAIN_AMAX_ROW
+        self._row_top = top  # rows are handed out below, the arena is sized after the op loop
         # ---- parameters: forward packing, dgrad packing, ones / zeros ---------------------------
         maxc = max(op.cout for op in g.ops)
         self.maxc = maxc
@@ -104,12 +112,20 @@ class TrainPlan:
             m.hin, m.win, m.hout, m.wout = hin, win, hout, wout
             m.up, m.relu, m.in_nchw, m.out_nchw = op.up, int(op.relu), int(in_nchw), int(out_nchw)
             m.algo = ALGO_DIRECT
-            bf3 = _conv_mode() in ("bf3", "h2")  # training always uses the scale-free bf16x3 split
+            bf3 = _conv_mode() in ("bf3", "h2")
+            h2 = _conv_mode() == "h2"  # fp16x2 split (3 products) where it applies, else bf16x3 (6)
             if _mfma_ok(op, in_nchw) and lib.mval_op_mfma_supported(C.byref(m), C.c_int(n)):
                 m.algo = ALGO_MFMA
-                if (bf3 and op.kind == "conv" and op.k in (1, 3) and (op.cin % 32 == 0 or op.cin == 48)
-                        and lib.mval_op_algo_supported(C.byref(m), C.c_int(n), C.c_int(ALGO_MFMA_BF3))):
-                    m.algo = ALGO_MFMA_BF3
+                if bf3 and op.kind == "conv" and op.k in (1, 3) and (op.cin % 32 == 0 or op.cin == 48):
+                    for cand in ((ALGO_MFMA_H2, ALGO_MFMA_BF3) if (h2 and op.src != g.input) else (ALGO_MFMA_BF3,)):
+                        if lib.mval_op_algo_supported(C.byref(m), C.c_int(n), C.c_int(cand)):
+                            m.algo = cand
+                            break
+            if m.algo == ALGO_MFMA_H2:
+                if op.src not in amax_row:
+                    amax_row[op.src] = self._row_top
+                    self._row_top += TRAIN_AMAX_ROW
+                m.in_amax_off = amax_row[op.src]
             m.in_off = -1 if op.src == g.input else act_off[op.src]
             m.out_off = -1 if op.dst == g.output else act_off[op.dst]
             m.res1_off = -1 if op.res1 is None else act_off[op.res1]
@@ -158,6 +174,14 @@ class TrainPlan:
                 # stride-1 data gradients are plain convs with cin' = cout: bf16x3-split kernel
                 if ok and bf3 and (op.cout % 32 == 0 or op.cout == 48) and ((op.k == 3 and op.cin % 16 == 0) or (op.stride == 1 and op.cin % 16 == 0)):
                     t.dgrad_algo = ALGO_MFMA_BF3
+                    # stride-1 data gradients of BatchNorm'd convs: fp16x2 (dz's magnitude comes from the BN backward)
+                    if h2 and op.bn and op.stride == 1 and op.cin % 16 == 0:
+                        d = MvalOp()
+                        d.kind, d.k, d.stride, d.pad, d.cin, d.cout = 0, op.k, 1, op.k - 1 - op.pad, op.cout, op.cin
+                        d.hin, d.win, d.hout, d.wout = hout, wout, hin, win
+                        if lib.mval_op_algo_supported(C.byref(d), C.c_int(n), C.c_int(ALGO_MFMA_H2)):
+                            t.dgrad_algo = ALGO_MFMA_H2
+                            t.gz_amax_off = self.gz_amax_off
                 dpack = _PACK_OF[t.dgrad_algo]
                 # the data-gradient conv has cin' = cout, cout' = cin
                 nd = int(lib.mval_packed_weight_floats(C.c_int(dpack), C.c_int(op.cin), C.c_int(op.cout), C.c_int(op.k)))
@@ -168,6 +192,11 @@ class TrainPlan:
             stat_top += 2 * _align(op.cout)
             gz_max = max(gz_max, n * hout * wout * op.cout)
             wsf_max = max(wsf_max, int(lib.mval_conv_wgrad_workspace_floats(C.c_int(op.cin), C.c_int(op.cout), C.c_int(op.k))))
+        for i, op in enumerate(g.ops):  # producers leave max |out| where a split conv will look for it
+            self.ops[i].out_amax_off = amax_row.get(op.dst, 0)
+        if g.input in amax_row:
+            raise _lib.MvalError("the network input cannot feed an fp16-split conv")
+        self.arena_floats = _align(self._row_top)
         # first writer of every activation-gradient slot (backward order) stores, later ones accumulate;
         # slots nobody writes (activations without a consumer) are the only ones zero-filled
         touched = {g.output}
@@ -243,10 +272,10 @@ class TrainPlan:
                 return
             fmode, dmode = (2, 0) if op.kind == "deconv" else (0, 2)
             todo = []
-            if fpack == PACK_MFMA16_BF3:
-                todo.append((base + 4 * t.op.w_off, fmode, op.cout, op.cin))
-            if dpack == PACK_MFMA16_BF3:
-                todo.append((base + 4 * t.wd_off, dmode, op.cin, op.cout))
+            if fpack in (PACK_MFMA16_BF3, PACK_MFMA16_H2):  # (bit 8 of the mode: fp16-split packing, mval_pack_split_jobs)
+                todo.append((base + 4 * t.op.w_off, fmode | (0x100 if fpack == PACK_MFMA16_H2 else 0), op.cout, op.cin))
+            if dpack in (PACK_MFMA16_BF3, PACK_MFMA16_H2):
+                todo.append((base + 4 * t.wd_off, dmode | (0x100 if dpack == PACK_MFMA16_H2 else 0), op.cin, op.cout))
             for dst, mode, cout, cin in todo:
                 total = op.k * op.k * ((cin + 31) // 32) * ((cout + 15) // 16) * 512
                 rows.append((w.data_ptr(), dst, mode, cout, cin, op.k))
@@ -276,7 +305,7 @@ class TrainPlan:
             self._pack_ptrs = ptrs
         if repack and self._pack_jobs is not None:
             # every split-bf16 packing (forward and data-gradient forms) in one launch
-            _lib._check(lib.mval_pack_bf3_jobs(C.c_void_p(self._pack_jobs.data_ptr()), C.c_void_p(self._pack_first.data_ptr()),
+            _lib._check(lib.mval_pack_split_jobs(C.c_void_p(self._pack_jobs.data_ptr()), C.c_void_p(self._pack_first.data_ptr()),
                                                C.c_int(self._pack_n), C.c_int(self._pack_blocks), st), "pack (batched)")
         for (i, fpack, dpack), op in zip(self.jobs, self.graph.ops):
             t = self.ops[i]
@@ -292,10 +321,10 @@ class TrainPlan:
                 # Conv2d: forward as stored (0), data gradient tap-flipped / channel-swapped (2);
                 # ConvTranspose2d: the other way round (forward = conv over the zero-dilated input)
                 fmode, dmode = (2, 0) if op.kind == "deconv" else (0, 2)
-                if not (batched and fpack == PACK_MFMA16_BF3):
+                if not (batched and fpack in (PACK_MFMA16_BF3, PACK_MFMA16_H2)):
                     _lib._check(lib.mval_pack_conv_weights(C.c_int(fpack), C.c_int(fmode), wp, C.c_void_p(base + 4 * t.op.w_off),
                                                            C.c_int(op.cout), C.c_int(op.cin), C.c_int(op.k), st), "pack fwd")
-                if dpack is not None and not (batched and dpack == PACK_MFMA16_BF3):
+                if dpack is not None and not (batched and dpack in (PACK_MFMA16_BF3, PACK_MFMA16_H2)):
                     _lib._check(lib.mval_pack_conv_weights(C.c_int(dpack), C.c_int(dmode), wp, C.c_void_p(base + 4 * t.wd_off),
                                                            C.c_int(op.cin), C.c_int(op.cout), C.c_int(op.k), st), "pack dgrad")
                 if getattr(conv, "bias", None) is not None:
