@@ -317,6 +317,10 @@ int mval_bn_bwd_amax(const float* gout, const float* out, const float* z, const 
 size_t mval_conv_wgrad_workspace_floats(int cin, int cout, int k);
 int mval_conv_wgrad(const float* x, const float* dz, float* dw, float* ws, int N, int Hin, int Win, int Cin,
                     int Hout, int Wout, int Cout, int k, int stride, int pad, int x_nchw, void* stream);
+/* The same; with both magnitude rows ([count, partials], one row per tensor) the split kernels use the fp16x2 form. */
+int mval_conv_wgrad_scaled(const float* x, const float* dz, float* dw, float* ws, int N, int Hin, int Win, int Cin,
+                           int Hout, int Wout, int Cout, int k, int stride, int pad, int x_nchw,
+                           const uint32_t* x_amax_row, const uint32_t* dz_amax_row, void* stream);
 int mval_slab_reduce(const float* slabs, int S, int64_t n, float* out, int accumulate, void* stream);
 /* Backward of MaxPool2d(k, stride, pad) (pose_resnet.py:35 under autograd): gin (+)= gout routed to the
  * first maximum of each window in ATen's scan order (NaN wins); x / gin NHWC [N,Hin,Win,C], gout

@@ -21,7 +21,9 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 int mval_launch_wgrad_bf3(const float* x, const float* dz, float* slabs, int N, int Hin, int Win, int Cin, int Hout,
-                          int Wout, int Cout, int k, int stride, int max_slabs, hipStream_t s);  // conv_wgrad_bf3.hip
+                          int Wout, int Cout, int k, int stride, int max_slabs, const unsigned* x_amax,
+                          const unsigned* dz_amax, hipStream_t s);
+  // conv_wgrad_bf3.hip
 
 #define WG_CB 32   // cin / cout block
 #define WG_LD 48   // LDS row stride (floats)
@@ -337,6 +339,12 @@ extern "C" size_t mval_conv_wgrad_workspace_floats(int cin, int cout, int k) {
 // x NHWC (or NCHW when x_nchw), dz NHWC, dw [cout][cin][k][k]; ws >= mval_conv_wgrad_workspace_floats
 extern "C" int mval_conv_wgrad(const float* x, const float* dz, float* dw, float* ws, int N, int Hin, int Win, int Cin,
                                int Hout, int Wout, int Cout, int k, int stride, int pad, int x_nchw, void* stream) {
+  return mval_conv_wgrad_scaled(x, dz, dw, ws, N, Hin, Win, Cin, Hout, Wout, Cout, k, stride, pad, x_nchw, nullptr, nullptr, stream);
+}
+
+extern "C" int mval_conv_wgrad_scaled(const float* x, const float* dz, float* dw, float* ws, int N, int Hin, int Win, int Cin,
+                                      int Hout, int Wout, int Cout, int k, int stride, int pad, int x_nchw,
+                                      const uint32_t* x_amax_row, const uint32_t* dz_amax_row, void* stream) {
   MVAL_REQUIRE(N > 0 && Cin > 0 && Cout > 0 && k > 0 && stride > 0, "mval_conv_wgrad: bad dims");
   hipStream_t s = mval_stream(stream);
   const int T = k * k;
@@ -348,7 +356,8 @@ extern "C" int mval_conv_wgrad(const float* x, const float* dz, float* dw, float
   const bool stem = x_nchw && Cin == 3 && (k == 3 || k == 7) && stride == 2 && pad == k / 2 && (Cout & 15) == 0 && Cout <= 64;
   int PS = 0;
   if (!x_nchw && pad == k / 2)  // split-bf16 kernel (conv_wgrad_bf3.hip); 0 = shape not covered
-    PS = mval_launch_wgrad_bf3(x, dz, ws, N, Hin, Win, Cin, Hout, Wout, Cout, k, stride, wg_splits(Cin, Cout, 1024), s);
+    PS = mval_launch_wgrad_bf3(x, dz, ws, N, Hin, Win, Cin, Hout, Wout, Cout, k, stride, wg_splits(Cin, Cout, 1024),
+                               x_amax_row, dz_amax_row, s);
   if (PS > 0) {
     MVAL_CHECK_LAUNCH("mval_conv_wgrad/bf3");
   } else if (stem) {

@@ -1,6 +1,8 @@
-// Weight gradient of the 3x3 (stride 1 / 2) and wide 1x1 convs on the bf16 matrix cores with the exact
-// three-way bf16 split (see conv_mfma_bf3.hip): 2.67x the MFMA rate of the exact-fp32 kernel in
-// conv_wgrad.hip, same results to fp32 rounding.
+// Weight gradient of the 3x3 (stride 1 / 2) and wide 1x1 convs on the 16-bit matrix cores with the splits of
+// conv_mfma_split.hip: PL = 3, the exact three-way bf16 split of both operands (six products, 2.67x the MFMA rate of
+// the exact-fp32 kernel in conv_wgrad.hip), or PL = 2, the scaled two-way fp16 split (three products, 5.3x) when the
+// magnitude rows of x and dz are at hand (training with MVAL_CONV=h2: x's row from its producer's BatchNorm apply,
+// dz's from this op's BatchNorm backward); same results to fp32 rounding.
 //
 //   dW[tap][ci][co] = sum over pixels p of  x[p + tap][ci] * dz[p][co]
 //
@@ -29,6 +31,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
@@ -40,6 +44,8 @@ struct WgradBf3Args {
   float* slabs;     // [PS][k*k][Cin][Cout]
   int N, Hin, Win, H, W, Cin, Cout;
   int tiles_x, tiles_y, ntiles, PS;
+  const unsigned* x_amax;   // PL = 2: magnitude rows ([count, partials], one row per tensor) of x and dz
+  const unsigned* dz_amax;
 };
 
 __device__ __forceinline__ void wb_split_pair(const f32x2 x, unsigned& h, unsigned& m, unsigned& l) {
@@ -61,16 +67,39 @@ __device__ __forceinline__ void wb_split_store(const f32x4 v, char* dst, int pla
   *reinterpret_cast<u32x2*>(dst + 2 * plane_bytes) = (u32x2){l0, l1};
 }
 
+// scaled two-way fp16 split: v * mul = h + l (+ 2^-22 relative); 8-byte plane entries
+__device__ __forceinline__ void wb_split_store2(const f32x4 v, float mul, char* dst, int plane_bytes) {
+  const f32x4 vs = v * mul;
+  const f16x4 h = __builtin_convertvector(vs, f16x4);
+  const f16x4 l = __builtin_convertvector(vs - __builtin_convertvector(h, f32x4), f16x4);
+  *reinterpret_cast<f16x4*>(dst) = h;
+  *reinterpret_cast<f16x4*>(dst + plane_bytes) = l;
+}
+
 // 16 channels x 8 k of one plane: two transposed reads (k 0..3 and 4..7 of this lane's k-group)
-__device__ __forceinline__ bf16x8 wb_frag(const char* lo, const char* hi) {
+__device__ __forceinline__ s16x8 wb_frag(const char* lo, const char* hi) {
   const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(lo));
   const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(hi));
-  const s16x8 v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
-  return __builtin_bit_cast(bf16x8, v);
+  return (s16x8){a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+}
+template <int PL>
+__device__ __forceinline__ f32x4 wb_mfma(const s16x8 a, const s16x8 b, const f32x4 c) {
+  if constexpr (PL == 3)
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+// power of two that puts a maximum with these float bits into [2^14, 2^15), and its inverse
+__device__ __forceinline__ void wb_scale(unsigned amax_bits, float& mul, float& inv) {
+  const int e = (int)((amax_bits >> 23) & 0xff);
+  int s = (e == 0 || e == 255) ? 0 : 14 - (e - 127);
+  s = max(-110, min(110, s));
+  mul = __uint_as_float((unsigned)(127 + s) << 23);
+  inv = __uint_as_float((unsigned)(127 - s) << 23);
 }
 
 // KS x KS taps, stride S, tile TH x TW output pixels, NT cout tiles and MI cin tiles (of 16) per wave
-template <int KS, int S, int TH, int TW, int NT, int MI>
+template <int PL, int KS, int S, int TH, int TW, int NT, int MI>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((KS == 3 && S == 1 && TH == 8 && NT == 2) ? 2 : 1, 8))) void conv_wgrad_bf3_kernel(WgradBf3Args a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int T = KS * KS, MT = TH * TW;
@@ -80,8 +109,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((KS == 3 &&
   constexpr int XPLANE = PPX * XROW, ZPLANE = MT * ZROW;
   constexpr int XQ = CI / 4, ZQ = CO / 4;     // float4 per pixel
   constexpr int NEX = (PPX * XQ + 255) / 256, NEZ = (MT * ZQ + 255) / 256;
-  char* xl = smem;                 // [3][PPX][XROW]
-  char* zl = smem + 3 * XPLANE;    // [3][MT][ZROW]
+  char* xl = smem;                 // [PL][PPX][XROW]
+  char* zl = smem + PL * XPLANE;   // [PL][MT][ZROW]
+  float x_mul = 1.f, z_mul = 1.f, unscale = 1.f;
+  if constexpr (PL == 2) {
+    float xi, zi;
+    wb_scale(conv_amax_read(a.x_amax), x_mul, xi);
+    wb_scale(conv_amax_read(a.dz_amax), z_mul, zi);
+    unscale = xi * zi;
+  }
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ci_g = wave & 1, co_g = wave >> 1;  // cin group (16 * MI) / cout group (16 * NT) of this wave
   const int ci0 = blockIdx.y * CI, co0 = blockIdx.z * CO;
@@ -149,24 +185,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((KS == 3 &&
 #pragma unroll
     for (int i = 0; i < NEX; i++) {
       const int e = tid + 256 * i;
-      if (e < PPX * XQ) wb_split_store(xr[i], xl + (e / XQ) * XROW + (e % XQ) * 8, XPLANE);
+      if (e < PPX * XQ) {
+        if constexpr (PL == 3) wb_split_store(xr[i], xl + (e / XQ) * XROW + (e % XQ) * 8, XPLANE);
+        else wb_split_store2(xr[i], x_mul, xl + (e / XQ) * XROW + (e % XQ) * 8, XPLANE);
+      }
     }
 #pragma unroll
     for (int i = 0; i < NEZ; i++) {
       const int e = tid + 256 * i;
-      if (e < MT * ZQ) wb_split_store(zr[i], zl + (e / ZQ) * ZROW + (e % ZQ) * 8, ZPLANE);
+      if (e < MT * ZQ) {
+        if constexpr (PL == 3) wb_split_store(zr[i], zl + (e / ZQ) * ZROW + (e % ZQ) * 8, ZPLANE);
+        else wb_split_store2(zr[i], z_mul, zl + (e / ZQ) * ZROW + (e % ZQ) * 8, ZPLANE);
+      }
     }
     __syncthreads();
     if (tile + a.PS < a.ntiles) load_tile(tile + a.PS);
 #pragma unroll
     for (int ks = 0; ks < TH / KROWS; ks++) {
       // dz fragments of this k-step: [cout tile][plane]
-      bf16x8 zf[NT][3];
+      s16x8 zf[NT][PL];
       const char* zb = zl + zoff + ks * KROWS * TW * ZROW;
 #pragma unroll
       for (int nt = 0; nt < NT; nt++)
 #pragma unroll
-        for (int pl = 0; pl < 3; pl++)
+        for (int pl = 0; pl < PL; pl++)
           zf[nt][pl] = wb_frag(zb + pl * ZPLANE + nt * 32, zb + pl * ZPLANE + nt * 32 + py_step * TW * ZROW);
       const char* xb = xl + xoff + ks * KROWS * S * PW * XROW;
 #pragma unroll
@@ -174,18 +216,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((KS == 3 &&
 #pragma unroll
         for (int mi = 0; mi < MI; mi++) {
           const char* xt = xb + ((t / KS) * PW + t % KS) * XROW + mi * 32;
-          const bf16x8 xh = wb_frag(xt, xt + py_step * S * PW * XROW);
-          const bf16x8 xm = wb_frag(xt + XPLANE, xt + XPLANE + py_step * S * PW * XROW);
-          const bf16x8 xlo = wb_frag(xt + 2 * XPLANE, xt + 2 * XPLANE + py_step * S * PW * XROW);
+          s16x8 xf[PL];
+#pragma unroll
+          for (int pl = 0; pl < PL; pl++) xf[pl] = wb_frag(xt + pl * XPLANE, xt + pl * XPLANE + py_step * S * PW * XROW);
 #pragma unroll
           for (int nt = 0; nt < NT; nt++) {
             f32x4 c = acc[t][mi][nt];  // small terms first
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xlo, zf[nt][0], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, zf[nt][2], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xm, zf[nt][1], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xm, zf[nt][0], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, zf[nt][1], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, zf[nt][0], c, 0, 0, 0);
+            if constexpr (PL == 3) {
+              c = wb_mfma<3>(xf[2], zf[nt][0], c);
+              c = wb_mfma<3>(xf[0], zf[nt][2], c);
+              c = wb_mfma<3>(xf[1], zf[nt][1], c);
+              c = wb_mfma<3>(xf[1], zf[nt][0], c);
+              c = wb_mfma<3>(xf[0], zf[nt][1], c);
+              c = wb_mfma<3>(xf[0], zf[nt][0], c);
+            } else {
+              c = wb_mfma<2>(xf[1], zf[nt][0], c);
+              c = wb_mfma<2>(xf[0], zf[nt][1], c);
+              c = wb_mfma<2>(xf[0], zf[nt][0], c);
+            }
             acc[t][mi][nt] = c;
           }
         }
@@ -204,7 +252,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((KS == 3 &&
         for (int r = 0; r < 4; r++) {
           const int ci = ci0 + ci_g * (16 * MI) + mi * 16 + (lane >> 4) * 4 + r;
           if (ci < a.Cin && co < a.Cout)
-            a.slabs[(((int64_t)blockIdx.x * T + t) * a.Cin + ci) * a.Cout + co] = acc[t][mi][nt][r];
+            a.slabs[(((int64_t)blockIdx.x * T + t) * a.Cin + ci) * a.Cout + co] = acc[t][mi][nt][r] * unscale;
         }
   }
 }
@@ -212,16 +260,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((KS == 3 &&
 template <int KS, int S, int TH, int TW, int NT, int MI>
 static void wb_launch(const WgradBf3Args& a, dim3 grid, hipStream_t s) {
   constexpr int PPX = ((TH - 1) * S + KS) * ((TW - 1) * S + KS);
-  constexpr size_t smem = (size_t)3 * PPX * (64 * MI + 32) + (size_t)3 * TH * TW * (64 * NT + 32);
-  hipLaunchKernelGGL((conv_wgrad_bf3_kernel<KS, S, TH, TW, NT, MI>), grid, dim3(256), smem, s, a);
+  constexpr size_t plane = (size_t)PPX * (64 * MI + 32) + (size_t)TH * TW * (64 * NT + 32);
+  if (a.x_amax && a.dz_amax)
+    hipLaunchKernelGGL((conv_wgrad_bf3_kernel<2, KS, S, TH, TW, NT, MI>), grid, dim3(256), 2 * plane, s, a);
+  else
+    hipLaunchKernelGGL((conv_wgrad_bf3_kernel<3, KS, S, TH, TW, NT, MI>), grid, dim3(256), 3 * plane, s, a);
 }
 
 // Launches the split-bf16 weight gradient of a conv (3x3 stride 1 / 2, pad 1; 1x1 stride 1 with >= 64
 // channels on both sides) into `slabs` ([PS][k*k][Cin][Cout]); returns the number of slabs written, or
 // 0 when the shape is not covered (the caller then uses the exact-fp32 kernel).  max_slabs bounds PS
 // (workspace size).  x is (N, Hin, Win, Cin), dz (N, Hout, Wout, Cout).
+// x_amax / dz_amax: both non-null = the fp16x2 split with those magnitude rows, else bf16x3.
 int mval_launch_wgrad_bf3(const float* x, const float* dz, float* slabs, int N, int Hin, int Win, int Cin, int Hout,
-                          int Wout, int Cout, int k, int stride, int max_slabs, hipStream_t s) {
+                          int Wout, int Cout, int k, int stride, int max_slabs, const unsigned* x_amax,
+                          const unsigned* dz_amax, hipStream_t s) {
   static int enabled = -1;
   if (enabled < 0) {
     const char* e = getenv("MVAL_CONV");
@@ -234,6 +287,7 @@ int mval_launch_wgrad_bf3(const float* x, const float* dz, float* slabs, int N, 
   WgradBf3Args a;
   a.x = x; a.dz = dz; a.slabs = slabs;
   a.N = N; a.Hin = Hin; a.Win = Win; a.H = Hout; a.W = Wout; a.Cin = Cin; a.Cout = Cout;
+  a.x_amax = x_amax; a.dz_amax = dz_amax;
   // 8-wide tiles also for widths like 72 / 36 / 18 / 24 where they waste fewer (zero-padded) columns than 16-wide ones
   const int tw = (Wout > 8 && ((Wout + 15) / 16) * 16 <= ((Wout + 7) / 8) * 8) ? 16 : 8;
   const int th = (stride == 2 ? 32 : 64) / tw;  // stride-2 patches are ~4x larger per pixel: 32-pixel tiles

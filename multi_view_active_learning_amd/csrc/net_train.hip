@@ -193,8 +193,11 @@ extern "C" int mval_train_backward(const mval_train_op* ops, int n_ops, int n_im
       }
       continue;
     }
-    rc = mval_conv_wgrad(x, gz, t.dweight, wsf, n_images, op.hin, op.win, op.cin, op.hout, op.wout, op.cout, op.k,
-                         op.stride, op.pad, op.in_nchw, stream);
+    // fp16-split weight gradient when the magnitudes of both operands are at hand (x's row from its producer, dz's
+    // from this op's BatchNorm backward)
+    const uint32_t* x_row = (gz_row && op.in_amax_off > 0) ? reinterpret_cast<const uint32_t*>(arena + op.in_amax_off) : nullptr;
+    rc = mval_conv_wgrad_scaled(x, gz, t.dweight, wsf, n_images, op.hin, op.win, op.cin, op.hout, op.wout, op.cout, op.k,
+                                op.stride, op.pad, op.in_nchw, x_row, x_row ? gz_row : nullptr, stream);
     if (rc) return rc;
     if (t.gin_off >= 0) {
       MVAL_REQUIRE(t.dgrad_algo != MVAL_ALGO_MFMA_H2 || gz_row, "mval_train_backward: op %d: fp16-split data gradient without dz's magnitude row", i);

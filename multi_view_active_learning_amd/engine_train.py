@@ -139,6 +139,8 @@ class TrainPlan:
             t.gres2_off = -1 if op.res2 is None else act_off[op.res2]
             t.wd_off = -1
             t.dgrad_algo = ALGO_DIRECT
+            if h2 and op.bn:  # dz's magnitude row: the fp16-split data / weight gradients read it
+                t.gz_amax_off = self.gz_amax_off
             if op.kind == "maxpool":  # no parameters; backward routes the gradient to the window arg-max
                 self.jobs.append((i, None, None))
                 self.stat_off.append(stat_top)
