@@ -207,7 +207,7 @@ typedef struct mval_op {
    * MVAL_ALGO_MFMA_H2 (single-op callers fill them with mval_amax). */
   int64_t in_amax_off, out_amax_off;
   /* MVAL_OP_BLOCK (hrnet.py:19-52, a whole BasicBlock in one launch, csrc/conv_block.hip):
-   *   out = relu(bn2(conv3x3(relu(bn1(conv3x3(in))))) + in),  cin = cout in {32, 64}, k 3, stride 1, pad 1,
+   *   out = relu(bn2(conv3x3(relu(bn1(conv3x3(in))))) + in),  cin = cout in {32, 48, 64}, k 3, stride 1, pad 1,
    * algo MVAL_ALGO_MFMA_H2.  w_off / scale_off / shift_off are conv1 + bn1, these three conv2 + bn2 (both
    * weights packed MVAL_PACK_MFMA16_H2); res1_off must equal in_off (or be -1). */
   int64_t w2_off, scale2_off, shift2_off;

@@ -1,6 +1,7 @@
 // Fused BasicBlock on the fp16 matrix cores (hrnet.py:19-52 in eval mode):
 //
-//     out = relu( bn2(conv3x3(relu(bn1(conv3x3(x))))) + x )          x, out: NHWC fp32, C = 32 or 64 channels
+//     out = relu( bn2(conv3x3(relu(bn1(conv3x3(x))))) + x )          x, out: NHWC fp32, C = 32, 48 or 64 channels
+//     (48 = HRNet-W48's first branch: two 32-channel K chunks whose upper 16 channels are zeros in LDS)
 //
 // ONE launch instead of two conv launches, and the intermediate activation never leaves the CU.  These are the
 // high-resolution branches of HRNet (32 channels on 64x64 maps, 64 on 32x32 at 256x256 input): 128 of HRNet-W32's 293
@@ -75,11 +76,13 @@ struct BlockArgs {
 };
 
 template <int C>
-__global__ __launch_bounds__(BK_NTH) __attribute__((amdgpu_waves_per_eu(C == 32 ? 2 : 1, 8))) void conv_block_kernel(BlockArgs a) {
-  constexpr int NCH = C / 32;   // 32-channel chunks
-  constexpr int NS = C / 16;    // 16-cout sub-tiles: every wave computes all of them
-  constexpr int Q = C / 4;      // float4 per pixel
-  constexpr int NE = (BK_XPX * Q + BK_NTH - 1) / BK_NTH;
+__global__ __launch_bounds__(BK_NTH) __attribute__((amdgpu_waves_per_eu(C == 32 ? 4 : 2, 8))) void conv_block_kernel(BlockArgs a) {
+  constexpr int NCH = (C + 31) / 32;  // 32-channel K chunks (C = 48: the second one is half zeros)
+  constexpr int NS = C / 16;          // 16-cout sub-tiles: every wave computes all of them
+  constexpr int NSP = NCH * 2;        // sub-tiles of the padded channel count (what the LDS planes hold)
+  constexpr int Q = C / 4;            // float4 per pixel in memory
+  constexpr int QP = NCH * 8;         // ... and in the LDS planes
+  constexpr int NE = (BK_XPX * QP + BK_NTH - 1) / BK_NTH;
   // weight fragments in flight: one (tap, chunk) step is ~0.1 us of MFMAs per wave, an L2 hit several times that; two
   // steps ahead where the registers allow it (64 channels: 96 registers would cost the second wave per SIMD)
   constexpr int WD = C == 32 ? 3 : 2;
@@ -106,10 +109,10 @@ __global__ __launch_bounds__(BK_NTH) __attribute__((amdgpu_waves_per_eu(C == 32 
 #pragma unroll
   for (int i = 0; i < NE; i++) {
     const int e = tid + BK_NTH * i;
-    const int px = e / Q, q = e % Q;
+    const int px = e / QP, q = e % QP;
     const int py = px / BK_XW, pxx = px - py * BK_XW;
     const int iy = oy0 - 2 + py, ix = ox0 - 2 + pxx;
-    const bool ok = e < BK_XPX * Q && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+    const bool ok = e < BK_XPX * QP && q < Q && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
     stage[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, ok ? ((iy * a.W + ix) * C + q * 4) * 4 : -1, 0, 0));
   }
   float in_mul, in_inv;
@@ -117,8 +120,8 @@ __global__ __launch_bounds__(BK_NTH) __attribute__((amdgpu_waves_per_eu(C == 32 
 #pragma unroll
   for (int i = 0; i < NE; i++) {
     const int e = tid + BK_NTH * i;
-    if (e < BK_XPX * Q) {
-      const int px = e / Q, q = e % Q;
+    if (e < BK_XPX * QP) {
+      const int px = e / QP, q = e % QP;
       f16x4 h, l;
       bk_split(stage[i] * in_mul, h, l);
       const int off = (q >> 3) * XCHUNK + px * BK_ROWB + (q & 7) * 8;
@@ -152,6 +155,7 @@ __global__ __launch_bounds__(BK_NTH) __attribute__((amdgpu_waves_per_eu(C == 32 
   // BN factors of the lane's 4 channels per sub-tile: with 32 channels they are fetched BEFORE the MFMA loop that
   // precedes their use (16 registers); with 64 channels those 32 registers would cost the second wave per SIMD
   constexpr bool PRE = C == 32;
+  static_assert(C == 32 || C == 48 || C == 64, "fused BasicBlock: 32, 48 or 64 channels");
   f32x4 bn_sc[NS], bn_sh[NS];
   auto load_bn = [&](const float* sc, const float* sh) {
 #pragma unroll
@@ -234,9 +238,9 @@ __global__ __launch_bounds__(BK_NTH) __attribute__((amdgpu_waves_per_eu(C == 32 
 #pragma unroll
   for (int ms = 0; ms < MS1; ms++) {
 #pragma unroll
-    for (int ns = 0; ns < NS; ns++) {
+    for (int ns = 0; ns < NSP; ns++) {  // (sub-tiles past C are the zero padding of conv2's last K chunk)
       f16x4 h, l;
-      bk_split(acc1[ms][ns] * m_mul, h, l);
+      bk_split(ns < NS ? acc1[ms][ns < NS ? ns : 0] * m_mul : (f32x4){0.f, 0.f, 0.f, 0.f}, h, l);
       const int off = (ns >> 1) * MCHUNK + mpix[ms] * BK_ROWB + ((ns & 1) * 16 + (lane >> 4) * 4) * 2;
       *reinterpret_cast<f16x4*>(smem + off) = h;
       *reinterpret_cast<f16x4*>(smem + MPLANE + off) = l;
@@ -323,7 +327,7 @@ __global__ __launch_bounds__(BK_NTH) __attribute__((amdgpu_waves_per_eu(C == 32 
 
 // 1 when the fused kernel covers this geometry
 int mval_conv_block_supported(int C, int N, int H, int W) {
-  if (C != 32 && C != 64) return 0;
+  if (C != 32 && C != 48 && C != 64) return 0;
   if (H < 8 || W < 16) return 0;  // small maps: the unfused kernels pack several images into a tile instead
   if ((int64_t)N * H * W * C >= (int64_t)1 << 31) return 0;
   return 1;
@@ -345,10 +349,12 @@ int mval_launch_conv_block(int C, const float* in, float* out, const float* w1, 
   const int tiles = a.tiles_x * a.tiles_y;
   if (out_amax && (int64_t)tiles * BK_WAVES > MVAL_AMAX_ROW - 1)
     mval_launch_zero_rows(out_amax, (int64_t)N * MVAL_AMAX_ROW, s);
-  const size_t smem = (size_t)2 * (C / 32) * BK_XPX * BK_ROWB;
+  const size_t smem = (size_t)2 * ((C + 31) / 32) * BK_XPX * BK_ROWB;
   dim3 grid((unsigned)(tiles * N));
   if (C == 32)
     hipLaunchKernelGGL(conv_block_kernel<32>, grid, dim3(BK_NTH), smem, s, a);
+  else if (C == 48)
+    hipLaunchKernelGGL(conv_block_kernel<48>, grid, dim3(BK_NTH), smem, s, a);
   else
     hipLaunchKernelGGL(conv_block_kernel<64>, grid, dim3(BK_NTH), smem, s, a);
   return 0;

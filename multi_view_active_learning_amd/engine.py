@@ -236,7 +236,7 @@ class InferencePlan:
             b = g.ops[i + 1] if i + 1 < len(g.ops) else None
             ma = self.graph_ops[i]
             if (fuse and b is not None and a.kind == b.kind == "conv" and a.k == b.k == 3 and a.stride == b.stride == 1
-                    and a.pad == b.pad == 1 and a.cin == a.cout == b.cin == b.cout and a.cin in (32, 64) and a.bn and b.bn
+                    and a.pad == b.pad == 1 and a.cin == a.cout == b.cin == b.cout and a.cin in (32, 48, 64) and a.bn and b.bn
                     and a.relu and b.relu and a.res1 is None and a.res2 is None and a.up == b.up == 0 and b.src == a.dst
                     and b.res1 == a.src and b.res2 is None and uses.get(a.dst, 0) == 1 and a.dst != g.output
                     and (a.phase, a.lane) == (b.phase, b.lane)

@@ -133,7 +133,7 @@ def test_fused_conv_vs_torch_cpu(dev, algo, case):
             assert rms_gpu <= 1.25 * rms_f32 + 1e-8 and err_gpu <= 2.5 * err_f32 + 1e-7, (algo, err_gpu, err_f32, rms_gpu, rms_f32)
 
 
-@pytest.mark.parametrize("shape", [(3, 32, 64, 64), (2, 64, 32, 32), (2, 32, 21, 37), (1, 64, 9, 16), (5, 32, 8, 16)],
+@pytest.mark.parametrize("shape", [(3, 32, 64, 64), (2, 64, 32, 32), (2, 32, 21, 37), (1, 64, 9, 16), (5, 32, 8, 16), (2, 48, 24, 40), (1, 48, 96, 72)],
                          ids=lambda s: "n%d_c%d_%dx%d" % s)
 def test_fused_basic_block_vs_torch_cpu(dev, shape):
     """MVAL_OP_BLOCK (a whole hrnet.py:19-52 BasicBlock in one launch) against torch-CPU fp32 and float64, and
