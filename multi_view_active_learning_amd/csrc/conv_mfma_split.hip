@@ -107,7 +107,7 @@ __device__ __forceinline__ void split3(const f32x4 v, bf16x4& h, bf16x4& m, bf16
 // the sub-chunks take the place of the taps in the inner loop.
 template <int PL, int KS, int S, int WN, int WM, int NT, int MS, int NE, bool RS = false, bool PA = false, int G = 1>
 __global__ __launch_bounds__(64 * WN * WM)
-    __attribute__((amdgpu_waves_per_eu((KS == 1 && G == 2 && NT == 2) ? (PA ? 3 : 4) : (PA && KS >= 2 && NE <= 6) ? 3 : (PL == 2 && NE <= 6 && !PA) ? 4 : 1, 8))) void conv_split_kernel(ConvArgs a) {
+    __attribute__((amdgpu_waves_per_eu((KS == 1 && G == 2 && NT == 2) ? (PA ? 3 : 4) : (PA && KS >= 2 && NE <= 6) ? 3 : (PL == 2 && NE <= 6 && !PA) ? (NT * WM >= 4 ? 2 : WM > 1 ? 3 : 4) : 1, 8))) void conv_split_kernel(ConvArgs a) {
   static_assert(G == 1 || (KS == 1 && S == 1), "multi-chunk staging is for 1x1 convs");
   constexpr int NP = split_np<PL>();
   constexpr int TAPS = G > 1 ? G : KS * KS;
