@@ -146,6 +146,99 @@ def cpu_baseline(wl, sd_np, seconds_target=20.0):
     )
 
 
+def cpu_baseline_train(wl, sd_np, seconds_target=20.0):
+    """CPU oracle training step (stock torch fp32 HRNet-W32 in train mode + masked MSE + autograd backward, the
+    reference's inner loop strategy.py:460-487 without the optimizer) on a bounded sample of the same shapes."""
+    from multi_view_active_learning_amd import synth
+    from oracle import models
+
+    v, h, w, j = wl["v"], wl["h"], wl["w"], wl["j"]
+    frames_per_call = 2
+    x = torch.from_numpy(synth.images(123, frames_per_call, v, h, w)).reshape(-1, 3, h, w)
+    gt = torch.rand(x.shape[0], j, h // 4, w // 4)
+    arch = models.HRNET_W48 if wl["arch"] == "hrnet_w48" else models.HRNET_W32
+
+    def step():
+        sd = {k: torch.from_numpy(a).clone().requires_grad_(a.dtype == np.float32 and "running" not in k) for k, a in sd_np.items()}
+        loss = models.pose_2d_mse(models.hrnet_forward(sd, x, arch, training=True), gt)
+        loss.backward()
+
+    ncpu = os.cpu_count() or 1
+    tried = {}
+    for nt in sorted({t for t in (16, 32, 64) if t <= ncpu} | {min(ncpu, 8)}):
+        torch.set_num_threads(nt)
+        t0 = time.perf_counter()
+        step()
+        tried[nt] = time.perf_counter() - t0
+    best = min(tried, key=tried.get)
+    torch.set_num_threads(best)
+    done, t0 = 0, time.perf_counter()
+    while True:
+        step()
+        done += frames_per_call
+        el = time.perf_counter() - t0
+        if el > seconds_target or done >= 16:
+            break
+    return dict(value=done * v / el, unit="frames*views/s", cores=best, kind="port",
+                sample=f"{done} frames x {v} views of the same shapes, {el:.1f} s, stock torch fp32 train-mode forward + masked MSE + "
+                       f"autograd backward (oracle/), {best} threads (best of {sorted(tried)}); no optimizer step",
+                threads_tried={str(k): round(frames_per_call * v / t, 2) for k, t in tried.items()})
+
+
+def train_rooflines(model, step, frames, v, mode):
+    """Per-kernel-family rooflines of the training step: mval_train_timing brackets every launch group with hipEvents
+    (measurement mode, outside the timed region); conv families against the matrix-core peak of the split in use,
+    the BatchNorm streams against HBM with their algorithmic bytes."""
+    import ctypes as C
+
+    from multi_view_active_learning_amd import _lib
+
+    lib = _lib.lib()
+    plan = next(iter(model._train_plans.values()))
+    ms = (C.c_float * 6)()
+    reps = 3
+    _lib._check(lib.mval_train_timing(ms), "mval_train_timing")
+    for _ in range(reps):
+        step()
+    torch.cuda.synchronize()
+    _lib._check(lib.mval_train_timing(None), "mval_train_timing")
+    t = [float(x) * 1e-3 / reps for x in ms]
+    n = frames * v
+    fl_fwd = sum(float(lib.mval_op_flops(C.byref(o.op), C.c_int(n))) for o in plan.ops)
+    fl_dgrad = sum(float(lib.mval_op_flops(C.byref(o.op), C.c_int(n))) for o in plan.ops if o.gin_off >= 0)
+    # BatchNorm streams, float32 bytes per step: z = raw conv outputs, out = activations (at the upsampled size)
+    zb = sum(4.0 * n * o.op.hout * o.op.wout * o.op.cout for o in plan.ops if o.has_bn)
+    ob = sum(4.0 * n * (o.op.hout << o.op.up) * (o.op.wout << o.op.up) * o.op.cout * (1 + (o.op.res1_off >= 0) + (o.op.res2_off >= 0))
+             for o in plan.ops if o.has_bn)
+    peak = PEAK_BF16_MFMA_TFLOPS / SPLIT_PRODUCTS.get(mode, 6) if mode != "fp32" else PEAK_FP32_MFMA_TFLOPS
+    note = (f"dense 16-bit MFMA peak 2500 TFLOP/s / {SPLIT_PRODUCTS.get(mode, 6)} products (layers the fp16 split does not cover run "
+            "the bf16x3 or exact-fp32 kernels: their time is in, the peak is the default split's)")
+
+    def mf(name, f, tt):
+        return dict(bound="mfma", achieved=round(f / tt / 1e12, 2), peak=round(peak, 1), unit="TFLOP/s", frac=round(f / tt / 1e12 / peak, 4),
+                    traffic=None, kernel=name, peak_note=note, seconds_in_kernel_per_step=round(tt, 6), flops_per_step=f)
+
+    def hb(name, b, tt):
+        return dict(bound="hbm", achieved=round(b / tt / 1e9, 1), peak=PEAK_HBM_GBPS, unit="GB/s", frac=round(b / tt / 1e9 / PEAK_HBM_GBPS, 4),
+                    traffic=None, kernel=name, peak_note="HBM3E ~8 TB/s (guide); ~6.3 TB/s achievable",
+                    seconds_in_kernel_per_step=round(tt, 6), bytes_per_step=b)
+
+    fams = [
+        mf("conv forward (conv_split_kernel / conv_mfma_kernel, raw z, bias-free accumulate)", fl_fwd, t[0]),
+        hb("BatchNorm statistics (bn_stats_partial + finalize: one read of z, float64 two-stage sums)", zb, t[1]),
+        hb("BatchNorm apply (bn_apply_fwd: z -> normalise + residuals + ReLU (+ upsample) -> out)", zb + ob, t[2]),
+        hb("BatchNorm backward (bn_bwd_reduce + finalize + bn_bwd_apply: gout, out, z -> dz, dgamma, dbeta, residual gradients)",
+           2.0 * ob + 4.0 * zb, t[3]),
+        mf("weight gradient (conv_wgrad_bf3_kernel split-K + float64 slab reduction)", fl_fwd, t[4]),
+        mf("data gradient (forward kernels on flipped weights)", fl_dgrad, t[5]),
+    ]
+    fams.sort(key=lambda f: -f["seconds_in_kernel_per_step"])
+    top = fams[0]
+    top["other_kernels"] = fams[1:]
+    top["sum_of_families_ms"] = round(sum(t) * 1e3, 3)
+    return top
+
+
 def path_kernels(dev, frames, v, j, hh, wh):
     """The non-conv kernels of the path at this workload's sizes, each against its own bound: events
     on torch's current stream, which is the stream the wrappers launch on."""
@@ -303,15 +396,17 @@ def main():
         by batch (heat-maps, triangulation, MPE -- the per-batch body of _compute_sal_dict), then ONE packed
         all_gather of the (frames, 6 + 3J) result tables and the nlargest selection on every rank."""
         from multi_view_active_learning_amd import parallel
-        from multi_view_active_learning_amd.strategy import score_heatmaps_batch
+        from multi_view_active_learning_amd.strategy import score_decode_heatmaps_batch
 
         lo, hi = parallel.shard_range(wl["pool"], rank, world)
         tables = []
         for f0 in range(lo, hi, frames):
             nb = min(frames, hi - f0)
             hm = model(images[: nb * v]).reshape(nb, v, j, h // 4, w // 4)
-            r = triangulate_batch(hm, proj[:nb], 4, valid[:nb])
-            al = score_heatmaps_batch(wl["score"], "AVG", hm, valid[:nb])[0]
+            # one read of the heat-maps: uncertainty statistic + arg-max key-points (as ActiveLearningStrategy.score_batch)
+            sc = score_decode_heatmaps_batch(wl["score"], "AVG", hm, valid[:nb], 4)
+            al = sc[0]
+            r = triangulate_batch(hm, proj[:nb], 4, valid[:nb], keypoints_2d=sc[4])
             fid = torch.arange(f0, f0 + nb, device=dev, dtype=torch.float64)
             tables.append(torch.cat([torch.zeros_like(fid)[:, None], fid[:, None], al[:, None], r["metric"][:, None],
                                      r["inlier_count"].to(torch.float64)[:, None], torch.zeros_like(fid)[:, None],
@@ -334,12 +429,14 @@ def main():
         if wl.get("pool"):
             return coreset_pass() if wl.get("picks") else scoring_pass()
         hm = model(images).reshape(frames, v, j, h // 4, w // 4)
-        r = triangulate_batch(hm, proj, 4, valid)
-        if wl.get("score"):
-            from multi_view_active_learning_amd.strategy import score_heatmaps_batch
+        if wl.get("score"):  # one read of the heat-maps for the statistic and the key-points (score_batch's path)
+            from multi_view_active_learning_amd.strategy import score_decode_heatmaps_batch
 
-            r["al_metric"] = score_heatmaps_batch(wl["score"], "AVG", hm, valid)[0]
-        return r
+            sc = score_decode_heatmaps_batch(wl["score"], "AVG", hm, valid, 4)
+            r = triangulate_batch(hm, proj, 4, valid, keypoints_2d=sc[4])
+            r["al_metric"] = sc[0]
+            return r
+        return triangulate_batch(hm, proj, 4, valid)
 
     def sync():
         torch.cuda.synchronize()
@@ -365,12 +462,10 @@ def main():
     # ---- roofline of the dominant kernel family (outside the timed region) ------------------------
     roof = None
     if rank == 0 and train:
-        # convention: a training step is 3x the forward conv FLOPs
-        fl = 3.0 * FLOP_PER_IMAGE["hrnet_w32_256"] * frames * v
-        ach = fl / (el / args.steps) / 1e12
-        roof = dict(bound="mfma", achieved=round(ach, 2), peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s",
-                    frac=round(ach / PEAK_FP32_MFMA_TFLOPS, 4), traffic=None,
-                    kernel="whole training step (3 x forward conv FLOPs / step wall time; includes BN/elementwise/Adam)")
+        with torch.enable_grad():
+            roof = train_rooflines(model, step, frames, v, _conv_mode())
+        # (SURVEY 8d convention for the whole step: 3 x the forward conv FLOPs over the step's wall time)
+        roof["whole_step_tflops_3x_forward"] = round(3.0 * FLOP_PER_IMAGE["hrnet_w32_256"] * frames * v / (el / args.steps) / 1e12, 2)
     if rank == 0 and not train:
         plan = _plan_for(model, images)
         with torch.no_grad():
@@ -423,8 +518,10 @@ def main():
             peak = PEAK_BF16_MFMA_TFLOPS / SPLIT_PRODUCTS[pl]
             note = f"dense 16-bit MFMA peak 2500 TFLOP/s / {SPLIT_PRODUCTS[pl]} MFMA products per algorithmic product"
             fams += [
-                family(m_ & k3 & s1, f"conv_split_kernel<{2 if pl == 'h2' else 3}, 3, 1, ...> (fused 3x3 stride-1 conv+BN+residual+ReLU; "
-                                     f"{what}, fp32 accumulate)", peak, note),
+                family(m_ & k3 & s1, f"conv_split_kernel<{2 if pl == 'h2' else 3}, 3, 1, ...>"
+                                     + (" + conv_block_kernel<C> (whole BasicBlocks: two 3x3 convs, BNs, residual, ReLUs in one launch)"
+                                        if any(o.kind == 3 for o in plan.ops) and pl == "h2" else "")
+                                     + f" (fused 3x3 stride-1 conv+BN+residual+ReLU; {what}, fp32 accumulate)", peak, note),
                 family(m_ & k3 & ~s1, f"conv_split_kernel<{2 if pl == 'h2' else 3}, 3, 2, ...> (same, stride 2)", peak, note),
                 hbm_family(m_ & ~k3, f"conv_split_kernel<{2 if pl == 'h2' else 3}, 1, 1, ...> (fused 1x1 conv+BN+residual+ReLU(+upsample): "
                                      "channel GEMMs of the bottleneck blocks and fuse up-paths; 2x2 parity convs of transposed convs)"),
@@ -443,8 +540,8 @@ def main():
         summary = os.path.join("profiles", "r02", f"bench_c2_{_conv_mode()}_summary.json")
         try:
             with open(os.path.join(ROOT, summary)) as f:
-                rows = [r for r in json.load(f)["hbm_traffic_by_instantiation"]
-                        if r["kernel"].startswith(roof["kernel"].split(" ...>")[0])]
+                pre = (roof["kernel"].split(" ...>")[0],) + (("conv_block_kernel",) if "conv_block_kernel" in roof["kernel"] else ())
+                rows = [r for r in json.load(f)["hbm_traffic_by_instantiation"] if r["kernel"].startswith(pre)]
             if args.workload == "c2" and rows:
                 nl = sum(r["launches"] for r in rows)
                 roof["traffic"] = round(sum(r["launches"] * r["total_bytes"] for r in rows) / nl)
@@ -453,6 +550,9 @@ def main():
         except (OSError, KeyError, ValueError):
             pass
         allc = split_any | f32
+        roof["frac_of_bf16x3_peak"] = round(roof["achieved"] / (PEAK_BF16_MFMA_TFLOPS / 6.0), 4) if roof.get("unit") == "TFLOP/s" else None
+        roof["frac_note"] = ("frac is against the peak of the split in use (fp16x2: 2500 / 3 = 833 TFLOP/s); frac_of_bf16x3_peak is the same "
+                             "achieved rate against round 1's 416.7 TFLOP/s, for comparison across rounds")
         roof["all_conv_tflops"] = round(float(flops[allc].sum()) / (float(ms[allc].sum()) * 1e-3) / 1e12, 2)
         roof["all_conv_frac_of_fp32_mfma_peak"] = round(roof["all_conv_tflops"] / PEAK_FP32_MFMA_TFLOPS, 4)
         roof["whole_forward_ms"] = round(float(ms.sum()), 3)
@@ -486,6 +586,8 @@ def main():
             "roofline": roof,
             "parity_unpinned": PARITY_UNPINNED,
         }
+        if not args.no_cpu_baseline and train and world == 1:
+            out["cpu_baseline"] = cpu_baseline_train(wl, sd_np, args.cpu_seconds)
         if not args.no_cpu_baseline and not train and world == 1:  # rank 0 at N = 1 only
             cpu = cpu_baseline(wl, sd_np, args.cpu_seconds)
             # BASELINE.json's "MPJPE vs ref": the HIP path on the oracle's first sample (outside every timed region)

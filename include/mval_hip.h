@@ -379,6 +379,12 @@ int mval_train_backward(const mval_train_op* ops, int n_ops, int n_images, float
                         const float* params, int64_t ones_off, int64_t zeros_off, const float* input_nchw,
                         float* gz, float* wsf, double* ws, float* sums, void* stream);
 
+/* Measurement only (bench.py, training workload): with a non-NULL HOST array of 6 floats every later
+ * mval_train_forward / mval_train_backward call brackets its launches with hipEvents and ADDS the elapsed
+ * milliseconds per kernel family -- [conv forward, BN statistics, BN apply, BN backward, weight gradient, data
+ * gradient] -- synchronising the stream at the end of the call; NULL switches it off again. */
+int mval_train_timing(float* ms_per_family);
+
 #ifdef __cplusplus
 }
 #endif

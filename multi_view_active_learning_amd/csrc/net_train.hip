@@ -21,6 +21,47 @@ extern "C" int mval_bn_batch_stats(const float*, int64_t, int, float, float, flo
 extern "C" int mval_bn_apply_fwd(const float*, const float*, const float*, const float*, const float*, const float*,
                                  const float*, float*, int, int, int, int, int, int, void*);
 
+// ---- measurement mode (bench.py, the c3 line's per-kernel roofline): hipEvents around every launch group of a
+// training step, summed per kernel family.  Off unless mval_train_timing() armed it; the events are resolved (one
+// stream synchronisation) at the end of each forward / backward call.
+#include <vector>
+enum { TT_CONV_FWD = 0, TT_BN_STATS, TT_BN_APPLY, TT_BN_BWD, TT_WGRAD, TT_DGRAD, TT_N };
+static float* g_tt_out = nullptr;
+struct TtSpan { int cat; hipEvent_t a, b; };
+static std::vector<TtSpan> g_tt_spans;
+struct TtScope {
+  int cat; hipStream_t s; hipEvent_t a = nullptr, b = nullptr;
+  TtScope(int c, hipStream_t st) : cat(c), s(st) {
+    if (!g_tt_out) return;
+    (void)hipEventCreate(&a);
+    (void)hipEventCreate(&b);
+    (void)hipEventRecord(a, s);
+  }
+  ~TtScope() {
+    if (!a) return;
+    (void)hipEventRecord(b, s);
+    g_tt_spans.push_back({cat, a, b});
+  }
+};
+static void tt_flush() {
+  if (!g_tt_out) return;
+  for (auto& sp : g_tt_spans) {
+    (void)hipEventSynchronize(sp.b);
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, sp.a, sp.b);
+    g_tt_out[sp.cat] += ms;
+    (void)hipEventDestroy(sp.a);
+    (void)hipEventDestroy(sp.b);
+  }
+  g_tt_spans.clear();
+}
+extern "C" int mval_train_timing(float* ms_per_family) {
+  g_tt_out = ms_per_family;
+  if (ms_per_family)
+    for (int i = 0; i < TT_N; i++) ms_per_family[i] = 0.f;
+  return 0;
+}
+
 static void geometry(ConvArgs& a, const mval_op& op, int n_images) {
   a.N = n_images;
   a.Hin = op.hin; a.Win = op.win; a.Cin = op.cin;
@@ -107,12 +148,20 @@ extern "C" int mval_train_forward(const mval_train_op* ops, int n_ops, int n_ima
       a.out = arena + t.z_off;
       a.scale = params + ones_off;
       a.shift = params + zeros_off;
-      int rc = run_conv(a, op.algo, s, "mval_train_forward/conv");
+      int rc;
+      {
+        TtScope tt(TT_CONV_FWD, s);
+        rc = run_conv(a, op.algo, s, "mval_train_forward/conv");
+      }
       if (rc) return rc;
       const int64_t M = (int64_t)n_images * op.hout * op.wout;
-      rc = mval_bn_batch_stats(a.out, M, op.cout, eps, momentum, t.mean, t.invstd, t.running_mean, t.running_var, ws,
-                               stream);
+      {
+        TtScope tt(TT_BN_STATS, s);
+        rc = mval_bn_batch_stats(a.out, M, op.cout, eps, momentum, t.mean, t.invstd, t.running_mean, t.running_var, ws,
+                                 stream);
+      }
       if (rc) return rc;
+      TtScope tt(TT_BN_APPLY, s);
       rc = mval_bn_apply_fwd_amax(a.out, t.mean, t.invstd, t.gamma, t.beta, op.res1_off >= 0 ? arena + op.res1_off : nullptr,
                                   op.res2_off >= 0 ? arena + op.res2_off : nullptr, out, n_images, op.hout, op.wout, op.cout,
                                   op.up, op.relu, t.out_amax_off > 0 ? reinterpret_cast<uint32_t*>(arena + t.out_amax_off) : nullptr,
@@ -127,10 +176,12 @@ extern "C" int mval_train_forward(const mval_train_op* ops, int n_ops, int n_ima
       a.shift = params + op.shift_off;
       a.res1 = op.res1_off >= 0 ? arena + op.res1_off : nullptr;
       a.res2 = op.res2_off >= 0 ? arena + op.res2_off : nullptr;
+      TtScope tt(TT_CONV_FWD, s);
       int rc = run_conv(a, op.algo, s, "mval_train_forward/conv");
       if (rc) return rc;
     }
   }
+  tt_flush();
   return 0;
 }
 
@@ -156,10 +207,14 @@ extern "C" int mval_train_backward(const mval_train_op* ops, int n_ops, int n_im
     const float* outp = op.out_off >= 0 ? arena + op.out_off : nullptr;
     MVAL_REQUIRE(!(op.relu && !outp), "mval_train_backward: op %d: ReLU on an external output", i);
     uint32_t* gz_row = (t.has_bn && t.gz_amax_off > 0) ? reinterpret_cast<uint32_t*>(arena + t.gz_amax_off) : nullptr;
-    int rc = mval_bn_bwd_amax(garena + t.gout_off, outp, t.has_bn ? arena + t.z_off : nullptr, t.mean, t.invstd, t.gamma,
+    int rc;
+    {
+    TtScope tt(TT_BN_BWD, s);
+    rc = mval_bn_bwd_amax(garena + t.gout_off, outp, t.has_bn ? arena + t.z_off : nullptr, t.mean, t.invstd, t.gamma,
                               t.gres1_off >= 0 ? garena + t.gres1_off : nullptr,
                               t.gres2_off >= 0 ? garena + t.gres2_off : nullptr, gz, t.dgamma, t.dbeta, ws, sums, n_images,
                               op.hout, op.wout, op.cout, op.up, op.relu, t.has_bn, t.first_touch >> 1, gz_row, stream);
+    }
     if (rc) return rc;
     const float* x = op.in_off >= 0 ? arena + op.in_off : input_nchw;
     if (op.kind == MVAL_OP_DECONV) {
@@ -196,11 +251,15 @@ extern "C" int mval_train_backward(const mval_train_op* ops, int n_ops, int n_im
     // fp16-split weight gradient when the magnitudes of both operands are at hand (x's row from its producer, dz's
     // from this op's BatchNorm backward)
     const uint32_t* x_row = (gz_row && op.in_amax_off > 0) ? reinterpret_cast<const uint32_t*>(arena + op.in_amax_off) : nullptr;
+    {
+    TtScope tt(TT_WGRAD, s);
     rc = mval_conv_wgrad_scaled(x, gz, t.dweight, wsf, n_images, op.hin, op.win, op.cin, op.hout, op.wout, op.cout, op.k,
                                 op.stride, op.pad, op.in_nchw, x_row, x_row ? gz_row : nullptr, stream);
+    }
     if (rc) return rc;
     if (t.gin_off >= 0) {
       MVAL_REQUIRE(t.dgrad_algo != MVAL_ALGO_MFMA_H2 || gz_row, "mval_train_backward: op %d: fp16-split data gradient without dz's magnitude row", i);
+      TtScope tt(TT_DGRAD, s);
       rc = mval_conv_dgrad_scaled(gz, params + t.wd_off, params + ones_off, params + zeros_off, garena + t.gin_off,
                                   !(t.first_touch & 1), n_images,
                                   op.hin, op.win, op.cin, op.hout, op.wout, op.cout, op.k, op.stride, op.pad, t.dgrad_algo,
@@ -208,6 +267,7 @@ extern "C" int mval_train_backward(const mval_train_op* ops, int n_ops, int n_im
       if (rc) return rc;
     }
   }
+  tt_flush();
   return 0;
 }
 
