@@ -581,8 +581,13 @@ def main():
                       "h2": "f32 (convs: fp32 values as scaled 2-way fp16 splits on the fp16 MFMA, fp32 accumulate; "
                             "measured at the exact-fp32 MFMA chain's error)"}[_conv_mode()],
             "data": "synthetic (random variance-preserving weights, N(0,1) frames, ring cameras)",
-            "config": {"workload": wl["desc"], "frames_per_step_per_gpu": frames, "views": v,
-                       "images_per_step_per_gpu": frames * v, "parallelism": f"frame-sharded x{world}, no collective"},
+            "config": ({"workload": wl["desc"].replace("256-frame pool", f"{wl['pool']}-frame pool")
+                                   + ("" if wl.get("picks") else f"; one step = one pass over a {wl['pool']}-frame pool sharded over the ranks"),
+                        "pool_frames": wl["pool"], "frames_per_batch": frames, "views": v,
+                        "parallelism": f"pool sharded x{world} by frames, ONE packed all_gather per pass (RCCL), selection replicated"}
+                       if wl.get("pool") else
+                       {"workload": wl["desc"], "frames_per_step_per_gpu": frames, "views": v,
+                        "images_per_step_per_gpu": frames * v, "parallelism": f"frame-sharded x{world}, no collective"}),
             "roofline": roof,
             "parity_unpinned": PARITY_UNPINNED,
         }
