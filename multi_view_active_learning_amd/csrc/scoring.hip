@@ -89,10 +89,12 @@ __global__ __launch_bounds__(SC_THREADS) void score_maps_kernel(const float* __r
       float* t = tile + y * ld + x;
       t[0] = q.x; t[1] = q.y; t[2] = q.z; t[3] = q.w;
       if (DECODE) {
-        if (sc_better(q.x, base, bv, bi)) { bv = q.x; bi = base; }
-        if (sc_better(q.y, base + 1, bv, bi)) { bv = q.y; bi = base + 1; }
-        if (sc_better(q.z, base + 2, bv, bi)) { bv = q.z; bi = base + 2; }
-        if (sc_better(q.w, base + 3, bv, bi)) { bv = q.w; bi = base + 3; }
+        // a thread meets its pixels in increasing index order, so "strictly greater, or the first NaN" is the whole
+        // torch.argmax order here (the cross-lane reduction below uses the full comparison)
+        if (q.x > bv || (q.x != q.x && bv == bv)) { bv = q.x; bi = base; }
+        if (q.y > bv || (q.y != q.y && bv == bv)) { bv = q.y; bi = base + 1; }
+        if (q.z > bv || (q.z != q.z && bv == bv)) { bv = q.z; bi = base + 2; }
+        if (q.w > bv || (q.w != q.w && bv == bv)) { bv = q.w; bi = base + 3; }
       }
     }
   } else {
@@ -100,7 +102,7 @@ __global__ __launch_bounds__(SC_THREADS) void score_maps_kernel(const float* __r
       const int y = i / wh, x = i - y * wh;
       const float q = p[i];
       tile[y * ld + x] = q;
-      if (DECODE && sc_better(q, i, bv, bi)) { bv = q; bi = i; }
+      if (DECODE && (q > bv || (q != q && bv == bv))) { bv = q; bi = i; }
     }
   }
   if (tid == 0) { sm->n_cand = 0; sm->overflow = 0; }
@@ -111,13 +113,14 @@ __global__ __launch_bounds__(SC_THREADS) void score_maps_kernel(const float* __r
       const int oi = __shfl_xor(bi, o, 64);
       if (sc_better(ov, oi, bv, bi)) { bv = ov; bi = oi; }
     }
-    if ((tid & 63) == 0) { sm->red[tid >> 6] = bv; sm->red[4 + (tid >> 6)] = __int_as_float(bi); }
+    // (slots 16.. of red[]: the reductions further down use 0..3, so no barrier is needed between the two)
+    if ((tid & 63) == 0) { sm->red[16 + (tid >> 6)] = bv; sm->red[20 + (tid >> 6)] = __int_as_float(bi); }
   }
   __syncthreads();
   if (DECODE && tid == 0) {
     for (int w = 1; w < SC_THREADS / 64; w++) {
-      const float ov = sm->red[w];
-      const int oi = __float_as_int(sm->red[4 + w]);
+      const float ov = sm->red[16 + w];
+      const int oi = __float_as_int(sm->red[20 + w]);
       if (sc_better(ov, oi, bv, bi)) { bv = ov; bi = oi; }
     }
     if (bi == 0x7fffffff) bi = 0;  // all -inf: first element
@@ -127,7 +130,6 @@ __global__ __launch_bounds__(SC_THREADS) void score_maps_kernel(const float* __r
     d.kp2d[map * 2] = ok ? (int64_t)(bi % d.split_width) * d.stride : 0;
     d.kp2d[map * 2 + 1] = ok ? (int64_t)(bi / d.split_width) * d.stride : 0;
   }
-  if (DECODE) __syncthreads();  // red[] is reused below
 
   // ---- row-wise softmax statistics (HP, BSB): T lanes per row ---------------------------------
   if (KIND == MVAL_SCORE_HP || KIND == MVAL_SCORE_BSB) {
@@ -140,16 +142,19 @@ __global__ __launch_bounds__(SC_THREADS) void score_maps_kernel(const float* __r
       const int r = r0 + tid / T;
       const bool live = r < hh;
       float* row = tile + (live ? r : 0) * ld;
+      // lane `sub` owns the contiguous column segment [c0, c1): with the odd row stride (wh + 1) the 64 lanes of a
+      // wave (16 rows x 4 segments on 64-wide maps) then hit 64 different banks (interleaved columns: 2-4-way conflicts)
+      const int seg = (wh + T - 1) / T, c0 = sub * seg, c1 = min(wh, c0 + seg);
       float m = -INFINITY;
-      for (int c = sub; c < wh; c += T) m = fmaxf(m, row[c]);
+      for (int c = c0; c < c1; c++) m = fmaxf(m, row[c]);
       for (int o = T >> 1; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
       // the reference sums exp(x - m) over a row left to right in float32 (torch softmax on CPU vectorises, so the
-      // last bits differ anyway: tests allow 3e-6 relative); partial sums over interleaved columns here
+      // last bits differ anyway: tests allow 3e-6 relative); partial sums over the lanes' segments here
       float s = 0.f;
-      for (int c = sub; c < wh; c += T) s += expf(row[c] - m);
+      for (int c = c0; c < c1; c++) s += expf(row[c] - m);
       for (int o = T >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
       if (KIND == MVAL_SCORE_BSB && live) {
-        for (int c = sub; c < wh; c += T) row[c] = expf(row[c] - m) / s;
+        for (int c = c0; c < c1; c++) row[c] = expf(row[c] - m) / s;
       }
       if (live) best = fmaxf(best, 1.0f / s);
     }

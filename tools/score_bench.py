@@ -1,0 +1,19 @@
+import sys, os, torch, numpy as np
+sys.path.insert(0, "/root/repo")
+from multi_view_active_learning_amd import _lib
+dev = torch.device("cuda:0")
+for (f, v, j, hh, wh) in ((32, 4, 19, 64, 64), (8, 8, 19, 96, 72), (256, 4, 19, 64, 64)):
+    hm = torch.rand(f, v, j, hh, wh, device=dev)
+    valid = torch.ones(f, j, dtype=torch.uint8, device=dev)
+    def timed(fn, reps=50):
+        for _ in range(5): fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps): fn()
+        e1.record(); e1.synchronize()
+        return e0.elapsed_time(e1) * 1e-3 / reps
+    b = hm.numel() * 4
+    t0 = timed(lambda: _lib.argmax_decode(hm, valid, f, v, j, hh, wh, 4, hh))
+    t1 = timed(lambda: _lib.score_decode_maps(_lib.SCORE_HP, hm, valid, f, v, j, hh, wh, 4, hh))
+    t2 = timed(lambda: _lib.score_maps(_lib.SCORE_HP, hm, f * v * j, hh, wh))
+    print(f"{f}x{v}x{j} maps {hh}x{wh} ({b/1e6:.1f} MB): argmax {t0*1e6:.1f} us {b/t0/1e9:.0f} GB/s | HP+decode {t1*1e6:.1f} us {b/t1/1e9:.0f} GB/s | HP {t2*1e6:.1f} us {b/t2/1e9:.0f} GB/s")
