@@ -274,6 +274,63 @@ int mval_conv_split_supported(const ConvArgs& a);
 int mval_pack_bf3(int mode, const float* w, float* packed, int cout, int cin, int k, hipStream_t s);
 int mval_pack_h2(int mode, const float* w, float* packed, int cout, int cin, int k, hipStream_t s);
 // net.hip: rows[i][*] = max(rows[i][*], max |x| over image i) for n_images images of per_image floats each
+// ---- branch concurrency (net.hip, net_train.hip) ---------------------------------------------------------------
+// Ops carry (phase, lane) hints: ops of one phase on different lanes are independent (HRNet branches / fuse outputs).
+// Lanes > 0 run on per-device side streams that fork from / join into the caller's stream with events at every phase
+// change (no host synchronisation; capturable).  The streams and events are created once per device and never
+// destroyed (stream churn around hipGraph captures crashed a later replay inside the HIP runtime).
+#define MVAL_MAX_LANES 4
+struct MvalLanes {
+  hipStream_t side[MVAL_MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t fork_ev = nullptr;
+  hipEvent_t join_ev[MVAL_MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};
+  bool ready = false;
+};
+MvalLanes* mval_device_lanes();  // net.hip; nullptr on failure
+
+// One pass over an op list: stream_for() per op in list order, finish() at the end.
+struct MvalLaneWalk {
+  MvalLanes* L;
+  hipStream_t main_s;
+  bool used[MVAL_MAX_LANES] = {false, false, false, false};
+  bool forked = false, started = false;
+  int phase = 0;
+  MvalLaneWalk(MvalLanes* lanes, hipStream_t s) : L(lanes), main_s(s) {}
+  void join() {  // side streams -> main
+    for (int l = 1; l < MVAL_MAX_LANES; l++)
+      if (used[l]) {
+        (void)hipEventRecord(L->join_ev[l], L->side[l]);
+        (void)hipStreamWaitEvent(main_s, L->join_ev[l], 0);
+        used[l] = false;
+      }
+  }
+  hipStream_t stream_for(int op_phase, int op_lane) {
+    if (!L) return main_s;
+    if (!started || op_phase != phase) {
+      if (started) join();
+      phase = op_phase;
+      started = true;
+      forked = false;
+    }
+    if (!forked) {
+      // recorded at the START of the phase, before its lane-0 ops are enqueued: the side lanes then wait for the
+      // previous phases only, not for this phase's (longest) lane-0 chain as well
+      (void)hipEventRecord(L->fork_ev, main_s);
+      forked = true;
+    }
+    const int lane = (op_lane > 0 && op_lane < MVAL_MAX_LANES) ? op_lane : 0;
+    if (lane == 0) return main_s;
+    if (!used[lane]) {
+      (void)hipStreamWaitEvent(L->side[lane], L->fork_ev, 0);
+      used[lane] = true;
+    }
+    return L->side[lane];
+  }
+  void finish() {
+    if (L) join();
+  }
+};
+
 // conv_block.hip: a whole BasicBlock (two 3x3 convs + BNs + residual + ReLUs) in one launch; returns 1 if unsupported
 int mval_conv_block_supported(int C, int N, int H, int W);
 int mval_launch_conv_block(int C, const float* in, float* out, const float* w1, const float* scale1, const float* shift1,

@@ -428,22 +428,6 @@ extern "C" int mval_op_launch(const mval_op* op, int n_images, float* workspace,
   return 0;
 }
 
-// Lanes > 0 run on private non-blocking streams that fork from / join into the caller's stream
-// at every phase change (events, no host synchronisation), so the short tail of one branch's
-// kernel overlaps the head of another's instead of leaving CUs idle at ~300 kernel boundaries.
-#define MVAL_MAX_LANES 4
-
-// The side streams and the fork / join events are per DEVICE, created on first use and never destroyed: nets come
-// and go with their plans (every (N, H, W) of every model has one), and creating / destroying streams around
-// hipGraph captures made a later capture's replay crash inside the HIP runtime (round 2: five plans' worth of
-// stream churn before a capture).  Forwards of different nets on one device therefore share the lanes; stream order
-// keeps that correct.
-struct MvalLanes {
-  hipStream_t side[MVAL_MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};
-  hipEvent_t fork_ev = nullptr;
-  hipEvent_t join_ev[MVAL_MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};
-  bool ready = false;
-};
 #define MVAL_MAX_DEVICES 16
 static MvalLanes g_lanes[MVAL_MAX_DEVICES];
 
@@ -485,7 +469,7 @@ extern "C" void mval_net_destroy(void* net) {
   delete reinterpret_cast<MvalNet*>(net);
 }
 
-static MvalLanes* device_lanes() {
+MvalLanes* mval_device_lanes() {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MVAL_MAX_DEVICES) return nullptr;
   MvalLanes* L = &g_lanes[dev];
@@ -505,47 +489,16 @@ extern "C" int mval_net_forward(void* net, int n_images, float* workspace, const
   MvalNet* n = reinterpret_cast<MvalNet*>(net);
   hipStream_t main_s = mval_stream(stream);
   const bool multi = n->n_lanes > 1 && (n->lanes_override < 0 ? multi_stream_enabled() : n->lanes_override != 0);
-  MvalLanes* L = multi ? device_lanes() : nullptr;
+  MvalLanes* L = multi ? mval_device_lanes() : nullptr;
   if (multi) MVAL_REQUIRE(L != nullptr, "mval_net_forward: could not create the side streams");
-  bool used[MVAL_MAX_LANES] = {false, false, false, false};
-  int phase = n->ops.empty() ? 0 : n->ops[0].phase;
-  auto join = [&]() {  // side streams -> main
-    for (int l = 1; l < n->n_lanes; l++)
-      if (used[l]) {
-        (void)hipEventRecord(L->join_ev[l], L->side[l]);
-        (void)hipStreamWaitEvent(main_s, L->join_ev[l], 0);
-        used[l] = false;
-      }
-  };
-  bool forked = false;
+  MvalLaneWalk walk(L, main_s);
   for (size_t i = 0; i < n->ops.size(); i++) {
     const mval_op& op = n->ops[i];
-    hipStream_t s = main_s;
-    if (multi) {
-      if (op.phase != phase) {
-        join();
-        phase = op.phase;
-        forked = false;
-      }
-      if (!forked) {
-        // recorded at the START of the phase, before its lane-0 ops are enqueued: the side lanes then wait for the
-        // previous phases only, not for this phase's (longest) lane-0 chain as well
-        (void)hipEventRecord(L->fork_ev, main_s);
-        forked = true;
-      }
-      int lane = op.lane < n->n_lanes ? op.lane : 0;
-      if (lane > 0) {
-        if (!used[lane]) {
-          (void)hipStreamWaitEvent(L->side[lane], L->fork_ev, 0);
-          used[lane] = true;
-        }
-        s = L->side[lane];
-      }
-    }
+    hipStream_t s = walk.stream_for(op.phase, op.lane < n->n_lanes ? op.lane : 0);
     int rc = mval_op_launch(&n->ops[i], n_images, workspace, params, input_nchw, output_nchw, s);
     if (rc) return rc;
   }
-  if (multi) join();
+  walk.finish();
   return 0;
 }
 
