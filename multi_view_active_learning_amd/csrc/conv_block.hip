@@ -15,17 +15,19 @@
 //   * the intermediate tile is scaled by ITS OWN maximum (a workgroup-local reduction): the tile decomposition
 //     depends on the image geometry only, so results stay deterministic and independent of the batch.
 //
-// Workgroup = 2 waves, output tile 8 x 16 pixels (every wave streams ALL weight fragments of both convs from L2, so
-// weight traffic through the CU's L1 goes with the number of waves per pixel: four waves per tile measured 98 us
-// per 32-channel block, of which ~30 us of L1 time for weights alone):
-//   1. stage the 12 x 20 input patch (2-pixel halo), split, into LDS planes X[plane][chunk][pixel][32 ch + pad];
-//   2. conv1 over the 10 x 18 intermediate pixels (1-pixel halo for conv2; 12 sub-tiles of 16 pixel slots, 6 per
-//      wave, every wave all C output channels).  The WEIGHT fragment is the MFMA's first operand, so a lane ends up
-//      with 4 consecutive channels of one pixel: BN1 + ReLU (+ zero outside the image = conv2's zero padding) in
-//      registers, tile maximum through LDS, split, 8-byte LDS stores into M[plane][chunk][pixel][32 ch + pad],
-//      which overlays X (conv1 is done with it);
-//   3. conv2 over the 8 x 16 output pixels from M (4 sub-tile rows per wave); BN2 + residual + ReLU in registers,
-//      float4 stores straight from the accumulators (64-byte runs per pixel; no LDS round trip, no barrier).
+// Workgroup = 4 waves on an 8 x 16 output tile (the kernel is written for TH / 2 waves on TH x 16 tiles).  Every wave
+// streams ALL weight fragments of both convs from L2 and computes all C output channels for its pixels:
+//   1. stage the 12 x 20 input patch (2-pixel halo) through a buffer descriptor (out-of-image lanes read zeros
+//      without a branch), split, into LDS planes X[plane][chunk][pixel][32 ch + pad];
+//   2. conv1 over the 10 x 18 intermediate pixels (1-pixel halo for conv2; 12 sub-tiles of 16 pixel slots, 3 per
+//      wave).  The WEIGHT fragment is the MFMA's first operand, so a lane ends up with 4 consecutive channels of one
+//      pixel: BN1 + ReLU (+ zero outside the image = conv2's zero padding) in registers, tile maximum through LDS,
+//      split, 8-byte LDS stores into M[plane][chunk][pixel][32 ch + pad], which overlays X (conv1 is done with it);
+//   3. conv2 over the 8 x 16 output pixels from M (2 rows per wave); BN2 + residual + ReLU in registers, float4
+//      stores straight from the accumulators (64-byte runs per pixel; no LDS round trip, no barrier).
+// Measured alternatives (32-channel block, 128 images of 64 x 64; this form: 96 us): two waves per workgroup with
+// twice the pixels each (half the weight stream through L1) 102 us; 16 x 16 tiles with 8 waves (10 % fewer conv1
+// MFMAs, 17 % fewer staged pixels) 96.8 us.
 // Halo recompute: conv1 does 12 / 8 = 1.5x the MFMAs of a plain conv; at 3 MFMAs per product that is cheaper than
 // the two staging passes, two epilogues and 3 tensor round trips it replaces.
 #include "conv_common.h"
