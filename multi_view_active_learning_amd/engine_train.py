@@ -236,7 +236,9 @@ class TrainPlan:
         holders = model._holders
         self.param_list, self.grad_slots = [], []
         gtop = 0
+        cum = []  # gradient floats up to and including op i
         for op in g.ops:
+            cum.append(gtop)
             if op.kind == "maxpool":
                 self.grad_slots.append({})
                 continue
@@ -254,7 +256,33 @@ class TrainPlan:
                 self.param_list += [bn.weight, bn.bias]
                 gtop += 2 * _align(op.cout, 4)
             self.grad_slots.append(slots)
+            cum[-1] = gtop
         self.grad_floats = gtop
+        # Segments of the op list for the autograd chain (run_network_train): ~equal shares of the gradient bytes, so
+        # that DistributedDataParallel sees the gradients of the LAST layers while the backward of the earlier ones is
+        # still running and can overlap its bucketed all-reduce (RCCL) with it.  One segment = one autograd node.
+        nseg = max(1, min(6, gtop // (4 << 20)))  # (no point in splitting a few MB of gradients)
+        bounds = [0]
+        for k in range(1, nseg):
+            i = next(i for i, c_ in enumerate(cum) if c_ >= k * gtop / nseg) + 1
+            if bounds[-1] < i < len(g.ops):
+                bounds.append(i)
+        bounds.append(len(g.ops))
+        self.segments = [(a, b) for a, b in zip(bounds, bounds[1:]) if b > a]
+        self.seg_params = []
+        for lo, hi in self.segments:
+            ps = []
+            for op in g.ops[lo:hi]:
+                if op.kind == "maxpool":
+                    continue
+                conv = holders[op.conv]
+                ps.append(conv.weight)
+                if getattr(conv, "bias", None) is not None:
+                    ps.append(conv.bias)
+                if op.bn:
+                    ps += [holders[op.bn].weight, holders[op.bn].bias]
+            self.seg_params.append(ps)
+        assert sum(len(p_) for p_ in self.seg_params) == len(self.param_list)
         self.bn_counters = [holders[op.bn].num_batches_tracked for op in g.ops if op.bn]
 
     # ---- parameters ---------------------------------------------------------------------------
@@ -357,8 +385,18 @@ class TrainPlan:
         return out
 
     def backward(self, x, gout_nchw):
+        """Whole backward in one go (the segmented autograd chain calls the two halves below separately)."""
+        self.backward_begin(x, gout_nchw)
+        out = []
+        for k in range(len(self.segments) - 1, -1, -1):
+            out = self.backward_segment(k, x) + out
+        return out
+
+    def backward_begin(self, x, gout_nchw):
+        """Gradient buffer, the first-touch bookkeeping's zero fills, and the loss gradient into the gradient arena."""
         g = self.graph
         grads = torch.empty(self.grad_floats, dtype=torch.float32, device=self.device)
+        self._grads = grads
         gb = grads.data_ptr()
         for t, slots, op in zip(self.ops, self.grad_slots, g.ops):
             if not slots:
@@ -371,9 +409,17 @@ class TrainPlan:
         last = self.ops[len(self.ops) - 1]
         gn = gout_nchw.to(torch.float32).permute(0, 2, 3, 1).contiguous()
         self.garena[last.gout_off : last.gout_off + gn.numel()] = gn.reshape(-1)
+
+    def backward_segment(self, k, x):
+        """Backward of the ops [lo, hi) of segment k (segments MUST be run last to first: the gradient arena carries
+        the state between them) -> that segment's parameter gradients, in param_list order."""
+        g = self.graph
+        lo, hi = self.segments[k]
+        grads = self._grads
+        sub = (MvalTrainOp * (hi - lo)).from_address(C.addressof(self.ops) + lo * C.sizeof(MvalTrainOp))
         _lib._check(
             _lib.lib().mval_train_backward(
-                self.ops, C.c_int(len(self.ops)), C.c_int(self.n), C.c_void_p(self.arena.data_ptr()),
+                sub, C.c_int(hi - lo), C.c_int(self.n), C.c_void_p(self.arena.data_ptr()),
                 C.c_void_p(self.garena.data_ptr()), C.c_void_p(self.params.data_ptr()), C.c_int64(self.ones_off),
                 C.c_int64(self.zeros_off), C.c_void_p(x.data_ptr()), C.c_void_p(self.gz.data_ptr()),
                 C.c_void_p(self.wsf.data_ptr()), C.c_void_p(self.ws.data_ptr()), C.c_void_p(self.sums.data_ptr()),
@@ -381,7 +427,7 @@ class TrainPlan:
             "mval_train_backward")
         out = []
         holders = self.model._holders
-        for slots, op in zip(self.grad_slots, g.ops):
+        for slots, op in zip(self.grad_slots[lo:hi], g.ops[lo:hi]):
             if not slots:
                 continue
             conv = holders[op.conv]
@@ -394,26 +440,39 @@ class TrainPlan:
         return out
 
 
-class _NetTrainFn(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, x, plan, *params):
-        ctx.plan = plan
-        ctx.save_for_backward(x)
-        out = plan.forward(x)
-        ctx.generation = plan.generation
-        return out
+_STALE = ("backward() of a train-mode forward whose saved activations were overwritten by a later train-mode "
+          "forward of the same model and input shape (the training plan keeps ONE set of activations): call "
+          "backward() before the next forward, as the reference's loop does (strategy.py:470-484), or run the "
+          "extra forward under model.eval()")
+
+
+class _SegFn(torch.autograd.Function):
+    """One segment of the training graph as an autograd node.  Segment 0's forward runs the WHOLE forward (one C
+    call); the nodes are chained through 1-element tokens and the last one returns the heat-maps, so autograd runs the
+    backward segments last to first and hands every segment's parameter gradients to their AccumulateGrad nodes (and
+    DDP's hooks) as soon as that segment is done."""
 
     @staticmethod
-    def backward(ctx, gout):
-        (x,) = ctx.saved_tensors
-        if ctx.generation != ctx.plan.generation:
-            raise _lib.MvalError(
-                "backward() of a train-mode forward whose saved activations were overwritten by a later train-mode "
-                "forward of the same model and input shape (the training plan keeps ONE set of activations): call "
-                "backward() before the next forward, as the reference's loop does (strategy.py:470-484), or run the "
-                "extra forward under model.eval()")
-        grads = ctx.plan.backward(x, gout.contiguous())
-        return (None, None, *grads)
+    def forward(ctx, carry, plan, k, *params):
+        ctx.plan, ctx.k = plan, k
+        if k == 0:
+            plan._x = carry
+            plan._out = plan.forward(carry)
+        ctx.generation = plan.generation
+        if k == len(plan.segments) - 1:
+            return plan._out
+        return torch.zeros(1, dtype=torch.float32, device=plan.device)
+
+    @staticmethod
+    def backward(ctx, g):
+        plan, k = ctx.plan, ctx.k
+        if ctx.generation != plan.generation:
+            raise _lib.MvalError(_STALE)
+        if k == len(plan.segments) - 1:
+            plan.backward_begin(plan._x, g.contiguous())
+        grads = plan.backward_segment(k, plan._x)
+        carry_grad = None if k == 0 else torch.zeros(1, dtype=torch.float32, device=plan.device)
+        return (carry_grad, None, None, *grads)
 
 
 def run_network_train(model, x):
@@ -424,4 +483,7 @@ def run_network_train(model, x):
     if plan is None:
         cache.clear()  # one training geometry at a time: the arenas are large
         plan = cache[key] = TrainPlan(model, n, h, w, x.device)
-    return _NetTrainFn.apply(x, plan, *plan.param_list)
+    carry = x
+    for k in range(len(plan.segments)):
+        carry = _SegFn.apply(carry, plan, k, *plan.seg_params[k])
+    return carry

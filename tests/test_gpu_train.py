@@ -385,3 +385,32 @@ def test_batched_weight_pack_equals_single_packs(dev):
         assert torch.equal(batched[t.op.w_off : t.op.w_off + nw], single[t.op.w_off : t.op.w_off + nw]), op.conv
         if dpack is not None:
             assert torch.equal(batched[t.wd_off : t.wd_off + nw], single[t.wd_off : t.wd_off + nw]), op.conv
+
+
+def test_backward_runs_in_segments_last_layers_first(dev):
+    """The training graph is a chain of autograd nodes (engine_train._SegFn), one per segment of the op list, so that the
+    gradients of the last layers reach their AccumulateGrad nodes (where DistributedDataParallel hooks its bucketed
+    all-reduce) while the backward of the earlier layers has not run yet.  Checked with post-accumulate hooks: when the
+    first parameter of the LAST segment gets its gradient, no parameter of the FIRST segment has one."""
+    from multi_view_active_learning_amd.pose_estimators import PoseHighResolutionNet
+
+    torch.manual_seed(3)
+    m = PoseHighResolutionNet(5).to(dev).train()
+    x = torch.randn(2, 3, 64, 64, device=dev)
+    y = m(x)
+    plan = next(iter(m._train_plans.values()))
+    assert len(plan.segments) >= 3 and plan.segments[0][0] == 0 and plan.segments[-1][1] == len(plan.ops)
+    assert all(a[1] == b[0] for a, b in zip(plan.segments, plan.segments[1:]))
+    assert [id(p) for seg in plan.seg_params for p in seg] == [id(p) for p in plan.param_list]
+    first_seg, last_seg = plan.seg_params[0], plan.seg_params[-1]
+    seen = {}
+
+    def hook(p):
+        if "first_has_grad" not in seen:
+            seen["first_has_grad"] = any(q.grad is not None for q in first_seg)
+
+    h = last_seg[-1].register_post_accumulate_grad_hook(hook)
+    y.square().mean().backward()
+    h.remove()
+    assert seen == {"first_has_grad": False}
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in plan.param_list)
