@@ -330,6 +330,7 @@ int mval_conv_block_supported(int C, int N, int H, int W) {
   if (C != 32 && C != 48 && C != 64) return 0;
   if (H < 8 || W < 16) return 0;  // small maps: the unfused kernels pack several images into a tile instead
   if ((int64_t)N * H * W * C >= (int64_t)1 << 31) return 0;
+  if ((int64_t)H * W * C >= (int64_t)1 << 29) return 0;  // one image's bytes index a 32-bit buffer descriptor
   return 1;
 }
 
