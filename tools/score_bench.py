@@ -1,7 +1,10 @@
 import sys, os, torch, numpy as np
 sys.path.insert(0, "/root/repo")
 from multi_view_active_learning_amd import _lib
+from multi_view_active_learning_amd import synth
 dev = torch.device("cuda:0")
+def proj(f, v, hh, wh):
+    return torch.from_numpy(np.stack([synth.ring_cameras(v, hh * 4, wh * 4, seed=s) for s in range(f)])).to(dev)
 for (f, v, j, hh, wh) in ((32, 4, 19, 64, 64), (8, 8, 19, 96, 72), (256, 4, 19, 64, 64)):
     hm = torch.rand(f, v, j, hh, wh, device=dev)
     valid = torch.ones(f, j, dtype=torch.uint8, device=dev)
@@ -16,4 +19,8 @@ for (f, v, j, hh, wh) in ((32, 4, 19, 64, 64), (8, 8, 19, 96, 72), (256, 4, 19, 
     t0 = timed(lambda: _lib.argmax_decode(hm, valid, f, v, j, hh, wh, 4, hh))
     t1 = timed(lambda: _lib.score_decode_maps(_lib.SCORE_HP, hm, valid, f, v, j, hh, wh, 4, hh))
     t2 = timed(lambda: _lib.score_maps(_lib.SCORE_HP, hm, f * v * j, hh, wh))
+    t3 = timed(lambda: _lib.score_decode_maps(_lib.SCORE_MPE, hm, valid, f, v, j, hh, wh, 4, hh), 10)
+    pm = proj(f, v, hh, wh)
+    t4 = timed(lambda: _lib.triangulate_ransac(_lib.argmax_decode(hm, valid, f, v, j, hh, wh, 4, hh), pm, valid, f, v, j, 5.0), 10)
+    print(f"   MPE+decode {t3*1e6:.1f} us | decode+RANSAC-DLT {t4*1e6:.1f} us")
     print(f"{f}x{v}x{j} maps {hh}x{wh} ({b/1e6:.1f} MB): argmax {t0*1e6:.1f} us {b/t0/1e9:.0f} GB/s | HP+decode {t1*1e6:.1f} us {b/t1/1e9:.0f} GB/s | HP {t2*1e6:.1f} us {b/t2/1e9:.0f} GB/s")
