@@ -405,3 +405,21 @@ def test_large_batches_run_as_slices(dev, monkeypatch):
         sliced = model(x)
     assert sliced.shape == whole.shape == (7, 19, 16, 16)
     assert torch.equal(sliced, whole)
+
+
+def test_magnitude_row_overflow_falls_back_to_atomics(dev):
+    """More producing waves per image than a magnitude row has slots (stem conv on a 1024 x 512 image: 1024 tiles x 4
+    waves > 4095): the launcher zeroes the rows and the waves fold into slot % 4095 with atomicMax; the row's maximum is
+    still exactly max |out|, and an fp16-split conv that reads it matches torch."""
+    from multi_view_active_learning_amd import ops
+
+    rng = np.random.default_rng(5)
+    x = torch.from_numpy(rng.standard_normal((1, 3, 1024, 512)).astype(np.float32))
+    wt = torch.from_numpy((rng.standard_normal((64, 3, 3, 3)) * 0.2).astype(np.float32))
+    sc = torch.from_numpy(rng.uniform(0.5, 1.5, 64).astype(np.float32))
+    sh = torch.from_numpy(rng.standard_normal(64).astype(np.float32))
+    got = ops.fused_conv(x.to(dev), wt.to(dev), sc.to(dev), sh.to(dev), stride=2, relu=True, algo=ops.ALGO_DIRECT, in_nchw=True)
+    kept = ops.fused_conv.last_out_amax.cpu().view(torch.float32)
+    assert torch.equal(kept, got.abs().amax(dim=(1, 2, 3)).cpu())
+    want = F.relu(F.conv2d(x, wt, None, 2, 1) * sc[None, :, None, None] + sh[None, :, None, None])
+    np.testing.assert_allclose(got.permute(0, 3, 1, 2).cpu().numpy(), want.numpy(), rtol=1e-4, atol=2e-5)
