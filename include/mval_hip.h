@@ -181,7 +181,7 @@ int mval_kcenter_select(const double* feat, int64_t n_obs, int D, const int64_t*
  * written by mval_pack_conv_weights; scale/shift are the folded eval-mode BatchNorm
  * (y = x * scale + shift, torch's batch_norm inference formula) or (1, bias). */
 enum { MVAL_OP_CONV = 0, MVAL_OP_MAXPOOL = 1, MVAL_OP_DECONV = 2, MVAL_OP_BLOCK = 3 };
-enum { MVAL_ALGO_DIRECT = 0, MVAL_ALGO_MFMA = 1, MVAL_ALGO_MFMA_BF3 = 2, MVAL_ALGO_MFMA_H2 = 3 };
+enum { MVAL_ALGO_DIRECT = 0, MVAL_ALGO_MFMA = 1, MVAL_ALGO_MFMA_BF3 = 2, MVAL_ALGO_MFMA_H2 = 3, MVAL_ALGO_MFMA_P2 = 4 };
 enum { MVAL_PACK_HWIO = 0, MVAL_PACK_MFMA16 = 1, MVAL_PACK_MFMA16_BF3 = 2, MVAL_PACK_MFMA16_H2 = 3 };
 
 typedef struct mval_op {
@@ -211,6 +211,14 @@ typedef struct mval_op {
    * algo MVAL_ALGO_MFMA_H2.  w_off / scale_off / shift_off are conv1 + bn1, these three conv2 + bn2 (both
    * weights packed MVAL_PACK_MFMA16_H2); res1_off must equal in_off (or be -1). */
   int64_t w2_off, scale2_off, shift2_off;
+  /* MVAL_ALGO_MFMA_P2 (csrc/conv_p2.h): the op reads AND writes "P2" activations -- each fp32 value kept as the pair
+   * of fp16 planes the fp16-split MFMA consumes, halves [n][plane h,l][C/8][H][W][8] at in_off / res1_off / res2_off /
+   * out_off (4 bytes per element, so the float offsets and sizes are those of the fp32 tensor), the per-image rows at
+   * in_amax_off / res1_amax_off / res2_amax_off / out_amax_off carrying 2^-s in their last dword.  out_nchw != 0:
+   * the output is fp32 NCHW instead (the heat-map layer).  bound_off: params offset of two floats
+   * [A = max_c |scale_c| * sum |w_c|, B = max_c |shift_c|], the output's magnitude bound (bound2_off: conv2 of a
+   * MVAL_OP_BLOCK).  Weights are packed MVAL_PACK_MFMA16_H2. */
+  int64_t bound_off, bound2_off, res1_amax_off, res2_amax_off;
 } mval_op;
 
 /* Weight packing.  MVAL_PACK_HWIO: [k*k][cin][cout] (direct kernels, deconv);
@@ -254,6 +262,12 @@ int mval_bn_fold(const float* gamma, const float* beta, const float* mean, const
  * per_image consecutive floats each: for tensors that did not come out of an op of the plan. */
 #define MVAL_AMAX_ROW 4096
 int mval_amax(const float* x, int64_t per_image, int n_images, uint32_t* rows, void* stream);
+/* fp32 NHWC [n][H][W][C] (C % 8 == 0) whose rows_in ([count, partials ...], as every NHWC producer keeps them) hold
+ * its per-image max |x| -> P2 planes (csrc/conv_p2.h) and their rows ([P2 partial slots ... 2^-s]; zero-initialised
+ * by the caller once).  And back (tests, network boundaries). */
+int mval_nhwc_to_p2(const float* x, const uint32_t* rows_in, void* planes, uint32_t* rows, int n_images, int H, int W, int C,
+                    void* stream);
+int mval_p2_to_nhwc(const void* planes, const uint32_t* rows, float* out, int n_images, int H, int W, int C, void* stream);
 
 /* 1 when the MFMA kernel family has a configuration for this op geometry (the plan builder
  * asks before choosing MVAL_ALGO_MFMA / MVAL_PACK_MFMA16), else 0. */

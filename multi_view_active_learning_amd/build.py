@@ -18,7 +18,7 @@ OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(CSRC, "libmval_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
-         "-I", os.path.join(os.path.dirname(HERE), "include")]
+         "-I", os.path.join(os.path.dirname(HERE), "include")] + os.environ.get("MVAL_EXTRA_CFLAGS", "").split()
 
 
 def _sources():

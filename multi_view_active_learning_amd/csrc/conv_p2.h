@@ -1,0 +1,118 @@
+// "P2" activations: every fp32 activation value kept as the PAIR of fp16 planes the fp16x2-split MFMA convs consume,
+// written once by the producer's epilogue (csrc/conv_p2.hip, conv_block_p2.hip).
+//
+//   tensor of N images, C channels (C % 8 == 0), H x W:
+//       halves  [n][plane p = 0 (h), 1 (l)][C / 8][H][W][8]          4 bytes per element, like fp32
+//       x[n][c][y][x] = (h + l) * 2^-s[n]         h = RNE_fp16(x * 2^s), l = RNE_fp16(x * 2^s - h)
+//   row of the tensor's image n (MVAL_AMAX_ROW dwords):
+//       row[0 .. P2_SLOTS - 1] = partial max |x| (float bits; one slot per producing workgroup, unused slots stay 0:
+//                                the rows are zeroed once when the plan is built and a slot only ever belongs to one
+//                                workgroup, so a consumer reads a FIXED number of slots -- no count, no dependent load),
+//       row[P2_INV_SLOT] = float bits of 2^-s[n]
+//
+// Why: with fp32 NHWC activations every CONSUMER re-splits each element it stages (12 vector instructions per
+// float4, two 8-byte LDS stores) -- 2.4x per element for a 3x3 conv's halo and once more per cout group.  With
+// P2 the consumer's staging is a 16-byte copy (global -> register -> LDS, no arithmetic), and the channel-blocked
+// layout makes the LDS image [8-channel block][pixel][16 B] conflict-free for ds_read_b128 at ANY pixel offset
+// (a 16-lane fragment read covers 256 consecutive bytes per block), so the 3x3 taps are plain immediate offsets.
+//
+// The scale 2^s[n] must be known BEFORE the producer's first store, i.e. before the image's true maximum exists.
+// It comes from a rigorous per-image bound of the fused operator out = act((bn(conv(x)) + r1) + r2):
+//       |out| <= A * max|x| + B + max|r1| + max|r2|,   A = max_c |scale_c| * sum_k |w_ck|,  B = max_c |shift_c|
+// (A, B per layer at parameter-refresh time; the maxima are the exact per-image maxima the producers keep).  The
+// bound is typically 2^4 .. 2^7 above the true maximum; fp16's 5 exponent bits absorb that: 2^s puts the BOUND in
+// [2^13, 2^14), every value above 2^-3 (scaled) keeps all 22 significand bits of the pair and smaller ones an
+// absolute error <= 2^-25, i.e. <= 2^-38 of the bound.  Per IMAGE, so results do not depend on the batch.
+#pragma once
+#include "conv_common.h"
+
+#define P2_INV_SLOT (MVAL_AMAX_ROW - 1)
+#define P2_SLOTS 256  // partial maxima per image: 4 per lane of the reading wave
+
+typedef _Float16 p2_f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 p2_f16x8 __attribute__((ext_vector_type(8)));
+typedef float p2_f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int p2_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int p2_u32x2 __attribute__((ext_vector_type(2)));
+
+// 2^s that puts `bound` in [2^13, 2^14) and its inverse (zero / inf / NaN bound: unscaled)
+__device__ __forceinline__ void p2_scale_of(float bound, float& mul, float& inv) {
+  const int e = (int)((__float_as_uint(bound) >> 23) & 0xff);
+  int s = (e == 0 || e == 255) ? 0 : 13 - (e - 127);
+  s = max(-110, min(110, s));
+  mul = __uint_as_float((unsigned)(127 + s) << 23);
+  inv = __uint_as_float((unsigned)(127 - s) << 23);
+}
+
+__device__ __forceinline__ void p2_split(const p2_f32x4 v, p2_f16x4& h, p2_f16x4& l) {
+  h = __builtin_convertvector(v, p2_f16x4);
+  l = __builtin_convertvector(v - __builtin_convertvector(h, p2_f32x4), p2_f16x4);
+}
+__device__ __forceinline__ p2_f32x4 p2_join(const p2_f16x4 h, const p2_f16x4 l) {
+  return __builtin_convertvector(h, p2_f32x4) + __builtin_convertvector(l, p2_f32x4);  // exact (22 bits)
+}
+
+// A workgroup's max |x| of what it stored of image n -> its slot of the row.  More producing workgroups per image than
+// slots (inputs above ~512 x 512): they fold into slot % P2_SLOTS with atomicMax (the launcher zeroes the rows first).
+__device__ __forceinline__ void p2_slot_put(unsigned* row, int slot, int total, unsigned bits) {
+  if (total <= P2_SLOTS) row[slot] = bits;
+  else atomicMax(row + slot % P2_SLOTS, bits);
+}
+// Consumer side: the lanes' share of the partial slots of image n (4 independent loads) ...
+struct P2RowRegs {
+  unsigned v[P2_SLOTS / 64];
+  unsigned inv;
+};
+__device__ __forceinline__ void p2_row_request(const unsigned* rows, int n, P2RowRegs& r) {
+  const unsigned* row = rows + (int64_t)n * MVAL_AMAX_ROW;
+#pragma unroll
+  for (int i = 0; i < P2_SLOTS / 64; i++) r.v[i] = row[i * 64 + (threadIdx.x & 63)];
+  r.inv = row[P2_INV_SLOT];
+}
+// Maximum over the wave of non-negative float bits (they order like unsigned integers), uniform result: four DPP
+// steps inside the 16-lane rows, then the four rows through scalar registers -- a dozen instructions; the
+// __shfl_xor butterfly is six dependent ds_bpermute round trips (~0.3 us each time it is used in an epilogue).
+__device__ __forceinline__ unsigned p2_wave_umax(unsigned m) {
+  m = max(m, (unsigned)__builtin_amdgcn_update_dpp(0, (int)m, 0xB1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]
+  m = max(m, (unsigned)__builtin_amdgcn_update_dpp(0, (int)m, 0x4E, 0xf, 0xf, false));   // quad_perm [2,3,0,1]
+  m = max(m, (unsigned)__builtin_amdgcn_update_dpp(0, (int)m, 0x141, 0xf, 0xf, false));  // row_half_mirror
+  m = max(m, (unsigned)__builtin_amdgcn_update_dpp(0, (int)m, 0x140, 0xf, 0xf, false));  // row_mirror
+  const unsigned a = (unsigned)__builtin_amdgcn_readlane((int)m, 0), b = (unsigned)__builtin_amdgcn_readlane((int)m, 16);
+  const unsigned c = (unsigned)__builtin_amdgcn_readlane((int)m, 32), d = (unsigned)__builtin_amdgcn_readlane((int)m, 48);
+  return max(max(a, b), max(c, d));
+}
+// ... and their maximum (uniform over the wave)
+__device__ __forceinline__ float p2_row_amax(const P2RowRegs& r) {
+  unsigned m = r.v[0];
+#pragma unroll
+  for (int i = 1; i < P2_SLOTS / 64; i++) m = max(m, r.v[i]);
+  return __uint_as_float(p2_wave_umax(m));
+}
+
+struct P2Args {
+  const _Float16* in;  // P2 planes of the input tensor
+  const float* w;      // MVAL_PACK_MFMA16_H2 fragments (+ trailer)
+  const float* w_unscale;
+  const float* scale;
+  const float* shift;
+  const float* bound;  // [A, B]
+  const _Float16* res1;
+  const _Float16* res2;
+  const unsigned* in_row;
+  const unsigned* res1_row;
+  const unsigned* res2_row;
+  unsigned* out_row;
+  _Float16* out;    // P2 planes ...
+  float* out_f32;   // ... or fp32 NCHW (the heat-map layer)
+  int N, Hin, Win, Cin, Hout, Wout, Cout;  // Hout / Wout before the fused upsample
+  int k, stride;
+  int up, relu;
+  int th, tw, tiles_x, tiles_y;
+  int NS_total;
+  int amax_tiles;
+  int tiles_total, wgs_x;  // persistent tile walk: tiles_x * tiles_y * N tiles over wgs_x workgroups per cout group
+  unsigned long long* dbg;  // diagnostic builds (-DP2_STAMP): per-wave phase time stamps; nullptr otherwise
+};
+
+int mval_launch_conv_p2(const P2Args& a, hipStream_t s);  // conv_p2.hip; 1 = unsupported (dry != 0: no launch)
+int mval_conv_p2_supported(int k, int stride, int cin, int cout, int hin, int win, int up, int out_nchw, int n);

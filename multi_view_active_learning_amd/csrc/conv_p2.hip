@@ -1,0 +1,707 @@
+// Fused conv on the fp16 matrix cores over "P2" activations (conv_p2.h: every activation kept as the pair of fp16
+// planes of the fp16x2 split, channel-blocked [n][plane][C/8][H][W][8]).
+//
+//     out = act(((conv(x, w) * scale + shift + res1) + res2))   [nearest-upsampled by 2^up on store]
+//     (hrnet.py:36-52,75-95,199-287 in eval mode: conv + BN + residual add(s) + ReLU + upsample of the fuse layers)
+//
+// Arithmetic = conv_mfma_split.hip's PL = 2: three v_mfma_f32_16x16x32_f16 per 32-deep k-step (wl*xh, wh*xl, wh*xh,
+// fp32 accumulate), power-of-two scales undone exactly in the epilogue.  What differs is where the work sits:
+//   * staging is a COPY: 16-byte granules (8 channels of one pixel of one plane) global -> register -> LDS, no
+//     conversion, no scale, no split.  LDS image of a 32-channel chunk: [plane h,l][8-channel block 0..3][slot][16 B];
+//     a fragment read (16 consecutive slots of one block per 16-lane group) covers 256 consecutive bytes: conflict-free
+//     for every tap offset, no row padding.  Stride-2 convs store the patch columns de-interleaved by parity, so their
+//     fragments are consecutive slots too;
+//   * two LDS buffers, ONE barrier per chunk: the next chunk's granules travel to registers during the MFMA loop and
+//     are stored into the other buffer behind it;
+//   * the WEIGHT fragment is the MFMA's first operand: a lane ends up with 4 consecutive output channels of one
+//     pixel, so BN / residuals / ReLU / max |x| / the output split all happen in registers and the stores go straight
+//     to the output planes (8 bytes per lane and plane; a wave instruction writes four full 128-byte lines).  No LDS
+//     round trip, no epilogue barrier;
+//   * a wave covers 8 pixel sub-tiles per weight fragment on the large problems (half the L2 -> register weight
+//     stream per MFMA of the NHWC kernels: that stream was as busy as the matrix pipe).
+#include <stdlib.h>
+
+#include "conv_p2.h"
+
+typedef p2_f32x4 f32x4;
+typedef p2_f16x8 f16x8;
+typedef p2_f16x4 f16x4;
+typedef p2_u32x4 u32x4;
+typedef p2_u32x2 u32x2;
+
+#ifdef P2_STAMP
+// Diagnostic build only: lane 0 of every wave leaves the 100 MHz wall clock at phase boundaries in a.dbg[wave][16].
+#define P2_MARK(k)                                                                                                       \
+  do {                                                                                                                   \
+    if (a.dbg && lane == 0) a.dbg[(((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (NTH / 64) + wave) * 16 + (k)] = wall_clock64(); \
+  } while (0)
+// phase timers: P2_T0 starts, P2_ACC(k) adds the time since the last P2_T0 / P2_ACC to dbg slot 8 + k
+#define P2_T0 unsigned long long p2_t = wall_clock64(); unsigned long long p2_acc[6] = {0, 0, 0, 0, 0, 0}
+#define P2_ACC(k)                              \
+  do {                                         \
+    const unsigned long long t_ = wall_clock64(); \
+    p2_acc[k] += t_ - p2_t;                    \
+    p2_t = t_;                                 \
+  } while (0)
+#define P2_FLUSH                                                                                                         \
+  do {                                                                                                                   \
+    if (a.dbg && lane == 0)                                                                                              \
+      for (int k_ = 0; k_ < 6; k_++)                                                                                     \
+        a.dbg[(((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (NTH / 64) + wave) * 16 + 8 + k_] = p2_acc[k_];         \
+  } while (0)
+static unsigned long long* g_p2_dbg = nullptr;
+extern "C" void mval_p2_debug_buffer(void* p) { g_p2_dbg = reinterpret_cast<unsigned long long*>(p); }
+#else
+#define P2_MARK(k)
+#define P2_T0
+#define P2_ACC(k)
+#define P2_FLUSH
+#endif
+
+__device__ __forceinline__ f32x4 p2_mfma(const u32x4 a, const u32x4 b, const f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
+// KS: 1 or 3 (pad KS / 2); S: stride; G: 32-channel chunks staged per barrier (1x1 convs: 2 or 4 -- one tap per
+// chunk is too little MFMA work per barrier); WN x WM waves (couts x pixels); NT cout sub-tiles and MS pixel
+// sub-tiles of 16 per wave; NE staged granules per thread; RS: row sharing (3x3 stride 1, 16-wide tiles: the wave's
+// MS sub-tiles are consecutive tile rows, a patch-row fragment feeds the three row taps).
+//
+// A workgroup is PERSISTENT: it walks tiles (an XCD-contiguous range, so neighbouring tiles' halos meet in one L2)
+// and, per tile, the K chunks -- one flat sequence of stages, one barrier each.  In-kernel stamps of the
+// one-tile-per-workgroup form showed why (128 -> 128 on 16x16 maps, 35 us): the MFMA phases ran near the rate two
+// waves per SIMD can share, but every wave spent 2.9 us waiting for its scale rows before anything else, 6.7 us in an
+// epilogue whose residual / BN-factor loads started after the last MFMA, and ~1 us per barrier -- half its life, with
+// all workgroups of the launch in the same phase at the same time.  Here every load is requested a stage before its
+// use: the next stage's granules (the NEXT TILE's first chunk during a tile's last stage), the next weight blocks
+// (also across tiles), and at the start of a tile's last stage everything its epilogue needs (scale rows, residual
+// granules, BN factors), so the epilogue is arithmetic and stores.
+template <int KS, int S, int G, int WN, int WM, int NT, int MS, int TW, bool RS>
+__global__ __launch_bounds__(64 * WN * WM) __attribute__((amdgpu_waves_per_eu(2, 8))) void conv_p2_kernel(P2Args a) {
+  constexpr int NTH = 64 * WN * WM, TAPS = KS * KS, SPN = 8 * G, SPN_LOG2 = G == 1 ? 3 : G == 2 ? 4 : 5;
+  constexpr int pad = KS / 2;
+  static_assert(G == 1 || G == 2 || G == 4, "chunks per stage");
+  static_assert(!RS || (KS == 3 && S == 1 && G == 1), "row sharing is for 3x3 stride 1");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wn = wave % WN, wm = wave / WN;
+  // the tile is TH x TW output pixels: every patch / LDS quantity is a compile-time constant (tap offsets become
+  // ds_read immediates; with a run-time tile the unrolled loop kept ~60 address registers alive)
+  constexpr int TH = 16 * MS * WM / TW, TW_LOG2 = TW == 8 ? 3 : TW == 16 ? 4 : TW == 32 ? 5 : 6;
+  static_assert(TH * TW == 16 * MS * WM && (TW == 8 || TW == 16 || TW == 32 || TW == 64), "tile shape");
+  static_assert(!RS || TW == 16, "row sharing: 16-wide tiles");
+  constexpr int PH = (TH - 1) * S + KS, PW = (TW - 1) * S + KS, PWh = (PW + 1) >> 1;
+  constexpr int slots = S == 1 ? PH * PW : 2 * PH * PWh;
+  constexpr int PPX = (slots + 15) & ~15;  // slots per 8-channel block (256-byte aligned blocks)
+  constexpr int buf_bytes = SPN * PPX * 16;
+  constexpr int NE = (PH * SPN * PW + NTH - 1) / NTH;  // staged granules per thread
+  static_assert(PH * SPN * PW < 4096 && PH < 32 && PW < 127, "staging plan packing");
+  unsigned* wgred = reinterpret_cast<unsigned*>(smem + 2 * buf_bytes);  // [max |x| of the tile, waves that added]
+  const int ns0 = (blockIdx.y * WN + wn) * NT;
+  const bool wave_active = ns0 < a.NS_total;
+
+  // ---- tile walk: workgroup b of this cout group -> XCD group b % X, contiguous tile range per XCD group ----------
+  const int X = a.wgs_x >= 8 ? 8 : 1;
+  const int per = (a.tiles_total + X - 1) / X, wgx = a.wgs_x / X;
+  const int xg = (int)blockIdx.x % X;
+  int tile = xg * per + (int)blockIdx.x / X;
+  const int tile_end = min(a.tiles_total, (xg + 1) * per);
+  if (tile >= tile_end) return;
+  const int tiles_img = a.tiles_x * a.tiles_y;
+  int tn, toy, tox;  // the tile being computed: image, first output row / column
+  auto decode = [&](int t, int& n, int& oy0, int& ox0) {
+    n = t / tiles_img;
+    const int r = t - n * tiles_img;
+    const int tyi = r / a.tiles_x;
+    oy0 = tyi * TH;
+    ox0 = (r - tyi * a.tiles_x) * TW;
+  };
+
+  // ---- staging plan: granule e = tid + NTH * i -> (patch row py, block sp = g*8 + plane*4 + c8, column px) ------
+  const int C8 = a.Cin >> 3;
+  const unsigned hw = (unsigned)(a.Hin * a.Win), hw16 = hw * 16u;  // bytes of one 8-channel block of one plane
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<_Float16*>(a.in), 0, (unsigned)min((int64_t)0xffffffff, (int64_t)a.N * 2 * C8 * hw16), 0x00020000);
+  unsigned lp[NE];    // LDS byte offset << 16 | c8 << 12 | py << 7 | px   (px = 127: no granule)
+  unsigned cb[NE];    // (plane * C8 + c8) * H * W * 16
+  unsigned goff[NE];  // byte offset of the granule of the tile being staged, chunk 0 (0xffffffff: zero padding)
+#pragma unroll
+  for (int i = 0; i < NE; i++) {
+    const int e = tid + NTH * i;
+    const int r = e / PW;
+    const int px = e - r * PW;
+    const int sp = r & (SPN - 1), py = r >> SPN_LOG2;
+    const int g = sp >> 3, pl = (sp >> 2) & 1, c8 = g * 4 + (sp & 3);
+    const int slot = S == 1 ? py * PW + px : ((px & 1) * PH + py) * PWh + (px >> 1);
+    lp[i] = py < PH ? ((unsigned)((sp * PPX + slot) * 16) << 16) | (c8 << 12) | (py << 7) | px : 127u;
+    cb[i] = (unsigned)(pl * C8 + c8) * hw16;
+  }
+  auto plan = [&](int n, int oy0, int ox0) {
+    const int iy0 = oy0 * S - pad, ix0 = ox0 * S - pad;
+    const unsigned nbase = (unsigned)n * 2u * (unsigned)C8 * hw16;
+#pragma unroll
+    for (int i = 0; i < NE; i++) {
+      const int px = lp[i] & 127, py = (lp[i] >> 7) & 31;
+      const int iy = iy0 + py, ix = ix0 + px;
+      const bool inb = px != 127 && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
+      goff[i] = inb ? nbase + cb[i] + (unsigned)(iy * a.Win + ix) * 16u : 0xffffffffu;
+    }
+  };
+  const int nchunks = (a.Cin + 31) >> 5;
+  const int nst = (nchunks + G - 1) / G;  // stages per tile
+  u32x4 stage[NE];
+  auto load_stage = [&](int st) {
+    const int c8b = st * 4 * G;
+#pragma unroll
+    for (int i = 0; i < NE; i++) {
+      const bool v = goff[i] != 0xffffffffu && c8b + (int)((lp[i] >> 12) & 15) < C8;
+      stage[i] = __builtin_amdgcn_raw_buffer_load_b128(xr, v ? goff[i] + (unsigned)c8b * hw16 : 0xffffffffu, 0, 0);
+    }
+  };
+  auto store_stage = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < NE; i++)
+      if ((lp[i] & 127) != 127) *reinterpret_cast<u32x4*>(smem + buf * buf_bytes + (lp[i] >> 16)) = stage[i];
+  };
+
+  // ---- fragment addressing ------------------------------------------------------------------------------------
+  // x fragment (MFMA B operand): lane -> pixel slot (lane & 15) of the sub-tile, k octet = 8-channel block (lane >> 4)
+  int xb[RS ? 1 : MS];
+  if constexpr (RS) {
+    xb[0] = ((lane >> 4) * PPX + wm * MS * PW + (lane & 15)) * 16;
+  } else {
+#pragma unroll
+    for (int ms = 0; ms < MS; ms++) {
+      const int p = (wm * MS + ms) * 16 + (lane & 15);
+      const int ty = p >> TW_LOG2, tx = p & (TW - 1);
+      xb[ms] = ((lane >> 4) * PPX + (S == 1 ? ty * PW + tx : 2 * ty * PWh + tx)) * 16;
+    }
+  }
+  constexpr int plane_b = 4 * PPX * 16;  // plane l behind plane h inside a chunk
+  constexpr int chunk_b = 8 * PPX * 16;
+  // weight fragments through a buffer descriptor: block offset in SGPRs, per-lane 32-bit offset, plane as immediate
+  const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, 0x7fffffff, 0x00020000);
+  const int blk_bytes = a.NS_total * 2048;
+  // The MFMA row (= output channel of the sub-tile) a lane SUPPLIES is permuted: rows 4..7 carry couts 8..11 and rows
+  // 8..11 couts 4..7.  Output lanes (quarter q = lane >> 4 holds rows 4q .. 4q+3) then own couts cq(q) = {0, 8, 4, 12}
+  // + 0..3, i.e. lanes l and l + 32 hold the two halves of ONE 16-byte granule (8 channels) of the same pixel: one
+  // v_permlane32_swap pair turns two 8-byte stores / residual loads per lane into one 16-byte one.
+  const int wrow = lane & 15, wsrc = (lane & 48) | ((wrow & 3) | ((wrow & 4) << 1) | ((wrow & 8) >> 1));
+  const int cq = ((lane >> 4) & 1) * 8 + (lane >> 5) * 4;  // first cout (inside the sub-tile) of the lane's four
+  int wlane[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; nt++) wlane[nt] = (min(ns0 + nt, a.NS_total - 1) * 128 + wsrc) * 16;
+  auto wfrag = [&](int blk, int nt, int p) -> u32x4 {
+    return __builtin_amdgcn_raw_buffer_load_b128(wr, wlane[nt] + p * 1024, blk * blk_bytes, 0);
+  };
+  const float w_unscale = *a.w_unscale;
+  const float bound_a = a.out_f32 ? 0.f : a.bound[0], bound_b = a.out_f32 ? 0.f : a.bound[1];
+  const int Ho = a.Hout << a.up, Wo = a.Wout << a.up, rep = 1 << a.up;
+  const int C8o = a.Cout >> 3;
+  const int64_t oplane = (int64_t)C8o * Ho * Wo * 8;  // halves per plane of one image
+
+  f32x4 acc[MS][NT];
+  constexpr int SB = 0;  // sched_barrier mask: nothing crosses.  Left to itself the compiler sinks every weight load and
+                         // LDS fragment read next to its first use (buffer_load; s_waitcnt vmcnt(1); v_mfma).
+  constexpr int STEPS = G * TAPS;
+  u32x4 B[2][RS ? 3 : 1][NT][2];  // weight fragments [parity][row tap (RS)][cout sub-tile][plane]
+  // RS: a "column" = the three row taps of column tap kx; else a "step" = one (chunk of the stage, tap) block
+  auto wload = [&](int par, int stg, int u) {
+    if constexpr (RS) {
+#pragma unroll
+      for (int ky = 0; ky < 3; ky++)
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+          for (int p = 0; p < 2; p++) B[par][ky][nt][p] = wfrag((ky * 3 + u) * nchunks + stg, nt, p);
+    } else {
+      const int blk = (u % TAPS) * nchunks + min(stg * G + u / TAPS, nchunks - 1);
+#pragma unroll
+      for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+        for (int p = 0; p < 2; p++) B[par][0][nt][p] = wfrag(blk, nt, p);
+    }
+  };
+  auto toff_of = [&](int step) {
+    const int g = step / TAPS, tap = step % TAPS;
+    const int ky = tap / KS, kx = tap % KS;
+    return g * chunk_b + (S == 1 ? ky * PW + kx : ((kx & 1) * PH + ky) * PWh + (kx >> 1)) * 16;
+  };
+
+  // One stage's MFMAs from LDS buffer `buf`; `pre` != 0: request the first weight blocks of stage `nst_next` at the end.
+  auto mfma_stage = [&](int buf, int st, bool pre, int st_next) {
+    if constexpr (RS) {
+      const char* xs = smem + buf * buf_bytes + xb[0];
+      constexpr int Q = 3 * (MS + 2);  // (column tap kx, patch row pr) steps
+      u32x4 Xf[2][2];
+      Xf[0][0] = *reinterpret_cast<const u32x4*>(xs);
+      Xf[0][1] = *reinterpret_cast<const u32x4*>(xs + plane_b);
+#pragma unroll
+      for (int q = 0; q < Q; q++) {
+        const int kx = q / (MS + 2), pr = q % (MS + 2);
+        if (pr == 0) {  // request the next column's weights (kx = 2: the first column of the next stage, into parity 1)
+          if (kx < 2) wload((kx + 1) & 1, st, kx + 1);
+          else if (pre) wload(1, st_next, 0);
+        }
+        if (q + 1 < Q) {
+          const int kx1 = (q + 1) / (MS + 2), pr1 = (q + 1) % (MS + 2);
+          const char* ap = xs + (pr1 * PW + kx1) * 16;
+          Xf[(q + 1) & 1][0] = *reinterpret_cast<const u32x4*>(ap);
+          Xf[(q + 1) & 1][1] = *reinterpret_cast<const u32x4*>(ap + plane_b);
+        }
+        __builtin_amdgcn_sched_barrier(SB);
+        const u32x4 xh = Xf[q & 1][0], xl = Xf[q & 1][1];
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++) {
+#pragma unroll
+          for (int t3 = 0; t3 < 3; t3++) {  // small products first, interleaved over the accumulators the fragment feeds
+#pragma unroll
+            for (int ky = 0; ky < 3; ky++) {
+              const int ms = pr - ky;
+              if (ms < 0 || ms >= MS) continue;
+              const u32x4* wv = B[kx & 1][ky][nt];
+              acc[ms][nt] = t3 == 0 ? p2_mfma(wv[1], xh, acc[ms][nt]) : t3 == 1 ? p2_mfma(wv[0], xl, acc[ms][nt]) : p2_mfma(wv[0], xh, acc[ms][nt]);
+            }
+          }
+        }
+        __builtin_amdgcn_sched_barrier(SB);
+      }
+      if (pre) {  // the next stage starts on parity 0
+#pragma unroll
+        for (int ky = 0; ky < 3; ky++)
+#pragma unroll
+          for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+            for (int p = 0; p < 2; p++) B[0][ky][nt][p] = B[1][ky][nt][p];
+      }
+    } else {
+      const char* xs = smem + buf * buf_bytes;
+      constexpr int Q = STEPS * MS;
+      u32x4 Xf[2][2];
+      Xf[0][0] = *reinterpret_cast<const u32x4*>(xs + xb[0] + toff_of(0));
+      Xf[0][1] = *reinterpret_cast<const u32x4*>(xs + xb[0] + toff_of(0) + plane_b);
+#pragma unroll
+      for (int q = 0; q < Q; q++) {
+        const int step = q / MS, ms = q % MS;
+        if (ms == 0) {
+          if (step + 1 < STEPS) wload((step + 1) & 1, st, step + 1);
+          else if (pre) wload(STEPS & 1, st_next, 0);
+        }
+        if (q + 1 < Q) {
+          const int s1 = (q + 1) / MS, m1 = (q + 1) % MS;
+          const char* ap = xs + xb[m1] + toff_of(s1);
+          Xf[(q + 1) & 1][0] = *reinterpret_cast<const u32x4*>(ap);
+          Xf[(q + 1) & 1][1] = *reinterpret_cast<const u32x4*>(ap + plane_b);
+        }
+        __builtin_amdgcn_sched_barrier(SB);
+        if (G == 1 || st * G + step / TAPS < nchunks) {  // (chunk count not a multiple of G: the tail stage is short)
+          const u32x4 xh = Xf[q & 1][0], xl = Xf[q & 1][1];
+#pragma unroll
+          for (int nt = 0; nt < NT; nt++) {
+            f32x4 c = acc[ms][nt];
+            c = p2_mfma(B[step & 1][0][nt][1], xh, c);
+            c = p2_mfma(B[step & 1][0][nt][0], xl, c);
+            acc[ms][nt] = p2_mfma(B[step & 1][0][nt][0], xh, c);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(SB);
+      }
+      if (pre && (STEPS & 1)) {  // an odd number of steps: the next stage's first block sits in parity 1
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+          for (int p = 0; p < 2; p++) B[0][0][nt][p] = B[1][0][nt][p];
+      }
+    }
+  };
+
+  // ---- prologue: first tile's first stage --------------------------------------------------------------------------
+  decode(tile, tn, toy, tox);
+  plan(tn, toy, tox);
+  P2_MARK(0);
+  load_stage(0);
+  if (tid == 0) wgred[0] = wgred[1] = 0u;
+  if (wave_active) wload(0, 0, 0);
+  store_stage(0);
+  __syncthreads();
+  P2_MARK(1);
+  P2_T0;
+  int buf = 0;
+
+  for (;;) {  // tiles
+#pragma unroll
+    for (int ms = 0; ms < MS; ms++)
+#pragma unroll
+      for (int nt = 0; nt < NT; nt++) acc[ms][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int st = 0; st + 1 < nst; st++) {  // all but the tile's last stage
+      load_stage(st + 1);
+      if (wave_active) mfma_stage(buf, st, true, st + 1);
+      P2_ACC(0);
+      store_stage(buf ^ 1);
+      __syncthreads();
+      P2_ACC(1);
+      buf ^= 1;
+    }
+    // ---- the tile's last stage: next tile's first stage and the epilogue's operands are requested before its MFMAs ----
+    const int n = tn, oy0 = toy, ox0 = tox;
+    const int next_tile = tile + wgx;
+    const bool have_next = next_tile < tile_end;
+    if (have_next) {
+      decode(next_tile, tn, toy, tox);
+      plan(tn, toy, tox);
+      load_stage(0);
+    }
+    P2_ACC(2);
+    P2RowRegs row_in, row_r1, row_r2;
+    f32x4 sc[NT], sh[NT];
+    // residual granules: lanes < 32 request the h-plane granule of (pixel, 8-channel block), lanes >= 32 the l-plane one
+    u32x4 R1[MS][NT];
+    const _Float16* r1img = a.res1 ? a.res1 + (int64_t)n * 2 * oplane : nullptr;
+    const _Float16* r2img = a.res2 ? a.res2 + (int64_t)n * 2 * oplane : nullptr;
+    const bool pre_res = a.up == 0 && !a.out_f32;
+    const int64_t hl = lane >= 32 ? oplane : 0;  // the plane this lane loads / stores whole granules of
+    // granule of (sub-tile nt, pixel sub-tile ms) this lane addresses: halves offset inside the image's plane 0, or -1
+    auto gran = [&](int nt, int ms) -> int64_t {
+      const int c0 = (ns0 + nt) * 16 + cq;
+      const int p = (wm * MS + ms) * 16 + (lane & 15);
+      const int ty = RS ? wm * MS + ms : p >> TW_LOG2, tx = RS ? (lane & 15) : p & (TW - 1);
+      const int y = oy0 + ty, x = ox0 + tx;
+      return (y < a.Hout && x < a.Wout && c0 < a.Cout) ? (((int64_t)(c0 >> 3) * Ho + y) * Wo + x) * 8 : -1;
+    };
+    if (wave_active) {
+      p2_row_request(a.in_row, n, row_in);
+      if (a.res1) p2_row_request(a.res1_row, n, row_r1);
+      if (a.res2) p2_row_request(a.res2_row, n, row_r2);
+#pragma unroll
+      for (int nt = 0; nt < NT; nt++) {
+        const int c0 = (ns0 + nt) * 16 + cq;
+        if (c0 + 3 < a.Cout) {
+          sc[nt] = *reinterpret_cast<const f32x4*>(a.scale + c0);
+          sh[nt] = *reinterpret_cast<const f32x4*>(a.shift + c0);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            sc[nt][j] = c0 + j < a.Cout ? a.scale[c0 + j] : 0.f;
+            sh[nt][j] = c0 + j < a.Cout ? a.shift[c0 + j] : 0.f;
+          }
+        }
+        if (pre_res && r1img) {
+#pragma unroll
+          for (int ms = 0; ms < MS; ms++) {
+            const int64_t o = gran(nt, ms);
+            R1[ms][nt] = *reinterpret_cast<const u32x4*>(r1img + hl + (o < 0 ? 0 : o));
+          }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(SB);
+      mfma_stage(buf, nst - 1, have_next, 0);
+    }
+    P2_ACC(3);
+
+    // ---- epilogue in registers: lane = (pixel lane & 15 of the sub-tile, couts cq .. cq + 3 of the sub-tile) -------------
+    float amax = 0.f;
+    if (wave_active) {
+      const float in_inv = __uint_as_float(row_in.inv);
+      float r1_inv = 0.f, r2_inv = 0.f, out_mul = 1.f, out_inv = 1.f;
+      if (!a.out_f32) {
+        float bound = bound_a * p2_row_amax(row_in) + bound_b;
+        if (a.res1) {
+          bound += p2_row_amax(row_r1);
+          r1_inv = __uint_as_float(row_r1.inv);
+        }
+        if (a.res2) {
+          bound += p2_row_amax(row_r2);
+          r2_inv = __uint_as_float(row_r2.inv);
+        }
+        p2_scale_of(bound, out_mul, out_inv);
+        if (oy0 == 0 && ox0 == 0 && blockIdx.y == 0 && tid == 0)
+          a.out_row[(int64_t)n * MVAL_AMAX_ROW + P2_INV_SLOT] = __float_as_uint(out_inv);
+      }
+      const float unscale = in_inv * w_unscale;
+      _Float16* oimg = a.out + (int64_t)n * 2 * oplane;
+      u32x4 R2[MS][NT];  // a second residual (fuse layers) is requested here: its registers are the weight fragments'
+      if (pre_res && r2img) {
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+          for (int ms = 0; ms < MS; ms++) {
+            const int64_t o = gran(nt, ms);
+            R2[ms][nt] = *reinterpret_cast<const u32x4*>(r2img + hl + (o < 0 ? 0 : o));
+          }
+      }
+      // residual granule as loaded (lanes < 32: [h of couts 0..3 | h of couts 4..7], lanes >= 32: [l 0..3 | l 4..7]) ->
+      // this lane's four values: after the swap every lane has h in .xy and l in .zw
+      auto res_of = [&](u32x4 g, float inv) -> f32x4 {
+        const auto s0 = __builtin_amdgcn_permlane32_swap(g.x, g.z, false, false);
+        const auto s1 = __builtin_amdgcn_permlane32_swap(g.y, g.w, false, false);
+        const u32x2 h = {s0[0], s1[0]}, l = {s0[1], s1[1]};
+        return p2_join(__builtin_bit_cast(f16x4, h), __builtin_bit_cast(f16x4, l)) * inv;
+      };
+      // four finished values -> scaled, split, the halves exchanged with the partner lane, ONE 16-byte store
+      auto put = [&](f32x4 r, int64_t o) {
+        if (a.relu) {
+          r.x = fmaxf(r.x, 0.f); r.y = fmaxf(r.y, 0.f); r.z = fmaxf(r.z, 0.f); r.w = fmaxf(r.w, 0.f);
+        }
+        amax = conv_amax4(amax, r.x, r.y, r.z, r.w);
+        f16x4 h, l;
+        p2_split(r * out_mul, h, l);
+        const u32x2 hu = __builtin_bit_cast(u32x2, h), lu = __builtin_bit_cast(u32x2, l);
+        // lanes < 32 end with [own h | partner's h], lanes >= 32 with [partner's l | own l]
+        const auto s0 = __builtin_amdgcn_permlane32_swap(hu.x, lu.x, false, false);
+        const auto s1 = __builtin_amdgcn_permlane32_swap(hu.y, lu.y, false, false);
+        if (o >= 0) *reinterpret_cast<u32x4*>(oimg + hl + o) = (u32x4){s0[0], s1[0], s0[1], s1[1]};
+      };
+#pragma unroll
+      for (int nt = 0; nt < NT; nt++) {
+        const int c0 = (ns0 + nt) * 16 + cq;
+        const f32x4 scu = sc[nt] * unscale;
+#pragma unroll
+        for (int ms = 0; ms < MS; ms++) {
+          const f32x4 v = acc[ms][nt] * scu + sh[nt];
+          const int64_t o = gran(nt, ms);  // (all lanes take part in the lane exchanges; -1: nothing to store)
+          if (a.out_f32) {  // the heat-map layer: fp32 NCHW, no residuals, no upsample
+            const int p = (wm * MS + ms) * 16 + (lane & 15);
+            const int ty = RS ? wm * MS + ms : p >> TW_LOG2, tx = RS ? (lane & 15) : p & (TW - 1);
+            const int y = oy0 + ty, x = ox0 + tx;
+            if (y < a.Hout && x < a.Wout) {
+#pragma unroll
+              for (int j = 0; j < 4; j++)
+                if (c0 + j < a.Cout) a.out_f32[(((int64_t)n * a.Cout + c0 + j) * Ho + y) * Wo + x] = a.relu ? fmaxf(v[j], 0.f) : v[j];
+            }
+            continue;
+          }
+          if (pre_res) {
+            f32x4 r = v;
+            if (r1img) r += res_of(R1[ms][nt], r1_inv);
+            if (r2img) r += res_of(R2[ms][nt], r2_inv);
+            put(r, o);
+            continue;
+          }
+          // fused nearest upsample: 2^up x 2^up replicas, each with its own residuals (uniform loop: every lane runs it)
+          const int p = (wm * MS + ms) * 16 + (lane & 15);
+          const int ty = RS ? wm * MS + ms : p >> TW_LOG2, tx = RS ? (lane & 15) : p & (TW - 1);
+          const int y = oy0 + ty, x = ox0 + tx;
+          for (int dy = 0; dy < rep; dy++)
+            for (int dx = 0; dx < rep; dx++) {
+              const int Y = (y << a.up) + dy, Xc = (x << a.up) + dx;
+              const int64_t oo = o < 0 ? -1 : (((int64_t)(c0 >> 3) * Ho + Y) * Wo + Xc) * 8;
+              f32x4 r = v;
+              if (r1img) r += res_of(*reinterpret_cast<const u32x4*>(r1img + hl + (oo < 0 ? 0 : oo)), r1_inv);
+              if (r2img) r += res_of(*reinterpret_cast<const u32x4*>(r2img + hl + (oo < 0 ? 0 : oo)), r2_inv);
+              put(r, oo);
+            }
+        }
+      }
+    }
+    if (!a.out_f32) {
+      // the workgroup's max |x| without a barrier: LDS atomics, the wave that arrives last publishes and re-arms
+      const unsigned amax_bits = p2_wave_umax(__float_as_uint(amax));
+      if (lane == 0) {
+        atomicMax(&wgred[0], amax_bits);
+        __threadfence_block();
+        if (atomicAdd(&wgred[1], 1u) == (unsigned)(WN * WM - 1)) {
+          const unsigned m = atomicExch(&wgred[0], 0u);
+          wgred[1] = 0u;
+          const int timg = (oy0 / TH) * a.tiles_x + ox0 / TW;
+          p2_slot_put(a.out_row + (int64_t)n * MVAL_AMAX_ROW, timg * (int)gridDim.y + (int)blockIdx.y, tiles_img * (int)gridDim.y, m);
+        }
+      }
+    }
+    P2_ACC(4);
+    if (!have_next) break;
+    store_stage(buf ^ 1);
+    __syncthreads();
+    P2_ACC(5);
+    buf ^= 1;
+    tile = next_tile;
+  }
+  P2_FLUSH;
+  P2_MARK(4);
+}
+
+static thread_local int g_p2_dry = 0;
+
+template <int KS, int S, int G, int WN, int WM, int NT, int MS, int TW, bool RS = false>
+static int launch_p2(P2Args a, hipStream_t s) {
+  constexpr int TH = 16 * MS * WM / TW;
+  constexpr int PH = (TH - 1) * S + KS, PW = (TW - 1) * S + KS, PWh = (PW + 1) / 2;
+  constexpr int slots = S == 1 ? PH * PW : 2 * PH * PWh;
+  constexpr int PPX = (slots + 15) & ~15;
+  constexpr size_t smem = (size_t)2 * 8 * G * PPX * 16 + 16;
+  static_assert(smem <= 160 * 1024, "LDS");
+  constexpr int NTH = 64 * WN * WM;
+  a.th = TH; a.tw = TW;
+  a.tiles_x = (a.Wout + TW - 1) / TW;
+  a.tiles_y = (a.Hout + TH - 1) / TH;
+  const unsigned groups = (unsigned)((a.NS_total + WN * NT - 1) / (WN * NT));
+  a.amax_tiles = a.tiles_x * a.tiles_y;
+  a.tiles_total = a.amax_tiles * a.N;
+  if (g_p2_dry) return 0;
+#ifdef P2_STAMP
+  a.dbg = g_p2_dbg;
+#endif
+  // persistent workgroups: as many as stay resident (LDS- and register-limited), a multiple of 8 per cout group so
+  // that every XCD walks its own contiguous tile range; fewer tiles than that: one tile each
+  int per_cu = (int)((160 * 1024) / smem);
+  constexpr int reg_waves = 2;  // (amdgpu_waves_per_eu of the kernel)
+  if (per_cu > reg_waves * 4 / (WN * WM)) per_cu = reg_waves * 4 / (WN * WM);
+  if (per_cu < 1) per_cu = 1;
+  const char* pe = getenv("MVAL_P2_WGS");  // measurement override: workgroups per CU
+  if (pe && atoi(pe) > 0) per_cu = atoi(pe);
+  int wgs = (256 * per_cu / (int)groups) & ~7;
+  if (wgs < 8) wgs = 8;
+  if (wgs >= a.tiles_total) wgs = a.tiles_total;
+  else {  // equal shares: the XCD groups' ranges are walked in steps of wgs / 8
+    const int per = (a.tiles_total + 7) / 8, rounds = (per + wgs / 8 - 1) / (wgs / 8);
+    wgs = 8 * ((per + rounds - 1) / rounds);
+  }
+  a.wgs_x = wgs;
+  dim3 grid((unsigned)wgs, groups);
+  if (!a.out_f32 && (int64_t)a.amax_tiles * groups > P2_SLOTS)
+    mval_launch_zero_rows(a.out_row, (int64_t)a.N * MVAL_AMAX_ROW, s);  // (the kernel rewrites the scale slots)
+  static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_p2_kernel<KS, S, G, WN, WM, NT, MS, TW, RS>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  (void)once;
+  hipLaunchKernelGGL((conv_p2_kernel<KS, S, G, WN, WM, NT, MS, TW, RS>), grid, dim3(NTH), smem, s, a);
+  return 0;
+}
+
+// MVAL_P2_TILE: measurement override of the tile choice (tools/p2_sweep.py): "ms,nt,g" (0 = default)
+static void p2_override(int& ms, int& nt, int& g) {
+  const char* e = getenv("MVAL_P2_TILE");
+  if (e) (void)sscanf(e, "%d,%d,%d", &ms, &nt, &g);
+}
+
+int mval_launch_conv_p2(const P2Args& a0, hipStream_t s) {
+  P2Args a = a0;
+  a.NS_total = (a.Cout + 15) / 16;
+  if ((a.Cin & 7) || (!a.out_f32 && (a.Cout & 7))) return 1;
+  if (a.out_f32 && (a.up || a.res1 || a.res2)) return 1;
+  if ((int64_t)a.N * a.Hin * a.Win * a.Cin >= (int64_t)1 << 30) return 1;  // 32-bit byte offsets into the planes
+  if ((int64_t)a.N * (a.Hout << a.up) * (a.Wout << a.up) * a.Cout >= (int64_t)1 << 30) return 1;
+  int oms = 0, ont = 0, og = 0;
+  p2_override(oms, ont, og);
+  const int64_t px = (int64_t)a.N * a.Hout * a.Wout;
+  if (a.k == 3 && a.stride == 1) {
+    if (a.Wout >= 16 && a.Hout >= 4) {
+      if (a.NS_total <= 2) return launch_p2<3, 1, 1, 2, 2, 1, 4, 16, true>(a, s);  // 32 couts: 2 x 2 waves, 4 rows each
+      const int64_t wgs8 = ((px + 127) / 128) * ((a.NS_total + 3) / 4);
+      const int ms = oms ? oms : (wgs8 >= 512 && a.Hout >= 8 ? 8 : 4);
+      if (ms == 8) return launch_p2<3, 1, 1, 4, 1, 1, 8, 16, true>(a, s);
+      if (ont == 2) return launch_p2<3, 1, 1, 4, 1, 2, 4, 16, true>(a, s);
+      return launch_p2<3, 1, 1, 4, 1, 1, 4, 16, true>(a, s);
+    }
+    if (a.Wout >= 8 && a.Hout >= 8) {
+      if (a.NS_total <= 2) return launch_p2<3, 1, 1, 2, 2, 1, 2, 8>(a, s);
+      if (ont == 2) return launch_p2<3, 1, 1, 4, 1, 2, 4, 8>(a, s);
+      return launch_p2<3, 1, 1, 4, 1, 1, 4, 8>(a, s);
+    }
+    return 1;
+  }
+  if (a.k == 3 && a.stride == 2) {
+    if (a.Wout < 8 || a.Hout < 4) return 1;
+    const int ms = oms ? oms : 2;
+    if (a.NS_total <= 2) return launch_p2<3, 2, 1, 2, 2, 1, 1, 8>(a, s);
+    if (ms == 4) return launch_p2<3, 2, 1, 4, 1, 1, 4, 8>(a, s);
+    return launch_p2<3, 2, 1, 4, 1, 1, 2, 8>(a, s);
+  }
+  if (a.k == 1 && a.stride == 1) {
+    if (a.Wout < 8 || a.Hout * a.Wout < 64) return 1;
+    const int g = og ? og : 2;
+    const int ms = oms ? oms : 4;
+    const int nt = ont ? ont : ((a.NS_total % 8 == 0 && ((px + 63) / 64) * (a.NS_total / 8) >= 1024) ? 2 : 1);
+#define P2_1X1(TW_)                                                                                              \
+  do {                                                                                                           \
+    if (a.NS_total <= 2) return g == 1 ? launch_p2<1, 1, 1, 2, 2, 1, 2, TW_>(a, s) : launch_p2<1, 1, 2, 2, 2, 1, 2, TW_>(a, s); \
+    if (ms == 8 && a.Hout * a.Wout >= 128)                                                                       \
+      return nt == 2 ? launch_p2<1, 1, 2, 4, 1, 2, 8, TW_>(a, s) : launch_p2<1, 1, 2, 4, 1, 1, 8, TW_>(a, s);     \
+    if (nt == 2) return g == 4 ? launch_p2<1, 1, 4, 4, 1, 2, 4, TW_>(a, s) : launch_p2<1, 1, 2, 4, 1, 2, 4, TW_>(a, s); \
+    return g == 4 ? launch_p2<1, 1, 4, 4, 1, 1, 4, TW_>(a, s) : g == 1 ? launch_p2<1, 1, 1, 4, 1, 1, 4, TW_>(a, s) : launch_p2<1, 1, 2, 4, 1, 1, 4, TW_>(a, s); \
+  } while (0)
+    if (a.Wout >= 64) P2_1X1(64);
+    if (a.Wout >= 32) P2_1X1(32);
+    if (a.Wout >= 16) P2_1X1(16);
+    P2_1X1(8);
+#undef P2_1X1
+  }
+  return 1;
+}
+
+int mval_conv_p2_supported(int k, int stride, int cin, int cout, int hin, int win, int up, int out_nchw, int n) {
+  P2Args a = {};
+  a.k = k; a.stride = stride;
+  a.Cin = cin; a.Cout = cout; a.Hin = hin; a.Win = win; a.N = n;
+  const int pad = k / 2;
+  a.Hout = (hin + 2 * pad - k) / stride + 1;
+  a.Wout = (win + 2 * pad - k) / stride + 1;
+  a.up = up;
+  a.out_f32 = out_nchw ? reinterpret_cast<float*>(1) : nullptr;
+  g_p2_dry = 1;
+  const int rc = mval_launch_conv_p2(a, nullptr);
+  g_p2_dry = 0;
+  return rc == 0;
+}
+
+// ---- format conversion (network boundaries, tests) -----------------------------------------------------------------
+// fp32 NHWC [n][H][W][C] with its max |x| rows (kept by the producer) -> P2 planes; the image's exact maximum is known
+// here, so the scale puts IT in [2^13, 2^14).  One thread per (pixel, 8-channel block).
+__global__ __launch_bounds__(256) void nhwc_to_p2_kernel(const float* __restrict__ x, _Float16* __restrict__ out, const unsigned* rows_in,
+                                                       unsigned* rows_out, int HW, int C8) {
+  const int n = blockIdx.y;
+  const unsigned amax = conv_amax_read(rows_in + (int64_t)n * MVAL_AMAX_ROW);
+  float mul, inv;
+  p2_scale_of(__uint_as_float(amax), mul, inv);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    unsigned* row = rows_out + (int64_t)n * MVAL_AMAX_ROW;
+    row[0] = amax;  // (the other partial slots stay zero)
+    row[P2_INV_SLOT] = __float_as_uint(inv);
+  }
+  const int64_t total = (int64_t)HW * C8;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c8 = (int)(i / HW), p = (int)(i - (int64_t)c8 * HW);  // pixel-fastest: 16-byte stores coalesce
+    const float* src = x + ((int64_t)n * HW + p) * (C8 * 8) + c8 * 8;
+    const f32x4 v0 = *reinterpret_cast<const f32x4*>(src), v1 = *reinterpret_cast<const f32x4*>(src + 4);
+    f16x4 h0, l0, h1, l1;
+    p2_split(v0 * mul, h0, l0);
+    p2_split(v1 * mul, h1, l1);
+    _Float16* d = out + (((int64_t)n * 2 * C8 + c8) * HW + p) * 8;
+    *reinterpret_cast<f16x8*>(d) = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+    *reinterpret_cast<f16x8*>(d + (int64_t)C8 * HW * 8) = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+  }
+}
+
+__global__ __launch_bounds__(256) void p2_to_nhwc_kernel(const _Float16* __restrict__ x, const unsigned* rows, float* __restrict__ out,
+                                                       int HW, int C8) {
+  const int n = blockIdx.y;
+  const float inv = __uint_as_float(rows[(int64_t)n * MVAL_AMAX_ROW + P2_INV_SLOT]);
+  const int64_t total = (int64_t)HW * C8;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c8 = (int)(i / HW), p = (int)(i - (int64_t)c8 * HW);
+    const _Float16* s = x + (((int64_t)n * 2 * C8 + c8) * HW + p) * 8;
+    const f16x8 h = *reinterpret_cast<const f16x8*>(s), l = *reinterpret_cast<const f16x8*>(s + (int64_t)C8 * HW * 8);
+    float* d = out + ((int64_t)n * HW + p) * (C8 * 8) + c8 * 8;
+#pragma unroll
+    for (int j = 0; j < 8; j++) d[j] = ((float)h[j] + (float)l[j]) * inv;
+  }
+}
+
+extern "C" int mval_nhwc_to_p2(const float* x, const uint32_t* rows_in, void* planes, uint32_t* rows, int n_images, int H, int W, int C,
+                               void* stream) {
+  MVAL_REQUIRE(x && planes && rows && rows_in && n_images > 0 && H > 0 && W > 0 && C > 0 && (C & 7) == 0, "mval_nhwc_to_p2: bad arguments");
+  int64_t blocks = ((int64_t)H * W * (C / 8) + 255) / 256;
+  if (blocks > 256) blocks = 256;
+  hipLaunchKernelGGL(nhwc_to_p2_kernel, dim3((unsigned)blocks, (unsigned)n_images), dim3(256), 0, mval_stream(stream), x,
+                     reinterpret_cast<_Float16*>(planes), rows_in, rows, H * W, C / 8);
+  MVAL_CHECK_LAUNCH("mval_nhwc_to_p2");
+  return 0;
+}
+
+extern "C" int mval_p2_to_nhwc(const void* planes, const uint32_t* rows, float* out, int n_images, int H, int W, int C, void* stream) {
+  MVAL_REQUIRE(out && planes && rows && n_images > 0 && H > 0 && W > 0 && C > 0 && (C & 7) == 0, "mval_p2_to_nhwc: bad arguments");
+  int64_t blocks = ((int64_t)H * W * (C / 8) + 255) / 256;
+  if (blocks > 256) blocks = 256;
+  hipLaunchKernelGGL(p2_to_nhwc_kernel, dim3((unsigned)blocks, (unsigned)n_images), dim3(256), 0, mval_stream(stream),
+                     reinterpret_cast<const _Float16*>(planes), rows, out, H * W, C / 8);
+  MVAL_CHECK_LAUNCH("mval_p2_to_nhwc");
+  return 0;
+}

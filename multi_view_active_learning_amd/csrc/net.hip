@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "conv_common.h"
+#include "conv_p2.h"
 
 // ---- weight packing ---------------------------------------------------------------------
 extern "C" size_t mval_packed_weight_floats(int pack, int cout, int cin, int k) {
@@ -340,6 +341,9 @@ extern "C" int mval_op_algo_supported(const mval_op* op, int n_images, int algo)
            !op->up && !op->in_nchw && !op->out_nchw && op->hin == op->hout && op->win == op->wout &&
            mval_conv_block_supported(op->cin, n_images, op->hin, op->win);
   if (algo == MVAL_ALGO_MFMA) return mval_op_mfma_supported(op, n_images);
+  if (algo == MVAL_ALGO_MFMA_P2)
+    return op && op->kind == MVAL_OP_CONV && n_images > 0 && !op->in_nchw && op->pad == op->k / 2 &&
+           mval_conv_p2_supported(op->k, op->stride, op->cin, op->cout, op->hin, op->win, op->up, op->out_nchw, n_images);
   if ((algo != MVAL_ALGO_MFMA_BF3 && algo != MVAL_ALGO_MFMA_H2) || !op || n_images <= 0) return 0;
   if (op->kind != MVAL_OP_CONV && op->kind != MVAL_OP_DECONV) return 0;
   ConvArgs a = {};
@@ -380,6 +384,37 @@ extern "C" int mval_op_launch(const mval_op* op, int n_images, float* workspace,
                                     n_images, op->hin, op->win, s);
     MVAL_REQUIRE(rc == 0, "mval_op_launch: no fused BasicBlock kernel for c%d %dx%d", op->cin, op->hin, op->win);
     MVAL_CHECK_LAUNCH("mval_op_launch/block");
+    return 0;
+  }
+  if (op->algo == MVAL_ALGO_MFMA_P2) {
+    MVAL_REQUIRE(op->kind == MVAL_OP_CONV && a.w && a.scale && a.shift && op->in_amax_off > 0 && op->in_off >= 0 &&
+                     (op->out_nchw || (op->out_amax_off > 0 && op->bound_off >= 0)) &&
+                     (op->res1_off < 0 || op->res1_amax_off > 0) && (op->res2_off < 0 || op->res2_amax_off > 0),
+                 "mval_op_launch: malformed MVAL_ALGO_MFMA_P2 op");
+    P2Args p = {};
+    p.in = reinterpret_cast<const _Float16*>(a.in);
+    p.w = a.w;
+    p.w_unscale = a.w + mval_packed_weight_floats(MVAL_PACK_MFMA16_H2, op->cout, op->cin, op->k) - 4;
+    p.scale = a.scale; p.shift = a.shift;
+    p.bound = op->bound_off >= 0 ? params + op->bound_off : nullptr;
+    p.res1 = reinterpret_cast<const _Float16*>(a.res1);
+    p.res2 = reinterpret_cast<const _Float16*>(a.res2);
+    p.in_row = reinterpret_cast<const unsigned*>(workspace + op->in_amax_off);
+    p.res1_row = a.res1 ? reinterpret_cast<const unsigned*>(workspace + op->res1_amax_off) : nullptr;
+    p.res2_row = a.res2 ? reinterpret_cast<const unsigned*>(workspace + op->res2_amax_off) : nullptr;
+    if (op->out_nchw) {
+      p.out_f32 = a.out;
+    } else {
+      p.out = reinterpret_cast<_Float16*>(a.out);
+      p.out_row = reinterpret_cast<unsigned*>(workspace + op->out_amax_off);
+    }
+    p.N = n_images; p.Hin = op->hin; p.Win = op->win; p.Cin = op->cin;
+    p.Hout = op->hout; p.Wout = op->wout; p.Cout = op->cout;
+    p.k = op->k; p.stride = op->stride; p.up = op->up; p.relu = op->relu;
+    int rc = mval_launch_conv_p2(p, s);
+    MVAL_REQUIRE(rc == 0, "mval_op_launch: no P2 kernel for conv k%d s%d cin%d cout%d %dx%d", op->k, op->stride, op->cin,
+                 op->cout, op->hin, op->win);
+    MVAL_CHECK_LAUNCH("mval_op_launch/p2");
     return 0;
   }
   const bool split = op->algo == MVAL_ALGO_MFMA_BF3 || op->algo == MVAL_ALGO_MFMA_H2;

@@ -26,10 +26,11 @@ from . import _lib
 from .pose_estimators import params as _params
 
 OP_CONV, OP_MAXPOOL, OP_DECONV, OP_BLOCK = 0, 1, 2, 3
-ALGO_DIRECT, ALGO_MFMA, ALGO_MFMA_BF3, ALGO_MFMA_H2 = 0, 1, 2, 3
+ALGO_DIRECT, ALGO_MFMA, ALGO_MFMA_BF3, ALGO_MFMA_H2, ALGO_MFMA_P2 = 0, 1, 2, 3, 4
 PACK_HWIO, PACK_MFMA16, PACK_MFMA16_BF3, PACK_MFMA16_H2 = 0, 1, 2, 3
 AMAX_ROW = 4096
-_PACK_OF = {ALGO_DIRECT: PACK_HWIO, ALGO_MFMA: PACK_MFMA16, ALGO_MFMA_BF3: PACK_MFMA16_BF3, ALGO_MFMA_H2: PACK_MFMA16_H2}
+_PACK_OF = {ALGO_DIRECT: PACK_HWIO, ALGO_MFMA: PACK_MFMA16, ALGO_MFMA_BF3: PACK_MFMA16_BF3, ALGO_MFMA_H2: PACK_MFMA16_H2,
+            ALGO_MFMA_P2: PACK_MFMA16_H2}
 
 
 class MvalOp(C.Structure):
@@ -46,6 +47,7 @@ class MvalOp(C.Structure):
         ("phase", C.c_int32), ("lane", C.c_int32),
         ("in_amax_off", C.c_int64), ("out_amax_off", C.c_int64),
         ("w2_off", C.c_int64), ("scale2_off", C.c_int64), ("shift2_off", C.c_int64),
+        ("bound_off", C.c_int64), ("bound2_off", C.c_int64), ("res1_amax_off", C.c_int64), ("res2_amax_off", C.c_int64),
     ]
 
 

@@ -169,3 +169,116 @@ def conv_dgrad(dz, weight, in_hw, stride=1, algo=ALGO_MFMA, accumulate_into=None
                             C.c_int(algo), _lib._stream()),
         "mval_conv_dgrad")
     return dx
+
+
+def p2_bound(weight, scale, shift):
+    """[A, B] of csrc/conv_p2.h: |bn(conv(x))| <= A * max|x| + B with A = max_c |scale_c| * sum |w_c|, B = max_c |shift_c|
+    (one float32 rounding of slack each: the kernel's scale leaves a factor 2)."""
+    a = (weight.detach().abs().double().sum(dim=(1, 2, 3)) * scale.detach().abs().double()).max() * (1.0 + 1e-6)
+    b = shift.detach().abs().double().max()
+    return torch.stack([a, b]).to(torch.float32)
+
+
+def to_p2(x_nhwc):
+    """fp32 NHWC -> (P2 planes as a float32-typed buffer of the same element count, rows (n, AMAX_ROW) int32)."""
+    lib = _lib.lib()
+    n, h, w, c = x_nhwc.shape
+    x = x_nhwc.contiguous()
+    rows_in = torch.zeros(n * AMAX_ROW, dtype=torch.int32, device=x.device)
+    rows = torch.zeros(n * AMAX_ROW, dtype=torch.int32, device=x.device)
+    planes = torch.empty(x.numel(), dtype=torch.float32, device=x.device)
+    _lib._check(lib.mval_amax(_lib._p(x), C.c_int64(h * w * c), C.c_int(n), _lib._p(rows_in), _lib._stream()), "mval_amax")
+    _lib._check(lib.mval_nhwc_to_p2(_lib._p(x), _lib._p(rows_in), _lib._p(planes), _lib._p(rows), C.c_int(n), C.c_int(h), C.c_int(w),
+                                    C.c_int(c), _lib._stream()), "mval_nhwc_to_p2")
+    return planes, rows
+
+
+def from_p2(planes, rows, n, h, w, c):
+    out = torch.empty((n, h, w, c), dtype=torch.float32, device=planes.device)
+    _lib._check(_lib.lib().mval_p2_to_nhwc(_lib._p(planes), _lib._p(rows), _lib._p(out), C.c_int(n), C.c_int(h), C.c_int(w),
+                                           C.c_int(c), _lib._stream()), "mval_p2_to_nhwc")
+    return out
+
+
+class P2Conv:
+    """One MVAL_ALGO_MFMA_P2 conv set up once (arena, packed weights, converted inputs) and launched many times:
+    layer-wise tests and tools/p2_sweep.py.  x / res1 / res2 are fp32 NHWC (converted to P2 here); result() converts
+    the output planes back (or returns the fp32 NCHW heat-maps when out_nchw)."""
+
+    def __init__(self, x, weight, scale, shift, stride=1, relu=False, res1=None, res2=None, up=0, out_nchw=False):
+        dev = x.device
+        lib = _lib.lib()
+        cout, cin, k, _ = weight.shape
+        n, hin, win, _ = x.shape
+        pad = k // 2
+        hout, wout = (hin + 2 * pad - k) // stride + 1, (win + 2 * pad - k) // stride + 1
+        ho, wo = hout << up, wout << up
+        self.shape = (n, ho, wo, cout)
+        self.out_nchw = out_nchw
+        parts = [to_p2(x)] + [to_p2(t) for t in (res1, res2) if t is not None]
+        offs, top = [], 0
+        for pl, _ in parts:
+            offs.append(top)
+            top += _align(pl.numel())
+        out_off = top
+        top += _align(n * ho * wo * cout)
+        row_off = top
+        nrows = len(parts) + 1
+        self.arena = torch.zeros(top + _align(nrows * n * AMAX_ROW), dtype=torch.float32, device=dev)
+        for i, (pl, rows) in enumerate(parts):
+            self.arena[offs[i] : offs[i] + pl.numel()] = pl
+            self.arena[row_off + i * n * AMAX_ROW : row_off + (i + 1) * n * AMAX_ROW] = rows.view(torch.float32)
+        pw = pack_weights(weight, ALGO_MFMA_H2)
+        s_off = _align(pw.numel())
+        b_off = s_off + _align(cout)
+        bd_off = b_off + _align(cout)
+        self.params = torch.zeros(bd_off + 64, dtype=torch.float32, device=dev)
+        self.params[: pw.numel()] = pw
+        self.params[s_off : s_off + cout] = scale
+        self.params[b_off : b_off + cout] = shift
+        self.params[bd_off : bd_off + 2] = p2_bound(weight, scale, shift).to(dev)
+        m = MvalOp()
+        m.kind, m.algo = OP_CONV, 4
+        m.k, m.stride, m.pad, m.cin, m.cout = k, stride, pad, cin, cout
+        m.hin, m.win, m.hout, m.wout = hin, win, hout, wout
+        m.up, m.relu, m.in_nchw, m.out_nchw = up, int(relu), 0, int(out_nchw)
+        m.in_off, m.out_off = 0, out_off
+        m.in_amax_off = row_off
+        it = iter(range(1, len(parts)))
+        m.res1_off = m.res2_off = -1
+        if res1 is not None:
+            i = next(it)
+            m.res1_off, m.res1_amax_off = offs[i], row_off + i * n * AMAX_ROW
+        if res2 is not None:
+            i = next(it)
+            m.res2_off, m.res2_amax_off = offs[i], row_off + i * n * AMAX_ROW
+        m.out_amax_off = row_off + len(parts) * n * AMAX_ROW
+        m.w_off, m.scale_off, m.shift_off, m.bound_off = 0, s_off, b_off, bd_off
+        self.op, self.out_off, self.n = m, out_off, n
+        if not lib.mval_op_algo_supported(C.byref(m), C.c_int(n), C.c_int(4)):
+            raise _lib.MvalError("no P2 kernel for this geometry")
+
+    def launch(self):
+        _lib._check(_lib.lib().mval_op_launch(C.byref(self.op), C.c_int(self.n), _lib._p(self.arena), _lib._p(self.params),
+                                              C.c_void_p(0), C.c_void_p(0), _lib._stream()), "mval_op_launch")
+
+    def out_rows(self):
+        n = self.n
+        return self.arena[self.op.out_amax_off : self.op.out_amax_off + n * AMAX_ROW].view(torch.int32).reshape(n, AMAX_ROW)
+
+    def result(self):
+        n, ho, wo, cout = self.shape
+        out = self.arena[self.out_off : self.out_off + n * ho * wo * cout]
+        if self.out_nchw:
+            return out.reshape(n, cout, ho, wo).clone()
+        return from_p2(out, self.out_rows().reshape(-1), n, ho, wo, cout)
+
+    def kept_amax(self):
+        return self.out_rows()[:, :256].amax(1).view(torch.float32)  # (non-negative floats order like their bits)
+
+
+def fused_conv_p2(x, weight, scale, shift, **kw):
+    c = P2Conv(x, weight, scale, shift, **kw)
+    c.launch()
+    fused_conv_p2.last = c
+    return c.result()
