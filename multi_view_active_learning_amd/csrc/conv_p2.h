@@ -110,6 +110,7 @@ struct P2Args {
   int th, tw, tiles_x, tiles_y;
   int NS_total;
   int amax_tiles;
+  unsigned tiles_img_magic, tiles_x_magic;  // 2^32 / d + 1: tile index -> (image, tile row) without a divide
   int tiles_total, wgs_x;  // persistent tile walk: tiles_x * tiles_y * N tiles over wgs_x workgroups per cout group
   unsigned long long* dbg;  // diagnostic builds (-DP2_STAMP): per-wave phase time stamps; nullptr otherwise
 };

@@ -21,6 +21,8 @@
 //     stream per MFMA of the NHWC kernels: that stream was as busy as the matrix pipe).
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "conv_p2.h"
 
 typedef p2_f32x4 f32x4;
@@ -109,10 +111,10 @@ __global__ __launch_bounds__(64 * WN * WM) __attribute__((amdgpu_waves_per_eu(2,
   if (tile >= tile_end) return;
   const int tiles_img = a.tiles_x * a.tiles_y;
   int tn, toy, tox;  // the tile being computed: image, first output row / column
-  auto decode = [&](int t, int& n, int& oy0, int& ox0) {
-    n = t / tiles_img;
+  auto decode = [&](int t, int& n, int& oy0, int& ox0) {  // (t / d as a multiply: magic = 2^32 / d + 1, t * d < 2^32)
+    n = a.tiles_img_magic ? (int)__umulhi((unsigned)t, a.tiles_img_magic) : t;
     const int r = t - n * tiles_img;
-    const int tyi = r / a.tiles_x;
+    const int tyi = a.tiles_x_magic ? (int)__umulhi((unsigned)r, a.tiles_x_magic) : r;
     oy0 = tyi * TH;
     ox0 = (r - tyi * a.tiles_x) * TW;
   };
@@ -195,6 +197,15 @@ __global__ __launch_bounds__(64 * WN * WM) __attribute__((amdgpu_waves_per_eu(2,
     return __builtin_amdgcn_raw_buffer_load_b128(wr, wlane[nt] + p * 1024, blk * blk_bytes, 0);
   };
   const float w_unscale = *a.w_unscale;
+  // output / residual planes through buffer descriptors: per tile ONE per-lane 32-bit byte offset (+ a scalar offset per
+  // pixel sub-tile); lanes outside the image or past Cout get offset 2^31 and the range check drops them -- the
+  // epilogue has no branches and no 64-bit address arithmetic (the tensors are below 2^31 bytes: the launcher checks)
+  const unsigned obytes = a.out_f32 ? 0u : (unsigned)((int64_t)a.N * (a.Cout >> 3) * (a.Hout << a.up) * (a.Wout << a.up) * 32);
+  const __amdgpu_buffer_rsrc_t orr = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, obytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r1r = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(a.res1), 0, a.res1 ? obytes : 0u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r2r = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(a.res2), 0, a.res2 ? obytes : 0u, 0x00020000);
+  // lane -> (row, column) inside a 16-pixel sub-tile, and the sub-tile's own (row, column) inside the tile
+  const int ly = TW == 8 ? (lane >> 3) & 1 : 0, lx = TW == 8 ? lane & 7 : lane & 15;
   const float bound_a = a.out_f32 ? 0.f : a.bound[0], bound_b = a.out_f32 ? 0.f : a.bound[1];
   const int Ho = a.Hout << a.up, Wo = a.Wout << a.up, rep = 1 << a.up;
   const int C8o = a.Cout >> 3;
@@ -356,18 +367,22 @@ __global__ __launch_bounds__(64 * WN * WM) __attribute__((amdgpu_waves_per_eu(2,
     f32x4 sc[NT], sh[NT];
     // residual granules: lanes < 32 request the h-plane granule of (pixel, 8-channel block), lanes >= 32 the l-plane one
     u32x4 R1[MS][NT];
-    const _Float16* r1img = a.res1 ? a.res1 + (int64_t)n * 2 * oplane : nullptr;
-    const _Float16* r2img = a.res2 ? a.res2 + (int64_t)n * 2 * oplane : nullptr;
     const bool pre_res = a.up == 0 && !a.out_f32;
-    const int64_t hl = lane >= 32 ? oplane : 0;  // the plane this lane loads / stores whole granules of
-    // granule of (sub-tile nt, pixel sub-tile ms) this lane addresses: halves offset inside the image's plane 0, or -1
-    auto gran = [&](int nt, int ms) -> int64_t {
+    const unsigned plane_bytes = (unsigned)(oplane * 2);
+    const int yl = oy0 + ly, xl = ox0 + lx;
+    unsigned vb[NT];  // byte offset of the lane's granule of sub-tile row 0 / column 0 (its plane: h for lanes < 32)
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++) {
       const int c0 = (ns0 + nt) * 16 + cq;
-      const int p = (wm * MS + ms) * 16 + (lane & 15);
-      const int ty = RS ? wm * MS + ms : p >> TW_LOG2, tx = RS ? (lane & 15) : p & (TW - 1);
-      const int y = oy0 + ty, x = ox0 + tx;
-      return (y < a.Hout && x < a.Wout && c0 < a.Cout) ? (((int64_t)(c0 >> 3) * Ho + y) * Wo + x) * 8 : -1;
-    };
+      vb[nt] = (xl < a.Wout && c0 < a.Cout) ? (unsigned)n * 2u * plane_bytes + (lane >= 32 ? plane_bytes : 0u) +
+                                                  (unsigned)(((c0 >> 3) * Ho + yl) * Wo + xl) * 16u
+                                            : 0x80000000u;
+    }
+    // pixel sub-tile ms of the wave: its first row / column inside the tile (uniform)
+    auto sub_ty = [&](int ms) { return TW == 8 ? 2 * (wm * MS + ms) : ((wm * MS + ms) * 16) >> TW_LOG2; };
+    auto sub_tx = [&](int ms) { return TW == 8 ? 0 : ((wm * MS + ms) * 16) & (TW - 1); };
+    auto voff = [&](int nt, int ms) -> unsigned { return yl + sub_ty(ms) < a.Hout ? vb[nt] : 0x80000000u; };
+    auto soff = [&](int ms) -> int { return (sub_ty(ms) * Wo + sub_tx(ms)) * 16; };
     if (wave_active) {
       p2_row_request(a.in_row, n, row_in);
       if (a.res1) p2_row_request(a.res1_row, n, row_r1);
@@ -385,13 +400,12 @@ __global__ __launch_bounds__(64 * WN * WM) __attribute__((amdgpu_waves_per_eu(2,
             sh[nt][j] = c0 + j < a.Cout ? a.shift[c0 + j] : 0.f;
           }
         }
-        if (pre_res && r1img) {
+      }
+      if (pre_res && a.res1) {
 #pragma unroll
-          for (int ms = 0; ms < MS; ms++) {
-            const int64_t o = gran(nt, ms);
-            R1[ms][nt] = *reinterpret_cast<const u32x4*>(r1img + hl + (o < 0 ? 0 : o));
-          }
-        }
+        for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+          for (int ms = 0; ms < MS; ms++) R1[ms][nt] = __builtin_amdgcn_raw_buffer_load_b128(r1r, voff(nt, ms), soff(ms), 0);
       }
       __builtin_amdgcn_sched_barrier(SB);
       mfma_stage(buf, nst - 1, have_next, 0);
@@ -418,16 +432,12 @@ __global__ __launch_bounds__(64 * WN * WM) __attribute__((amdgpu_waves_per_eu(2,
           a.out_row[(int64_t)n * MVAL_AMAX_ROW + P2_INV_SLOT] = __float_as_uint(out_inv);
       }
       const float unscale = in_inv * w_unscale;
-      _Float16* oimg = a.out + (int64_t)n * 2 * oplane;
       u32x4 R2[MS][NT];  // a second residual (fuse layers) is requested here: its registers are the weight fragments'
-      if (pre_res && r2img) {
+      if (pre_res && a.res2) {
 #pragma unroll
         for (int nt = 0; nt < NT; nt++)
 #pragma unroll
-          for (int ms = 0; ms < MS; ms++) {
-            const int64_t o = gran(nt, ms);
-            R2[ms][nt] = *reinterpret_cast<const u32x4*>(r2img + hl + (o < 0 ? 0 : o));
-          }
+          for (int ms = 0; ms < MS; ms++) R2[ms][nt] = __builtin_amdgcn_raw_buffer_load_b128(r2r, voff(nt, ms), soff(ms), 0);
       }
       // residual granule as loaded (lanes < 32: [h of couts 0..3 | h of couts 4..7], lanes >= 32: [l 0..3 | l 4..7]) ->
       // this lane's four values: after the swap every lane has h in .xy and l in .zw
@@ -438,10 +448,9 @@ __global__ __launch_bounds__(64 * WN * WM) __attribute__((amdgpu_waves_per_eu(2,
         return p2_join(__builtin_bit_cast(f16x4, h), __builtin_bit_cast(f16x4, l)) * inv;
       };
       // four finished values -> scaled, split, the halves exchanged with the partner lane, ONE 16-byte store
-      auto put = [&](f32x4 r, int64_t o) {
-        if (a.relu) {
-          r.x = fmaxf(r.x, 0.f); r.y = fmaxf(r.y, 0.f); r.z = fmaxf(r.z, 0.f); r.w = fmaxf(r.w, 0.f);
-        }
+      const float floor_ = a.relu ? 0.f : -INFINITY;  // (ReLU without a branch)
+      auto put = [&](f32x4 r, unsigned vo, int so) {
+        r.x = fmaxf(r.x, floor_); r.y = fmaxf(r.y, floor_); r.z = fmaxf(r.z, floor_); r.w = fmaxf(r.w, floor_);
         amax = conv_amax4(amax, r.x, r.y, r.z, r.w);
         f16x4 h, l;
         p2_split(r * out_mul, h, l);
@@ -449,47 +458,74 @@ __global__ __launch_bounds__(64 * WN * WM) __attribute__((amdgpu_waves_per_eu(2,
         // lanes < 32 end with [own h | partner's h], lanes >= 32 with [partner's l | own l]
         const auto s0 = __builtin_amdgcn_permlane32_swap(hu.x, lu.x, false, false);
         const auto s1 = __builtin_amdgcn_permlane32_swap(hu.y, lu.y, false, false);
-        if (o >= 0) *reinterpret_cast<u32x4*>(oimg + hl + o) = (u32x4){s0[0], s1[0], s0[1], s1[1]};
+        // The sub-tile offset goes into the VECTOR offset, not soffset.  Measured on gfx950 (ROCm 7.2): after
+        //     buffer_store_dwordx4 v[a:a+3], v, s[..], sN offen        (soffset in an SGPR)
+        // a VALU write of v[a:a+1] in the very next instruction reaches memory in lanes 12-15 / 28-31 / ... of dword 1:
+        // the store is still reading its data.  hipcc pads that hazard (s_nop 1) only when soffset is NOT a register.
+        __builtin_amdgcn_raw_buffer_store_b128((u32x4){s0[0], s1[0], s0[1], s1[1]}, orr, vo == 0x80000000u ? vo : vo + (unsigned)so, 0, 0);
+        asm volatile("s_nop 1");
       };
+      f32x4 scu[NT];
 #pragma unroll
-      for (int nt = 0; nt < NT; nt++) {
-        const int c0 = (ns0 + nt) * 16 + cq;
-        const f32x4 scu = sc[nt] * unscale;
+      for (int nt = 0; nt < NT; nt++) scu[nt] = sc[nt] * unscale;
+      // the residual / output-form cases are separate copies of the loop: tested per granule inside ONE unrolled loop
+      // they were a dozen scalar branches per granule
+      auto plain = [&](auto has_r1, auto has_r2) {
 #pragma unroll
-        for (int ms = 0; ms < MS; ms++) {
-          const f32x4 v = acc[ms][nt] * scu + sh[nt];
-          const int64_t o = gran(nt, ms);  // (all lanes take part in the lane exchanges; -1: nothing to store)
-          if (a.out_f32) {  // the heat-map layer: fp32 NCHW, no residuals, no upsample
-            const int p = (wm * MS + ms) * 16 + (lane & 15);
-            const int ty = RS ? wm * MS + ms : p >> TW_LOG2, tx = RS ? (lane & 15) : p & (TW - 1);
-            const int y = oy0 + ty, x = ox0 + tx;
+        for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+          for (int ms = 0; ms < MS; ms++) {
+            f32x4 r = acc[ms][nt] * scu[nt] + sh[nt];
+            if constexpr (decltype(has_r1)::value) r += res_of(R1[ms][nt], r1_inv);
+            if constexpr (decltype(has_r2)::value) r += res_of(R2[ms][nt], r2_inv);
+            put(r, voff(nt, ms), soff(ms));
+#ifndef P2_NO_EPI_SB
+            __builtin_amdgcn_sched_barrier(SB);  // one granule at a time: interleaving them all costs ~60 registers
+#endif
+          }
+      };
+      using T_ = std::true_type;
+      using F_ = std::false_type;
+      if (a.out_f32) {  // the heat-map layer: fp32 NCHW, no residuals, no upsample
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++) {
+          const int c0 = (ns0 + nt) * 16 + cq;
+#pragma unroll
+          for (int ms = 0; ms < MS; ms++) {
+            const f32x4 v = acc[ms][nt] * scu[nt] + sh[nt];
+            const int y = yl + sub_ty(ms), x = xl + sub_tx(ms);
             if (y < a.Hout && x < a.Wout) {
 #pragma unroll
               for (int j = 0; j < 4; j++)
-                if (c0 + j < a.Cout) a.out_f32[(((int64_t)n * a.Cout + c0 + j) * Ho + y) * Wo + x] = a.relu ? fmaxf(v[j], 0.f) : v[j];
+                if (c0 + j < a.Cout) a.out_f32[(((int64_t)n * a.Cout + c0 + j) * Ho + y) * Wo + x] = fmaxf(v[j], floor_);
             }
-            continue;
           }
-          if (pre_res) {
-            f32x4 r = v;
-            if (r1img) r += res_of(R1[ms][nt], r1_inv);
-            if (r2img) r += res_of(R2[ms][nt], r2_inv);
-            put(r, o);
-            continue;
+        }
+      } else if (pre_res) {
+        if (a.res1 && a.res2) plain(T_{}, T_{});
+        else if (a.res1) plain(T_{}, F_{});
+        else plain(F_{}, F_{});
+      } else {
+        // fused nearest upsample: 2^up x 2^up replicas, each with its own residuals (uniform loops: every lane runs them)
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++) {
+          const int c0 = (ns0 + nt) * 16 + cq;
+#pragma unroll
+          for (int ms = 0; ms < MS; ms++) {
+            const f32x4 v = acc[ms][nt] * scu[nt] + sh[nt];
+            const int y = yl + sub_ty(ms), x = xl + sub_tx(ms);
+            const bool ok = y < a.Hout && x < a.Wout && c0 < a.Cout;
+            const unsigned vo0 = (unsigned)n * 2u * plane_bytes + (lane >= 32 ? plane_bytes : 0u) +
+                                 (unsigned)(((c0 >> 3) * Ho + (y << a.up)) * Wo + (x << a.up)) * 16u;
+            for (int dy = 0; dy < rep; dy++)
+              for (int dx = 0; dx < rep; dx++) {
+                const unsigned vo = ok ? vo0 + (unsigned)(dy * Wo + dx) * 16u : 0x80000000u;
+                f32x4 r = v;
+                if (a.res1) r += res_of(__builtin_amdgcn_raw_buffer_load_b128(r1r, vo, 0, 0), r1_inv);
+                if (a.res2) r += res_of(__builtin_amdgcn_raw_buffer_load_b128(r2r, vo, 0, 0), r2_inv);
+                put(r, vo, 0);
+              }
           }
-          // fused nearest upsample: 2^up x 2^up replicas, each with its own residuals (uniform loop: every lane runs it)
-          const int p = (wm * MS + ms) * 16 + (lane & 15);
-          const int ty = RS ? wm * MS + ms : p >> TW_LOG2, tx = RS ? (lane & 15) : p & (TW - 1);
-          const int y = oy0 + ty, x = ox0 + tx;
-          for (int dy = 0; dy < rep; dy++)
-            for (int dx = 0; dx < rep; dx++) {
-              const int Y = (y << a.up) + dy, Xc = (x << a.up) + dx;
-              const int64_t oo = o < 0 ? -1 : (((int64_t)(c0 >> 3) * Ho + Y) * Wo + Xc) * 8;
-              f32x4 r = v;
-              if (r1img) r += res_of(*reinterpret_cast<const u32x4*>(r1img + hl + (oo < 0 ? 0 : oo)), r1_inv);
-              if (r2img) r += res_of(*reinterpret_cast<const u32x4*>(r2img + hl + (oo < 0 ? 0 : oo)), r2_inv);
-              put(r, oo);
-            }
         }
       }
     }
@@ -497,8 +533,11 @@ __global__ __launch_bounds__(64 * WN * WM) __attribute__((amdgpu_waves_per_eu(2,
       // the workgroup's max |x| without a barrier: LDS atomics, the wave that arrives last publishes and re-arms
       const unsigned amax_bits = p2_wave_umax(__float_as_uint(amax));
       if (lane == 0) {
-        atomicMax(&wgred[0], amax_bits);
+#ifdef P2_FENCE
         __threadfence_block();
+#endif
+        atomicMax(&wgred[0], amax_bits);  // (a wave's LDS operations execute in order: no fence -- a fence here also
+                                          // waits for every store and prefetch in flight, 2 us per tile)
         if (atomicAdd(&wgred[1], 1u) == (unsigned)(WN * WM - 1)) {
           const unsigned m = atomicExch(&wgred[0], 0u);
           wgred[1] = 0u;
@@ -536,6 +575,8 @@ static int launch_p2(P2Args a, hipStream_t s) {
   const unsigned groups = (unsigned)((a.NS_total + WN * NT - 1) / (WN * NT));
   a.amax_tiles = a.tiles_x * a.tiles_y;
   a.tiles_total = a.amax_tiles * a.N;
+  a.tiles_img_magic = a.amax_tiles > 1 ? (unsigned)(((uint64_t)1 << 32) / (unsigned)a.amax_tiles + 1) : 0u;  // (0: divide by one)
+  a.tiles_x_magic = a.tiles_x > 1 ? (unsigned)(((uint64_t)1 << 32) / (unsigned)a.tiles_x + 1) : 0u;
   if (g_p2_dry) return 0;
 #ifdef P2_STAMP
   a.dbg = g_p2_dbg;
@@ -577,8 +618,8 @@ int mval_launch_conv_p2(const P2Args& a0, hipStream_t s) {
   a.NS_total = (a.Cout + 15) / 16;
   if ((a.Cin & 7) || (!a.out_f32 && (a.Cout & 7))) return 1;
   if (a.out_f32 && (a.up || a.res1 || a.res2)) return 1;
-  if ((int64_t)a.N * a.Hin * a.Win * a.Cin >= (int64_t)1 << 30) return 1;  // 32-bit byte offsets into the planes
-  if ((int64_t)a.N * (a.Hout << a.up) * (a.Wout << a.up) * a.Cout >= (int64_t)1 << 30) return 1;
+  if ((int64_t)a.N * a.Hin * a.Win * a.Cin >= (int64_t)1 << 29) return 1;  // byte offsets into the planes below 2^31
+  if ((int64_t)a.N * (a.Hout << a.up) * (a.Wout << a.up) * a.Cout >= (int64_t)1 << 29) return 1;
   int oms = 0, ont = 0, og = 0;
   p2_override(oms, ont, og);
   const int64_t px = (int64_t)a.N * a.Hout * a.Wout;
