@@ -47,7 +47,7 @@ import torch.distributed as dist  # noqa: E402
 PEAK_FP32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, dense fp32-input MFMA
 PEAK_HBM_GBPS = 8000.0  # same guide: HBM3E
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # same guide: dense bf16 / fp16 MFMA (the 5 PF headline includes 2:1 sparsity)
-SPLIT_PRODUCTS = {"h2": 3, "bf3": 6}  # MFMA products per algorithmic product of the 16-bit splits
+SPLIT_PRODUCTS = {"p2": 3, "h2": 3, "bf3": 6}  # MFMA products per algorithmic product of the 16-bit splits
 PARITY_UNPINNED = ["soft_argmax (kornia absent)", "MPE peak_local_max (skimage absent)", "BSB peak_local_max (skimage absent)"]
 FLOP_PER_IMAGE = {"hrnet_w32_256": 20.387e9}  # conv FLOPs (2*MAC) per frame x view
 
@@ -345,7 +345,7 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     from multi_view_active_learning_amd import _lib, synth
-    from multi_view_active_learning_amd.engine import ALGO_MFMA, ALGO_MFMA_BF3, ALGO_MFMA_H2, _conv_mode, _plan_for
+    from multi_view_active_learning_amd.engine import ALGO_MFMA, ALGO_MFMA_BF3, ALGO_MFMA_H2, ALGO_MFMA_P2, _conv_mode, _plan_for
     from multi_view_active_learning_amd.utils.triangulation import triangulate_batch
 
     _lib.lib()  # fail loudly if the HIP extension is missing
@@ -504,26 +504,27 @@ def main():
                         launches_per_step=n, avg_launch_us=round(t / n * 1e6, 2), bytes_per_step=b,
                         seconds_in_kernel_per_step=round(t, 6))
 
-        conv = np.asarray([o.kind != 1 for o in plan.ops])
+        conv = np.asarray([o.kind not in (1, 4) for o in plan.ops])  # (not max-pool, not the fp32 -> P2 format change)
         f32 = np.asarray([o.algo == ALGO_MFMA for o in plan.ops]) & conv
         k3 = np.asarray([o.k == 3 for o in plan.ops])
         s1 = np.asarray([o.stride == 1 for o in plan.ops])
         stem = np.asarray([o.kind == 0 and o.in_nchw == 1 for o in plan.ops])
         fams = []
         split_any = np.zeros(len(plan.ops), dtype=bool)
-        for algo, pl, what in ((ALGO_MFMA_H2, "h2", "fp32 values as scaled 2-way fp16 splits, 3 x v_mfma_f32_16x16x32_f16 per 32-deep step"),
+        for algo, pl, what in ((ALGO_MFMA_P2, "p2", "activations kept as fp16 (h, l) plane pairs in HBM, 3 x v_mfma_f32_16x16x32_f16 per 32-deep step"),
+                               (ALGO_MFMA_H2, "h2", "fp32 values as scaled 2-way fp16 splits, 3 x v_mfma_f32_16x16x32_f16 per 32-deep step"),
                                (ALGO_MFMA_BF3, "bf3", "fp32 values as exact 3-way bf16 splits, 6 x v_mfma_f32_16x16x32_bf16 per 32-deep step")):
             m_ = np.asarray([o.algo == algo for o in plan.ops]) & conv
             split_any |= m_
             peak = PEAK_BF16_MFMA_TFLOPS / SPLIT_PRODUCTS[pl]
             note = f"dense 16-bit MFMA peak 2500 TFLOP/s / {SPLIT_PRODUCTS[pl]} MFMA products per algorithmic product"
             fams += [
-                family(m_ & k3 & s1, f"conv_split_kernel<{2 if pl == 'h2' else 3}, 3, 1, ...>"
+                family(m_ & k3 & s1, ("conv_p2_kernel<3, 1, ...>" if pl == "p2" else f"conv_split_kernel<{2 if pl == 'h2' else 3}, 3, 1, ...>")
                                      + (" + conv_block_kernel<C> (whole BasicBlocks: two 3x3 convs, BNs, residual, ReLUs in one launch)"
                                         if any(o.kind == 3 for o in plan.ops) and pl == "h2" else "")
                                      + f" (fused 3x3 stride-1 conv+BN+residual+ReLU; {what}, fp32 accumulate)", peak, note),
-                family(m_ & k3 & ~s1, f"conv_split_kernel<{2 if pl == 'h2' else 3}, 3, 2, ...> (same, stride 2)", peak, note),
-                hbm_family(m_ & ~k3, f"conv_split_kernel<{2 if pl == 'h2' else 3}, 1, 1, ...> (fused 1x1 conv+BN+residual+ReLU(+upsample): "
+                family(m_ & k3 & ~s1, ("conv_p2_kernel<3, 2, ...>" if pl == "p2" else f"conv_split_kernel<{2 if pl == 'h2' else 3}, 3, 2, ...>") + " (same, stride 2)", peak, note),
+                hbm_family(m_ & ~k3, ("conv_p2_kernel<1, 1, ...>" if pl == "p2" else f"conv_split_kernel<{2 if pl == 'h2' else 3}, 1, 1, ...>") + " (fused 1x1 conv+BN+residual+ReLU(+upsample): "
                                      "channel GEMMs of the bottleneck blocks and fuse up-paths; 2x2 parity convs of transposed convs)"),
             ]
         fams += [
@@ -579,7 +580,9 @@ def main():
             "vs_baseline": None,
             "dtype": {"fp32": "f32", "bf3": "f32 (convs: fp32 values as exact 3-way bf16 splits on the bf16 MFMA, fp32 accumulate)",
                       "h2": "f32 (convs: fp32 values as scaled 2-way fp16 splits on the fp16 MFMA, fp32 accumulate; "
-                            "measured at the exact-fp32 MFMA chain's error)"}[_conv_mode()],
+                            "measured at the exact-fp32 MFMA chain's error)",
+                      "p2": "f32 (activations held as scaled fp16 (h, l) pairs = 22-bit significands, weights likewise; convs: 3 fp16 MFMA "
+                            "products per fp32 product, lo x lo dropped, fp32 accumulate; measured below the exact-fp32 MFMA chain's error)"}[_conv_mode()],
             "data": "synthetic (random variance-preserving weights, N(0,1) frames, ring cameras)",
             "config": ({"workload": wl["desc"].replace("256-frame pool", f"{wl['pool']}-frame pool")
                                    + ("" if wl.get("picks") else f"; one step = one pass over a {wl['pool']}-frame pool sharded over the ranks"),

@@ -180,7 +180,7 @@ int mval_kcenter_select(const double* feat, int64_t n_obs, int D, const int64_t*
  * floats from the workspace base; -1 = absent.  Weights are in the packed fragment order
  * written by mval_pack_conv_weights; scale/shift are the folded eval-mode BatchNorm
  * (y = x * scale + shift, torch's batch_norm inference formula) or (1, bias). */
-enum { MVAL_OP_CONV = 0, MVAL_OP_MAXPOOL = 1, MVAL_OP_DECONV = 2, MVAL_OP_BLOCK = 3 };
+enum { MVAL_OP_CONV = 0, MVAL_OP_MAXPOOL = 1, MVAL_OP_DECONV = 2, MVAL_OP_BLOCK = 3, MVAL_OP_TO_P2 = 4 };
 enum { MVAL_ALGO_DIRECT = 0, MVAL_ALGO_MFMA = 1, MVAL_ALGO_MFMA_BF3 = 2, MVAL_ALGO_MFMA_H2 = 3, MVAL_ALGO_MFMA_P2 = 4 };
 enum { MVAL_PACK_HWIO = 0, MVAL_PACK_MFMA16 = 1, MVAL_PACK_MFMA16_BF3 = 2, MVAL_PACK_MFMA16_H2 = 3 };
 
@@ -219,6 +219,9 @@ typedef struct mval_op {
    * [A = max_c |scale_c| * sum |w_c|, B = max_c |shift_c|], the output's magnitude bound (bound2_off: conv2 of a
    * MVAL_OP_BLOCK).  Weights are packed MVAL_PACK_MFMA16_H2. */
   int64_t bound_off, bound2_off, res1_amax_off, res2_amax_off;
+  /* MVAL_OP_TO_P2: format change at the head of a P2 plan -- the fp32 NHWC tensor at in_off ([n][hin][win][cin], its
+   * rows [count, partials ...] at in_amax_off, as every NHWC producer keeps them) becomes P2 planes at out_off with
+   * their rows at out_amax_off. */
 } mval_op;
 
 /* Weight packing.  MVAL_PACK_HWIO: [k*k][cin][cout] (direct kernels, deconv);

@@ -116,4 +116,13 @@ struct P2Args {
 };
 
 int mval_launch_conv_p2(const P2Args& a, hipStream_t s);  // conv_p2.hip; 1 = unsupported (dry != 0: no launch)
+int mval_launch_nhwc_to_p2(const float* x, const unsigned* rows_in, _Float16* planes, unsigned* rows, int n_images, int HW, int C,
+                            hipStream_t s);
 int mval_conv_p2_supported(int k, int stride, int cin, int cout, int hin, int win, int up, int out_nchw, int n);
+
+// conv_block_p2.hip: a whole BasicBlock over P2 activations in one launch; 1 = unsupported
+int mval_conv_block_p2_supported(int C, int N, int H, int W);
+int mval_launch_conv_block_p2(int C, const void* in, void* out, const float* w1, const float* w1_unscale, const float* scale1,
+                              const float* shift1, const float* bound1, const float* w2, const float* w2_unscale, const float* scale2,
+                              const float* shift2, const float* bound2, const unsigned* in_row, unsigned* out_row, int N, int H, int W,
+                              hipStream_t s);

@@ -25,6 +25,10 @@
 
 #include "conv_p2.h"
 
+#ifndef P2_VALU_PRIO
+#define P2_VALU_PRIO 2
+#endif
+
 typedef p2_f32x4 f32x4;
 typedef p2_f16x8 f16x8;
 typedef p2_f16x4 f16x4;
@@ -52,7 +56,8 @@ typedef p2_u32x2 u32x2;
         a.dbg[(((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (NTH / 64) + wave) * 16 + 8 + k_] = p2_acc[k_];         \
   } while (0)
 static unsigned long long* g_p2_dbg = nullptr;
-extern "C" void mval_p2_debug_buffer(void* p) { g_p2_dbg = reinterpret_cast<unsigned long long*>(p); }
+unsigned long long* g_p2_dbg_shared = nullptr;
+extern "C" void mval_p2_debug_buffer(void* p) { g_p2_dbg = g_p2_dbg_shared = reinterpret_cast<unsigned long long*>(p); }
 #else
 #define P2_MARK(k)
 #define P2_T0
@@ -374,14 +379,13 @@ __global__ __launch_bounds__(64 * WN * WM) __attribute__((amdgpu_waves_per_eu(2,
 #pragma unroll
     for (int nt = 0; nt < NT; nt++) {
       const int c0 = (ns0 + nt) * 16 + cq;
-      vb[nt] = (xl < a.Wout && c0 < a.Cout) ? (unsigned)n * 2u * plane_bytes + (lane >= 32 ? plane_bytes : 0u) +
-                                                  (unsigned)(((c0 >> 3) * Ho + yl) * Wo + xl) * 16u
-                                            : 0x80000000u;
+      vb[nt] = c0 < a.Cout ? (unsigned)n * 2u * plane_bytes + (lane >= 32 ? plane_bytes : 0u) + (unsigned)(((c0 >> 3) * Ho + yl) * Wo + xl) * 16u
+                           : 0x80000000u;
     }
     // pixel sub-tile ms of the wave: its first row / column inside the tile (uniform)
     auto sub_ty = [&](int ms) { return TW == 8 ? 2 * (wm * MS + ms) : ((wm * MS + ms) * 16) >> TW_LOG2; };
     auto sub_tx = [&](int ms) { return TW == 8 ? 0 : ((wm * MS + ms) * 16) & (TW - 1); };
-    auto voff = [&](int nt, int ms) -> unsigned { return yl + sub_ty(ms) < a.Hout ? vb[nt] : 0x80000000u; };
+    auto voff = [&](int nt, int ms) -> unsigned { return (yl + sub_ty(ms) < a.Hout && xl + sub_tx(ms) < a.Wout) ? vb[nt] : 0x80000000u; };
     auto soff = [&](int ms) -> int { return (sub_ty(ms) * Wo + sub_tx(ms)) * 16; };
     if (wave_active) {
       p2_row_request(a.in_row, n, row_in);
@@ -413,6 +417,7 @@ __global__ __launch_bounds__(64 * WN * WM) __attribute__((amdgpu_waves_per_eu(2,
     P2_ACC(3);
 
     // ---- epilogue in registers: lane = (pixel lane & 15 of the sub-tile, couts cq .. cq + 3 of the sub-tile) -------------
+    __builtin_amdgcn_s_setprio(P2_VALU_PRIO);  // the vector phase wins issue arbitration against the partner wave's MFMA stream
     float amax = 0.f;
     if (wave_active) {
       const float in_inv = __uint_as_float(row_in.inv);
@@ -546,6 +551,7 @@ __global__ __launch_bounds__(64 * WN * WM) __attribute__((amdgpu_waves_per_eu(2,
         }
       }
     }
+    __builtin_amdgcn_s_setprio(0);
     P2_ACC(4);
     if (!have_next) break;
     store_stage(buf ^ 1);
@@ -726,13 +732,18 @@ __global__ __launch_bounds__(256) void p2_to_nhwc_kernel(const _Float16* __restr
   }
 }
 
+int mval_launch_nhwc_to_p2(const float* x, const unsigned* rows_in, _Float16* planes, unsigned* rows, int n_images, int HW, int C,
+                            hipStream_t s) {
+  int64_t blocks = ((int64_t)HW * (C / 8) + 255) / 256;
+  if (blocks > 64) blocks = 64;
+  hipLaunchKernelGGL(nhwc_to_p2_kernel, dim3((unsigned)blocks, (unsigned)n_images), dim3(256), 0, s, x, planes, rows_in, rows, HW, C / 8);
+  return 0;
+}
+
 extern "C" int mval_nhwc_to_p2(const float* x, const uint32_t* rows_in, void* planes, uint32_t* rows, int n_images, int H, int W, int C,
                                void* stream) {
   MVAL_REQUIRE(x && planes && rows && rows_in && n_images > 0 && H > 0 && W > 0 && C > 0 && (C & 7) == 0, "mval_nhwc_to_p2: bad arguments");
-  int64_t blocks = ((int64_t)H * W * (C / 8) + 255) / 256;
-  if (blocks > 256) blocks = 256;
-  hipLaunchKernelGGL(nhwc_to_p2_kernel, dim3((unsigned)blocks, (unsigned)n_images), dim3(256), 0, mval_stream(stream), x,
-                     reinterpret_cast<_Float16*>(planes), rows_in, rows, H * W, C / 8);
+  mval_launch_nhwc_to_p2(x, rows_in, reinterpret_cast<_Float16*>(planes), rows, n_images, H * W, C, mval_stream(stream));
   MVAL_CHECK_LAUNCH("mval_nhwc_to_p2");
   return 0;
 }

@@ -336,6 +336,9 @@ static void deconv_parity(ConvArgs& a, const mval_op* op, int parity, const floa
 }
 
 extern "C" int mval_op_algo_supported(const mval_op* op, int n_images, int algo) {
+  if (op && op->kind == MVAL_OP_BLOCK && algo == MVAL_ALGO_MFMA_P2)
+    return n_images > 0 && op->cin == op->cout && op->k == 3 && op->stride == 1 && op->pad == 1 && !op->up && !op->in_nchw &&
+           !op->out_nchw && op->hin == op->hout && op->win == op->wout && mval_conv_block_p2_supported(op->cin, n_images, op->hin, op->win);
   if (op && op->kind == MVAL_OP_BLOCK)
     return algo == MVAL_ALGO_MFMA_H2 && n_images > 0 && op->cin == op->cout && op->k == 3 && op->stride == 1 && op->pad == 1 &&
            !op->up && !op->in_nchw && !op->out_nchw && op->hin == op->hout && op->win == op->wout &&
@@ -370,6 +373,28 @@ extern "C" int mval_op_launch(const mval_op* op, int n_images, float* workspace,
   fill_geometry(a, op, n_images);
   MVAL_REQUIRE(a.in && a.out, "mval_op_launch: missing input/output buffer");
   hipStream_t s = mval_stream(stream);
+  if (op->kind == MVAL_OP_TO_P2) {
+    MVAL_REQUIRE(op->in_off >= 0 && op->out_off >= 0 && op->in_amax_off > 0 && op->out_amax_off > 0 && (op->cin & 7) == 0,
+                 "mval_op_launch: malformed MVAL_OP_TO_P2");
+    mval_launch_nhwc_to_p2(a.in, reinterpret_cast<const unsigned*>(workspace + op->in_amax_off), reinterpret_cast<_Float16*>(a.out),
+                           reinterpret_cast<unsigned*>(workspace + op->out_amax_off), n_images, op->hin * op->win, op->cin, s);
+    MVAL_CHECK_LAUNCH("mval_op_launch/to_p2");
+    return 0;
+  }
+  if (op->kind == MVAL_OP_BLOCK && op->algo == MVAL_ALGO_MFMA_P2) {
+    MVAL_REQUIRE(op->in_amax_off > 0 && op->out_amax_off > 0 && a.w && a.scale && a.shift && op->w2_off >= 0 && op->scale2_off >= 0 &&
+                     op->shift2_off >= 0 && op->bound_off >= 0 && op->bound2_off >= 0 && op->in_off >= 0 && op->out_off >= 0,
+                 "mval_op_launch: malformed P2 MVAL_OP_BLOCK");
+    const size_t nw = mval_packed_weight_floats(MVAL_PACK_MFMA16_H2, op->cout, op->cin, 3);
+    const float* w2 = params + op->w2_off;
+    int rc = mval_launch_conv_block_p2(op->cin, a.in, a.out, a.w, a.w + nw - 4, a.scale, a.shift, params + op->bound_off, w2, w2 + nw - 4,
+                                       params + op->scale2_off, params + op->shift2_off, params + op->bound2_off,
+                                       reinterpret_cast<const unsigned*>(workspace + op->in_amax_off),
+                                       reinterpret_cast<unsigned*>(workspace + op->out_amax_off), n_images, op->hin, op->win, s);
+    MVAL_REQUIRE(rc == 0, "mval_op_launch: no fused P2 BasicBlock kernel for c%d %dx%d", op->cin, op->hin, op->win);
+    MVAL_CHECK_LAUNCH("mval_op_launch/block_p2");
+    return 0;
+  }
   if (op->kind == MVAL_OP_BLOCK) {
     MVAL_REQUIRE(op->algo == MVAL_ALGO_MFMA_H2 && op->in_amax_off > 0 && a.w && a.scale && a.shift && op->w2_off >= 0 &&
                      op->scale2_off >= 0 && op->shift2_off >= 0 && (op->res1_off < 0 || op->res1_off == op->in_off) &&
@@ -538,7 +563,7 @@ extern "C" int mval_net_forward(void* net, int n_images, float* workspace, const
 }
 
 extern "C" double mval_op_flops(const mval_op* op, int n_images) {
-  if (!op || op->kind == MVAL_OP_MAXPOOL) return 0.0;
+  if (!op || op->kind == MVAL_OP_MAXPOOL || op->kind == MVAL_OP_TO_P2) return 0.0;
   if (op->kind == MVAL_OP_BLOCK)  // algorithmic work of the two convs (the halo recompute is not counted)
     return 2.0 * 2.0 * n_images * op->hout * op->wout * (double)op->cin * op->cout * 9;
   if (op->kind == MVAL_OP_DECONV)  // every input pixel meets every tap once

@@ -25,7 +25,7 @@ import torch
 from . import _lib
 from .pose_estimators import params as _params
 
-OP_CONV, OP_MAXPOOL, OP_DECONV, OP_BLOCK = 0, 1, 2, 3
+OP_CONV, OP_MAXPOOL, OP_DECONV, OP_BLOCK, OP_TO_P2 = 0, 1, 2, 3, 4
 ALGO_DIRECT, ALGO_MFMA, ALGO_MFMA_BF3, ALGO_MFMA_H2, ALGO_MFMA_P2 = 0, 1, 2, 3, 4
 PACK_HWIO, PACK_MFMA16, PACK_MFMA16_BF3, PACK_MFMA16_H2 = 0, 1, 2, 3
 AMAX_ROW = 4096
@@ -60,14 +60,18 @@ def _align(n, a=64):
 
 def _conv_mode():
     """MVAL_CONV selects the conv kernel family of inference plans:
-    h2 (default) -- fp32 values as scaled two-way fp16 splits on the fp16 matrix cores (3 MFMA products per
+    p2 (default) -- the h2 arithmetic on "P2" activations (csrc/conv_p2.h): every activation stays in HBM as the pair
+                    of fp16 planes the split MFMA consumes, written once by its producer's epilogue, so the consumers
+                    stage by copying; plans whose ops the P2 kernels do not all cover (PoseResNet: max-pool,
+                    transposed convs) run as h2;
+    h2           -- fp32 values as scaled two-way fp16 splits on the fp16 matrix cores (3 MFMA products per
                     32-deep step, fp32 accumulate; the per-tensor power-of-two scales come from max |x| slots the
                     producers keep; measured as accurate as the fp32-MFMA chain);
     bf3          -- exact three-way bf16 splits (6 MFMA products; what training plans always use);
     fp32         -- exact fp32-input MFMA (v_mfma_f32_16x16x4_f32) everywhere."""
-    mode = os.environ.get("MVAL_CONV", "h2")
-    if mode not in ("h2", "bf3", "fp32"):
-        raise ValueError("MVAL_CONV must be h2, bf3 or fp32")
+    mode = os.environ.get("MVAL_CONV", "p2")
+    if mode not in ("p2", "h2", "bf3", "fp32"):
+        raise ValueError("MVAL_CONV must be p2, h2, bf3 or fp32")
     return mode
 
 
@@ -164,6 +168,15 @@ class InferencePlan:
         self.ops = (MvalOp * len(g.ops))()
         self.param_jobs = []  # (op index, packing, w_off, scale_off, shift_off)
         ptop = 0
+        # P2 plan (csrc/conv_p2.h): every op but the image stem reads and writes fp16-pair planes; all or nothing
+        self.p2 = _conv_mode() == "p2" and os.environ.get("MVAL_FORCE_DIRECT") != "1" and self._p2_covers(lib, g, geo, n)
+        mode = "h2" if _conv_mode() == "p2" else _conv_mode()
+        row_of = {}  # P2: activation id -> float offset of its n rows
+        if self.p2:
+            for a in g.acts:
+                if a.id in dims and a.id not in (g.input, g.output):
+                    row_of[a.id] = self._amax_top
+                    self._amax_top += n * AMAX_ROW
         for i, op in enumerate(g.ops):
             hin, win, hout, wout = geo[i]
             in_nchw = g.acts[op.src].layout == "nchw"
@@ -179,10 +192,12 @@ class InferencePlan:
                 # fp32-accurate 16-bit splits on the matrix cores (fp16x2: 5.3x, bf16x3: 2.67x the fp32-MFMA rate)
                 # (the fp16 split wants one image per tile; maps under 8 rows fall back to bf16x3)
                 if (op.k in (1, 3) or op.kind == "deconv") and (op.cin % 32 == 0 or op.cin == 48) and op.src != g.input:
-                    for split in {"h2": (ALGO_MFMA_H2, ALGO_MFMA_BF3), "bf3": (ALGO_MFMA_BF3,)}.get(_conv_mode(), ()):
+                    for split in {"h2": (ALGO_MFMA_H2, ALGO_MFMA_BF3), "bf3": (ALGO_MFMA_BF3,)}.get(mode, ()):
                         if lib.mval_op_algo_supported(C.byref(m), C.c_int(n), C.c_int(split)):
                             m.algo = split
                             break
+            if self.p2 and op.src != g.input:
+                m.algo = ALGO_MFMA_P2
             m.in_off = -1 if op.src == g.input else offset[op.src]
             m.out_off = -1 if op.dst == g.output else offset[op.dst]
             m.res1_off = -1 if op.res1 is None else offset[op.res1]
@@ -203,23 +218,117 @@ class InferencePlan:
                 ptop += _align(op.cout)
                 m.shift_off = ptop
                 ptop += _align(op.cout)
+                if m.algo == ALGO_MFMA_P2:
+                    m.bound_off = ptop
+                    ptop += 64
                 self.param_jobs.append((i, pack, m.w_off, m.scale_off, m.shift_off))
         # producers keep max |x| only for tensors an fp16-split conv reads
         if g.input in amax_slot:
             raise _lib.MvalError("the network input cannot feed an fp16-split conv (no producer to keep its max |x|)")
         for i, op in enumerate(g.ops):
             self.ops[i].out_amax_off = amax_slot.get(op.dst, 0)
-        self.arena_floats = _align(self._amax_top)
         self.graph_ops = self.ops  # one per graph op (what param_jobs index); self.ops becomes the launch list
-        self.ops = self._fuse_blocks(lib, g, n)
+        if self.p2:
+            self.ops = self._p2_launch_list(g, n, dims, offset, row_of)
+        else:
+            self.ops = self._fuse_blocks(lib, g, n)
+        self.arena_floats = _align(self._amax_top)
         self.param_floats = max(ptop, 64)
         self.arena = torch.empty(self.arena_floats, dtype=torch.float32, device=device)
+        if self.p2:  # P2 rows: a partial slot belongs to ONE producing workgroup, the others must read as zero
+            self.arena[self.amax_base :].zero_()
         self.params = torch.zeros(self.param_floats, dtype=torch.float32, device=device)
         self.param_sig = None
         self._graph, self._graph_failed = None, False
         self.net = lib.mval_net_create(self.ops, C.c_int(len(self.ops)))
         if not self.net:
             raise _lib.MvalError("mval_net_create failed: " + lib.mval_last_error().decode())
+
+    @staticmethod
+    def _p2_covers(lib, g, geo, n):
+        """Every op after the image stem has a P2 kernel (HRNet: yes; PoseResNet's max-pool / transposed convs: no)."""
+        if os.environ.get("MVAL_P2", "1") == "0":
+            return False
+        stems = 0
+        for op, (hin, win, hout, wout) in zip(g.ops, geo):
+            if op.src == g.input:
+                stems += 1
+                if op.kind != "conv" or op.cout % 8 or op.res1 is not None or op.res2 is not None or op.up:
+                    return False
+                continue
+            if op.kind != "conv" or g.acts[op.src].layout == "nchw":
+                return False
+            m = MvalOp()
+            m.kind, m.algo = OP_CONV, ALGO_MFMA_P2
+            m.k, m.stride, m.pad, m.cin, m.cout = op.k, op.stride, op.pad, op.cin, op.cout
+            m.hin, m.win, m.hout, m.wout = hin, win, hout, wout
+            m.up, m.relu, m.out_nchw = op.up, int(op.relu), int(g.acts[op.dst].layout == "nchw")
+            if not lib.mval_op_algo_supported(C.byref(m), C.c_int(n), C.c_int(ALGO_MFMA_P2)):
+                return False
+        return stems == 1
+
+    def _p2_launch_list(self, g, n, dims, offset, row_of):
+        """Launch list of a P2 plan: the stem conv keeps its fp32 NHWC kernel and writes into a slot of its own, a
+        MVAL_OP_TO_P2 launch turns that into planes; every other op is MVAL_ALGO_MFMA_P2 with the rows of its input,
+        residuals and output; BasicBlocks of the 32- / 64-channel branches (hrnet.py:36-52) become ONE MVAL_OP_BLOCK
+        launch (csrc/conv_block_p2.hip; MVAL_FUSE_BLOCKS=0 keeps the pair: the on-device cross-check)."""
+        lib = _lib.lib()
+        fuse = os.environ.get("MVAL_FUSE_BLOCKS", "1") != "0"
+        uses = {}
+        for op in g.ops:
+            for a in (op.src, op.res1, op.res2):
+                if a is not None:
+                    uses[a] = uses.get(a, 0) + 1
+        launch, i = [], 0
+        while i < len(g.ops):
+            op = g.ops[i]
+            m = MvalOp()
+            C.memmove(C.byref(m), C.byref(self.graph_ops[i]), C.sizeof(MvalOp))
+            if op.src == g.input:
+                ho, wo = dims[op.dst]
+                stem_floats = _align(n * ho * wo * op.cout)
+                stem_off = self._amax_top  # (behind the rows: only this plan form needs it)
+                self._amax_top += stem_floats
+                stem_rows = self._amax_top
+                self._amax_top += n * AMAX_ROW
+                m.out_off, m.out_amax_off = stem_off, stem_rows
+                launch.append(m)
+                t = MvalOp()
+                t.kind, t.algo = OP_TO_P2, ALGO_MFMA_P2
+                t.hin, t.win, t.cin, t.hout, t.wout, t.cout = ho, wo, op.cout, ho, wo, op.cout
+                t.in_off, t.in_amax_off = stem_off, stem_rows
+                t.out_off, t.out_amax_off = offset[op.dst], row_of[op.dst]
+                t.res1_off = t.res2_off = t.w_off = t.scale_off = t.shift_off = -1
+                t.phase, t.lane = m.phase, m.lane
+                launch.append(t)
+                i += 1
+                continue
+            m.in_amax_off = row_of[op.src]
+            m.res1_amax_off = row_of[op.res1] if op.res1 is not None else 0
+            m.res2_amax_off = row_of[op.res2] if op.res2 is not None else 0
+            m.out_amax_off = row_of.get(op.dst, 0)
+            b = g.ops[i + 1] if i + 1 < len(g.ops) else None
+            if (fuse and b is not None and op.kind == b.kind == "conv" and op.k == b.k == 3 and op.stride == b.stride == 1
+                    and op.cin == op.cout == b.cin == b.cout and op.bn and b.bn and op.relu and b.relu and op.res1 is None
+                    and op.res2 is None and op.up == b.up == 0 and b.src == op.dst and b.res1 == op.src and b.res2 is None
+                    and uses.get(op.dst, 0) == 1 and op.dst != g.output and (op.phase, op.lane) == (b.phase, b.lane)):
+                mb = self.graph_ops[i + 1]
+                blk = MvalOp()
+                C.memmove(C.byref(blk), C.byref(m), C.sizeof(MvalOp))
+                blk.kind = OP_BLOCK
+                blk.out_off, blk.res1_off, blk.res2_off = mb.out_off, m.in_off, -1
+                blk.out_amax_off = row_of[b.dst]
+                blk.w2_off, blk.scale2_off, blk.shift2_off, blk.bound2_off = mb.w_off, mb.scale_off, mb.shift_off, mb.bound_off
+                if lib.mval_op_algo_supported(C.byref(blk), C.c_int(n), C.c_int(ALGO_MFMA_P2)):
+                    launch.append(blk)
+                    i += 2
+                    continue
+            launch.append(m)
+            i += 1
+        arr = (MvalOp * len(launch))()
+        for k, m in enumerate(launch):
+            C.memmove(C.byref(arr[k]), C.byref(m), C.sizeof(MvalOp))
+        return arr
 
     def _fuse_blocks(self, lib, g, n):
         """Launch list: every BasicBlock of the 32- / 64-channel branches (conv3x3+BN+ReLU -> conv3x3+BN+residual+ReLU,
@@ -310,6 +419,12 @@ class InferencePlan:
                     self.params[b_off : b_off + op.cout] = conv.bias.detach()
                 else:
                     self.params[b_off : b_off + op.cout] = 0.0
+            gm = self.graph_ops[i]
+            if gm.algo == ALGO_MFMA_P2:
+                # [A, B] of the output bound |bn(conv(x))| <= A max|x| + B (csrc/conv_p2.h): A = max_c |scale_c| sum |w_c|
+                a_ = (w.abs().double().sum(dim=(1, 2, 3)) * self.params[s_off : s_off + op.cout].abs().double()).max() * (1.0 + 1e-6)
+                b_ = self.params[b_off : b_off + op.cout].abs().double().max()
+                self.params[gm.bound_off : gm.bound_off + 2] = torch.stack([a_, b_]).to(torch.float32)
         self.param_sig = sig
 
     # ---- run ---------------------------------------------------------------------------------
@@ -415,7 +530,10 @@ def _max_images_per_launch(model, h, w):
             hout, wout = (hin + 2 * op.pad - op.k) // op.stride + 1, (win + 2 * op.pad - op.k) // op.stride + 1
         dims[op.dst] = (hout << op.up, wout << op.up)
         biggest = max(biggest, hin * win * op.cin, (hout << op.up) * (wout << op.up) * op.cout)
-    return max(1, (2**31 - 1) // biggest)
+    # (P2 plans address their planes with byte offsets below 2^31: 2^29 elements)
+    p2_candidate = _conv_mode() == "p2" and all(op.kind == "conv" for op in g.ops)  # (HRNet; InferencePlan._p2_covers)
+    limit = 2**29 if p2_candidate else 2**31
+    return max(1, (limit - 1) // biggest)
 
 
 def run_network(model, x):

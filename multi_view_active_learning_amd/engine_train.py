@@ -112,8 +112,8 @@ class TrainPlan:
             m.hin, m.win, m.hout, m.wout = hin, win, hout, wout
             m.up, m.relu, m.in_nchw, m.out_nchw = op.up, int(op.relu), int(in_nchw), int(out_nchw)
             m.algo = ALGO_DIRECT
-            bf3 = _conv_mode() in ("bf3", "h2")
-            h2 = _conv_mode() == "h2"  # fp16x2 split (3 products) where it applies, else bf16x3 (6)
+            bf3 = _conv_mode() in ("bf3", "h2", "p2")  # (p2 is an inference activation format: training runs its h2 arithmetic)
+            h2 = _conv_mode() in ("h2", "p2")  # fp16x2 split (3 products) where it applies, else bf16x3 (6)
             if _mfma_ok(op, in_nchw) and lib.mval_op_mfma_supported(C.byref(m), C.c_int(n)):
                 m.algo = ALGO_MFMA
                 if bf3 and op.kind == "conv" and op.k in (1, 3) and (op.cin % 32 == 0 or op.cin == 48):

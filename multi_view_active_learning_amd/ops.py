@@ -282,3 +282,54 @@ def fused_conv_p2(x, weight, scale, shift, **kw):
     c.launch()
     fused_conv_p2.last = c
     return c.result()
+
+
+class P2Block:
+    """One fused BasicBlock over P2 activations (MVAL_OP_BLOCK with MVAL_ALGO_MFMA_P2, csrc/conv_block_p2.hip), set up once
+    and launched many times: relu(bn2(conv3x3(relu(bn1(conv3x3(x))))) + x), x fp32 NHWC (converted here), C in {32, 64}."""
+
+    def __init__(self, x, w1, scale1, shift1, w2, scale2, shift2):
+        dev = x.device
+        n, h, w, c = x.shape
+        self.shape = (n, h, w, c)
+        planes, rows = to_p2(x)
+        out_off = _align(planes.numel())
+        row_off = out_off + _align(planes.numel())
+        self.arena = torch.zeros(row_off + _align(2 * n * AMAX_ROW), dtype=torch.float32, device=dev)
+        self.arena[: planes.numel()] = planes
+        self.arena[row_off : row_off + n * AMAX_ROW] = rows.view(torch.float32)
+        chunks = [pack_weights(w1, ALGO_MFMA_H2), scale1, shift1, p2_bound(w1, scale1, shift1), pack_weights(w2, ALGO_MFMA_H2), scale2, shift2,
+                  p2_bound(w2, scale2, shift2)]
+        offs, top = [], 0
+        for t in chunks:
+            offs.append(top)
+            top += _align(t.numel())
+        self.params = torch.zeros(top, dtype=torch.float32, device=dev)
+        for o, t in zip(offs, chunks):
+            self.params[o : o + t.numel()] = t.to(dev, torch.float32).reshape(-1)
+        m = MvalOp()
+        m.kind, m.algo = OP_BLOCK, 4
+        m.k, m.stride, m.pad, m.cin, m.cout = 3, 1, 1, c, c
+        m.hin, m.win, m.hout, m.wout = h, w, h, w
+        m.up, m.relu, m.in_nchw, m.out_nchw = 0, 1, 0, 0
+        m.in_off, m.out_off, m.res1_off, m.res2_off = 0, out_off, 0, -1
+        m.w_off, m.scale_off, m.shift_off, m.bound_off, m.w2_off, m.scale2_off, m.shift2_off, m.bound2_off = offs
+        m.in_amax_off, m.out_amax_off = row_off, row_off + n * AMAX_ROW
+        self.op, self.out_off, self.n = m, out_off, n
+        if not _lib.lib().mval_op_algo_supported(C.byref(m), C.c_int(n), C.c_int(4)):
+            raise _lib.MvalError("no fused P2 BasicBlock kernel for this geometry")
+
+    launch = P2Conv.launch
+    out_rows = P2Conv.out_rows
+    kept_amax = P2Conv.kept_amax
+
+    def result(self):
+        n, h, w, c = self.shape
+        return from_p2(self.arena[self.out_off : self.out_off + n * h * w * c], self.out_rows().reshape(-1), n, h, w, c)
+
+
+def fused_basic_block_p2(x, w1, scale1, shift1, w2, scale2, shift2):
+    b = P2Block(x, w1, scale1, shift1, w2, scale2, shift2)
+    b.launch()
+    fused_basic_block_p2.last = b
+    return b.result()

@@ -256,7 +256,7 @@ def _load(c, dev):
     return m.to(dev).eval(), sd
 
 
-@pytest.mark.parametrize("mode", ["h2", "bf3", "fp32"])
+@pytest.mark.parametrize("mode", ["p2", "h2", "bf3", "fp32"])
 @pytest.mark.parametrize("name", list(cases.model_cases()))
 def test_network_vs_reference_golden(dev, name, mode, monkeypatch):
     """Whole-network heat-maps against the real reference's output (tests/golden/models.npz), for every conv
@@ -284,7 +284,8 @@ def test_network_vs_reference_golden(dev, name, mode, monkeypatch):
     np.testing.assert_allclose(flat.mean(-1), z[name + "/mean"], rtol=0, atol=tol)
 
 
-def test_network_fused_blocks_vs_unfused(dev, monkeypatch):
+@pytest.mark.parametrize("mode", ["p2", "h2"])
+def test_network_fused_blocks_vs_unfused(dev, mode, monkeypatch):
     """HRNet-W32 at 256 x 256 (the 32- and 64-channel BasicBlocks run as MVAL_OP_BLOCK launches) against the
     same plan with MVAL_FUSE_BLOCKS=0 and against the reference golden."""
     c = cases.model_cases()["w32"]
@@ -293,6 +294,7 @@ def test_network_fused_blocks_vs_unfused(dev, monkeypatch):
     x = torch.from_numpy(cases.model_input(c)).to(dev)
     from multi_view_active_learning_amd import engine
 
+    monkeypatch.setenv("MVAL_CONV", mode)
     with torch.no_grad():
         y1 = m(x).cpu()
         kinds = [o.kind for o in engine._plan_for(m, x).ops]

@@ -41,6 +41,22 @@ CHECK = [
     (1, 48, 48, 96, 72, 3, 1, True, True, False, 0, False),
     (2, 96, 96, 48, 36, 3, 1, True, True, False, 0, False),
     (1, 96, 192, 48, 36, 3, 2, True, True, True, 0, False),
+    # HRNet-W48 at 384 x 288: maps 96x72 / 48x36 / 24x18 / 12x9 (partial tiles everywhere), 48-channel first branch
+    (2, 192, 192, 24, 18, 3, 1, True, True, False, 0, False),
+    (3, 384, 384, 12, 9, 3, 1, True, True, False, 0, False),
+    (2, 48, 96, 96, 72, 3, 2, True, False, False, 0, False),
+    (2, 192, 384, 24, 18, 3, 2, True, True, True, 0, False),
+    (2, 48, 48, 96, 72, 3, 2, True, False, False, 0, False),
+    (2, 96, 48, 48, 36, 1, 1, False, True, False, 1, False),
+    (1, 192, 48, 24, 18, 1, 1, False, True, False, 2, False),
+    (2, 384, 48, 12, 9, 1, 1, True, True, True, 3, False),
+    (2, 384, 192, 12, 9, 1, 1, False, True, False, 1, False),
+    (2, 64, 256, 96, 72, 1, 1, True, True, False, 0, False),
+    (2, 256, 64, 96, 72, 1, 1, True, False, False, 0, False),
+    (2, 256, 48, 96, 72, 3, 1, True, False, False, 0, False),
+    (2, 256, 96, 96, 72, 3, 2, True, False, False, 0, False),
+    (2, 48, 19, 96, 72, 1, 1, False, False, False, 0, True),
+    (2, 64, 64, 192, 144, 3, 2, True, False, False, 0, False),
 ]
 
 
@@ -163,6 +179,49 @@ def timing():
               f"({fl / t_p2 / 1e12:6.1f} TFLOP/s)  x{t_h2 / t_p2:.2f}", flush=True)
 
 
+BLOCKS = [(3, 32, 64, 64), (2, 64, 32, 32), (2, 32, 21, 37), (1, 64, 9, 16), (5, 32, 8, 16), (2, 64, 24, 40), (2, 32, 96, 72), (1, 64, 48, 36)]
+
+
+def check_blocks():
+    bad = 0
+    for n, c, h, w in BLOCKS:
+        rng = np.random.default_rng(7 + h)
+        x = torch.from_numpy(np.maximum(rng.standard_normal((n, c, h, w)), 0).astype(np.float32) * 1.5)
+        ws = [torch.from_numpy((rng.standard_normal((c, c, 3, 3)) * np.sqrt(2.0 / (c * 9))).astype(np.float32)) for _ in range(2)]
+        sc = [torch.from_numpy(rng.uniform(0.5, 1.5, c).astype(np.float32)) for _ in range(2)]
+        sh = [torch.from_numpy(rng.standard_normal(c).astype(np.float32) * 0.1) for _ in range(2)]
+        d = torch.float64
+        mid = ref_conv(x.to(d), ws[0].to(d), sc[0].to(d), sh[0].to(d), 1, True, None, None, 0)
+        want = ref_conv(mid, ws[1].to(d), sc[1].to(d), sh[1].to(d), 1, True, x.to(d), None, 0)
+        xd = x.permute(0, 2, 3, 1).contiguous().to(dev)
+        got = ops.fused_basic_block_p2(xd, ws[0].to(dev), sc[0].to(dev), sh[0].to(dev), ws[1].to(dev), sc[1].to(dev), sh[1].to(dev))
+        kept = ops.fused_basic_block_p2.last.kept_amax().cpu()
+        got = got.permute(0, 3, 1, 2).cpu()
+        ref = ops.fused_basic_block(xd, ws[0].to(dev), sc[0].to(dev), sh[0].to(dev), ws[1].to(dev), sc[1].to(dev), sh[1].to(dev)).permute(0, 3, 1, 2).cpu()
+        err, rms = (got.double() - want).abs().max().item(), (got.double() - want).pow(2).mean().sqrt().item()
+        rms_h2 = (ref.double() - want).pow(2).mean().sqrt().item()
+        ok = err <= 1e-4 * max(1.0, want.abs().max().item()) and torch.allclose(kept, got.abs().amax(dim=(1, 2, 3)), rtol=1e-6, atol=0)
+        bad += 0 if ok else 1
+        print(("ok  " if ok else "FAIL") + f" block {(n, c, h, w)}: max {err:.2e} rms {rms:.2e} (h2 block rms {rms_h2:.2e})", flush=True)
+    print("blocks:", "ALL OK" if bad == 0 else f"{bad} FAILED", flush=True)
+
+
+def time_blocks():
+    n = n_img
+    for c, h, w in ((32, 64, 64), (64, 32, 32)):
+        x = torch.relu(torch.randn(n, h, w, c, device=dev))
+        ws = [torch.randn(c, c, 3, 3, device=dev) * (2.0 / (c * 9)) ** 0.5 for _ in range(2)]
+        one, zero = torch.ones(c, device=dev), torch.zeros(c, device=dev)
+        b = ops.P2Block(x, ws[0], one, zero, ws[1], one, zero)
+        t = time_loop(b.launch)
+        fl = 2 * 2.0 * n * h * w * c * c * 9
+        print(f"P2 block {c}ch {h}x{w} n={n}: {t * 1e6:7.1f} us  {fl / t / 1e12:6.1f} TFLOP/s (two convs)", flush=True)
+
+
+if what in ("check", "all", "blocks"):
+    check_blocks()
+if what in ("time", "all", "blocks"):
+    time_blocks()
 if what in ("check", "all"):
     check()
 if what in ("time", "all"):
