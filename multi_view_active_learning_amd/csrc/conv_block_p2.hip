@@ -432,8 +432,23 @@ static int launch_block_p2(P2BlockArgs a, hipStream_t s) {
 #ifdef P2_STAMP
   a.dbg = g_p2_dbg_shared;
 #endif
-  int per_cu = (int)((160 * 1024) / smem);
-  if (per_cu > 2) per_cu = 2;  // (two waves per SIMD by registers)
+  static int occ = 0;
+  if (!occ) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_block_p2_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    // resident workgroups per CU: LDS, and registers (allocation granule 8, 512 per SIMD lane; the occupancy API's
+    // answer was not usable here: with it the 32-channel block kernel ran 20x slower)
+    hipFuncAttributes fa;
+    int nb = (int)((160 * 1024) / smem);
+    if (hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&conv_block_p2_kernel<C>)) == hipSuccess && fa.numRegs > 0) {
+      const int waves_simd = 512 / ((fa.numRegs + 7) / 8 * 8);
+      nb = min(nb, max(1, waves_simd * 4 / (256 / 64)));
+    } else {
+      nb = min(nb, 2);
+    }
+    if (nb < 1) nb = 1;
+    occ = nb;
+  }
+  int per_cu = occ;
   const char* pe = getenv("MVAL_P2_WGS");
   if (pe && atoi(pe) > 0) per_cu = atoi(pe);
   int wgs = 256 * per_cu;
@@ -443,10 +458,8 @@ static int launch_block_p2(P2BlockArgs a, hipStream_t s) {
     wgs = 8 * ((per + rounds - 1) / rounds);
   }
   a.wgs_x = wgs;
+  if (getenv("MVAL_P2_DEBUG")) fprintf(stderr, "block_p2<%d> N %d %dx%d tiles %d per_cu %d wgs %d smem %zu\n", C, a.N, a.H, a.W, a.tiles_total, per_cu, wgs, smem);
   if (tiles_img > P2_SLOTS) mval_launch_zero_rows(a.out_row, (int64_t)a.N * MVAL_AMAX_ROW, s);
-  static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_block_p2_kernel<C>),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  (void)once;
   hipLaunchKernelGGL((conv_block_p2_kernel<C>), dim3((unsigned)wgs), dim3(256), smem, s, a);
   return 0;
 }

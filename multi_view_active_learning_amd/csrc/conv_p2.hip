@@ -83,7 +83,10 @@ __device__ __forceinline__ f32x4 p2_mfma(const u32x4 a, const u32x4 b, const f32
 // use: the next stage's granules (the NEXT TILE's first chunk during a tile's last stage), the next weight blocks
 // (also across tiles), and at the start of a tile's last stage everything its epilogue needs (scale rows, residual
 // granules, BN factors), so the epilogue is arithmetic and stores.
-template <int KS, int S, int G, int WN, int WM, int NT, int MS, int TW, bool RS>
+// EPI: 0 = P2 planes out (residuals at the conv resolution), 1 = P2 planes out through the fused nearest upsample (the 1x1
+// convs of the fuse layers), 2 = fp32 NCHW out (the heat-map layer) -- separate instantiations: one kernel with all three
+// epilogues spilled ~50-100 registers in every hot instantiation.
+template <int KS, int S, int G, int WN, int WM, int NT, int MS, int TW, bool RS, int EPI>
 __global__ __launch_bounds__(64 * WN * WM) __attribute__((amdgpu_waves_per_eu(2, 8))) void conv_p2_kernel(P2Args a) {
   constexpr int NTH = 64 * WN * WM, TAPS = KS * KS, SPN = 8 * G, SPN_LOG2 = G == 1 ? 3 : G == 2 ? 4 : 5;
   constexpr int pad = KS / 2;
@@ -371,8 +374,8 @@ __global__ __launch_bounds__(64 * WN * WM) __attribute__((amdgpu_waves_per_eu(2,
     P2RowRegs row_in, row_r1, row_r2;
     f32x4 sc[NT], sh[NT];
     // residual granules: lanes < 32 request the h-plane granule of (pixel, 8-channel block), lanes >= 32 the l-plane one
-    u32x4 R1[MS][NT];
-    const bool pre_res = a.up == 0 && !a.out_f32;
+    u32x4 R1[EPI == 0 ? MS : 1][EPI == 0 ? NT : 1];
+    constexpr bool pre_res = EPI == 0;
     const unsigned plane_bytes = (unsigned)(oplane * 2);
     const int yl = oy0 + ly, xl = ox0 + lx;
     unsigned vb[NT];  // byte offset of the lane's granule of sub-tile row 0 / column 0 (its plane: h for lanes < 32)
@@ -422,7 +425,7 @@ __global__ __launch_bounds__(64 * WN * WM) __attribute__((amdgpu_waves_per_eu(2,
     if (wave_active) {
       const float in_inv = __uint_as_float(row_in.inv);
       float r1_inv = 0.f, r2_inv = 0.f, out_mul = 1.f, out_inv = 1.f;
-      if (!a.out_f32) {
+      if constexpr (EPI != 2) {
         float bound = bound_a * p2_row_amax(row_in) + bound_b;
         if (a.res1) {
           bound += p2_row_amax(row_r1);
@@ -437,7 +440,7 @@ __global__ __launch_bounds__(64 * WN * WM) __attribute__((amdgpu_waves_per_eu(2,
           a.out_row[(int64_t)n * MVAL_AMAX_ROW + P2_INV_SLOT] = __float_as_uint(out_inv);
       }
       const float unscale = in_inv * w_unscale;
-      u32x4 R2[MS][NT];  // a second residual (fuse layers) is requested here: its registers are the weight fragments'
+      u32x4 R2[EPI == 0 ? MS : 1][EPI == 0 ? NT : 1];  // a second residual (fuse layers) is requested here: its registers are the weight fragments'
       if (pre_res && a.res2) {
 #pragma unroll
         for (int nt = 0; nt < NT; nt++)
@@ -491,7 +494,7 @@ __global__ __launch_bounds__(64 * WN * WM) __attribute__((amdgpu_waves_per_eu(2,
       };
       using T_ = std::true_type;
       using F_ = std::false_type;
-      if (a.out_f32) {  // the heat-map layer: fp32 NCHW, no residuals, no upsample
+      if constexpr (EPI == 2) {  // the heat-map layer: fp32 NCHW, no residuals, no upsample
 #pragma unroll
         for (int nt = 0; nt < NT; nt++) {
           const int c0 = (ns0 + nt) * 16 + cq;
@@ -506,7 +509,7 @@ __global__ __launch_bounds__(64 * WN * WM) __attribute__((amdgpu_waves_per_eu(2,
             }
           }
         }
-      } else if (pre_res) {
+      } else if constexpr (EPI == 0) {
         if (a.res1 && a.res2) plain(T_{}, T_{});
         else if (a.res1) plain(T_{}, F_{});
         else plain(F_{}, F_{});
@@ -522,19 +525,31 @@ __global__ __launch_bounds__(64 * WN * WM) __attribute__((amdgpu_waves_per_eu(2,
             const bool ok = y < a.Hout && x < a.Wout && c0 < a.Cout;
             const unsigned vo0 = (unsigned)n * 2u * plane_bytes + (lane >= 32 ? plane_bytes : 0u) +
                                  (unsigned)(((c0 >> 3) * Ho + (y << a.up)) * Wo + (x << a.up)) * 16u;
-            for (int dy = 0; dy < rep; dy++)
-              for (int dx = 0; dx < rep; dx++) {
-                const unsigned vo = ok ? vo0 + (unsigned)(dy * Wo + dx) * 16u : 0x80000000u;
-                f32x4 r = v;
-                if (a.res1) r += res_of(__builtin_amdgcn_raw_buffer_load_b128(r1r, vo, 0, 0), r1_inv);
-                if (a.res2) r += res_of(__builtin_amdgcn_raw_buffer_load_b128(r2r, vo, 0, 0), r2_inv);
-                put(r, vo, 0);
+            // four replicas at a time (rep * rep is 4, 16 or 64): their residual granules are requested before the first
+            // one is used -- one replica per round trip left these layers at half their HBM rate
+            for (int i0 = 0; i0 < rep * rep; i0 += 4) {
+              unsigned vo[4];
+              u32x4 g1[4], g2[4];
+#pragma unroll
+              for (int u = 0; u < 4; u++) {
+                const int dy = (i0 + u) >> a.up, dx = (i0 + u) & (rep - 1);
+                vo[u] = ok ? vo0 + (unsigned)(dy * Wo + dx) * 16u : 0x80000000u;
+                if (a.res1) g1[u] = __builtin_amdgcn_raw_buffer_load_b128(r1r, vo[u], 0, 0);
+                if (a.res2) g2[u] = __builtin_amdgcn_raw_buffer_load_b128(r2r, vo[u], 0, 0);
               }
+#pragma unroll
+              for (int u = 0; u < 4; u++) {
+                f32x4 r = v;
+                if (a.res1) r += res_of(g1[u], r1_inv);
+                if (a.res2) r += res_of(g2[u], r2_inv);
+                put(r, vo[u], 0);
+              }
+            }
           }
         }
       }
     }
-    if (!a.out_f32) {
+    if constexpr (EPI != 2) {
       // the workgroup's max |x| without a barrier: LDS atomics, the wave that arrives last publishes and re-arms
       const unsigned amax_bits = p2_wave_umax(__float_as_uint(amax));
       if (lane == 0) {
@@ -566,8 +581,8 @@ __global__ __launch_bounds__(64 * WN * WM) __attribute__((amdgpu_waves_per_eu(2,
 
 static thread_local int g_p2_dry = 0;
 
-template <int KS, int S, int G, int WN, int WM, int NT, int MS, int TW, bool RS = false>
-static int launch_p2(P2Args a, hipStream_t s) {
+template <int KS, int S, int G, int WN, int WM, int NT, int MS, int TW, bool RS, int EPI>
+static int launch_p2e(P2Args a, hipStream_t s) {
   constexpr int TH = 16 * MS * WM / TW;
   constexpr int PH = (TH - 1) * S + KS, PW = (TW - 1) * S + KS, PWh = (PW + 1) / 2;
   constexpr int slots = S == 1 ? PH * PW : 2 * PH * PWh;
@@ -587,12 +602,27 @@ static int launch_p2(P2Args a, hipStream_t s) {
 #ifdef P2_STAMP
   a.dbg = g_p2_dbg;
 #endif
-  // persistent workgroups: as many as stay resident (LDS- and register-limited), a multiple of 8 per cout group so
-  // that every XCD walks its own contiguous tile range; fewer tiles than that: one tile each
-  int per_cu = (int)((160 * 1024) / smem);
-  constexpr int reg_waves = 2;  // (amdgpu_waves_per_eu of the kernel)
-  if (per_cu > reg_waves * 4 / (WN * WM)) per_cu = reg_waves * 4 / (WN * WM);
-  if (per_cu < 1) per_cu = 1;
+  // persistent workgroups: as many as stay resident (the runtime's occupancy answer for this instantiation: LDS and
+  // registers), a multiple of 8 per cout group so that every XCD walks its own contiguous tile range; fewer tiles than
+  // that: one tile each.  (No workgroup waits for another one: an optimistic answer only costs a second round.)
+  static int occ = 0;
+  if (!occ) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_p2_kernel<KS, S, G, WN, WM, NT, MS, TW, RS, EPI>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    // resident workgroups per CU: LDS, and registers (allocation granule 8, 512 per SIMD lane; the occupancy API's
+    // answer was not usable here: with it the 32-channel block kernel ran 20x slower)
+    hipFuncAttributes fa;
+    int nb = (int)((160 * 1024) / smem);
+    if (hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&conv_p2_kernel<KS, S, G, WN, WM, NT, MS, TW, RS, EPI>)) == hipSuccess && fa.numRegs > 0) {
+      const int waves_simd = 512 / ((fa.numRegs + 7) / 8 * 8);
+      nb = min(nb, max(1, waves_simd * 4 / (NTH / 64)));
+    } else {
+      nb = min(nb, 2);
+    }
+    if (nb < 1) nb = 1;
+    occ = nb;
+  }
+  int per_cu = occ;
   const char* pe = getenv("MVAL_P2_WGS");  // measurement override: workgroups per CU
   if (pe && atoi(pe) > 0) per_cu = atoi(pe);
   int wgs = (256 * per_cu / (int)groups) & ~7;
@@ -606,11 +636,21 @@ static int launch_p2(P2Args a, hipStream_t s) {
   dim3 grid((unsigned)wgs, groups);
   if (!a.out_f32 && (int64_t)a.amax_tiles * groups > P2_SLOTS)
     mval_launch_zero_rows(a.out_row, (int64_t)a.N * MVAL_AMAX_ROW, s);  // (the kernel rewrites the scale slots)
-  static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_p2_kernel<KS, S, G, WN, WM, NT, MS, TW, RS>),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  (void)once;
-  hipLaunchKernelGGL((conv_p2_kernel<KS, S, G, WN, WM, NT, MS, TW, RS>), grid, dim3(NTH), smem, s, a);
+  hipLaunchKernelGGL((conv_p2_kernel<KS, S, G, WN, WM, NT, MS, TW, RS, EPI>), grid, dim3(NTH), smem, s, a);
   return 0;
+}
+
+template <int KS, int S, int G, int WN, int WM, int NT, int MS, int TW, bool RS = false>
+static int launch_p2(const P2Args& a, hipStream_t s) {
+  if (a.out_f32) {
+    if constexpr (KS == 1 && NT == 1 && MS <= 4) return launch_p2e<KS, S, G, WN, WM, NT, MS, TW, RS, 2>(a, s);
+    return 1;
+  }
+  if (a.up) {
+    if constexpr (KS == 1 && MS <= 4) return launch_p2e<KS, S, G, WN, WM, NT, MS, TW, RS, 1>(a, s);
+    return 1;
+  }
+  return launch_p2e<KS, S, G, WN, WM, NT, MS, TW, RS, 0>(a, s);
 }
 
 // MVAL_P2_TILE: measurement override of the tile choice (tools/p2_sweep.py): "ms,nt,g" (0 = default)
@@ -632,9 +672,10 @@ int mval_launch_conv_p2(const P2Args& a0, hipStream_t s) {
   if (a.k == 3 && a.stride == 1) {
     if (a.Wout >= 16 && a.Hout >= 4) {
       if (a.NS_total <= 2) return launch_p2<3, 1, 1, 2, 2, 1, 4, 16, true>(a, s);  // 32 couts: 2 x 2 waves, 4 rows each
-      const int64_t wgs8 = ((px + 127) / 128) * ((a.NS_total + 3) / 4);
-      const int ms = oms ? oms : (wgs8 >= 512 && a.Hout >= 8 ? 8 : 4);
-      if (ms == 8) return launch_p2<3, 1, 1, 4, 1, 1, 8, 16, true>(a, s);
+      // 64-pixel tiles: measured faster than 128-pixel ones on every HRNet shape (128 -> 128 on 16x16: 28.8 vs 30.6 us,
+      // 64 -> 64 on 32x32: 32.7 vs 39.5) -- more, shorter workgroups overlap their vector phases better
+      const int ms = oms ? oms : 4;
+      if (ms == 8 && a.Hout >= 8) return launch_p2<3, 1, 1, 4, 1, 1, 8, 16, true>(a, s);
       if (ont == 2) return launch_p2<3, 1, 1, 4, 1, 2, 4, 16, true>(a, s);
       return launch_p2<3, 1, 1, 4, 1, 1, 4, 16, true>(a, s);
     }
