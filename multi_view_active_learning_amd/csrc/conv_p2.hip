@@ -25,6 +25,13 @@
 
 #include "conv_p2.h"
 
+// register budget: 2 waves per SIMD (256 VGPRs); -DP2_W3: 3 for the light configurations (measurement)
+#ifdef P2_W3
+#define P2_WAVES(MS, NT, EPI) (((MS) * (NT) <= 4 && (EPI) == 0) ? 3 : 2)
+#else
+#define P2_WAVES(MS, NT, EPI) 2
+#endif
+
 #ifndef P2_VALU_PRIO
 #define P2_VALU_PRIO 2
 #endif
@@ -87,7 +94,7 @@ __device__ __forceinline__ f32x4 p2_mfma(const u32x4 a, const u32x4 b, const f32
 // convs of the fuse layers), 2 = fp32 NCHW out (the heat-map layer) -- separate instantiations: one kernel with all three
 // epilogues spilled ~50-100 registers in every hot instantiation.
 template <int KS, int S, int G, int WN, int WM, int NT, int MS, int TW, bool RS, int EPI>
-__global__ __launch_bounds__(64 * WN * WM) __attribute__((amdgpu_waves_per_eu(2, 8))) void conv_p2_kernel(P2Args a) {
+__global__ __launch_bounds__(64 * WN * WM) __attribute__((amdgpu_waves_per_eu(P2_WAVES(MS, NT, EPI), 8))) void conv_p2_kernel(P2Args a) {
   constexpr int NTH = 64 * WN * WM, TAPS = KS * KS, SPN = 8 * G, SPN_LOG2 = G == 1 ? 3 : G == 2 ? 4 : 5;
   constexpr int pad = KS / 2;
   static_assert(G == 1 || G == 2 || G == 4, "chunks per stage");

@@ -274,6 +274,10 @@ class InferencePlan:
         launch (csrc/conv_block_p2.hip; MVAL_FUSE_BLOCKS=0 keeps the pair: the on-device cross-check)."""
         lib = _lib.lib()
         fuse = os.environ.get("MVAL_FUSE_BLOCKS", "1") != "0"
+        # measured (128 images): 32 channels on 64x64 maps 81 us fused vs 2 x 44 us; 64 channels on 32x32 maps 77 us
+        # fused vs 2 x 33 us -- the two 64-channel convs are no longer HBM-bound one by one, so only the 32-channel
+        # blocks are fused by default (MVAL_P2_BLOCKS=32,64 fuses both)
+        fuse_c = {int(v) for v in os.environ.get("MVAL_P2_BLOCKS", "32").split(",") if v}
         uses = {}
         for op in g.ops:
             for a in (op.src, op.res1, op.res2):
@@ -309,7 +313,7 @@ class InferencePlan:
             m.out_amax_off = row_of.get(op.dst, 0)
             b = g.ops[i + 1] if i + 1 < len(g.ops) else None
             if (fuse and b is not None and op.kind == b.kind == "conv" and op.k == b.k == 3 and op.stride == b.stride == 1
-                    and op.cin == op.cout == b.cin == b.cout and op.bn and b.bn and op.relu and b.relu and op.res1 is None
+                    and op.cin == op.cout == b.cin == b.cout and op.cin in fuse_c and op.bn and b.bn and op.relu and b.relu and op.res1 is None
                     and op.res2 is None and op.up == b.up == 0 and b.src == op.dst and b.res1 == op.src and b.res2 is None
                     and uses.get(op.dst, 0) == 1 and op.dst != g.output and (op.phase, op.lane) == (b.phase, b.lane)):
                 mb = self.graph_ops[i + 1]
@@ -507,7 +511,8 @@ def _plan_for(model, x):
     if c != 3:
         raise ValueError("expected (N, 3, H, W) images")
     cache = model.__dict__.setdefault("_plans", {})
-    key = (n, h, w, x.device.index, os.environ.get("MVAL_FORCE_DIRECT") == "1", _conv_mode(), os.environ.get("MVAL_FUSE_BLOCKS", "1"))
+    key = (n, h, w, x.device.index, os.environ.get("MVAL_FORCE_DIRECT") == "1", _conv_mode(), os.environ.get("MVAL_FUSE_BLOCKS", "1"),
+           os.environ.get("MVAL_P2_BLOCKS", "32"), os.environ.get("MVAL_P2", "1"))
     plan = cache.get(key)
     if plan is None:
         if len(cache) >= 4:  # keep the arena footprint bounded

@@ -35,4 +35,4 @@ def test_pool_flag_is_for_pool_workloads():
     spec.loader.exec_module(m)
     assert {"c1", "c2", "c3", "c4", "c5"} <= set(m.WORKLOADS)
     assert m.WORKLOADS["c5"]["picks"] == 100 and m.WORKLOADS["c4"]["score"] == "MPE"
-    assert m.SPLIT_PRODUCTS == {"h2": 3, "bf3": 6}
+    assert m.SPLIT_PRODUCTS == {"p2": 3, "h2": 3, "bf3": 6}

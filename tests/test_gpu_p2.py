@@ -1,0 +1,265 @@
+"""GPU parity tests of the P2 path (csrc/conv_p2.h): activations kept in HBM as the pair of fp16 planes the fp16-split
+MFMA convs consume.  Single operators against float64 torch-CPU (and against the exact-fp32 MFMA chain's error), the
+fused BasicBlock, the format itself, and whole plans against the h2 / exact-fp32 plans."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import cases
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    from multi_view_active_learning_amd import _lib
+
+    _lib.lib()
+    return torch.device("cuda:0")
+
+
+def _ref_conv(x, w, scale, shift, stride, relu, res1, res2, up):
+    y = F.conv2d(x, w, None, stride=stride, padding=w.shape[-1] // 2)
+    y = y * scale[None, :, None, None] + shift[None, :, None, None]
+    if up:
+        y = F.interpolate(y, scale_factor=2**up, mode="nearest")
+    if res1 is not None:
+        y = y + res1
+    if res2 is not None:
+        y = y + res2
+    return F.relu(y) if relu else y
+
+
+# n, cin, cout, h, w, k, stride, relu, res1, res2, up, out_nchw
+P2_CASES = [
+    (3, 32, 32, 64, 64, 3, 1, True, True, False, 0, False),
+    (2, 64, 64, 32, 32, 3, 1, True, False, False, 0, False),
+    (2, 128, 128, 16, 16, 3, 1, True, True, False, 0, False),
+    (5, 256, 256, 8, 8, 3, 1, True, True, False, 0, False),
+    (2, 256, 32, 64, 64, 3, 1, True, False, False, 0, False),
+    (2, 32, 64, 64, 64, 3, 2, False, True, True, 0, False),
+    (2, 64, 128, 32, 32, 3, 2, True, True, True, 0, False),
+    (3, 128, 256, 16, 16, 3, 2, True, True, False, 0, False),
+    (2, 64, 32, 32, 32, 1, 1, False, True, False, 1, False),
+    (2, 128, 32, 16, 16, 1, 1, True, True, False, 2, False),
+    (2, 256, 32, 8, 8, 1, 1, True, True, True, 3, False),
+    (2, 64, 256, 64, 64, 1, 1, True, True, False, 0, False),
+    # the x4-store / SGPR-soffset hazard showed on exactly these shapes (1x1, 64-wide tiles, several sub-tiles per row)
+    (2, 256, 64, 64, 64, 1, 1, True, False, False, 0, False),
+    (1, 64, 64, 16, 64, 1, 1, False, False, False, 0, False),
+    (2, 32, 19, 64, 64, 1, 1, False, False, False, 0, True),
+    # HRNet-W48 at 384 x 288: 48-channel first branch, maps that no tile divides
+    (1, 48, 48, 96, 72, 3, 1, True, True, False, 0, False),
+    (2, 192, 192, 24, 18, 3, 1, True, True, False, 0, False),
+    (3, 384, 384, 12, 9, 3, 1, True, True, False, 0, False),
+    (2, 48, 96, 96, 72, 3, 2, True, False, False, 0, False),
+    (2, 192, 384, 24, 18, 3, 2, True, True, True, 0, False),
+    (1, 192, 48, 24, 18, 1, 1, False, True, False, 2, False),
+    (2, 64, 256, 96, 72, 1, 1, True, True, False, 0, False),
+    (2, 48, 19, 96, 72, 1, 1, False, False, False, 0, True),
+]
+
+
+def _make(case):
+    n, cin, cout, h, w, k, stride, relu, r1, r2, up, out_nchw = case
+    rng = np.random.default_rng(abs(hash(case)) % 2**31)
+    x = torch.from_numpy(rng.standard_normal((n, cin, h, w)).astype(np.float32))
+    wt = torch.from_numpy((rng.standard_normal((cout, cin, k, k)) * np.sqrt(2.0 / (cin * k * k))).astype(np.float32))
+    scale = torch.from_numpy(rng.uniform(0.5, 1.5, cout).astype(np.float32))
+    shift = torch.from_numpy(rng.standard_normal(cout).astype(np.float32) * 0.1)
+    ho = ((h + 2 * (k // 2) - k) // stride + 1) << up
+    wo = ((w + 2 * (k // 2) - k) // stride + 1) << up
+    res1 = torch.from_numpy(rng.standard_normal((n, cout, ho, wo)).astype(np.float32)) if r1 else None
+    res2 = torch.from_numpy(rng.standard_normal((n, cout, ho, wo)).astype(np.float32)) if r2 else None
+    return x, wt, scale, shift, res1, res2
+
+
+@pytest.mark.parametrize("case", P2_CASES, ids=lambda c: "n%d_c%d-%d_%dx%d_k%ds%d_r%d%d%d_u%d_o%d" % tuple(int(v) for v in c))
+def test_p2_conv_vs_float64(dev, case):
+    from multi_view_active_learning_amd import ops
+
+    n, cin, cout, h, w, k, stride, relu, r1, r2, up, out_nchw = case
+    x, wt, scale, shift, res1, res2 = _make(case)
+    d = torch.float64
+    want = _ref_conv(x.to(d), wt.to(d), scale.to(d), shift.to(d), stride, relu, None if res1 is None else res1.to(d),
+                     None if res2 is None else res2.to(d), up)
+    nhwc = lambda t: None if t is None else t.permute(0, 2, 3, 1).contiguous().to(dev)
+    got = ops.fused_conv_p2(nhwc(x), wt.to(dev), scale.to(dev), shift.to(dev), stride=stride, relu=relu, res1=nhwc(res1), res2=nhwc(res2),
+                            up=up, out_nchw=out_nchw)
+    got = got.cpu() if out_nchw else got.permute(0, 3, 1, 2).cpu()
+    np.testing.assert_allclose(got.numpy(), want.float().numpy(), rtol=1e-4, atol=2e-5)
+    rms = (got.double() - want).pow(2).mean().sqrt().item()
+    if not out_nchw:
+        # every producer keeps the exact per-image max |x| of the fp32 values it then stored as (h, l) pairs
+        kept = ops.fused_conv_p2.last.kept_amax().cpu()
+        assert torch.allclose(kept, got.abs().amax(dim=(1, 2, 3)), rtol=2.0**-21, atol=0)
+    if cin % 32 == 0 and not out_nchw:
+        # the bound that makes this a legitimate fp32 path: not less accurate than the EXACT-fp32 MFMA chain
+        # (measured: rms 0.62 - 0.85 of it -- the inputs arrive already rounded to 22 bits, the chain's roundings dominate)
+        y = ops.fused_conv(nhwc(x), wt.to(dev), scale.to(dev), shift.to(dev), stride=stride, relu=relu, res1=nhwc(res1), res2=nhwc(res2),
+                           up=up, algo=ops.ALGO_MFMA).permute(0, 3, 1, 2).cpu()
+        rms32 = (y.double() - want).pow(2).mean().sqrt().item()
+        assert rms <= 1.25 * rms32 + 1e-8, (rms, rms32)
+
+
+@pytest.mark.parametrize("shape", [(3, 32, 64, 64), (2, 64, 32, 32), (2, 32, 21, 37), (1, 64, 9, 16), (5, 32, 8, 16), (2, 64, 24, 40), (2, 32, 96, 72)],
+                         ids=lambda s: "n%d_c%d_%dx%d" % s)
+def test_p2_basic_block_vs_float64(dev, shape):
+    """MVAL_OP_BLOCK over P2 activations (hrnet.py:19-52 in one launch) against float64, against the same block as two
+    P2 conv launches (not less accurate), and image 0 alone gives the same bits (per-image scales, fixed tiling)."""
+    from multi_view_active_learning_amd import ops
+
+    n, c, h, w = shape
+    rng = np.random.default_rng(7 + h)
+    x = torch.from_numpy(np.maximum(rng.standard_normal((n, c, h, w)), 0).astype(np.float32) * 1.5)
+    ws = [torch.from_numpy((rng.standard_normal((c, c, 3, 3)) * np.sqrt(2.0 / (c * 9))).astype(np.float32)) for _ in range(2)]
+    sc = [torch.from_numpy(rng.uniform(0.5, 1.5, c).astype(np.float32)) for _ in range(2)]
+    sh = [torch.from_numpy(rng.standard_normal(c).astype(np.float32) * 0.1) for _ in range(2)]
+    d = torch.float64
+    mid = _ref_conv(x.to(d), ws[0].to(d), sc[0].to(d), sh[0].to(d), 1, True, None, None, 0)
+    want = _ref_conv(mid, ws[1].to(d), sc[1].to(d), sh[1].to(d), 1, True, x.to(d), None, 0)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    args = [t.to(dev) for t in (ws[0], sc[0], sh[0], ws[1], sc[1], sh[1])]
+    got = ops.fused_basic_block_p2(xd, *args)
+    kept = ops.fused_basic_block_p2.last.kept_amax().cpu()
+    got = got.permute(0, 3, 1, 2).cpu()
+    np.testing.assert_allclose(got.numpy(), want.float().numpy(), rtol=1e-4, atol=2e-5)
+    assert torch.allclose(kept, got.abs().amax(dim=(1, 2, 3)), rtol=2.0**-21, atol=0)
+    m1 = ops.fused_conv_p2(xd, args[0], args[1], args[2], relu=True)
+    two = ops.fused_conv_p2(m1, args[3], args[4], args[5], relu=True, res1=xd).permute(0, 3, 1, 2).cpu()
+    rms = lambda y: (y.double() - want).pow(2).mean().sqrt().item()
+    assert rms(got) <= 1.25 * rms(two) + 1e-8, (rms(got), rms(two))
+    alone = ops.fused_basic_block_p2(xd[:1].contiguous(), *args).permute(0, 3, 1, 2).cpu()
+    assert torch.equal(alone[0], got[0])
+
+
+def test_p2_format(dev):
+    """The planes hold h = RNE_fp16(x 2^s), l = RNE_fp16(x 2^s - h) with 2^s a power of two that puts the image's bound in
+    [2^13, 2^14): (h + l) 2^-s reproduces x to 2^-22 relative (or 2^-25 of the scaled unit for tiny values), the row keeps
+    the exact maximum and 2^-s; images are scaled independently."""
+    from multi_view_active_learning_amd import ops
+    from multi_view_active_learning_amd.engine import AMAX_ROW
+
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((3, 16, 24, 40)).astype(np.float32)
+    x[1] *= 1000.0
+    x[2] *= 1e-3
+    xt = torch.from_numpy(x).to(dev)
+    planes, rows = ops.to_p2(xt)
+    rows = rows.reshape(3, AMAX_ROW)
+    inv = rows[:, AMAX_ROW - 1].view(torch.float32).cpu().numpy()
+    amax = rows[:, 0].view(torch.float32).cpu().numpy()
+    np.testing.assert_array_equal(amax, np.abs(x).reshape(3, -1).max(1))
+    for i in range(3):
+        m, e = np.frexp(inv[i])
+        assert m == 0.5, "the scale is a power of two"
+        assert 2.0**13 <= amax[i] / inv[i] < 2.0**14
+    back = ops.from_p2(planes, rows.reshape(-1), 3, 16, 24, 40).cpu().numpy()
+    err = np.abs(back - x)
+    assert np.all(err <= np.maximum(np.abs(x) * 2.0**-22, inv[:, None, None, None] * 2.0**-25))
+    h = planes.view(torch.float16).reshape(3, 2, 5, 16, 24, 8)[:, 0].float().cpu().numpy()  # [n][c8][H][W][8] with C = 40
+    assert np.isfinite(h).all() and np.abs(h).max() < 2.0**14
+
+
+def test_p2_bound_holds(dev):
+    """The output scale comes from a bound computed BEFORE the image's maximum exists: A max|x| + B + max|r1| + max|r2|.
+    Adversarial case: all-positive weights and inputs (no cancellation: the conv reaches its L1 bound)."""
+    from multi_view_active_learning_amd import ops
+    from multi_view_active_learning_amd.engine import AMAX_ROW
+
+    n, c, h, w = 2, 64, 16, 16
+    x = torch.full((n, h, w, c), 3.0, device=dev)
+    wt = torch.full((c, c, 3, 3), 0.25, device=dev)
+    one, sh = torch.full((c,), 2.0, device=dev), torch.full((c,), 5.0, device=dev)
+    res = torch.full((n, h, w, c), 7.0, device=dev)
+    y = ops.fused_conv_p2(x, wt, one, sh, relu=True, res1=res).cpu()
+    want = 3.0 * 0.25 * 9 * 64 * 2.0 + 5.0 + 7.0  # interior pixels: every tap inside the image
+    assert float(y.max()) == pytest.approx(want, rel=1e-6)
+    c_ = ops.fused_conv_p2.last
+    planes = c_.arena[c_.out_off : c_.out_off + y.numel()].view(torch.float16).float()
+    assert torch.isfinite(planes).all()
+    inv = c_.out_rows()[:, AMAX_ROW - 1].view(torch.float32).cpu()
+    assert float((want / inv).max()) < 2.0**14, "the bound put the true maximum below the top of the fp16 range"
+
+
+def test_p2_results_do_not_depend_on_the_batch(dev):
+    from multi_view_active_learning_amd import ops
+
+    case = (4, 64, 64, 32, 32, 3, 1, True, True, False, 0, False)
+    x, wt, scale, shift, res1, _ = _make(case)
+    nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().to(dev)
+    run = lambda xs, rs: ops.fused_conv_p2(nhwc(xs), wt.to(dev), scale.to(dev), shift.to(dev), relu=True, res1=nhwc(rs)).cpu()
+    whole, again = run(x, res1), run(x, res1)
+    assert torch.equal(whole, again), "deterministic (no atomics on the data path, fixed tiling)"
+    for i in (0, 3):
+        assert torch.equal(run(x[i : i + 1], res1[i : i + 1])[0], whole[i])
+
+
+def _load(c, dev):
+    m = cases.product_model(c)
+    sd = {k: torch.from_numpy(v) for k, v in cases.model_state_dict(c).items()}
+    m.load_state_dict(sd, strict=True)
+    return m.to(dev).eval(), sd
+
+
+def test_p2_plan_structure(dev, monkeypatch):
+    """HRNet plans run on P2 activations end to end (stem -> format change -> P2 ops -> fp32 heat-maps); PoseResNet
+    (max-pool, transposed convs) keeps the h2 kernels -- all or nothing per plan."""
+    from multi_view_active_learning_amd import engine
+
+    monkeypatch.setenv("MVAL_CONV", "p2")
+    c = cases.model_cases()["w32"]  # (256 x 256; on 64 x 64 inputs the deep branches' maps fall below the P2 tiles: h2 plan)
+    m, _ = _load(c, dev)
+    x = torch.from_numpy(cases.model_input(c)).to(dev)
+    with torch.no_grad():
+        m(x)
+    plan = engine._plan_for(m, x)
+    assert plan.p2
+    kinds = [o.kind for o in plan.ops]
+    assert kinds[0] == engine.OP_CONV and plan.ops[0].algo == engine.ALGO_DIRECT and kinds[1] == engine.OP_TO_P2
+    assert all(o.algo == engine.ALGO_MFMA_P2 for o in plan.ops[2:])
+    r = cases.model_cases()["r50"]
+    mr, _ = _load(r, dev)
+    xr = torch.from_numpy(cases.model_input(r)).to(dev)
+    with torch.no_grad():
+        mr(xr)
+    assert not engine._plan_for(mr, xr).p2
+
+
+def test_p2_argmax_census_vs_exact_fp32(dev, monkeypatch):
+    """BASELINE config C2 decode parity over 256 frames x 4 views: the P2 plan against the exact-fp32 MFMA plan
+    (MVAL_CONV=fp32).  Counts the (view, joint) maps whose arg-max differs and the top-2 margins involved: no map whose
+    margin exceeds twice the heat-map tolerance may flip."""
+    from multi_view_active_learning_amd import synth
+
+    c = dict(arch="hrnet_w32", seed=0, n=128, h=256, w=256, j=19)
+    m, _ = _load(c, dev)
+    frames, v = 256, 4
+    flips, flips_above, maps, worst_err, min_margin_agree = 0, 0, 0, 0.0, float("inf")
+    with torch.no_grad():
+        for b in range(frames * v // 128):
+            x = torch.from_numpy(synth.images(500 + b, 32, v, 256, 256)).reshape(128, 3, 256, 256).to(dev)
+            monkeypatch.setenv("MVAL_CONV", "p2")
+            y = m(x)
+            monkeypatch.setenv("MVAL_CONV", "fp32")
+            z = m(x)
+            tol = 2e-4 * float(z.abs().max())
+            worst_err = max(worst_err, float((y - z).abs().max()))
+            fy, fz = y.reshape(128, 19, -1), z.reshape(128, 19, -1)
+            top2 = torch.topk(fz, 2, dim=-1).values
+            margin = top2[..., 0] - top2[..., 1]
+            differ = fy.argmax(-1) != fz.argmax(-1)
+            flips += int(differ.sum())
+            flips_above += int((differ & (margin > 2 * tol)).sum())
+            maps += differ.numel()
+            if (~differ).any():
+                min_margin_agree = min(min_margin_agree, float(margin[~differ].min()))
+            assert worst_err <= tol, (worst_err, tol)
+    print(f"\narg-max census, P2 vs exact-fp32 plans: {maps} maps, {flips} flips ({flips_above} above margin 2*tol), "
+          f"max |heat-map difference| {worst_err:.2e}, smallest top-2 margin among agreeing maps {min_margin_agree:.2e}")
+    assert flips_above == 0
