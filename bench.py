@@ -16,14 +16,17 @@ One step = one pass of the hot path over one batch.  Frames are independent, so 
 frames with NO data-path collective (weak scaling: per-GPU work is fixed).
 
 Prints ONE JSON line on rank 0 with the driver's contract fields plus
-  roofline     dominant kernel (by time) = the fused 3x3 stride-1 conv on the matrix cores
-               (conv_bf3_kernel<3, 1, ...>): algorithmic conv FLOPs of its launches in one step / time
-               spent in them (hipEvents around every launch on the launch stream,
-               mval_net_forward_timed) against its peak (bf16x3-split: 2500 / 6 = 416.7 TFLOP/s);
-               the other kernels of the step under "other_kernels", each against its own bound
-               (stride-2 split conv and exact-fp32 MFMA conv: matrix-core peaks; 1x1 channel GEMMs
-               and the stem: algorithmic bytes / time against HBM); HBM bytes per launch from the
-               committed rocprofv3 PMC passes;
+  roofline     dominant kernel family (by time) = the fused 3x3 stride-1 convs on the fp16 matrix cores
+               (conv_p2_kernel<3, 1, ...> and the fused BasicBlocks conv_block_p2_kernel<C>; MVAL_CONV=h2 / bf3 / fp32
+               select round 2's kernel families): algorithmic conv FLOPs of its launches in one step / time spent in them
+               (hipEvents around every launch on the launch stream, mval_net_forward_timed) against the peak of the
+               split in use (three fp16 MFMA products per fp32 product: 2500 / 3 = 833 TFLOP/s); the other kernels of
+               the step under "other_kernels", each against its own bound (stride-2 convs: the same matrix-core peak;
+               1x1 channel GEMMs and the stem: algorithmic bytes / time against HBM); HBM bytes per launch from the
+               committed rocprofv3 PMC passes (profiles/r03);
+  exact_modes  ms per step of the same workload with the bit-faithful conv kernels (MVAL_CONV=bf3: exact 3-way bf16
+               split, six MFMA products; fp32: v_mfma_f32_16x16x4_f32) and with round 2's fp32-activation fp16 split
+               (h2), 20 steps each, outside the headline's timed region;
   cpu_baseline the CPU oracle (stock torch fp32 HRNet-W32 + numpy RANSAC-DLT restatement,
                oracle/) timed on the host on a bounded sample of the same workload; its "parity_sample" compares
                the HIP path with the oracle on that sample's first frames (the metric's "MPJPE vs ref": heat-map max
@@ -121,7 +124,7 @@ def cpu_baseline(wl, sd_np, seconds_target=20.0):
             torch.set_num_threads(nt)
             fwd(imgs[:v])
             t0 = time.perf_counter()
-            fwd(imgs[: 2 * v])
+            fwd(imgs)  # (the call size of the timed loop below: the two figures are comparable)
             tried[nt] = time.perf_counter() - t0
         best = min(tried, key=tried.get)
         torch.set_num_threads(best)
@@ -142,7 +145,9 @@ def cpu_baseline(wl, sd_np, seconds_target=20.0):
         sample=f"{done} frames x {v} views ({done * v} images) of the same workload, {el:.1f} s, "
                f"stock torch fp32 {wl['arch']} + numpy RANSAC-DLT (oracle/), {torch.get_num_threads()} threads "
                f"(best of {sorted(tried)}; {frames_per_call * v} images per call)",
-        threads_tried={str(k): round(2 * v / t, 2) for k, t in tried.items()},
+        threads_tried={str(k): round(frames_per_call * v / t, 2) for k, t in tried.items()},
+        threads_tried_note="frames*views/s of the network alone per thread count, same images per call as `value` (which adds the "
+                           "numpy RANSAC-DLT)",
     )
 
 
@@ -198,10 +203,12 @@ def train_rooflines(model, step, frames, v, mode):
     ms = (C.c_float * 6)()
     reps = 3
     _lib._check(lib.mval_train_timing(ms), "mval_train_timing")
-    for _ in range(reps):
-        step()
-    torch.cuda.synchronize()
-    _lib._check(lib.mval_train_timing(None), "mval_train_timing")
+    try:  # (the library holds a pointer into `ms` while armed)
+        for _ in range(reps):
+            step()
+        torch.cuda.synchronize()
+    finally:
+        _lib._check(lib.mval_train_timing(None), "mval_train_timing")
     t = [float(x) * 1e-3 / reps for x in ms]
     n = frames * v
     fl_fwd = sum(float(lib.mval_op_flops(C.byref(o.op), C.c_int(n))) for o in plan.ops)
@@ -306,6 +313,10 @@ def main():
     ap.add_argument("--pool", type=int, default=None,
                     help="c4 / c5: frames of the fixed pool sharded over the ranks (BASELINE: 50000); one step = one whole pass")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rccl-world-1", action="store_true",
+                    help="with --gpus 1: initialise the nccl (= RCCL) process group at world size 1 and keep the pool passes' "
+                         "collectives on (MVAL_DIST_NO_SHORTCUT=1): the single-GPU rehearsal of the multi-GPU pass")
+    ap.add_argument("--no-exact-modes", action="store_true", help="skip the companion timings of the other conv kernel families")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     args = ap.parse_args()
     pool_pass = args.pool is not None or WORKLOADS[args.workload].get("pool") is not None
@@ -338,8 +349,13 @@ def main():
                  "(or without torchrun: bench.py starts its own ranks)")
     if torch.cuda.device_count() <= local_rank:
         sys.exit(f"bench.py: rank {rank} needs device {local_rank}, this node has {torch.cuda.device_count()}")
-    if world > 1:
+    if world > 1 or args.rccl_world_1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29640")
+        if args.rccl_world_1:
+            os.environ["MVAL_DIST_NO_SHORTCUT"] = "1"
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -444,15 +460,29 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    # The timed region is K steps, repeated until it is at least ~2 s long (the driver's --steps 20 is 0.25 s of this
+    # workload: clocks and caches have not settled); every repeat runs exactly K steps, all of them are timed.
+    repeats = 1
     with torch.set_grad_enabled(train):
         for _ in range(max(args.warmup, 1)):
             r = step()
         sync()
+        if not wl.get("pool"):
+            t0 = time.perf_counter()
+            r = step()
+            sync()
+            est = max(time.perf_counter() - t0, 1e-4) * args.steps
+            repeats = int(min(64, max(1, np.ceil(2.0 / est))))
+            if world > 1:  # every rank runs the same number of steps
+                t = torch.tensor([repeats], dtype=torch.int64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                repeats = int(t.item())
+        sync()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        for _ in range(args.steps * repeats):
             r = step()
         sync()
-        el = time.perf_counter() - t0
+        el = (time.perf_counter() - t0) / repeats
     if world > 1:
         t = torch.tensor([el], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -519,7 +549,9 @@ def main():
             peak = PEAK_BF16_MFMA_TFLOPS / SPLIT_PRODUCTS[pl]
             note = f"dense 16-bit MFMA peak 2500 TFLOP/s / {SPLIT_PRODUCTS[pl]} MFMA products per algorithmic product"
             fams += [
-                family(m_ & k3 & s1, ("conv_p2_kernel<3, 1, ...>" if pl == "p2" else f"conv_split_kernel<{2 if pl == 'h2' else 3}, 3, 1, ...>")
+                family(m_ & k3 & s1, ("conv_p2_kernel<3, 1, ...>" + (" + conv_block_p2_kernel<C> (whole BasicBlocks: two 3x3 convs, BNs, residual, "
+                                                                      "ReLUs in one launch)" if any(o.kind == 3 for o in plan.ops) else "")
+                                      if pl == "p2" else f"conv_split_kernel<{2 if pl == 'h2' else 3}, 3, 1, ...>")
                                      + (" + conv_block_kernel<C> (whole BasicBlocks: two 3x3 convs, BNs, residual, ReLUs in one launch)"
                                         if any(o.kind == 3 for o in plan.ops) and pl == "h2" else "")
                                      + f" (fused 3x3 stride-1 conv+BN+residual+ReLU; {what}, fp32 accumulate)", peak, note),
@@ -538,10 +570,11 @@ def main():
         # HBM bytes per launch of the dominant kernel: PMC counters cannot be read from inside
         # the process, so this is the committed rocprofv3 measurement of THIS command (separate
         # --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE x2 gfx950 correction; tools/pmc_summary.py)
-        summary = os.path.join("profiles", "r02", f"bench_c2_{_conv_mode()}_summary.json")
+        summary = os.path.join("profiles", "r03", f"bench_c2_{_conv_mode()}_summary.json")
         try:
             with open(os.path.join(ROOT, summary)) as f:
-                pre = (roof["kernel"].split(" ...>")[0],) + (("conv_block_kernel",) if "conv_block_kernel" in roof["kernel"] else ())
+                pre = (roof["kernel"].split(" ...>")[0],) + (("conv_block_kernel",) if "conv_block_kernel" in roof["kernel"] else ()) + \
+                      (("conv_block_p2_kernel",) if "conv_block_p2_kernel" in roof["kernel"] else ())
                 rows = [r for r in json.load(f)["hbm_traffic_by_instantiation"] if r["kernel"].startswith(pre)]
             if args.workload == "c2" and rows:
                 nl = sum(r["launches"] for r in rows)
@@ -575,6 +608,7 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(el / args.steps * 1e3, 3),
+            "timed_repeats": repeats,  # the K-step region was timed this many times back to back (>= 2 s in all); value is per K
             "higher_is_better": True,
             "scaling": "strong" if wl.get("pool") else "weak",
             "vs_baseline": None,
@@ -594,6 +628,27 @@ def main():
             "roofline": roof,
             "parity_unpinned": PARITY_UNPINNED,
         }
+        if not train and not wl.get("pool") and world == 1 and not args.no_exact_modes:
+            # the same step with the other conv kernel families (plans are cached per mode), outside the timed region
+            exact = {}
+            headline_mode = _conv_mode()
+            for mode_ in ("h2", "bf3", "fp32"):
+                if mode_ == headline_mode:
+                    continue
+                os.environ["MVAL_CONV"] = mode_
+                with torch.no_grad():
+                    for _ in range(3):
+                        step()
+                    sync()
+                    t0 = time.perf_counter()
+                    for _ in range(20):
+                        step()
+                    sync()
+                exact[mode_] = round((time.perf_counter() - t0) / 20 * 1e3, 3)
+            os.environ["MVAL_CONV"] = headline_mode
+            exact["note"] = ("ms per step; h2 = round 2's kernels (fp32 NHWC activations, split while staging), bf3 = exact 3-way "
+                             "bf16 split (six MFMA products), fp32 = exact-fp32 MFMA (v_mfma_f32_16x16x4_f32) everywhere")
+            out["exact_modes"] = exact
         if not args.no_cpu_baseline and train and world == 1:
             out["cpu_baseline"] = cpu_baseline_train(wl, sd_np, args.cpu_seconds)
         if not args.no_cpu_baseline and not train and world == 1:  # rank 0 at N = 1 only
@@ -614,7 +669,7 @@ def main():
             }
             out["cpu_baseline"] = cpu
         print(json.dumps(out))
-    if world > 1:
+    if world > 1 or args.rccl_world_1:
         dist.barrier()
         dist.destroy_process_group()
 

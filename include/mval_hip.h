@@ -264,6 +264,7 @@ int mval_bn_fold(const float* gamma, const float* beta, const float* mean, const
 /* Writes the max-magnitude rows (see mval_op; [n_images][MVAL_AMAX_ROW] dwords) of a tensor of n_images images of
  * per_image consecutive floats each: for tensors that did not come out of an op of the plan. */
 #define MVAL_AMAX_ROW 4096
+#define MVAL_P2_ROW 512 /* dwords per (tensor, image) row of a P2 activation: 256 partial-maximum slots ... 2^-s in the last one */
 int mval_amax(const float* x, int64_t per_image, int n_images, uint32_t* rows, void* stream);
 /* fp32 NHWC [n][H][W][C] (C % 8 == 0) whose rows_in ([count, partials ...], as every NHWC producer keeps them) hold
  * its per-image max |x| -> P2 planes (csrc/conv_p2.h) and their rows ([P2 partial slots ... 2^-s]; zero-initialised

@@ -273,7 +273,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
     float m_mul, m_inv, out_mul, out_inv;
     p2_scale_of(mid_bound, m_mul, m_inv);
     p2_scale_of(b2a * mid_bound + b2b + x_amax, out_mul, out_inv);
-    if (oy0 == 0 && ox0 == 0 && tid == 0) a.out_row[(int64_t)n * MVAL_AMAX_ROW + P2_INV_SLOT] = __float_as_uint(out_inv);
+    if (oy0 == 0 && ox0 == 0 && tid == 0) a.out_row[(int64_t)n * P2_ROW + P2_INV_SLOT] = __float_as_uint(out_inv);
 
     if (OVERLAY) __syncthreads();  // every wave is done with X: M may overwrite it
 
@@ -396,7 +396,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
         if (atomicAdd(&wgred[1], 1u) == 3u) {
           const unsigned m = atomicExch(&wgred[0], 0u);
           wgred[1] = 0u;
-          p2_slot_put(a.out_row + (int64_t)n * MVAL_AMAX_ROW, (oy0 / TH) * a.tiles_x + ox0 / TW, tiles_img, m);
+          p2_slot_put(a.out_row + (int64_t)n * P2_ROW, (oy0 / TH) * a.tiles_x + ox0 / TW, tiles_img, m);
         }
       }
     }
@@ -459,7 +459,7 @@ static int launch_block_p2(P2BlockArgs a, hipStream_t s) {
   }
   a.wgs_x = wgs;
   if (getenv("MVAL_P2_DEBUG")) fprintf(stderr, "block_p2<%d> N %d %dx%d tiles %d per_cu %d wgs %d smem %zu\n", C, a.N, a.H, a.W, a.tiles_total, per_cu, wgs, smem);
-  if (tiles_img > P2_SLOTS) mval_launch_zero_rows(a.out_row, (int64_t)a.N * MVAL_AMAX_ROW, s);
+  if (tiles_img > P2_SLOTS) mval_launch_zero_rows(a.out_row, (int64_t)a.N * P2_ROW, s);
   hipLaunchKernelGGL((conv_block_p2_kernel<C>), dim3((unsigned)wgs), dim3(256), smem, s, a);
   return 0;
 }

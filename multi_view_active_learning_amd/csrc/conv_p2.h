@@ -4,7 +4,7 @@
 //   tensor of N images, C channels (C % 8 == 0), H x W:
 //       halves  [n][plane p = 0 (h), 1 (l)][C / 8][H][W][8]          4 bytes per element, like fp32
 //       x[n][c][y][x] = (h + l) * 2^-s[n]         h = RNE_fp16(x * 2^s), l = RNE_fp16(x * 2^s - h)
-//   row of the tensor's image n (MVAL_AMAX_ROW dwords):
+//   row of the tensor's image n (P2_ROW = 512 dwords; the fp32-activation kernels' rows are MVAL_AMAX_ROW = 4096):
 //       row[0 .. P2_SLOTS - 1] = partial max |x| (float bits; one slot per producing workgroup, unused slots stay 0:
 //                                the rows are zeroed once when the plan is built and a slot only ever belongs to one
 //                                workgroup, so a consumer reads a FIXED number of slots -- no count, no dependent load),
@@ -26,8 +26,9 @@
 #pragma once
 #include "conv_common.h"
 
-#define P2_INV_SLOT (MVAL_AMAX_ROW - 1)
+#define P2_ROW 512    // dwords per (tensor, image) row
 #define P2_SLOTS 256  // partial maxima per image: 4 per lane of the reading wave
+#define P2_INV_SLOT (P2_ROW - 1)
 
 typedef _Float16 p2_f16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 p2_f16x8 __attribute__((ext_vector_type(8)));
@@ -64,7 +65,7 @@ struct P2RowRegs {
   unsigned inv;
 };
 __device__ __forceinline__ void p2_row_request(const unsigned* rows, int n, P2RowRegs& r) {
-  const unsigned* row = rows + (int64_t)n * MVAL_AMAX_ROW;
+  const unsigned* row = rows + (int64_t)n * P2_ROW;
 #pragma unroll
   for (int i = 0; i < P2_SLOTS / 64; i++) r.v[i] = row[i * 64 + (threadIdx.x & 63)];
   r.inv = row[P2_INV_SLOT];

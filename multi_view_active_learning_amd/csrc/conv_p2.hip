@@ -444,7 +444,7 @@ __global__ __launch_bounds__(64 * WN * WM) __attribute__((amdgpu_waves_per_eu(P2
         }
         p2_scale_of(bound, out_mul, out_inv);
         if (oy0 == 0 && ox0 == 0 && blockIdx.y == 0 && tid == 0)
-          a.out_row[(int64_t)n * MVAL_AMAX_ROW + P2_INV_SLOT] = __float_as_uint(out_inv);
+          a.out_row[(int64_t)n * P2_ROW + P2_INV_SLOT] = __float_as_uint(out_inv);
       }
       const float unscale = in_inv * w_unscale;
       u32x4 R2[EPI == 0 ? MS : 1][EPI == 0 ? NT : 1];  // a second residual (fuse layers) is requested here: its registers are the weight fragments'
@@ -569,7 +569,7 @@ __global__ __launch_bounds__(64 * WN * WM) __attribute__((amdgpu_waves_per_eu(P2
           const unsigned m = atomicExch(&wgred[0], 0u);
           wgred[1] = 0u;
           const int timg = (oy0 / TH) * a.tiles_x + ox0 / TW;
-          p2_slot_put(a.out_row + (int64_t)n * MVAL_AMAX_ROW, timg * (int)gridDim.y + (int)blockIdx.y, tiles_img * (int)gridDim.y, m);
+          p2_slot_put(a.out_row + (int64_t)n * P2_ROW, timg * (int)gridDim.y + (int)blockIdx.y, tiles_img * (int)gridDim.y, m);
         }
       }
     }
@@ -642,7 +642,7 @@ static int launch_p2e(P2Args a, hipStream_t s) {
   a.wgs_x = wgs;
   dim3 grid((unsigned)wgs, groups);
   if (!a.out_f32 && (int64_t)a.amax_tiles * groups > P2_SLOTS)
-    mval_launch_zero_rows(a.out_row, (int64_t)a.N * MVAL_AMAX_ROW, s);  // (the kernel rewrites the scale slots)
+    mval_launch_zero_rows(a.out_row, (int64_t)a.N * P2_ROW, s);  // (the kernel rewrites the scale slots)
   hipLaunchKernelGGL((conv_p2_kernel<KS, S, G, WN, WM, NT, MS, TW, RS, EPI>), grid, dim3(NTH), smem, s, a);
   return 0;
 }
@@ -747,7 +747,7 @@ __global__ __launch_bounds__(256) void nhwc_to_p2_kernel(const float* __restrict
   float mul, inv;
   p2_scale_of(__uint_as_float(amax), mul, inv);
   if (blockIdx.x == 0 && threadIdx.x == 0) {
-    unsigned* row = rows_out + (int64_t)n * MVAL_AMAX_ROW;
+    unsigned* row = rows_out + (int64_t)n * P2_ROW;
     row[0] = amax;  // (the other partial slots stay zero)
     row[P2_INV_SLOT] = __float_as_uint(inv);
   }
@@ -768,7 +768,7 @@ __global__ __launch_bounds__(256) void nhwc_to_p2_kernel(const float* __restrict
 __global__ __launch_bounds__(256) void p2_to_nhwc_kernel(const _Float16* __restrict__ x, const unsigned* rows, float* __restrict__ out,
                                                        int HW, int C8) {
   const int n = blockIdx.y;
-  const float inv = __uint_as_float(rows[(int64_t)n * MVAL_AMAX_ROW + P2_INV_SLOT]);
+  const float inv = __uint_as_float(rows[(int64_t)n * P2_ROW + P2_INV_SLOT]);
   const int64_t total = (int64_t)HW * C8;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
     const int c8 = (int)(i / HW), p = (int)(i - (int64_t)c8 * HW);

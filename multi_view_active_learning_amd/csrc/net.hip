@@ -6,6 +6,7 @@
 // also the on-device cross-check for the MFMA kernels (MVAL_FORCE_DIRECT=1).
 #include <stdlib.h>
 
+#include <mutex>
 #include <vector>
 
 #include "conv_common.h"
@@ -529,10 +530,16 @@ extern "C" void mval_net_destroy(void* net) {
   delete reinterpret_cast<MvalNet*>(net);
 }
 
+// The side streams and the fork / join events are per DEVICE and shared by every plan: creation is guarded, and ONE forward
+// (or training pass) may be in flight per device at a time -- two host threads driving plans on the same GPU would record
+// and wait on the same events.  (One process per GPU, one stream of work per process: the package's execution model.)
+static std::mutex g_lanes_mutex;
+
 MvalLanes* mval_device_lanes() {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MVAL_MAX_DEVICES) return nullptr;
   MvalLanes* L = &g_lanes[dev];
+  std::lock_guard<std::mutex> lock(g_lanes_mutex);
   if (L->ready) return L;
   if (hipEventCreateWithFlags(&L->fork_ev, hipEventDisableTiming) != hipSuccess) return nullptr;
   for (int l = 1; l < MVAL_MAX_LANES; l++) {

@@ -65,16 +65,19 @@ struct ScoreDecodeArgs {
 template <int KIND, bool DECODE>
 __global__ __launch_bounds__(SC_THREADS) void score_maps_kernel(const float* __restrict__ hm, float* __restrict__ stat,
                                                                 int32_t* __restrict__ n_peaks, int hh, int wh,
-                                                                ScoreDecodeArgs d) {
+                                                                ScoreDecodeArgs d, int cap, int rescue) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const int ld = wh + 1;
   float* tile = reinterpret_cast<float*>(smem_raw);                      // hh * ld
   // (the HP kernel has no candidate list: its workgroups need only the tile, so twice as many fit a CU)
-  float* cval = tile + (((hh * ld) + 3) & ~3);                           // SC_MAX_PEAKS
-  int* cidx = reinterpret_cast<int*>(cval + (KIND == MVAL_SCORE_HP ? 0 : SC_MAX_PEAKS));  // SC_MAX_PEAKS
-  ScoreSmem* sm = reinterpret_cast<ScoreSmem*>(cidx + (KIND == MVAL_SCORE_HP ? 0 : SC_MAX_PEAKS));
+  float* cval = tile + (((hh * ld) + 3) & ~3);                           // cap
+  int* cidx = reinterpret_cast<int*>(cval + (KIND == MVAL_SCORE_HP ? 0 : cap));  // cap
+  ScoreSmem* sm = reinterpret_cast<ScoreSmem*>(cidx + (KIND == MVAL_SCORE_HP ? 0 : cap));
   const int tid = threadIdx.x;
   const int64_t map = blockIdx.x;
+  // second pass (candidate list as large as the map's interior, one workgroup per CU): only the maps whose list
+  // overflowed SC_MAX_PEAKS in the first pass -- wide plateaus, which network outputs do not have -- are redone
+  if (rescue && n_peaks[map] != -1) return;
   const float* p = hm + map * (int64_t)hh * wh;
   const int npix = hh * wh;
 
@@ -186,7 +189,7 @@ __global__ __launch_bounds__(SC_THREADS) void score_maps_kernel(const float* __r
         for (int dx = -2; dx <= 2; dx++) is_max = is_max && (tile[(y + dy) * ld + x + dx] <= v);
       if (is_max) {
         int slot = atomicAdd(&sm->n_cand, 1);
-        if (slot < SC_MAX_PEAKS) {
+        if (slot < cap) {
           cval[slot] = v;
           cidx[slot] = y * wh + x;
         } else {
@@ -279,15 +282,29 @@ __global__ __launch_bounds__(SC_THREADS) void score_maps_kernel(const float* __r
 template <bool DECODE>
 static int launch_score(int kind, const float* heatmaps, float* stat, int32_t* n_peaks, int64_t n_maps, int hh, int wh,
                         const ScoreDecodeArgs& d, hipStream_t s) {
-  size_t smem = (size_t)((hh * (wh + 1) + 3) & ~3) * 4 + (kind == MVAL_SCORE_HP ? 0 : SC_MAX_PEAKS * 8) + sizeof(ScoreSmem) + 16;
-  if (smem > 160 * 1024) return 1;
+  const size_t tile_b = (size_t)((hh * (wh + 1) + 3) & ~3) * 4, fixed_b = sizeof(ScoreSmem) + 16;
   dim3 grid((unsigned)n_maps), block(SC_THREADS);
-  if (kind == MVAL_SCORE_HP)
-    hipLaunchKernelGGL((score_maps_kernel<MVAL_SCORE_HP, DECODE>), grid, block, smem, s, heatmaps, stat, n_peaks, hh, wh, d);
-  else if (kind == MVAL_SCORE_MPE)
-    hipLaunchKernelGGL((score_maps_kernel<MVAL_SCORE_MPE, DECODE>), grid, block, smem, s, heatmaps, stat, n_peaks, hh, wh, d);
-  else
-    hipLaunchKernelGGL((score_maps_kernel<MVAL_SCORE_BSB, DECODE>), grid, block, smem, s, heatmaps, stat, n_peaks, hh, wh, d);
+  // the candidate list never needs more than the interior (hh-4)(wh-4), rounded up to the sort's power of two
+  int full = 1;
+  while (full < (hh - 4) * (wh - 4)) full <<= 1;
+  for (int pass = 0; pass < 2; pass++) {
+    const int cap = pass == 0 ? (full < SC_MAX_PEAKS ? full : SC_MAX_PEAKS) : full;
+    if (pass == 1 && (kind == MVAL_SCORE_HP || full <= SC_MAX_PEAKS)) break;
+    const size_t smem = tile_b + (kind == MVAL_SCORE_HP ? 0 : (size_t)cap * 8) + fixed_b;
+    if (smem > 160 * 1024) return pass == 0 ? 1 : 0;  // (no room for the rescue: overflowed maps keep NaN / -1)
+    if (smem > 64 * 1024) {
+      const void* fn = kind == MVAL_SCORE_HP    ? (const void*)score_maps_kernel<MVAL_SCORE_HP, DECODE>
+                       : kind == MVAL_SCORE_MPE ? (const void*)score_maps_kernel<MVAL_SCORE_MPE, DECODE>
+                                                : (const void*)score_maps_kernel<MVAL_SCORE_BSB, DECODE>;
+      if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return pass == 0 ? 1 : 0;
+    }
+    if (kind == MVAL_SCORE_HP)
+      hipLaunchKernelGGL((score_maps_kernel<MVAL_SCORE_HP, DECODE>), grid, block, smem, s, heatmaps, stat, n_peaks, hh, wh, d, cap, pass);
+    else if (kind == MVAL_SCORE_MPE)
+      hipLaunchKernelGGL((score_maps_kernel<MVAL_SCORE_MPE, DECODE>), grid, block, smem, s, heatmaps, stat, n_peaks, hh, wh, d, cap, pass);
+    else
+      hipLaunchKernelGGL((score_maps_kernel<MVAL_SCORE_BSB, DECODE>), grid, block, smem, s, heatmaps, stat, n_peaks, hh, wh, d, cap, pass);
+  }
   return 0;
 }
 

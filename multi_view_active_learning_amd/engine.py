@@ -29,6 +29,7 @@ OP_CONV, OP_MAXPOOL, OP_DECONV, OP_BLOCK, OP_TO_P2 = 0, 1, 2, 3, 4
 ALGO_DIRECT, ALGO_MFMA, ALGO_MFMA_BF3, ALGO_MFMA_H2, ALGO_MFMA_P2 = 0, 1, 2, 3, 4
 PACK_HWIO, PACK_MFMA16, PACK_MFMA16_BF3, PACK_MFMA16_H2 = 0, 1, 2, 3
 AMAX_ROW = 4096
+P2_ROW = 512  # include/mval_hip.h: MVAL_P2_ROW (rows of P2 activations)
 _PACK_OF = {ALGO_DIRECT: PACK_HWIO, ALGO_MFMA: PACK_MFMA16, ALGO_MFMA_BF3: PACK_MFMA16_BF3, ALGO_MFMA_H2: PACK_MFMA16_H2,
             ALGO_MFMA_P2: PACK_MFMA16_H2}
 
@@ -176,7 +177,7 @@ class InferencePlan:
             for a in g.acts:
                 if a.id in dims and a.id not in (g.input, g.output):
                     row_of[a.id] = self._amax_top
-                    self._amax_top += n * AMAX_ROW
+                    self._amax_top += n * P2_ROW
         for i, op in enumerate(g.ops):
             hin, win, hout, wout = geo[i]
             in_nchw = g.acts[op.src].layout == "nchw"
@@ -257,6 +258,10 @@ class InferencePlan:
                     return False
                 continue
             if op.kind != "conv" or g.acts[op.src].layout == "nchw":
+                return False
+            # HRNet-W48's 48- / 96-channel branches (half-empty second K chunk, no fused P2 block yet) measured SLOWER on
+            # P2 than on the h2 kernels with their fused 48-channel block (C4: 26.3 vs 22.7 ms): such plans stay h2
+            if op.cin % 32 and os.environ.get("MVAL_P2") != "force":
                 return False
             m = MvalOp()
             m.kind, m.algo = OP_CONV, ALGO_MFMA_P2
@@ -536,7 +541,7 @@ def _max_images_per_launch(model, h, w):
         dims[op.dst] = (hout << op.up, wout << op.up)
         biggest = max(biggest, hin * win * op.cin, (hout << op.up) * (wout << op.up) * op.cout)
     # (P2 plans address their planes with byte offsets below 2^31: 2^29 elements)
-    p2_candidate = _conv_mode() == "p2" and all(op.kind == "conv" for op in g.ops)  # (HRNet; InferencePlan._p2_covers)
+    p2_candidate = _conv_mode() == "p2" and all(op.kind == "conv" and (op.src == g.input or op.cin % 32 == 0) for op in g.ops)  # (InferencePlan._p2_covers)
     limit = 2**29 if p2_candidate else 2**31
     return max(1, (limit - 1) // biggest)
 

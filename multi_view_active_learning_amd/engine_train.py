@@ -101,6 +101,9 @@ class TrainPlan:
         stat_top = 0
         self.stat_off = []
         gz_max, wsf_max = 0, 0
+        # a tensor's magnitude row is written by its producer's BatchNorm apply (or max-pool) only: a conv WITHOUT BatchNorm
+        # leaves none, so its consumers may not use the fp16 split (latent today, only final_layer lacks BN)
+        keeps_row = {op.dst for op in g.ops if op.bn or op.kind == "maxpool"}
         for i, op in enumerate(g.ops):
             hin, win, hout, wout = geo[i]
             in_nchw = g.acts[op.src].layout == "nchw"
@@ -117,7 +120,7 @@ class TrainPlan:
             if _mfma_ok(op, in_nchw) and lib.mval_op_mfma_supported(C.byref(m), C.c_int(n)):
                 m.algo = ALGO_MFMA
                 if bf3 and op.kind == "conv" and op.k in (1, 3) and (op.cin % 32 == 0 or op.cin == 48):
-                    for cand in ((ALGO_MFMA_H2, ALGO_MFMA_BF3) if (h2 and op.src != g.input) else (ALGO_MFMA_BF3,)):
+                    for cand in ((ALGO_MFMA_H2, ALGO_MFMA_BF3) if (h2 and op.src != g.input and op.src in keeps_row) else (ALGO_MFMA_BF3,)):
                         if lib.mval_op_algo_supported(C.byref(m), C.c_int(n), C.c_int(cand)):
                             m.algo = cand
                             break
@@ -457,6 +460,7 @@ class _SegFn(torch.autograd.Function):
         ctx.plan, ctx.k = plan, k
         if k == 0:
             plan._x = carry
+            plan._x_version = carry._version  # (an in-place edit of the input between forward and backward must not go unnoticed)
             plan._out = plan.forward(carry)
         ctx.generation = plan.generation
         if k == len(plan.segments) - 1:
@@ -468,17 +472,21 @@ class _SegFn(torch.autograd.Function):
         plan, k = ctx.plan, ctx.k
         if ctx.generation != plan.generation:
             raise _lib.MvalError(_STALE)
+        if plan._x is None or plan._x._version != plan._x_version:
+            raise _lib.MvalError("the network input was modified in place (or released) between the train-mode forward and backward()")
         if k == len(plan.segments) - 1:
             plan.backward_begin(plan._x, g.contiguous())
         grads = plan.backward_segment(k, plan._x)
         carry_grad = None if k == 0 else torch.zeros(1, dtype=torch.float32, device=plan.device)
+        if k == 0:  # the step is over: do not keep the batch's input / output alive for the life of the model
+            plan._x = plan._out = None
         return (carry_grad, None, None, *grads)
 
 
 def run_network_train(model, x):
     n, c, h, w = x.shape
     cache = model.__dict__.setdefault("_train_plans", {})
-    key = (n, h, w, x.device.index)
+    key = (n, h, w, x.device.index, _conv_mode())  # (the mode selects the plan's kernels and packings)
     plan = cache.get(key)
     if plan is None:
         cache.clear()  # one training geometry at a time: the arenas are large

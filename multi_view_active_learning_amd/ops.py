@@ -9,7 +9,7 @@ import torch
 
 from . import _lib
 from .engine import (ALGO_DIRECT, ALGO_MFMA, ALGO_MFMA_BF3, ALGO_MFMA_H2, OP_BLOCK, OP_CONV, OP_DECONV, OP_MAXPOOL, PACK_HWIO,
-                     PACK_MFMA16, PACK_MFMA16_BF3, AMAX_ROW, _PACK_OF, MvalOp, _align)
+                     PACK_MFMA16, PACK_MFMA16_BF3, AMAX_ROW, P2_ROW, _PACK_OF, MvalOp, _align)
 
 
 def pack_weights(weight, algo, transposed=False):
@@ -185,7 +185,7 @@ def to_p2(x_nhwc):
     n, h, w, c = x_nhwc.shape
     x = x_nhwc.contiguous()
     rows_in = torch.zeros(n * AMAX_ROW, dtype=torch.int32, device=x.device)
-    rows = torch.zeros(n * AMAX_ROW, dtype=torch.int32, device=x.device)
+    rows = torch.zeros(n * P2_ROW, dtype=torch.int32, device=x.device)
     planes = torch.empty(x.numel(), dtype=torch.float32, device=x.device)
     _lib._check(lib.mval_amax(_lib._p(x), C.c_int64(h * w * c), C.c_int(n), _lib._p(rows_in), _lib._stream()), "mval_amax")
     _lib._check(lib.mval_nhwc_to_p2(_lib._p(x), _lib._p(rows_in), _lib._p(planes), _lib._p(rows), C.c_int(n), C.c_int(h), C.c_int(w),
@@ -224,10 +224,10 @@ class P2Conv:
         top += _align(n * ho * wo * cout)
         row_off = top
         nrows = len(parts) + 1
-        self.arena = torch.zeros(top + _align(nrows * n * AMAX_ROW), dtype=torch.float32, device=dev)
+        self.arena = torch.zeros(top + _align(nrows * n * P2_ROW), dtype=torch.float32, device=dev)
         for i, (pl, rows) in enumerate(parts):
             self.arena[offs[i] : offs[i] + pl.numel()] = pl
-            self.arena[row_off + i * n * AMAX_ROW : row_off + (i + 1) * n * AMAX_ROW] = rows.view(torch.float32)
+            self.arena[row_off + i * n * P2_ROW : row_off + (i + 1) * n * P2_ROW] = rows.view(torch.float32)
         pw = pack_weights(weight, ALGO_MFMA_H2)
         s_off = _align(pw.numel())
         b_off = s_off + _align(cout)
@@ -248,11 +248,11 @@ class P2Conv:
         m.res1_off = m.res2_off = -1
         if res1 is not None:
             i = next(it)
-            m.res1_off, m.res1_amax_off = offs[i], row_off + i * n * AMAX_ROW
+            m.res1_off, m.res1_amax_off = offs[i], row_off + i * n * P2_ROW
         if res2 is not None:
             i = next(it)
-            m.res2_off, m.res2_amax_off = offs[i], row_off + i * n * AMAX_ROW
-        m.out_amax_off = row_off + len(parts) * n * AMAX_ROW
+            m.res2_off, m.res2_amax_off = offs[i], row_off + i * n * P2_ROW
+        m.out_amax_off = row_off + len(parts) * n * P2_ROW
         m.w_off, m.scale_off, m.shift_off, m.bound_off = 0, s_off, b_off, bd_off
         self.op, self.out_off, self.n = m, out_off, n
         if not lib.mval_op_algo_supported(C.byref(m), C.c_int(n), C.c_int(4)):
@@ -264,7 +264,7 @@ class P2Conv:
 
     def out_rows(self):
         n = self.n
-        return self.arena[self.op.out_amax_off : self.op.out_amax_off + n * AMAX_ROW].view(torch.int32).reshape(n, AMAX_ROW)
+        return self.arena[self.op.out_amax_off : self.op.out_amax_off + n * P2_ROW].view(torch.int32).reshape(n, P2_ROW)
 
     def result(self):
         n, ho, wo, cout = self.shape
@@ -295,9 +295,9 @@ class P2Block:
         planes, rows = to_p2(x)
         out_off = _align(planes.numel())
         row_off = out_off + _align(planes.numel())
-        self.arena = torch.zeros(row_off + _align(2 * n * AMAX_ROW), dtype=torch.float32, device=dev)
+        self.arena = torch.zeros(row_off + _align(2 * n * P2_ROW), dtype=torch.float32, device=dev)
         self.arena[: planes.numel()] = planes
-        self.arena[row_off : row_off + n * AMAX_ROW] = rows.view(torch.float32)
+        self.arena[row_off : row_off + n * P2_ROW] = rows.view(torch.float32)
         chunks = [pack_weights(w1, ALGO_MFMA_H2), scale1, shift1, p2_bound(w1, scale1, shift1), pack_weights(w2, ALGO_MFMA_H2), scale2, shift2,
                   p2_bound(w2, scale2, shift2)]
         offs, top = [], 0
@@ -314,7 +314,7 @@ class P2Block:
         m.up, m.relu, m.in_nchw, m.out_nchw = 0, 1, 0, 0
         m.in_off, m.out_off, m.res1_off, m.res2_off = 0, out_off, 0, -1
         m.w_off, m.scale_off, m.shift_off, m.bound_off, m.w2_off, m.scale2_off, m.shift2_off, m.bound2_off = offs
-        m.in_amax_off, m.out_amax_off = row_off, row_off + n * AMAX_ROW
+        m.in_amax_off, m.out_amax_off = row_off, row_off + n * P2_ROW
         self.op, self.out_off, self.n = m, out_off, n
         if not _lib.lib().mval_op_algo_supported(C.byref(m), C.c_int(n), C.c_int(4)):
             raise _lib.MvalError("no fused P2 BasicBlock kernel for this geometry")

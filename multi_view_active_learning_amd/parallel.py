@@ -3,8 +3,10 @@ xGMI on ROCm) on the GPU box, "gloo" in the CPU tests.
 
 The reference shards frames with a DistributedSampler and then issues 8 tiny all_gathers
 PER SAMPLE (strategy.py:1106-1114).  Frames are independent through the whole hot path, so
-here ranks exchange exactly one packed table per scoring pass, and core-set features once
-before the (replicated, communication-free) greedy loop."""
+here a scoring pass ends with TWO collectives -- one exchange of three integers per rank (row count, batch count, error
+flag) and one padded all_gather of bytes that carries the packed result table together with the rank's batch-size list
+-- and the core-set pass gathers the features once before the (replicated, communication-free) greedy loop
+(SURVEY 8(e))."""
 from __future__ import annotations
 
 import numpy as np
@@ -25,18 +27,46 @@ def shard_range(n: int, rank: int, world_size: int):
     return lo, min(n, lo + per)
 
 
-def _gather_ragged(t: torch.Tensor):
-    """ONE size exchange + ONE padded all_gather; returns the per-rank tensors."""
-    rank, ws = world()
-    n = torch.tensor([t.shape[0]], dtype=torch.int64, device=t.device)
-    sizes = [torch.zeros_like(n) for _ in range(ws)]
-    dist.all_gather(sizes, n)
-    sizes = [int(s.item()) for s in sizes]
-    pad = torch.zeros((max(sizes),) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-    pad[: t.shape[0]] = t
+def _collectives_on():
+    """Collectives run when more than one rank exists -- or, with MVAL_DIST_NO_SHORTCUT=1, whenever a process group is
+    initialised (world 1 included: the RCCL path of a single-GPU box, tests/test_gpu_distributed.py)."""
+    import os
+
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or os.environ.get("MVAL_DIST_NO_SHORTCUT") == "1"
+
+
+def _gather_packed(t: torch.Tensor, extra=None, flag: int = 0):
+    """The two collectives of a pass: ONE exchange of three int64 per rank ([rows of t, len(extra), flag]) and ONE padded
+    all_gather of bytes carrying t's rows AND the int64 list ``extra`` (a rank's batch sizes) behind them.
+    Returns (per-rank tensors shaped like t, per-rank int64 lists, per-rank flags)."""
+    ws = dist.get_world_size()
+    dev = t.device
+    t = t.contiguous()
+    ex = torch.as_tensor(list(extra) if extra is not None else [], dtype=torch.int64, device=dev).reshape(-1)
+    head = torch.tensor([t.shape[0], ex.shape[0], int(flag)], dtype=torch.int64, device=dev)
+    heads = [torch.zeros_like(head) for _ in range(ws)]
+    dist.all_gather(heads, head)
+    heads = [h.cpu().tolist() for h in heads]
+    row_bytes = t.element_size() * int(np.prod(t.shape[1:], dtype=np.int64)) if t.dim() > 1 else t.element_size()
+    need = [h[0] * row_bytes + h[1] * 8 for h in heads]
+    pad = torch.zeros(max(max(need), 8), dtype=torch.uint8, device=dev)
+    mine = torch.cat([t.reshape(-1).view(torch.uint8), ex.view(torch.uint8)])
+    pad[: mine.shape[0]] = mine
     bufs = [torch.empty_like(pad) for _ in range(ws)]
-    dist.all_gather(bufs, pad.contiguous())
-    return [bufs[r][: sizes[r]] for r in range(ws)]
+    dist.all_gather(bufs, pad)
+    tabs, lists = [], []
+    for r in range(ws):
+        nb = heads[r][0] * row_bytes
+        tabs.append(bufs[r][:nb].clone().view(t.dtype).reshape((heads[r][0],) + tuple(t.shape[1:])))
+        lists.append(bufs[r][nb : nb + heads[r][1] * 8].clone().view(torch.int64).cpu().tolist())
+    return tabs, lists, [h[2] for h in heads]
+
+
+def _gather_ragged(t: torch.Tensor):
+    """Per-rank tensors of a ragged first dimension (one size exchange + one padded data gather)."""
+    return _gather_packed(t)[0]
 
 
 def reference_gather_order(sizes_per_rank):
@@ -59,11 +89,9 @@ def all_gather_reference_order(t: torch.Tensor, batch_sizes) -> torch.Tensor:
     """Rows of every rank's ``t`` (this rank's per-sample results, batch after batch) in the reference's gather
     order -- with DistributedSampler's strided shards that IS the dataset order, so order-sensitive float32
     reductions over the gathered rows (compute_mkpe) see the samples as the reference does."""
-    if world()[1] == 1:
+    if not _collectives_on():
         return t
-    per_rank = _gather_ragged(t)
-    mine = torch.tensor(list(batch_sizes), dtype=torch.int64, device=t.device).reshape(-1)
-    sizes = [x.cpu().tolist() for x in _gather_ragged(mine)]
+    per_rank, sizes, _ = _gather_packed(t, batch_sizes)  # one size exchange + one data gather
     base = np.concatenate([[0], np.cumsum([x.shape[0] for x in per_rank])])
     idx = torch.tensor([int(base[r]) + row for r, row in reference_gather_order(sizes)], dtype=torch.int64, device=t.device)
     return torch.cat(per_rank, dim=0).index_select(0, idx)
@@ -71,20 +99,22 @@ def all_gather_reference_order(t: torch.Tensor, batch_sizes) -> torch.Tensor:
 
 def all_gather_cat(t: torch.Tensor) -> torch.Tensor:
     """Concatenate a per-rank tensor along dim 0 in rank order (ragged first dim allowed)."""
-    if world()[1] == 1:
+    if not _collectives_on():
         return t
     return torch.cat(_gather_ragged(t), dim=0)
 
 
-def gather_tables(local: torch.Tensor, batch_sizes=None):
+def gather_tables(local: torch.Tensor, batch_sizes=None, error_flag: int = 0):
     """-> list over ranks of host float64 arrays (each rank's packed scoring table).  With ``batch_sizes`` (this
     rank's list of batch sizes) also every rank's list, so that all ranks can rebuild the reference's
-    (batch, sample, rank) order even when shards are ragged: (tables, sizes_per_rank)."""
-    if world()[1] == 1:
+    (batch, sample, rank) order even when shards are ragged: (tables, sizes_per_rank).  One size exchange + one data
+    gather per pass; ``error_flag`` != 0 on any rank comes back as RuntimeError on EVERY rank after the collectives
+    (a rank that raised before them would leave the others waiting)."""
+    if not _collectives_on():
         tabs = [local.cpu().numpy()]
         return tabs if batch_sizes is None else (tabs, [list(batch_sizes)])
-    tabs = [x.cpu().numpy() for x in _gather_ragged(local)]
-    if batch_sizes is None:
-        return tabs
-    mine = torch.tensor(list(batch_sizes), dtype=torch.int64, device=local.device).reshape(-1)
-    return tabs, [x.cpu().tolist() for x in _gather_ragged(mine)]
+    tabs, sizes, flags = _gather_packed(local, batch_sizes, error_flag)
+    if any(flags) and not error_flag:
+        raise RuntimeError(f"scoring pass failed on rank(s) {[r for r, f in enumerate(flags) if f]}")
+    tabs = [x.cpu().numpy() for x in tabs]
+    return tabs if batch_sizes is None else (tabs, sizes)

@@ -238,17 +238,27 @@ class ActiveLearningStrategy:
         from .parallel import world
 
         if not tables:
-            if world()[1] == 1:
+            from .parallel import _collectives_on
+
+            if not _collectives_on():
                 return sal_dict
             # an empty shard still takes part in the pass's collective (the other ranks would hang otherwise)
             j = self.num_joints
             dev = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
             tables = [torch.zeros((0, 6 + 3 * j), dtype=torch.float64, device=dev)]
-        self._raise_deferred_errors()
+        # the reference's per-sample error behaviour is checked once per pass -- AFTER the collectives (a rank that raised
+        # before them would leave the others waiting); the flag travels with the size exchange
+        err = None
+        try:
+            self._raise_deferred_errors()
+        except Exception as e:  # noqa: BLE001
+            err = e
         local = torch.cat(tables, dim=0)
         from .parallel import gather_tables
 
-        per_rank, per_rank_sizes = gather_tables(local, sizes)  # (n_r, 6+3J) host arrays + each rank's batch sizes
+        per_rank, per_rank_sizes = gather_tables(local, sizes, error_flag=int(err is not None))  # host arrays + every rank's batch sizes
+        if err is not None:
+            raise err
         return tables_to_sal_dict(per_rank, per_rank_sizes, sal_dict)
 
     def _raise_deferred_errors(self):
@@ -340,7 +350,8 @@ class ActiveLearningStrategy:
             local = torch.cat([torch.cat(preds).reshape(-1, 3 * j), torch.cat(gts).reshape(-1, rows * j),
                                torch.cat(valids).reshape(-1, j)], dim=1)
         else:  # an empty shard still takes part in the collective
-            local = torch.zeros((0, (4 + rows) * j), dtype=torch.float32, device=torch.device("cuda", torch.cuda.current_device()))
+            dev = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+            local = torch.zeros((0, (4 + rows) * j), dtype=torch.float32, device=dev)
         # the reference appends its per-sample all_gathers batch by batch, sample by sample, rank by rank
         # (strategy.py:600-636): same row order here, so the float32 sample-order sums of compute_mkpe match
         table = gather(local, sizes)

@@ -155,3 +155,48 @@ def test_shard_range_covers_everything():
             spans = [parallel.shard_range(n, r, w) for r in range(w)]
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+
+
+def _worker_counts(rank, world, path, out):
+    """One scoring pass with the collectives counted; then a pass in which rank 1's deferred check fails."""
+    _init(rank, world, path)
+    from multi_view_active_learning_amd import parallel
+
+    calls = []
+    real = dist.all_gather
+    dist.all_gather = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+    st = _strategy()
+    mine = ALL[rank::world]
+    st._compute_sal_dict(_loader(mine, 2), None)
+    n_pass = len(calls)
+    local = torch.tensor([[p, f] for p, f in mine], dtype=torch.float64).reshape(-1, 2)
+    parallel.all_gather_reference_order(local, [min(2, len(mine) - i) for i in range(0, len(mine), 2)])
+    n_eval = len(calls) - n_pass
+
+    class Failing(type(st)):
+        def _raise_deferred_errors(self):
+            if rank == 1:
+                raise IndexError("list index out of range")
+
+    st2 = Failing(st.al_cfg)
+    try:
+        st2._compute_sal_dict(_loader(mine, 2), None)
+        err = None
+    except Exception as e:  # noqa: BLE001
+        err = type(e).__name__
+    dist.all_gather = real
+    torch.save({"n_pass": n_pass, "n_eval": n_eval, "err": err}, out + ".%d" % rank)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_a_pass_is_two_collectives_and_errors_reach_every_rank(tmp_path):
+    """One size exchange + one data gather per scoring pass (the table AND the batch-size list travel together), the
+    same for evaluate_mkpe's ordered gather; a rank whose per-pass check fails still takes part in them and every rank
+    raises afterwards (the failing one its own error, the others a RuntimeError) -- nobody is left waiting."""
+    sync, out = str(tmp_path / "sync_c"), str(tmp_path / "out_c")
+    mp.spawn(_worker_counts, args=(2, sync, out), nprocs=2, join=True)
+    r0, r1 = (torch.load(out + ".%d" % r, weights_only=False) for r in range(2))
+    assert r0["n_pass"] == r1["n_pass"] == 2
+    assert r0["n_eval"] == r1["n_eval"] == 2
+    assert r1["err"] == "IndexError" and r0["err"] == "RuntimeError"

@@ -98,3 +98,44 @@ def test_two_ranks_one_gpu_equal_one_rank(tmp_path, strategy):
                 assert g["sal"][k][guid] == val or (val != val and g["sal"][k][guid] != g["sal"][k][guid]), (k, guid)
         assert g["picks"] == want["picks"]
         assert g["eval"] == want["eval"]  # float32 MKPE summed in the same sample order; PCK counts
+
+
+def test_rccl_world_1_carries_the_collectives(tmp_path, monkeypatch):
+    """A single-GPU box cannot run two RCCL ranks, but it can run the collectives themselves: with
+    MVAL_DIST_NO_SHORTCUT=1 the world-1 short-circuits are off and every gather of a pass goes through
+    torch.distributed's "nccl" backend (= RCCL) with device tensors -- ragged tables, the ordered gather, the
+    core-set concatenation -- and bench.py's core-set pool pass runs end to end under it."""
+    import subprocess
+    import sys
+
+    from multi_view_active_learning_amd import parallel
+
+    assert torch.cuda.is_available()
+    monkeypatch.setenv("MVAL_DIST_NO_SHORTCUT", "1")
+    monkeypatch.setenv("MASTER_ADDR", "127.0.0.1")
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, init_method="file://" + str(tmp_path / "rccl"), device_id=dev)
+    try:
+        calls = []
+        real = dist.all_gather
+        monkeypatch.setattr(dist, "all_gather", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+        t = torch.arange(7 * 5, dtype=torch.float64, device=dev).reshape(7, 5)
+        tabs, sizes = parallel.gather_tables(t, [3, 3, 1])
+        assert len(calls) == 2 and sizes == [[3, 3, 1]]
+        np.testing.assert_array_equal(tabs[0], t.cpu().numpy())
+        o = parallel.all_gather_reference_order(t.float(), [3, 3, 1])
+        assert torch.equal(o, t.float()) and len(calls) == 4
+        e = parallel.all_gather_cat(torch.zeros((0, 19, 3), device=dev))
+        assert e.shape == (0, 19, 3) and len(calls) == 6
+    finally:
+        dist.destroy_process_group()
+    env = dict(os.environ, MVAL_DIST_NO_SHORTCUT="1", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29641")
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--workload", "c5", "--pool", "16", "--steps", "1", "--no-cpu-baseline",
+                        "--rccl-world-1"], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    import json
+
+    # (RCCL prints its version banner to stdout when the process exits: the line is the last one that is JSON)
+    line = json.loads([l for l in r.stdout.strip().splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["config"]["pool_frames"] == 16 and line["value"] > 0

@@ -143,7 +143,7 @@ def test_p2_format(dev):
     [2^13, 2^14): (h + l) 2^-s reproduces x to 2^-22 relative (or 2^-25 of the scaled unit for tiny values), the row keeps
     the exact maximum and 2^-s; images are scaled independently."""
     from multi_view_active_learning_amd import ops
-    from multi_view_active_learning_amd.engine import AMAX_ROW
+    from multi_view_active_learning_amd.engine import P2_ROW as AMAX_ROW
 
     rng = np.random.default_rng(3)
     x = rng.standard_normal((3, 16, 24, 40)).astype(np.float32)
@@ -170,7 +170,7 @@ def test_p2_bound_holds(dev):
     """The output scale comes from a bound computed BEFORE the image's maximum exists: A max|x| + B + max|r1| + max|r2|.
     Adversarial case: all-positive weights and inputs (no cancellation: the conv reaches its L1 bound)."""
     from multi_view_active_learning_amd import ops
-    from multi_view_active_learning_amd.engine import AMAX_ROW
+    from multi_view_active_learning_amd.engine import P2_ROW as AMAX_ROW
 
     n, c, h, w = 2, 64, 16, 16
     x = torch.full((n, h, w, c), 3.0, device=dev)

@@ -105,6 +105,51 @@ def test_peak_local_max_known_answers():
     np.testing.assert_array_equal(scoring.peak_local_max(r, min_distance=2, num_peaks=2), [[10, 10], [4, 10]])
 
 
+def test_maximum_filter_restatement_vs_scipy():
+    """scikit-image's peak_local_max is built on scipy.ndimage.maximum_filter, and scipy IS in the image: the hand-written
+    5 x 5 constant-border maximum filter of the restatement equals it bit for bit -- on noise, on plateaus (ties), on maps
+    whose maxima sit in the border, on negative maps (where the constant-0 border wins) and on non-square maps.  What
+    stays unverified of peak_local_max is skimage's glue around the filter (threshold = image.min(), exclude_border,
+    the descending sort and ensure_spacing), covered by known-answer tests only."""
+    from scipy import ndimage
+
+    rng = np.random.default_rng(0)
+    maps = [rng.standard_normal((64, 64)).astype(np.float32), rng.standard_normal((64, 48)).astype(np.float32),
+            rng.standard_normal((96, 72)).astype(np.float32) - 3.0,                       # all negative: the border's zeros win
+            np.round(rng.standard_normal((32, 32)) * 2).astype(np.float32),               # plateaus / ties
+            np.zeros((16, 16), np.float32), np.full((9, 7), -1.0, np.float32)]
+    edge = np.zeros((20, 20), np.float32)
+    edge[0, 0] = edge[19, 5] = edge[7, 19] = 5.0
+    maps.append(edge)
+    for m in maps:
+        for r in (1, 2):
+            want = ndimage.maximum_filter(m, footprint=np.ones((2 * r + 1, 2 * r + 1)), mode="constant", cval=0.0)
+            np.testing.assert_array_equal(scoring._maximum_filter_constant0(m, r), want)
+
+
+def test_soft_argmax_independent_formulation():
+    """The soft-arg-max restatement against a second formulation that shares no code with it (torch.softmax over the
+    flattened map, torch.meshgrid pixel grid, float64), plus two properties of the definition: a shifted map shifts the
+    expectation by the shift (for mass that stays inside), and a dominant peak pins it.  kornia's own conventions that
+    remain unverified: pixel-centre grid origin (0 .. W-1, not 0.5-offset), (x, y) output order, temperature 1."""
+    import torch
+
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal((3, 5, 24, 40)).astype(np.float32) * 3
+    got = geometry.spatial_soft_argmax2d(x)
+    t = torch.from_numpy(x).double()
+    p = torch.softmax(t.reshape(3, 5, -1), dim=-1).reshape(3, 5, 24, 40)
+    ys, xs = torch.meshgrid(torch.arange(24, dtype=torch.float64), torch.arange(40, dtype=torch.float64), indexing="ij")
+    want = torch.stack([(p * xs).sum((-1, -2)), (p * ys).sum((-1, -2))], dim=-1).numpy()
+    np.testing.assert_allclose(got, want, rtol=0, atol=2e-4)  # float32 sums over 960 pixels
+    # translation: a blob well inside the map, moved by (dx, dy)
+    yy, xx = np.mgrid[0:32, 0:32]
+    blob = lambda cx, cy: (-((xx - cx) ** 2 + (yy - cy) ** 2) / 4.0).astype(np.float32)[None, None]
+    a, b = geometry.spatial_soft_argmax2d(blob(10, 12))[0, 0], geometry.spatial_soft_argmax2d(blob(17, 9))[0, 0]
+    np.testing.assert_allclose(b - a, [7, -3], atol=1e-4)
+    np.testing.assert_allclose(a, [10, 12], atol=1e-4)
+
+
 def test_soft_argmax_known_answers():
     m = np.full((1, 1, 8, 12), -1e4, dtype=np.float32)
     m[0, 0, 5, 9] = 0

@@ -6,16 +6,17 @@ tag=${1:-v0}
 out=gpurun_out/prof_$tag
 mkdir -p $out
 export TMPDIR=/tmp
-for w in c1 c1x16 c3 c4 c5; do
+for w in c1 c1x16 c4 c5; do
   python3 bench.py --workload $w --no-cpu-baseline --steps 20 2>/dev/null | tail -1 > $out/bench_${w}_$tag.json
 done
+python3 bench.py --workload c3 --steps 20 2>/dev/null | tail -1 > $out/bench_c3_$tag.json   # (with its cpu_baseline)
 python3 bench.py 2>/dev/null | tail -1 > $out/bench_c2_$tag.json
 export MVAL_STREAMS=1
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_c2 -o c2 -- python3 bench.py --no-cpu-baseline --steps 30 2>/dev/null | tail -1 > $out/bench_c2_${tag}_under_rocprof.json
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_c2 -o c2 -- python3 bench.py --no-cpu-baseline --no-exact-modes --steps 30 2>/dev/null | tail -1 > $out/bench_c2_${tag}_under_rocprof.json
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_c3 -o c3 -- python3 bench.py --workload c3 --no-cpu-baseline --steps 5 > /dev/null 2>&1
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -o c2 -- python3 bench.py --no-cpu-baseline --steps 5 > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -o c2 -- python3 bench.py --no-cpu-baseline --steps 5 > /dev/null 2>&1
-rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS --output-format csv -d $out/pmc_sq -o c2 -- python3 bench.py --no-cpu-baseline --steps 3 > /dev/null 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -o c2 -- python3 bench.py --no-cpu-baseline --no-exact-modes --steps 5 > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -o c2 -- python3 bench.py --no-cpu-baseline --no-exact-modes --steps 5 > /dev/null 2>&1
+rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS --output-format csv -d $out/pmc_sq -o c2 -- python3 bench.py --no-cpu-baseline --no-exact-modes --steps 3 > /dev/null 2>&1
 ks=$(find $out/kt_c2 -name '*kernel_stats.csv' | head -1)
 k3=$(find $out/kt_c3 -name '*kernel_stats.csv' | head -1)
 fe=$(find $out/pmc_fetch -name '*counter_collection.csv' | head -1)
