@@ -527,7 +527,8 @@ def main():
             for o, m_ in zip(plan.ops, mask):
                 if m_:
                     outp = (o.hout << o.up) * (o.wout << o.up) * o.cout
-                    b += 4.0 * nimg * (o.hin * o.win * o.cin + outp * (1 + (o.res1_off >= 0) + (o.res2_off >= 0)))
+                    # (a fused Bottleneck whose residual is its own input reads that tensor once, algorithmically)
+                    b += 4.0 * nimg * (o.hin * o.win * o.cin + outp * (1 + (o.res1_off >= 0 and o.res1_off != o.in_off) + (o.res2_off >= 0)))
             return dict(bound="hbm", achieved=round(b / t / 1e9, 1), peak=PEAK_HBM_GBPS, unit="GB/s",
                         frac=round(b / t / 1e9 / PEAK_HBM_GBPS, 4), traffic=None, kernel=name,
                         peak_note="HBM3E ~8 TB/s (guide); ~6.3 TB/s achievable",
@@ -539,6 +540,7 @@ def main():
         k3 = np.asarray([o.k == 3 for o in plan.ops])
         s1 = np.asarray([o.stride == 1 for o in plan.ops])
         stem = np.asarray([o.kind == 0 and o.in_nchw == 1 for o in plan.ops])
+        bneck = np.asarray([o.kind == 5 for o in plan.ops])
         fams = []
         split_any = np.zeros(len(plan.ops), dtype=bool)
         for algo, pl, what in ((ALGO_MFMA_P2, "p2", "activations kept as fp16 (h, l) plane pairs in HBM, 3 x v_mfma_f32_16x16x32_f16 per 32-deep step"),
@@ -556,7 +558,10 @@ def main():
                                         if any(o.kind == 3 for o in plan.ops) and pl == "h2" else "")
                                      + f" (fused 3x3 stride-1 conv+BN+residual+ReLU; {what}, fp32 accumulate)", peak, note),
                 family(m_ & k3 & ~s1, ("conv_p2_kernel<3, 2, ...>" if pl == "p2" else f"conv_split_kernel<{2 if pl == 'h2' else 3}, 3, 2, ...>") + " (same, stride 2)", peak, note),
-                hbm_family(m_ & ~k3, ("conv_p2_kernel<1, 1, ...>" if pl == "p2" else f"conv_split_kernel<{2 if pl == 'h2' else 3}, 1, 1, ...>") + " (fused 1x1 conv+BN+residual+ReLU(+upsample): "
+                hbm_family(m_ & bneck, "conv_bneck_p2_kernel<CIN> (whole Bottlenecks of layer1 in one launch: 1x1 -> 3x3 -> 1x1 convs, BNs, residual, "
+                                       "ReLUs; the 64-channel intermediates never leave the CU; HBM is the tighter of its two bounds: "
+                                       "1.07 GB / 8 TB/s = 134 us vs 80 GFLOP x 3 / 2500 TFLOP/s = 96 us per 128 images)"),
+                hbm_family(m_ & ~k3 & ~bneck, ("conv_p2_kernel<1, 1, ...>" if pl == "p2" else f"conv_split_kernel<{2 if pl == 'h2' else 3}, 1, 1, ...>") + " (fused 1x1 conv+BN+residual+ReLU(+upsample): "
                                      "channel GEMMs of the bottleneck blocks and fuse up-paths; 2x2 parity convs of transposed convs)"),
             ]
         fams += [

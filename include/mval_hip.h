@@ -180,7 +180,7 @@ int mval_kcenter_select(const double* feat, int64_t n_obs, int D, const int64_t*
  * floats from the workspace base; -1 = absent.  Weights are in the packed fragment order
  * written by mval_pack_conv_weights; scale/shift are the folded eval-mode BatchNorm
  * (y = x * scale + shift, torch's batch_norm inference formula) or (1, bias). */
-enum { MVAL_OP_CONV = 0, MVAL_OP_MAXPOOL = 1, MVAL_OP_DECONV = 2, MVAL_OP_BLOCK = 3, MVAL_OP_TO_P2 = 4 };
+enum { MVAL_OP_CONV = 0, MVAL_OP_MAXPOOL = 1, MVAL_OP_DECONV = 2, MVAL_OP_BLOCK = 3, MVAL_OP_TO_P2 = 4, MVAL_OP_BNECK = 5 };
 enum { MVAL_ALGO_DIRECT = 0, MVAL_ALGO_MFMA = 1, MVAL_ALGO_MFMA_BF3 = 2, MVAL_ALGO_MFMA_H2 = 3, MVAL_ALGO_MFMA_P2 = 4 };
 enum { MVAL_PACK_HWIO = 0, MVAL_PACK_MFMA16 = 1, MVAL_PACK_MFMA16_BF3 = 2, MVAL_PACK_MFMA16_H2 = 3 };
 
@@ -222,6 +222,13 @@ typedef struct mval_op {
   /* MVAL_OP_TO_P2: format change at the head of a P2 plan -- the fp32 NHWC tensor at in_off ([n][hin][win][cin], its
    * rows [count, partials ...] at in_amax_off, as every NHWC producer keeps them) becomes P2 planes at out_off with
    * their rows at out_amax_off. */
+  /* MVAL_OP_BNECK (hrnet.py:75-95, a whole Bottleneck with 64 planes in one launch, csrc/conv_bneck_p2.hip; algo
+   * MVAL_ALGO_MFMA_P2 only):
+   *   out = relu(bn3(conv1x1(relu(bn2(conv3x3(relu(bn1(conv1x1(in)))))))) + res1),  cin in {64, 256}, cout = 256, stride 1.
+   * w_off / scale_off / shift_off / bound_off are conv1 + bn1 (cin -> 64), the *2 fields conv2 + bn2 (64 -> 64, 3x3),
+   * these four conv3 + bn3 (64 -> 256); res1_off / res1_amax_off: the 256-channel residual (the block's input or its
+   * downsample branch), required. */
+  int64_t w3_off, scale3_off, shift3_off, bound3_off;
 } mval_op;
 
 /* Weight packing.  MVAL_PACK_HWIO: [k*k][cin][cout] (direct kernels, deconv);

@@ -1,5 +1,7 @@
-// fp32-accurate conv on the 16-bit matrix cores: every fp32 value is split EXACTLY into a few 16-bit planes and
-// the fp32 product is rebuilt from the plane products (exact in the MFMA, fp32 accumulate, small terms first).
+// fp32-level conv on the 16-bit matrix cores: every fp32 value is split into a few 16-bit planes and the fp32 product
+// is rebuilt from the plane products (exact in the MFMA, fp32 accumulate, small terms first).  The three-plane bf16
+// split represents every fp32 value exactly; the two-plane fp16 split does NOT: it keeps 11 + 11 (+ sign) of the 24
+// significand bits, a <= 2^-23 relative representation error per operand, and drops the lo x lo product.
 //
 // The exact-fp32 MFMA (v_mfma_f32_16x16x4_f32, conv_mfma.hip) runs at 1/16 of the 16-bit MFMA rate.  Two splits:
 //
@@ -7,10 +9,12 @@
 //     power-of-two scale 2^s puts the tensor's largest magnitude in [2^14, 2^15), so nothing overflows and the
 //     low parts of every value that matters stay normal numbers):
 //         a*b = ah*bh + (ah*bl + al*bh) + O(2^-22 |a||b|)
-//     THREE v_mfma_f32_16x16x32_f16 per 32-deep k-step: 5.3x the fp32-MFMA rate.  The split residual is
-//     <= 2^-22 |x| worst case / ~2^-24 rms -- the size of ONE fp32 rounding -- and there are half as many fp32
-//     accumulate roundings per k-step as with six products, so the measured error against float64 is the same
-//     as (or below) the exact-fp32 MFMA chain's (tests/test_gpu_models.py::test_fused_conv_vs_torch_cpu).
+//     THREE v_mfma_f32_16x16x32_f16 per 32-deep k-step: 5.3x the fp32-MFMA rate.  Not bit-faithful to fp32
+//     operands: per product the dropped terms are <= 2^-22 |a||b| worst case / ~2^-24 rms -- the size of one fp32
+//     rounding.  What the tests hold it to is an OUTPUT bound: error against float64 no larger than 1.25x (rms) /
+//     2.5x (max) the exact-fp32 MFMA chain's on the same problem (tests/test_gpu_models.py::
+//     test_fused_conv_vs_torch_cpu), and no arg-max flips over 19 456 heat-maps against the exact-fp32 plan
+//     (tests/test_gpu_p2.py census).  bench.py's exact_modes gives the cost of the bit-faithful kernels.
 //     The activation scale comes from the producer: every kernel that writes an activation keeps max|x| of
 //     the tensor in a 4-byte slot (wave maximum, then one conditional atomicMax per wave; order-independent,
 //     so deterministic) and the consumer turns its exponent into 2^s while staging.  Weights are scaled by

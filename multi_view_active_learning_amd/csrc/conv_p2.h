@@ -127,3 +127,10 @@ int mval_launch_conv_block_p2(int C, const void* in, void* out, const float* w1,
                               const float* shift1, const float* bound1, const float* w2, const float* w2_unscale, const float* scale2,
                               const float* shift2, const float* bound2, const unsigned* in_row, unsigned* out_row, int N, int H, int W,
                               hipStream_t s);
+// conv_bneck_p2.hip: a whole Bottleneck (cin -> 64 -> 64 -> 256, cin = 64 or 256) over P2 activations in one launch; the
+// arrays hold the FLOAT OFFSETS into `params` of conv1 / conv2 / conv3's packed weights, their trailers, BN vectors and
+// bounds; 1 = unsupported
+int mval_conv_bneck_p2_supported(int cin, int planes, int N, int H, int W);
+int mval_launch_conv_bneck_p2(int cin, const void* in, const void* res, void* out, const float* params, const int64_t* w, const int64_t* w_unscale,
+                              const int64_t* scale, const int64_t* shift, const int64_t* bound, const unsigned* in_row,
+                              const unsigned* res_row, unsigned* out_row, int N, int H, int W, hipStream_t s);

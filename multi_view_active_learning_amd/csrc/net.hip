@@ -337,6 +337,9 @@ static void deconv_parity(ConvArgs& a, const mval_op* op, int parity, const floa
 }
 
 extern "C" int mval_op_algo_supported(const mval_op* op, int n_images, int algo) {
+  if (op && op->kind == MVAL_OP_BNECK)
+    return algo == MVAL_ALGO_MFMA_P2 && n_images > 0 && op->cout == 256 && op->stride == 1 && !op->up && !op->in_nchw && !op->out_nchw &&
+           op->hin == op->hout && op->win == op->wout && op->relu && mval_conv_bneck_p2_supported(op->cin, 64, n_images, op->hin, op->win);
   if (op && op->kind == MVAL_OP_BLOCK && algo == MVAL_ALGO_MFMA_P2)
     return n_images > 0 && op->cin == op->cout && op->k == 3 && op->stride == 1 && op->pad == 1 && !op->up && !op->in_nchw &&
            !op->out_nchw && op->hin == op->hout && op->win == op->wout && mval_conv_block_p2_supported(op->cin, n_images, op->hin, op->win);
@@ -380,6 +383,26 @@ extern "C" int mval_op_launch(const mval_op* op, int n_images, float* workspace,
     mval_launch_nhwc_to_p2(a.in, reinterpret_cast<const unsigned*>(workspace + op->in_amax_off), reinterpret_cast<_Float16*>(a.out),
                            reinterpret_cast<unsigned*>(workspace + op->out_amax_off), n_images, op->hin * op->win, op->cin, s);
     MVAL_CHECK_LAUNCH("mval_op_launch/to_p2");
+    return 0;
+  }
+  if (op->kind == MVAL_OP_BNECK) {
+    MVAL_REQUIRE(op->algo == MVAL_ALGO_MFMA_P2 && op->in_amax_off > 0 && op->out_amax_off > 0 && op->res1_amax_off > 0 && a.res1 && a.w &&
+                     a.scale && a.shift && op->bound_off >= 0 && op->w2_off >= 0 && op->scale2_off >= 0 && op->shift2_off >= 0 &&
+                     op->bound2_off >= 0 && op->w3_off >= 0 && op->scale3_off >= 0 && op->shift3_off >= 0 && op->bound3_off >= 0 &&
+                     op->in_off >= 0 && op->out_off >= 0 && op->res2_off < 0 && op->relu,
+                 "mval_op_launch: malformed MVAL_OP_BNECK");
+    const size_t nw[3] = {mval_packed_weight_floats(MVAL_PACK_MFMA16_H2, 64, op->cin, 1), mval_packed_weight_floats(MVAL_PACK_MFMA16_H2, 64, 64, 3),
+                          mval_packed_weight_floats(MVAL_PACK_MFMA16_H2, 256, 64, 1)};
+    const int64_t w[3] = {op->w_off, op->w2_off, op->w3_off};
+    const int64_t wu[3] = {w[0] + (int64_t)nw[0] - 4, w[1] + (int64_t)nw[1] - 4, w[2] + (int64_t)nw[2] - 4};
+    const int64_t sc[3] = {op->scale_off, op->scale2_off, op->scale3_off};
+    const int64_t sh[3] = {op->shift_off, op->shift2_off, op->shift3_off};
+    const int64_t bd[3] = {op->bound_off, op->bound2_off, op->bound3_off};
+    int rc = mval_launch_conv_bneck_p2(op->cin, a.in, a.res1, a.out, params, w, wu, sc, sh, bd, reinterpret_cast<const unsigned*>(workspace + op->in_amax_off),
+                                       reinterpret_cast<const unsigned*>(workspace + op->res1_amax_off),
+                                       reinterpret_cast<unsigned*>(workspace + op->out_amax_off), n_images, op->hin, op->win, s);
+    MVAL_REQUIRE(rc == 0, "mval_op_launch: no fused P2 Bottleneck kernel for c%d %dx%d", op->cin, op->hin, op->win);
+    MVAL_CHECK_LAUNCH("mval_op_launch/bneck_p2");
     return 0;
   }
   if (op->kind == MVAL_OP_BLOCK && op->algo == MVAL_ALGO_MFMA_P2) {
@@ -571,6 +594,8 @@ extern "C" int mval_net_forward(void* net, int n_images, float* workspace, const
 
 extern "C" double mval_op_flops(const mval_op* op, int n_images) {
   if (!op || op->kind == MVAL_OP_MAXPOOL || op->kind == MVAL_OP_TO_P2) return 0.0;
+  if (op->kind == MVAL_OP_BNECK)  // the three convs (the halo recompute of conv1 is not counted)
+    return 2.0 * n_images * op->hout * op->wout * ((double)op->cin * 64 + 64.0 * 64 * 9 + 64.0 * 256);
   if (op->kind == MVAL_OP_BLOCK)  // algorithmic work of the two convs (the halo recompute is not counted)
     return 2.0 * 2.0 * n_images * op->hout * op->wout * (double)op->cin * op->cout * 9;
   if (op->kind == MVAL_OP_DECONV)  // every input pixel meets every tap once

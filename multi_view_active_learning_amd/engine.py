@@ -25,7 +25,7 @@ import torch
 from . import _lib
 from .pose_estimators import params as _params
 
-OP_CONV, OP_MAXPOOL, OP_DECONV, OP_BLOCK, OP_TO_P2 = 0, 1, 2, 3, 4
+OP_CONV, OP_MAXPOOL, OP_DECONV, OP_BLOCK, OP_TO_P2, OP_BNECK = 0, 1, 2, 3, 4, 5
 ALGO_DIRECT, ALGO_MFMA, ALGO_MFMA_BF3, ALGO_MFMA_H2, ALGO_MFMA_P2 = 0, 1, 2, 3, 4
 PACK_HWIO, PACK_MFMA16, PACK_MFMA16_BF3, PACK_MFMA16_H2 = 0, 1, 2, 3
 AMAX_ROW = 4096
@@ -49,6 +49,7 @@ class MvalOp(C.Structure):
         ("in_amax_off", C.c_int64), ("out_amax_off", C.c_int64),
         ("w2_off", C.c_int64), ("scale2_off", C.c_int64), ("shift2_off", C.c_int64),
         ("bound_off", C.c_int64), ("bound2_off", C.c_int64), ("res1_amax_off", C.c_int64), ("res2_amax_off", C.c_int64),
+        ("w3_off", C.c_int64), ("scale3_off", C.c_int64), ("shift3_off", C.c_int64), ("bound3_off", C.c_int64),
     ]
 
 
@@ -283,6 +284,7 @@ class InferencePlan:
         # fused vs 2 x 33 us -- the two 64-channel convs are no longer HBM-bound one by one, so only the 32-channel
         # blocks are fused by default (MVAL_P2_BLOCKS=32,64 fuses both)
         fuse_c = {int(v) for v in os.environ.get("MVAL_P2_BLOCKS", "32").split(",") if v}
+        fuse_bneck = fuse and os.environ.get("MVAL_P2_BNECK", "1") != "0"
         uses = {}
         for op in g.ops:
             for a in (op.src, op.res1, op.res2):
@@ -316,6 +318,30 @@ class InferencePlan:
             m.res1_amax_off = row_of[op.res1] if op.res1 is not None else 0
             m.res2_amax_off = row_of[op.res2] if op.res2 is not None else 0
             m.out_amax_off = row_of.get(op.dst, 0)
+            bn = self._bneck_at(g, i, uses) if fuse_bneck else None
+            if bn is not None:
+                # hrnet.py:75-95 with 64 planes: conv1x1 -> conv3x3 -> conv1x1 (+ residual) in ONE launch; a downsample branch
+                # (1x1 conv of the block's input, emitted between conv2 and conv3) runs first as its own op
+                i2, i3, skip = bn
+                for k in skip:
+                    ms = MvalOp()
+                    C.memmove(C.byref(ms), C.byref(self.graph_ops[k]), C.sizeof(MvalOp))
+                    ks = g.ops[k]
+                    ms.in_amax_off, ms.out_amax_off = row_of[ks.src], row_of[ks.dst]
+                    launch.append(ms)
+                m2, m3, o3 = self.graph_ops[i2], self.graph_ops[i3], g.ops[i3]
+                blk = MvalOp()
+                C.memmove(C.byref(blk), C.byref(m), C.sizeof(MvalOp))
+                blk.kind, blk.cout, blk.relu = OP_BNECK, o3.cout, 1
+                blk.out_off, blk.res1_off, blk.res2_off = m3.out_off, m3.res1_off, -1
+                blk.res1_amax_off, blk.res2_amax_off, blk.out_amax_off = row_of[o3.res1], 0, row_of[o3.dst]
+                blk.w2_off, blk.scale2_off, blk.shift2_off, blk.bound2_off = m2.w_off, m2.scale_off, m2.shift_off, m2.bound_off
+                blk.w3_off, blk.scale3_off, blk.shift3_off, blk.bound3_off = m3.w_off, m3.scale_off, m3.shift_off, m3.bound_off
+                if lib.mval_op_algo_supported(C.byref(blk), C.c_int(n), C.c_int(ALGO_MFMA_P2)):
+                    launch.append(blk)
+                    i = i3 + 1
+                    continue
+                del launch[len(launch) - len(skip):]
             b = g.ops[i + 1] if i + 1 < len(g.ops) else None
             if (fuse and b is not None and op.kind == b.kind == "conv" and op.k == b.k == 3 and op.stride == b.stride == 1
                     and op.cin == op.cout == b.cin == b.cout and op.cin in fuse_c and op.bn and b.bn and op.relu and b.relu and op.res1 is None
@@ -338,6 +364,35 @@ class InferencePlan:
         for k, m in enumerate(launch):
             C.memmove(C.byref(arr[k]), C.byref(m), C.sizeof(MvalOp))
         return arr
+
+    @staticmethod
+    def _bneck_at(g, i, uses):
+        """Ops i .. of the graph form a Bottleneck with 64 planes the fused P2 kernel covers -> (index of conv2, index of conv3,
+        indices of ops in between that must run first: the downsample branch), else None."""
+        a = g.ops[i]
+        if not (a.kind == "conv" and a.k == 1 and a.stride == 1 and a.cout == 64 and a.cin in (64, 256) and a.bn and a.relu
+                and a.res1 is None and a.res2 is None and a.up == 0 and uses.get(a.dst, 0) == 1 and i + 2 < len(g.ops)):
+            return None
+        b = g.ops[i + 1]
+        if not (b.kind == "conv" and b.k == 3 and b.stride == 1 and b.cin == b.cout == 64 and b.src == a.dst and b.bn and b.relu
+                and b.res1 is None and b.res2 is None and b.up == 0 and uses.get(b.dst, 0) == 1):
+            return None
+        skip, j = [], i + 2
+        if g.ops[j].src == a.src and g.ops[j].kind == "conv" and g.ops[j].k == 1 and j + 1 < len(g.ops):  # the downsample branch
+            d = g.ops[j]
+            if d.res1 is not None or d.res2 is not None or d.up or d.relu or uses.get(d.dst, 0) != 1:
+                return None
+            skip.append(j)
+            j += 1
+        c = g.ops[j]
+        if not (c.kind == "conv" and c.k == 1 and c.stride == 1 and c.cin == 64 and c.cout == 256 and c.src == b.dst and c.bn and c.relu
+                and c.res1 is not None and c.res2 is None and c.up == 0 and c.dst != g.output):
+            return None
+        if c.res1 != (g.ops[skip[0]].dst if skip else a.src):
+            return None
+        if len({(o.phase, o.lane) for o in [a, b, c] + [g.ops[k] for k in skip]}) != 1:
+            return None
+        return i + 1, j, skip
 
     def _fuse_blocks(self, lib, g, n):
         """Launch list: every BasicBlock of the 32- / 64-channel branches (conv3x3+BN+ReLU -> conv3x3+BN+residual+ReLU,
@@ -517,7 +572,7 @@ def _plan_for(model, x):
         raise ValueError("expected (N, 3, H, W) images")
     cache = model.__dict__.setdefault("_plans", {})
     key = (n, h, w, x.device.index, os.environ.get("MVAL_FORCE_DIRECT") == "1", _conv_mode(), os.environ.get("MVAL_FUSE_BLOCKS", "1"),
-           os.environ.get("MVAL_P2_BLOCKS", "32"), os.environ.get("MVAL_P2", "1"))
+           os.environ.get("MVAL_P2_BLOCKS", "32"), os.environ.get("MVAL_P2", "1"), os.environ.get("MVAL_P2_BNECK", "1"))
     plan = cache.get(key)
     if plan is None:
         if len(cache) >= 4:  # keep the arena footprint bounded

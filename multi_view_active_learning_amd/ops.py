@@ -333,3 +333,68 @@ def fused_basic_block_p2(x, w1, scale1, shift1, w2, scale2, shift2):
     b.launch()
     fused_basic_block_p2.last = b
     return b.result()
+
+
+class P2Bneck:
+    """One fused Bottleneck over P2 activations (MVAL_OP_BNECK, csrc/conv_bneck_p2.hip), set up once and launched many times:
+    relu(bn3(conv1x1(relu(bn2(conv3x3(relu(bn1(conv1x1(x)))))))) + res), x fp32 NHWC with 64 or 256 channels (converted here),
+    64 planes, res fp32 NHWC with 256 channels (None: x itself, which then has 256 channels).  convs = three (weight, scale,
+    shift) triples."""
+
+    def __init__(self, x, convs, res=None):
+        dev = x.device
+        n, h, w, cin = x.shape
+        self.shape = (n, h, w, 256)
+        parts = [to_p2(x)] + ([to_p2(res)] if res is not None else [])
+        offs_a, top = [], 0
+        for pl, _ in parts:
+            offs_a.append(top)
+            top += _align(pl.numel())
+        out_off = top
+        top += _align(n * h * w * 256)
+        row_off = top
+        self.arena = torch.zeros(top + _align((len(parts) + 1) * n * P2_ROW), dtype=torch.float32, device=dev)
+        for i, (pl, rows) in enumerate(parts):
+            self.arena[offs_a[i] : offs_a[i] + pl.numel()] = pl
+            self.arena[row_off + i * n * P2_ROW : row_off + (i + 1) * n * P2_ROW] = rows.view(torch.float32)
+        chunks = []
+        for wt, sc, sh in convs:
+            chunks += [pack_weights(wt, ALGO_MFMA_H2), sc, sh, p2_bound(wt, sc, sh)]
+        offs, top = [], 0
+        for t in chunks:
+            offs.append(top)
+            top += _align(t.numel())
+        self.params = torch.zeros(top, dtype=torch.float32, device=dev)
+        for o, t in zip(offs, chunks):
+            self.params[o : o + t.numel()] = t.to(dev, torch.float32).reshape(-1)
+        m = MvalOp()
+        m.kind, m.algo = 5, 4  # MVAL_OP_BNECK, MVAL_ALGO_MFMA_P2
+        m.k, m.stride, m.pad, m.cin, m.cout = 1, 1, 0, cin, 256
+        m.hin, m.win, m.hout, m.wout = h, w, h, w
+        m.up, m.relu, m.in_nchw, m.out_nchw = 0, 1, 0, 0
+        m.in_off, m.out_off, m.res2_off = 0, out_off, -1
+        m.res1_off = offs_a[1] if res is not None else 0
+        (m.w_off, m.scale_off, m.shift_off, m.bound_off, m.w2_off, m.scale2_off, m.shift2_off, m.bound2_off,
+         m.w3_off, m.scale3_off, m.shift3_off, m.bound3_off) = offs
+        m.in_amax_off = row_off
+        m.res1_amax_off = row_off + (n * P2_ROW if res is not None else 0)
+        m.out_amax_off = row_off + len(parts) * n * P2_ROW
+        self.op, self.out_off, self.n = m, out_off, n
+        if not _lib.lib().mval_op_algo_supported(C.byref(m), C.c_int(n), C.c_int(4)):
+            raise _lib.MvalError("no fused P2 Bottleneck kernel for this geometry")
+
+    launch = P2Conv.launch
+    out_rows = P2Conv.out_rows
+    kept_amax = P2Conv.kept_amax
+
+    def result(self):
+        n, h, w, c = self.shape
+        return from_p2(self.arena[self.out_off : self.out_off + n * h * w * c], self.out_rows().reshape(-1), n, h, w, c)
+
+
+def fused_bottleneck_p2(x, convs, res=None):
+    b = P2Bneck(x, convs, res)
+    b.launch()
+    fused_bottleneck_p2.last = b
+    return b.result()
+

