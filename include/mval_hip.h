@@ -180,7 +180,7 @@ int mval_kcenter_select(const double* feat, int64_t n_obs, int D, const int64_t*
  * floats from the workspace base; -1 = absent.  Weights are in the packed fragment order
  * written by mval_pack_conv_weights; scale/shift are the folded eval-mode BatchNorm
  * (y = x * scale + shift, torch's batch_norm inference formula) or (1, bias). */
-enum { MVAL_OP_CONV = 0, MVAL_OP_MAXPOOL = 1, MVAL_OP_DECONV = 2, MVAL_OP_BLOCK = 3, MVAL_OP_TO_P2 = 4, MVAL_OP_BNECK = 5 };
+enum { MVAL_OP_CONV = 0, MVAL_OP_MAXPOOL = 1, MVAL_OP_DECONV = 2, MVAL_OP_BLOCK = 3, MVAL_OP_TO_P2 = 4, MVAL_OP_BNECK = 5, MVAL_OP_STEM_P2 = 6 };
 enum { MVAL_ALGO_DIRECT = 0, MVAL_ALGO_MFMA = 1, MVAL_ALGO_MFMA_BF3 = 2, MVAL_ALGO_MFMA_H2 = 3, MVAL_ALGO_MFMA_P2 = 4 };
 enum { MVAL_PACK_HWIO = 0, MVAL_PACK_MFMA16 = 1, MVAL_PACK_MFMA16_BF3 = 2, MVAL_PACK_MFMA16_H2 = 3 };
 
@@ -229,6 +229,12 @@ typedef struct mval_op {
    * these four conv3 + bn3 (64 -> 256); res1_off / res1_amax_off: the 256-channel residual (the block's input or its
    * downsample branch), required. */
   int64_t w3_off, scale3_off, shift3_off, bound3_off;
+  /* MVAL_OP_STEM_P2 (hrnet.py:303-310, the two stride-2 stem convs in one launch, csrc/conv_stem_p2.hip; algo
+   * MVAL_ALGO_MFMA_P2 only):  out = relu(bn2(conv3x3 s2(relu(bn1(conv3x3 s2(image))))))  from the fp32 NCHW network input
+   * (in_off = -1, cin = 3, hin x win multiples of 4) to 64 channels of P2 planes at out_off (hout = hin / 4) with rows at
+   * out_amax_off.  w_off: conv1's weights packed MVAL_PACK_HWIO, scale_off / shift_off / bound_off: bn1 and its bound;
+   * the *2 fields: conv2 (packed MVAL_PACK_MFMA16_H2) + bn2.  in_amax_off: n_images P2 rows the launch fills with the
+   * images' max |x| (a small pass over the input first). */
 } mval_op;
 
 /* Weight packing.  MVAL_PACK_HWIO: [k*k][cin][cout] (direct kernels, deconv);

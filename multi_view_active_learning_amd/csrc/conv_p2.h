@@ -134,3 +134,9 @@ int mval_conv_bneck_p2_supported(int cin, int planes, int N, int H, int W);
 int mval_launch_conv_bneck_p2(int cin, const void* in, const void* res, void* out, const float* params, const int64_t* w, const int64_t* w_unscale,
                               const int64_t* scale, const int64_t* shift, const int64_t* bound, const unsigned* in_row,
                               const unsigned* res_row, unsigned* out_row, int N, int H, int W, hipStream_t s);
+// conv_stem_p2.hip: HRNet's stem (3 -> 64 -> 64 channels, two 3x3 stride-2 convs) from the fp32 NCHW image to P2 planes in
+// one launch (plus a small max |x| pass over the image into in_row); 1 = unsupported
+int mval_conv_stem_p2_supported(int N, int H, int W);
+int mval_launch_conv_stem_p2(const float* in, void* out, const float* w1, const float* scale1, const float* shift1, const float* bound1,
+                             const float* w2, const float* w2_unscale, const float* scale2, const float* shift2, const float* bound2,
+                             unsigned* in_row, unsigned* out_row, int N, int H, int W, hipStream_t s);

@@ -337,6 +337,9 @@ static void deconv_parity(ConvArgs& a, const mval_op* op, int parity, const floa
 }
 
 extern "C" int mval_op_algo_supported(const mval_op* op, int n_images, int algo) {
+  if (op && op->kind == MVAL_OP_STEM_P2)
+    return algo == MVAL_ALGO_MFMA_P2 && n_images > 0 && op->cin == 3 && op->cout == 64 && op->in_nchw && !op->out_nchw && !op->up && op->relu &&
+           op->hout * 4 == op->hin && op->wout * 4 == op->win && mval_conv_stem_p2_supported(n_images, op->hin, op->win);
   if (op && op->kind == MVAL_OP_BNECK)
     return algo == MVAL_ALGO_MFMA_P2 && n_images > 0 && op->cout == 256 && op->stride == 1 && !op->up && !op->in_nchw && !op->out_nchw &&
            op->hin == op->hout && op->win == op->wout && op->relu && mval_conv_bneck_p2_supported(op->cin, 64, n_images, op->hin, op->win);
@@ -383,6 +386,20 @@ extern "C" int mval_op_launch(const mval_op* op, int n_images, float* workspace,
     mval_launch_nhwc_to_p2(a.in, reinterpret_cast<const unsigned*>(workspace + op->in_amax_off), reinterpret_cast<_Float16*>(a.out),
                            reinterpret_cast<unsigned*>(workspace + op->out_amax_off), n_images, op->hin * op->win, op->cin, s);
     MVAL_CHECK_LAUNCH("mval_op_launch/to_p2");
+    return 0;
+  }
+  if (op->kind == MVAL_OP_STEM_P2) {
+    MVAL_REQUIRE(op->algo == MVAL_ALGO_MFMA_P2 && op->in_amax_off > 0 && op->out_amax_off > 0 && a.w && a.scale && a.shift && op->bound_off >= 0 &&
+                     op->w2_off >= 0 && op->scale2_off >= 0 && op->shift2_off >= 0 && op->bound2_off >= 0 && op->out_off >= 0 && net_input &&
+                     op->in_off < 0,
+                 "mval_op_launch: malformed MVAL_OP_STEM_P2");
+    const size_t nw2 = mval_packed_weight_floats(MVAL_PACK_MFMA16_H2, 64, 64, 3);
+    const float* w2 = params + op->w2_off;
+    int rc = mval_launch_conv_stem_p2(net_input, a.out, a.w, a.scale, a.shift, params + op->bound_off, w2, w2 + nw2 - 4, params + op->scale2_off,
+                                      params + op->shift2_off, params + op->bound2_off, reinterpret_cast<unsigned*>(workspace + op->in_amax_off),
+                                      reinterpret_cast<unsigned*>(workspace + op->out_amax_off), n_images, op->hin, op->win, s);
+    MVAL_REQUIRE(rc == 0, "mval_op_launch: no fused P2 stem kernel for %dx%d", op->hin, op->win);
+    MVAL_CHECK_LAUNCH("mval_op_launch/stem_p2");
     return 0;
   }
   if (op->kind == MVAL_OP_BNECK) {
@@ -594,6 +611,8 @@ extern "C" int mval_net_forward(void* net, int n_images, float* workspace, const
 
 extern "C" double mval_op_flops(const mval_op* op, int n_images) {
   if (!op || op->kind == MVAL_OP_MAXPOOL || op->kind == MVAL_OP_TO_P2) return 0.0;
+  if (op->kind == MVAL_OP_STEM_P2)  // both convs (conv1's halo recompute is not counted)
+    return 2.0 * n_images * ((double)(op->hin / 2) * (op->win / 2) * 3 * 64 * 9 + (double)op->hout * op->wout * 64 * 64 * 9);
   if (op->kind == MVAL_OP_BNECK)  // the three convs (the halo recompute of conv1 is not counted)
     return 2.0 * n_images * op->hout * op->wout * ((double)op->cin * 64 + 64.0 * 64 * 9 + 64.0 * 256);
   if (op->kind == MVAL_OP_BLOCK)  // algorithmic work of the two convs (the halo recompute is not counted)

@@ -25,7 +25,7 @@ import torch
 from . import _lib
 from .pose_estimators import params as _params
 
-OP_CONV, OP_MAXPOOL, OP_DECONV, OP_BLOCK, OP_TO_P2, OP_BNECK = 0, 1, 2, 3, 4, 5
+OP_CONV, OP_MAXPOOL, OP_DECONV, OP_BLOCK, OP_TO_P2, OP_BNECK, OP_STEM_P2 = 0, 1, 2, 3, 4, 5, 6
 ALGO_DIRECT, ALGO_MFMA, ALGO_MFMA_BF3, ALGO_MFMA_H2, ALGO_MFMA_P2 = 0, 1, 2, 3, 4
 PACK_HWIO, PACK_MFMA16, PACK_MFMA16_BF3, PACK_MFMA16_H2 = 0, 1, 2, 3
 AMAX_ROW = 4096
@@ -220,7 +220,7 @@ class InferencePlan:
                 ptop += _align(op.cout)
                 m.shift_off = ptop
                 ptop += _align(op.cout)
-                if m.algo == ALGO_MFMA_P2:
+                if m.algo == ALGO_MFMA_P2 or (self.p2 and op.src == g.input):  # (the stem's bound: the fused P2 stem needs it)
                     m.bound_off = ptop
                     ptop += 64
                 self.param_jobs.append((i, pack, m.w_off, m.scale_off, m.shift_off))
@@ -296,6 +296,25 @@ class InferencePlan:
             m = MvalOp()
             C.memmove(C.byref(m), C.byref(self.graph_ops[i]), C.sizeof(MvalOp))
             if op.src == g.input:
+                b = g.ops[i + 1] if i + 1 < len(g.ops) else None
+                if (fuse and os.environ.get("MVAL_P2_STEM", "1") != "0" and b is not None and op.kind == b.kind == "conv" and op.k == b.k == 3
+                        and op.stride == b.stride == 2 and op.pad == b.pad == 1 and op.cin == 3 and op.cout == b.cin == b.cout == 64 and op.bn and b.bn
+                        and op.relu and b.relu and b.src == op.dst and uses.get(op.dst, 0) == 1 and b.res1 is None and b.res2 is None
+                        and op.up == b.up == 0 and b.dst != g.output and (op.phase, op.lane) == (b.phase, b.lane)):
+                    # hrnet.py:303-310: both stride-2 stem convs in ONE launch, the 64-channel half-resolution map never leaves the CU
+                    mb = self.graph_ops[i + 1]
+                    st = MvalOp()
+                    C.memmove(C.byref(st), C.byref(m), C.sizeof(MvalOp))
+                    st.kind, st.algo = OP_STEM_P2, ALGO_MFMA_P2
+                    st.hout, st.wout = dims[b.dst]
+                    st.out_off, st.out_amax_off = mb.out_off, row_of[b.dst]
+                    st.in_amax_off = self._amax_top  # rows of the network input: the launch keeps the images' max |x| there
+                    st.w2_off, st.scale2_off, st.shift2_off, st.bound2_off = mb.w_off, mb.scale_off, mb.shift_off, mb.bound_off
+                    if lib.mval_op_algo_supported(C.byref(st), C.c_int(n), C.c_int(ALGO_MFMA_P2)):
+                        self._amax_top += n * P2_ROW
+                        launch.append(st)
+                        i += 2
+                        continue
                 ho, wo = dims[op.dst]
                 stem_floats = _align(n * ho * wo * op.cout)
                 stem_off = self._amax_top  # (behind the rows: only this plan form needs it)
@@ -484,7 +503,7 @@ class InferencePlan:
                 else:
                     self.params[b_off : b_off + op.cout] = 0.0
             gm = self.graph_ops[i]
-            if gm.algo == ALGO_MFMA_P2:
+            if gm.algo == ALGO_MFMA_P2 or (self.p2 and op.src == self.graph.input):
                 # [A, B] of the output bound |bn(conv(x))| <= A max|x| + B (csrc/conv_p2.h): A = max_c |scale_c| sum |w_c|
                 a_ = (w.abs().double().sum(dim=(1, 2, 3)) * self.params[s_off : s_off + op.cout].abs().double()).max() * (1.0 + 1e-6)
                 b_ = self.params[b_off : b_off + op.cout].abs().double().max()
@@ -572,7 +591,7 @@ def _plan_for(model, x):
         raise ValueError("expected (N, 3, H, W) images")
     cache = model.__dict__.setdefault("_plans", {})
     key = (n, h, w, x.device.index, os.environ.get("MVAL_FORCE_DIRECT") == "1", _conv_mode(), os.environ.get("MVAL_FUSE_BLOCKS", "1"),
-           os.environ.get("MVAL_P2_BLOCKS", "32"), os.environ.get("MVAL_P2", "1"), os.environ.get("MVAL_P2_BNECK", "1"))
+           os.environ.get("MVAL_P2_BLOCKS", "32"), os.environ.get("MVAL_P2", "1"), os.environ.get("MVAL_P2_BNECK", "1"), os.environ.get("MVAL_P2_STEM", "1"))
     plan = cache.get(key)
     if plan is None:
         if len(cache) >= 4:  # keep the arena footprint bounded

@@ -398,3 +398,55 @@ def fused_bottleneck_p2(x, convs, res=None):
     fused_bottleneck_p2.last = b
     return b.result()
 
+
+class P2Stem:
+    """HRNet's stem in one launch (MVAL_OP_STEM_P2, csrc/conv_stem_p2.hip): relu(bn2(conv3x3 s2(relu(bn1(conv3x3 s2(x)))))) from the
+    fp32 NCHW image x (n, 3, h, w) to 64 channels of P2 planes at a quarter of the resolution; result(): fp32 NHWC."""
+
+    def __init__(self, x, w1, scale1, shift1, w2, scale2, shift2):
+        dev = x.device
+        n, _, h, w = x.shape
+        ho, wo = h // 4, w // 4
+        self.shape = (n, ho, wo, 64)
+        self.x = x.contiguous()
+        out_floats = _align(n * ho * wo * 64)
+        self.arena = torch.zeros(out_floats + _align(2 * n * P2_ROW), dtype=torch.float32, device=dev)
+        chunks = [pack_weights(w1, ALGO_DIRECT), scale1, shift1, p2_bound(w1, scale1, shift1), pack_weights(w2, ALGO_MFMA_H2), scale2, shift2,
+                  p2_bound(w2, scale2, shift2)]
+        offs, top = [], 0
+        for t in chunks:
+            offs.append(top)
+            top += _align(t.numel())
+        self.params = torch.zeros(top, dtype=torch.float32, device=dev)
+        for o, t in zip(offs, chunks):
+            self.params[o : o + t.numel()] = t.to(dev, torch.float32).reshape(-1)
+        m = MvalOp()
+        m.kind, m.algo = 6, 4  # MVAL_OP_STEM_P2, MVAL_ALGO_MFMA_P2
+        m.k, m.stride, m.pad, m.cin, m.cout = 3, 2, 1, 3, 64
+        m.hin, m.win, m.hout, m.wout = h, w, ho, wo
+        m.up, m.relu, m.in_nchw, m.out_nchw = 0, 1, 1, 0
+        m.in_off, m.out_off, m.res1_off, m.res2_off = -1, 0, -1, -1
+        m.w_off, m.scale_off, m.shift_off, m.bound_off, m.w2_off, m.scale2_off, m.shift2_off, m.bound2_off = offs
+        m.in_amax_off, m.out_amax_off = out_floats, out_floats + n * P2_ROW
+        self.op, self.out_off, self.n = m, 0, n
+        if not _lib.lib().mval_op_algo_supported(C.byref(m), C.c_int(n), C.c_int(4)):
+            raise _lib.MvalError("no fused P2 stem kernel for this geometry")
+
+    def launch(self):
+        _lib._check(_lib.lib().mval_op_launch(C.byref(self.op), C.c_int(self.n), _lib._p(self.arena), _lib._p(self.params),
+                                              _lib._p(self.x), C.c_void_p(0), _lib._stream()), "mval_op_launch")
+
+    out_rows = P2Conv.out_rows
+    kept_amax = P2Conv.kept_amax
+
+    def result(self):
+        n, h, w, c = self.shape
+        return from_p2(self.arena[: n * h * w * c], self.out_rows().reshape(-1), n, h, w, c)
+
+
+def fused_stem_p2(x, w1, scale1, shift1, w2, scale2, shift2):
+    b = P2Stem(x, w1, scale1, shift1, w2, scale2, shift2)
+    b.launch()
+    fused_stem_p2.last = b
+    return b.result()
+

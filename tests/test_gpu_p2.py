@@ -176,6 +176,39 @@ def test_p2_bottleneck_vs_float64(dev, shape):
     assert torch.equal(alone[0], got[0])
 
 
+@pytest.mark.parametrize("shape", [(2, 256, 256), (3, 64, 64), (1, 384, 288), (2, 100, 76), (1, 16, 64)], ids=lambda s: "n%d_%dx%d" % s)
+def test_p2_stem_vs_float64(dev, shape):
+    """MVAL_OP_STEM_P2 (hrnet.py:303-310: both stride-2 stem convs in one launch, fp32 NCHW image -> P2 planes) against
+    float64, against the stand-alone fp32 stem kernel followed by a P2 conv launch (not less accurate), kept max |x|, and
+    image 0 alone gives the same bits."""
+    from multi_view_active_learning_amd import ops
+
+    n, h, w = shape
+    rng = np.random.default_rng(5 + h)
+    x = torch.from_numpy(rng.standard_normal((n, 3, h, w)).astype(np.float32) * 1.2)
+    x[-1] *= 3.0  # (per-image scales)
+    w1 = torch.from_numpy((rng.standard_normal((64, 3, 3, 3)) * np.sqrt(2.0 / 27)).astype(np.float32))
+    w2 = torch.from_numpy((rng.standard_normal((64, 64, 3, 3)) * np.sqrt(2.0 / 576)).astype(np.float32))
+    sc = [torch.from_numpy(rng.uniform(0.5, 1.5, 64).astype(np.float32)) for _ in range(2)]
+    sh = [torch.from_numpy(rng.standard_normal(64).astype(np.float32) * 0.1) for _ in range(2)]
+    d = torch.float64
+    y1 = _ref_conv(x.to(d), w1.to(d), sc[0].to(d), sh[0].to(d), 2, True, None, None, 0)
+    want = _ref_conv(y1, w2.to(d), sc[1].to(d), sh[1].to(d), 2, True, None, None, 0)
+    args = [t.to(dev) for t in (w1, sc[0], sh[0], w2, sc[1], sh[1])]
+    got = ops.fused_stem_p2(x.to(dev), *args)
+    kept = ops.fused_stem_p2.last.kept_amax().cpu()
+    got = got.permute(0, 3, 1, 2).cpu()
+    assert got.shape == want.shape
+    np.testing.assert_allclose(got.numpy(), want.float().numpy(), rtol=1e-4, atol=3e-5)
+    assert torch.allclose(kept, got.abs().amax(dim=(1, 2, 3)), rtol=2.0**-21, atol=0)
+    s1 = ops.fused_conv(x.to(dev), args[0], args[1], args[2], stride=2, relu=True, algo=ops.ALGO_DIRECT, in_nchw=True)
+    two = ops.fused_conv_p2(s1, args[3], args[4], args[5], stride=2, relu=True).permute(0, 3, 1, 2).cpu()
+    rms = lambda y: (y.double() - want).pow(2).mean().sqrt().item()
+    assert rms(got) <= 1.25 * rms(two) + 1e-8, (rms(got), rms(two))
+    alone = ops.fused_stem_p2(x[:1].contiguous().to(dev), *args).permute(0, 3, 1, 2).cpu()
+    assert torch.equal(alone[0], got[0])
+
+
 def test_p2_format(dev):
     """The planes hold h = RNE_fp16(x 2^s), l = RNE_fp16(x 2^s - h) with 2^s a power of two that puts the image's bound in
     [2^13, 2^14): (h + l) 2^-s reproduces x to 2^-22 relative (or 2^-25 of the scaled unit for tiny values), the row keeps
@@ -259,8 +292,9 @@ def test_p2_plan_structure(dev, monkeypatch):
     plan = engine._plan_for(m, x)
     assert plan.p2
     kinds = [o.kind for o in plan.ops]
-    assert kinds[0] == engine.OP_CONV and plan.ops[0].algo == engine.ALGO_DIRECT and kinds[1] == engine.OP_TO_P2
-    assert all(o.algo == engine.ALGO_MFMA_P2 for o in plan.ops[2:])
+    # the two stem convs are ONE launch from the fp32 image to P2 planes (MVAL_P2_STEM=0: stem, format change, P2 conv)
+    assert kinds[0] == engine.OP_STEM_P2 and plan.ops[0].in_off == -1 and engine.OP_TO_P2 not in kinds
+    assert all(o.algo == engine.ALGO_MFMA_P2 for o in plan.ops)
     # layer1's four Bottlenecks are one launch each (the first one behind its downsample conv), the 32-channel BasicBlocks too
     bn = [i for i, o in enumerate(plan.ops) if o.kind == engine.OP_BNECK]
     assert len(bn) == 4 and [plan.ops[i].cin for i in bn] == [64, 256, 256, 256]
