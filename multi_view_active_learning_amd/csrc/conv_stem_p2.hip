@@ -7,12 +7,12 @@
 // (the 64 -> 64 stride-2 conv reading those 537 MB again) per 128 images; fused, the only HBM traffic is the image
 // (100 MB) and the output planes (134 MB).
 //
-// Workgroup = 4 waves on a 2 x 16 tile of `out`, persistent over an XCD-contiguous range of tiles; 58 KB of LDS, two
+// Workgroup = 4 waves on a 2 x 16 tile of `out`, persistent over an XCD-contiguous range of tiles; 51 KB of LDS, three
 // workgroups per CU:
 //   P   the 11 x 67 input patch, 3 planes of fp32 (zero outside the image), the next tile's travelling in registers;
 //   1.  conv1 on the vector ALUs (K = 27 is one ragged MFMA step; the arithmetic stays exact fp32 like the stand-alone
 //       stem): lane = (cout quad, run of 11 pixels of one of the 5 x 33 intermediate rows), packed FMAs, weights
-//       [tap][cin][cout] in LDS; BN1 + ReLU + zero outside y1 -> scaled by the per-IMAGE bound A1 max|x| + B1, split,
+//       [tap][cin][cout] read through L1 (6.9 KB, the same for every lane of the chip); BN1 + ReLU + zero outside y1 -> scaled by the per-IMAGE bound A1 max|x| + B1, split,
 //       8-byte half-granules into Y1 = [chunk][plane h,l][8-ch block][column parity, row, column / 2][16 B];
 //   2.  conv2 on the matrix cores from Y1 (conv_p2.hip arithmetic: three fp16 MFMA products per fp32 product): wave =
 //       16 output channels x 2 rows, a row fragment = 16 consecutive slots of one column parity;
@@ -33,6 +33,29 @@ typedef p2_f16x4 f16x4;
 typedef p2_u32x4 u32x4;
 typedef p2_u32x2 u32x2;
 
+#ifdef P2_STAMP
+#define ST_T0 unsigned long long bp_t = wall_clock64(), bp_t00 = bp_t; unsigned long long bp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define ST_ACC(k)                                 \
+  do {                                            \
+    const unsigned long long t_ = wall_clock64(); \
+    bp_acc[k] += t_ - bp_t;                       \
+    bp_t = t_;                                    \
+  } while (0)
+#define ST_FLUSH                                                                                     \
+  do {                                                                                               \
+    if (g_dbg && lane == 0) {                                                                        \
+      unsigned long long* d_ = g_dbg + ((int64_t)blockIdx.x * 4 + wave) * 16;                        \
+      d_[0] = bp_t00; d_[4] = wall_clock64(); d_[1] = d_[0];                                         \
+      for (int k_ = 0; k_ < 8; k_++) d_[8 + k_] = bp_acc[k_];                                        \
+    }                                                                                                \
+  } while (0)
+extern unsigned long long* g_p2_dbg_shared;
+#else
+#define ST_T0
+#define ST_ACC(k)
+#define ST_FLUSH
+#endif
+
 struct StemP2Args {
   const float* in;   // [N][3][H][W]
   _Float16* out;     // P2 planes [N][2][8][H2][W2][8]
@@ -44,6 +67,7 @@ struct StemP2Args {
   int N, H, W, H1, W1, H2, W2;
   int tiles_x, tiles_y, tiles_total, wgs_x;
   unsigned tiles_img_magic, tiles_x_magic;
+  unsigned long long* dbg;  // diagnostic builds (-DP2_STAMP)
 };
 
 __device__ __forceinline__ f32x4 st_mfma(const u32x4 a, const u32x4 b, const f32x4 c) {
@@ -75,19 +99,19 @@ __global__ __launch_bounds__(256) void image_amax_rows_kernel(const float* __res
   if (threadIdx.x == 0) rows[(int64_t)n * P2_ROW + blockIdx.x] = red;
 }
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) void conv_stem_p2_kernel(StemP2Args a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) void conv_stem_p2_kernel(StemP2Args a) {
   constexpr int TH = 2, TW = 16;                       // tile of `out`
   constexpr int PH = 2 * TH + 1, PW = 2 * TW + 1;      // 5 x 33 pixels of y1
   constexpr int PWh = (PW + 1) / 2, SL = 2 * PH * PWh;  // 170 slots per 8-channel block: [column parity][row][column / 2]
   constexpr int YPL = 4 * SL * 16, YCH = 8 * SL * 16, YB = 2 * YCH;  // 43 520 bytes
   constexpr int IH = 2 * PH + 1, IW = 2 * PW + 1, IWP = 68;          // 11 x 67 input pixels, row stride 68 floats
   constexpr int PB = 3 * IH * IWP * 4;                               // 8 976 bytes
-  constexpr int P0 = YB, W0 = P0 + PB;                               // patch, conv1 weights [27][64]
+  constexpr int P0 = YB, W0 = P0 + PB;                               // patch, workgroup reduction words
   constexpr int NP = (3 * IH * IW + 255) / 256;                      // patch elements per thread: 9
   constexpr int RUN = 11;                                            // y1 pixels per lane: a third of a row
   static_assert(PW == 3 * RUN, "three runs per intermediate row");
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  unsigned* wgred = reinterpret_cast<unsigned*>(smem + W0 + 27 * 64 * 4);
+  unsigned* wgred = reinterpret_cast<unsigned*>(smem + W0);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
   // ---- tile walk (as conv_p2.hip) ------------------------------------------------------------------------------------
@@ -137,7 +161,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
   };
 
   // ---- prologue ----------------------------------------------------------------------------------------------------------
-  for (int i = tid; i < 27 * 64; i += 256) reinterpret_cast<float*>(smem + W0)[i] = a.w1[i];
   int tn, toy, tox;
   decode(tile, tn, toy, tox);
   load_patch(tn, toy, tox);
@@ -151,6 +174,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
   p2_row_request(a.in_row, tn, row_in);
   store_patch();
   __syncthreads();
+#ifdef P2_STAMP
+  unsigned long long* g_dbg = a.dbg;
+#endif
+  ST_T0;
 
   for (;;) {
     const int n = tn, oy0 = toy, ox0 = tox;
@@ -175,6 +202,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
         f32x4 acc[RUN];
 #pragma unroll
         for (int p = 0; p < RUN; p++) acc[p] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#ifndef ST_SKIP1
 #pragma unroll 1
         for (int c = 0; c < 3; c++) {
 #pragma unroll
@@ -190,7 +218,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
             }
 #pragma unroll
             for (int kx = 0; kx < 3; kx++) {
-              const f32x4 w4 = *reinterpret_cast<const f32x4*>(smem + W0 + (((ky * 3 + kx) * 3 + c) * 64 + q * 4) * 4);
+              const f32x4 w4 = *reinterpret_cast<const f32x4*>(a.w1 + ((ky * 3 + kx) * 3 + c) * 64 + q * 4);  // (6.9 KB shared by every lane: L1 hits)
 #pragma unroll
               for (int p = 0; p < RUN; p++) {
                 const f32x2 vv = {xv[2 * p + kx], xv[2 * p + kx]};
@@ -201,6 +229,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
             }
           }
         }
+#endif
+        ST_ACC(0);
         // BN1 + ReLU + zero outside y1 -> scaled, split, half-granules (4 channels x 2 bytes) of both planes
         const f32x4 s1 = sc1 * m1_mul, h1 = sh1 * m1_mul;
         const int yy = 2 * oy0 - 1 + py;
@@ -220,8 +250,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
         }
       }
     }
+    ST_ACC(1);
     __builtin_amdgcn_s_setprio(0);
     __syncthreads();  // Y1 is complete, the patch is free
+    ST_ACC(2);
     if (have_next) load_patch(tn, toy, tox);  // the next tile's patch travels during the matrix phase
 
     // ---- 2. conv2 on the matrix cores: wave = 16 output channels x 2 rows; step = (tap, chunk) ------------------------------------
@@ -242,6 +274,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
       u32x4 B[3][2];
       B[0][0] = wf(0, 0); B[0][1] = wf(0, 1);
       B[1][0] = wf(1, 0); B[1][1] = wf(1, 1);
+#ifndef ST_SKIP2
 #pragma unroll
       for (int step = 0; step < STEPS; step++) {
         if (step + 2 < STEPS) { B[(step + 2) % 3][0] = wf(step + 2, 0); B[(step + 2) % 3][1] = wf(step + 2, 1); }
@@ -259,7 +292,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
           acc2[ms] = st_mfma(B[step % 3][0], Xf[ms][0], c);
         }
       }
+#endif
     }
+    ST_ACC(3);
     __builtin_amdgcn_s_setprio(P2_VALU_PRIO);
     // ---- BN2 + ReLU + max |x| + split, 16-byte stores ------------------------------------------------------------------------------
     float amax = 0.f;
@@ -297,11 +332,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
       }
     }
     __builtin_amdgcn_s_setprio(0);
+    ST_ACC(4);
     if (!have_next) break;
     store_patch();    // (every wave passed the barrier behind conv1: the patch buffer is free)
+    ST_ACC(5);
     __syncthreads();  // every wave is done with Y1, the next patch is visible
+    ST_ACC(6);
     tile = next_tile;
   }
+  ST_FLUSH;
 }
 
 int mval_conv_stem_p2_supported(int N, int H, int W) {
@@ -330,7 +369,7 @@ int mval_launch_conv_stem_p2(const float* in, void* out, const float* w1, const 
   a.tiles_x_magic = a.tiles_x > 1 ? (unsigned)(((uint64_t)1 << 32) / (unsigned)a.tiles_x + 1) : 0u;
   // max |x| per image: 64 partial slots of the input's rows
   hipLaunchKernelGGL(image_amax_rows_kernel, dim3(64, (unsigned)N), dim3(256), 0, s, in, (int64_t)3 * H * W, in_row);
-  constexpr size_t smem = 2 * 8 * 170 * 16 + 3 * 11 * 68 * 4 + 27 * 64 * 4 + 16;
+  constexpr size_t smem = 2 * 8 * 170 * 16 + 3 * 11 * 68 * 4 + 16;
   static int occ = 0;
   if (!occ) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_stem_p2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -351,6 +390,9 @@ int mval_launch_conv_stem_p2(const float* in, void* out, const float* w1, const 
     const int per = (a.tiles_total + 7) / 8, rounds = (per + wgs / 8 - 1) / (wgs / 8);
     wgs = 8 * ((per + rounds - 1) / rounds);
   }
+#ifdef P2_STAMP
+  a.dbg = g_p2_dbg_shared;
+#endif
   a.wgs_x = wgs;
   if (getenv("MVAL_P2_DEBUG")) fprintf(stderr, "stem_p2 N %d %dx%d -> %dx%d tiles %d per_cu %d wgs %d smem %zu\n", N, H, W, a.H2, a.W2, a.tiles_total, per_cu, wgs, smem);
   if (tiles_img > P2_SLOTS) mval_launch_zero_rows(out_row, (int64_t)N * P2_ROW, s);
