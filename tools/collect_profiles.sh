@@ -1,7 +1,7 @@
 #!/bin/bash
 # Collect the per-round measurement set on the GPU box (run from the repo root through gpurun):
 #   bench lines of every workload, rocprofv3 kernel stats of C2 / C3, and the FETCH_SIZE / WRITE_SIZE counter passes of
-#   C2 (separate --pmc runs), summarised by tools/pmc_summary.py.  usage: tools/collect_profiles.sh <tag>
+#   C2 (separate --pmc runs), summarised by tools/pmc_summary.py.  usage: [POOL50K=1] tools/collect_profiles.sh <tag>
 tag=${1:-v0}
 out=gpurun_out/prof_$tag
 mkdir -p $out
@@ -26,4 +26,8 @@ cp $ks $out/bench_c2_kernel_stats_$tag.csv
 cp $k3 $out/bench_c3_kernel_stats_$tag.csv
 python3 tools/pmc_summary.py $ks $fe $wr $sq > $out/bench_c2_${tag}_summary.json
 rm -rf $out/kt_c2 $out/kt_c3 $out/pmc_fetch $out/pmc_write $out/pmc_sq
+if [ -n "$POOL50K" ]; then   # the BASELINE-size pool passes (about 140 s each): unedited bench lines
+  python3 bench.py --workload c4 --pool 50000 --no-cpu-baseline 2>/dev/null | tail -1 > $out/bench_c4_pool50000.json
+  python3 bench.py --workload c5 --pool 50000 --no-cpu-baseline 2>/dev/null | tail -1 > $out/bench_c5_pool50000.json
+fi
 ls -la $out
