@@ -525,7 +525,9 @@ def main():
             nimg = plan.n
             b = 0.0
             for o, m_ in zip(plan.ops, mask):
-                if m_:
+                if m_ and o.kind == 7:  # fused up-sampling terms: every term's input at its own resolution, partial sum in, sum out
+                    b += 4.0 * nimg * (sum((o.hout >> o.t_up[t]) * (o.wout >> o.t_up[t]) * o.t_cin[t] for t in range(o.n_terms)) + 2 * o.hout * o.wout * o.cout)
+                elif m_:
                     outp = (o.hout << o.up) * (o.wout << o.up) * o.cout
                     # (a fused Bottleneck whose residual is its own input reads that tensor once, algorithmically)
                     b += 4.0 * nimg * (o.hin * o.win * o.cin + outp * (1 + (o.res1_off >= 0 and o.res1_off != o.in_off) + (o.res2_off >= 0)))
@@ -542,6 +544,7 @@ def main():
         stem = np.asarray([o.kind == 0 and o.in_nchw == 1 for o in plan.ops])
         bneck = np.asarray([o.kind == 5 for o in plan.ops])
         stem2 = np.asarray([o.kind == 6 for o in plan.ops])
+        fuseup = np.asarray([o.kind == 7 for o in plan.ops])
         fams = []
         split_any = np.zeros(len(plan.ops), dtype=bool)
         for algo, pl, what in ((ALGO_MFMA_P2, "p2", "activations kept as fp16 (h, l) plane pairs in HBM, 3 x v_mfma_f32_16x16x32_f16 per 32-deep step"),
@@ -564,7 +567,9 @@ def main():
                 hbm_family(m_ & bneck, "conv_bneck_p2_kernel<CIN> (whole Bottlenecks of layer1 in one launch: 1x1 -> 3x3 -> 1x1 convs, BNs, residual, "
                                        "ReLUs; the 64-channel intermediates never leave the CU; HBM is the tighter of its two bounds: "
                                        "1.07 GB / 8 TB/s = 134 us vs 80 GFLOP x 3 / 2500 TFLOP/s = 96 us per 128 images)"),
-                hbm_family(m_ & ~k3 & ~bneck, ("conv_p2_kernel<1, 1, ...>" if pl == "p2" else f"conv_split_kernel<{2 if pl == 'h2' else 3}, 1, 1, ...>") + " (fused 1x1 conv+BN+residual+ReLU(+upsample): "
+                hbm_family(m_ & fuseup, "conv_fuse_up_p2_kernel<C> (the two or three up-sampling 1x1 terms of a fuse-layer output added to the partial sum in one "
+                                        "launch: the sum is read once and written once)"),
+                hbm_family(m_ & ~k3 & ~bneck & ~fuseup, ("conv_p2_kernel<1, 1, ...>" if pl == "p2" else f"conv_split_kernel<{2 if pl == 'h2' else 3}, 1, 1, ...>") + " (fused 1x1 conv+BN+residual+ReLU(+upsample): "
                                      "channel GEMMs of the bottleneck blocks and fuse up-paths; 2x2 parity convs of transposed convs)"),
             ]
         fams += [

@@ -180,7 +180,7 @@ int mval_kcenter_select(const double* feat, int64_t n_obs, int D, const int64_t*
  * floats from the workspace base; -1 = absent.  Weights are in the packed fragment order
  * written by mval_pack_conv_weights; scale/shift are the folded eval-mode BatchNorm
  * (y = x * scale + shift, torch's batch_norm inference formula) or (1, bias). */
-enum { MVAL_OP_CONV = 0, MVAL_OP_MAXPOOL = 1, MVAL_OP_DECONV = 2, MVAL_OP_BLOCK = 3, MVAL_OP_TO_P2 = 4, MVAL_OP_BNECK = 5, MVAL_OP_STEM_P2 = 6 };
+enum { MVAL_OP_CONV = 0, MVAL_OP_MAXPOOL = 1, MVAL_OP_DECONV = 2, MVAL_OP_BLOCK = 3, MVAL_OP_TO_P2 = 4, MVAL_OP_BNECK = 5, MVAL_OP_STEM_P2 = 6, MVAL_OP_FUSE_UP = 7 };
 enum { MVAL_ALGO_DIRECT = 0, MVAL_ALGO_MFMA = 1, MVAL_ALGO_MFMA_BF3 = 2, MVAL_ALGO_MFMA_H2 = 3, MVAL_ALGO_MFMA_P2 = 4 };
 enum { MVAL_PACK_HWIO = 0, MVAL_PACK_MFMA16 = 1, MVAL_PACK_MFMA16_BF3 = 2, MVAL_PACK_MFMA16_H2 = 3 };
 
@@ -235,6 +235,15 @@ typedef struct mval_op {
    * out_amax_off.  w_off: conv1's weights packed MVAL_PACK_HWIO, scale_off / shift_off / bound_off: bn1 and its bound;
    * the *2 fields: conv2 (packed MVAL_PACK_MFMA16_H2) + bn2.  in_amax_off: n_images P2 rows the launch fills with the
    * images' max |x| (a small pass over the input first). */
+  /* MVAL_OP_FUSE_UP (hrnet.py:424-447, the up-sampling terms of one fuse-layer output in one launch,
+   * csrc/conv_fuse_up_p2.hip; algo MVAL_ALGO_MFMA_P2 only):
+   *   out = act(((res1 + up(bn(conv1x1(t_0)))) + up(bn(conv1x1(t_1)))) [+ up(bn(conv1x1(t_2)))])   (left to right, fp32)
+   * cout in {32, 64} channels at hout x wout (= hin x win here); res1_off / res1_amax_off: the partial sum so far (required);
+   * n_terms in {2, 3}; term j: P2 input of t_cin[j] channels at (hout >> t_up[j]) x (wout >> t_up[j]) at t_in_off[j] with rows at
+   * t_in_amax_off[j], 1x1 weights packed MVAL_PACK_MFMA16_H2 at t_w_off[j], folded BN at t_scale_off[j] / t_shift_off[j], bound
+   * [A, B] at t_bound_off[j]; relu: the activation of the sum. */
+  int32_t n_terms, t_cin[3], t_up[3], _pad_terms;
+  int64_t t_in_off[3], t_in_amax_off[3], t_w_off[3], t_scale_off[3], t_shift_off[3], t_bound_off[3];
 } mval_op;
 
 /* Weight packing.  MVAL_PACK_HWIO: [k*k][cin][cout] (direct kernels, deconv);

@@ -140,3 +140,10 @@ int mval_conv_stem_p2_supported(int N, int H, int W);
 int mval_launch_conv_stem_p2(const float* in, void* out, const float* w1, const float* scale1, const float* shift1, const float* bound1,
                              const float* w2, const float* w2_unscale, const float* scale2, const float* shift2, const float* bound2,
                              unsigned* in_row, unsigned* out_row, int N, int H, int W, hipStream_t s);
+// conv_fuse_up_p2.hip: the two or three up-sampling 1x1 terms of a fuse-layer output (32 / 64 channels) added to the partial
+// sum `res` in one launch; arrays per term (float offsets into `params`); 1 = unsupported
+int mval_conv_fuse_up_p2_supported(int cout, int n_terms, const int* cin, const int* up, int N, int H, int W);
+int mval_launch_conv_fuse_up_p2(int cout, int n_terms, int relu, const void* res, const unsigned* res_row, void* out, unsigned* out_row, const float* params,
+                                const void* const* in, const unsigned* const* in_row, const int* cin, const int* up, const int64_t* w,
+                                const int64_t* w_unscale, const int64_t* scale, const int64_t* shift, const int64_t* bound, int N, int H, int W,
+                                hipStream_t s);

@@ -337,6 +337,9 @@ static void deconv_parity(ConvArgs& a, const mval_op* op, int parity, const floa
 }
 
 extern "C" int mval_op_algo_supported(const mval_op* op, int n_images, int algo) {
+  if (op && op->kind == MVAL_OP_FUSE_UP)
+    return algo == MVAL_ALGO_MFMA_P2 && n_images > 0 && !op->in_nchw && !op->out_nchw && op->res1_off >= 0 && op->res2_off < 0 &&
+           mval_conv_fuse_up_p2_supported(op->cout, op->n_terms, op->t_cin, op->t_up, n_images, op->hout, op->wout);
   if (op && op->kind == MVAL_OP_STEM_P2)
     return algo == MVAL_ALGO_MFMA_P2 && n_images > 0 && op->cin == 3 && op->cout == 64 && op->in_nchw && !op->out_nchw && !op->up && op->relu &&
            op->hout * 4 == op->hin && op->wout * 4 == op->win && mval_conv_stem_p2_supported(n_images, op->hin, op->win);
@@ -386,6 +389,28 @@ extern "C" int mval_op_launch(const mval_op* op, int n_images, float* workspace,
     mval_launch_nhwc_to_p2(a.in, reinterpret_cast<const unsigned*>(workspace + op->in_amax_off), reinterpret_cast<_Float16*>(a.out),
                            reinterpret_cast<unsigned*>(workspace + op->out_amax_off), n_images, op->hin * op->win, op->cin, s);
     MVAL_CHECK_LAUNCH("mval_op_launch/to_p2");
+    return 0;
+  }
+  if (op->kind == MVAL_OP_FUSE_UP) {
+    MVAL_REQUIRE(op->algo == MVAL_ALGO_MFMA_P2 && op->out_amax_off > 0 && op->res1_amax_off > 0 && a.res1 && op->out_off >= 0 && op->n_terms >= 2 &&
+                     op->n_terms <= 3,
+                 "mval_op_launch: malformed MVAL_OP_FUSE_UP");
+    const void* tin[3] = {nullptr, nullptr, nullptr};
+    const unsigned* trow[3] = {nullptr, nullptr, nullptr};
+    int64_t wu[3] = {0, 0, 0};
+    for (int j = 0; j < op->n_terms; j++) {
+      MVAL_REQUIRE(op->t_in_off[j] >= 0 && op->t_in_amax_off[j] > 0 && op->t_w_off[j] >= 0 && op->t_scale_off[j] >= 0 && op->t_shift_off[j] >= 0 &&
+                       op->t_bound_off[j] >= 0,
+                   "mval_op_launch: malformed MVAL_OP_FUSE_UP term %d", j);
+      tin[j] = workspace + op->t_in_off[j];
+      trow[j] = reinterpret_cast<const unsigned*>(workspace + op->t_in_amax_off[j]);
+      wu[j] = op->t_w_off[j] + (int64_t)mval_packed_weight_floats(MVAL_PACK_MFMA16_H2, op->cout, op->t_cin[j], 1) - 4;
+    }
+    int rc = mval_launch_conv_fuse_up_p2(op->cout, op->n_terms, op->relu, a.res1, reinterpret_cast<const unsigned*>(workspace + op->res1_amax_off), a.out,
+                                         reinterpret_cast<unsigned*>(workspace + op->out_amax_off), params, tin, trow, op->t_cin, op->t_up, op->t_w_off, wu,
+                                         op->t_scale_off, op->t_shift_off, op->t_bound_off, n_images, op->hout, op->wout, s);
+    MVAL_REQUIRE(rc == 0, "mval_op_launch: no fused up-path kernel for c%d %dx%d", op->cout, op->hout, op->wout);
+    MVAL_CHECK_LAUNCH("mval_op_launch/fuse_up_p2");
     return 0;
   }
   if (op->kind == MVAL_OP_STEM_P2) {
@@ -611,6 +636,11 @@ extern "C" int mval_net_forward(void* net, int n_images, float* workspace, const
 
 extern "C" double mval_op_flops(const mval_op* op, int n_images) {
   if (!op || op->kind == MVAL_OP_MAXPOOL || op->kind == MVAL_OP_TO_P2) return 0.0;
+  if (op->kind == MVAL_OP_FUSE_UP) {  // the terms' 1x1 convs at their own resolutions
+    double f = 0.0;
+    for (int j = 0; j < op->n_terms; j++) f += 2.0 * n_images * (double)(op->hout >> op->t_up[j]) * (op->wout >> op->t_up[j]) * op->t_cin[j] * op->cout;
+    return f;
+  }
   if (op->kind == MVAL_OP_STEM_P2)  // both convs (conv1's halo recompute is not counted)
     return 2.0 * n_images * ((double)(op->hin / 2) * (op->win / 2) * 3 * 64 * 9 + (double)op->hout * op->wout * 64 * 64 * 9);
   if (op->kind == MVAL_OP_BNECK)  // the three convs (the halo recompute of conv1 is not counted)

@@ -25,7 +25,7 @@ import torch
 from . import _lib
 from .pose_estimators import params as _params
 
-OP_CONV, OP_MAXPOOL, OP_DECONV, OP_BLOCK, OP_TO_P2, OP_BNECK, OP_STEM_P2 = 0, 1, 2, 3, 4, 5, 6
+OP_CONV, OP_MAXPOOL, OP_DECONV, OP_BLOCK, OP_TO_P2, OP_BNECK, OP_STEM_P2, OP_FUSE_UP = 0, 1, 2, 3, 4, 5, 6, 7
 ALGO_DIRECT, ALGO_MFMA, ALGO_MFMA_BF3, ALGO_MFMA_H2, ALGO_MFMA_P2 = 0, 1, 2, 3, 4
 PACK_HWIO, PACK_MFMA16, PACK_MFMA16_BF3, PACK_MFMA16_H2 = 0, 1, 2, 3
 AMAX_ROW = 4096
@@ -50,6 +50,9 @@ class MvalOp(C.Structure):
         ("w2_off", C.c_int64), ("scale2_off", C.c_int64), ("shift2_off", C.c_int64),
         ("bound_off", C.c_int64), ("bound2_off", C.c_int64), ("res1_amax_off", C.c_int64), ("res2_amax_off", C.c_int64),
         ("w3_off", C.c_int64), ("scale3_off", C.c_int64), ("shift3_off", C.c_int64), ("bound3_off", C.c_int64),
+        ("n_terms", C.c_int32), ("t_cin", C.c_int32 * 3), ("t_up", C.c_int32 * 3), ("_pad_terms", C.c_int32),
+        ("t_in_off", C.c_int64 * 3), ("t_in_amax_off", C.c_int64 * 3), ("t_w_off", C.c_int64 * 3), ("t_scale_off", C.c_int64 * 3),
+        ("t_shift_off", C.c_int64 * 3), ("t_bound_off", C.c_int64 * 3),
     ]
 
 
@@ -285,6 +288,7 @@ class InferencePlan:
         # blocks are fused by default (MVAL_P2_BLOCKS=32,64 fuses both)
         fuse_c = {int(v) for v in os.environ.get("MVAL_P2_BLOCKS", "32").split(",") if v}
         fuse_bneck = fuse and os.environ.get("MVAL_P2_BNECK", "1") != "0"
+        fuse_up = fuse and os.environ.get("MVAL_P2_FUSE_UP", "1") != "0"
         uses = {}
         for op in g.ops:
             for a in (op.src, op.res1, op.res2):
@@ -337,6 +341,27 @@ class InferencePlan:
             m.res1_amax_off = row_of[op.res1] if op.res1 is not None else 0
             m.res2_amax_off = row_of[op.res2] if op.res2 is not None else 0
             m.out_amax_off = row_of.get(op.dst, 0)
+            chain = self._up_chain_at(g, i, uses) if fuse_up else None
+            if chain is not None:
+                # hrnet.py:424-447: the consecutive up-sampling terms of a fuse-layer output in ONE launch; the partial sum is read
+                # once and written once instead of once per term
+                last = g.ops[chain[-1]]
+                fu = MvalOp()
+                C.memmove(C.byref(fu), C.byref(m), C.sizeof(MvalOp))
+                fu.kind, fu.relu, fu.up = OP_FUSE_UP, int(last.relu), 0
+                fu.hin, fu.win = fu.hout, fu.wout = dims[last.dst]
+                fu.out_off, fu.out_amax_off = self.graph_ops[chain[-1]].out_off, row_of[last.dst]
+                fu.res1_off, fu.res1_amax_off, fu.res2_off, fu.res2_amax_off = m.res1_off, row_of[op.res1], -1, 0
+                fu.n_terms = len(chain)
+                for j, k in enumerate(chain):
+                    gk, ok_ = self.graph_ops[k], g.ops[k]
+                    fu.t_cin[j], fu.t_up[j] = ok_.cin, ok_.up
+                    fu.t_in_off[j], fu.t_in_amax_off[j] = gk.in_off, row_of[ok_.src]
+                    fu.t_w_off[j], fu.t_scale_off[j], fu.t_shift_off[j], fu.t_bound_off[j] = gk.w_off, gk.scale_off, gk.shift_off, gk.bound_off
+                if lib.mval_op_algo_supported(C.byref(fu), C.c_int(n), C.c_int(ALGO_MFMA_P2)):
+                    launch.append(fu)
+                    i = chain[-1] + 1
+                    continue
             bn = self._bneck_at(g, i, uses) if fuse_bneck else None
             if bn is not None:
                 # hrnet.py:75-95 with 64 planes: conv1x1 -> conv3x3 -> conv1x1 (+ residual) in ONE launch; a downsample branch
@@ -383,6 +408,26 @@ class InferencePlan:
         for k, m in enumerate(launch):
             C.memmove(C.byref(arr[k]), C.byref(m), C.sizeof(MvalOp))
         return arr
+
+    @staticmethod
+    def _up_chain_at(g, i, uses):
+        """Ops i, i + 1 [, i + 2] are the consecutive up-sampling 1x1 terms of one fuse-layer output (each adds to the previous one's
+        result, only the last may have the ReLU) -> their indices, else None."""
+        chain = []
+        k = i
+        while k < len(g.ops) and len(chain) < 3:
+            o = g.ops[k]
+            if not (o.kind == "conv" and o.k == 1 and o.stride == 1 and o.up >= 1 and o.bn and o.res1 is not None and o.res2 is None
+                    and o.cin % 32 == 0 and o.cout in (32, 64) and o.dst != g.output):
+                break
+            if chain:
+                p = g.ops[chain[-1]]
+                if not (o.res1 == p.dst and uses.get(p.dst, 0) == 1 and not p.relu and o.cout == p.cout
+                        and (o.phase, o.lane) == (p.phase, p.lane)):
+                    break
+            chain.append(k)
+            k += 1
+        return chain if len(chain) >= 2 else None
 
     @staticmethod
     def _bneck_at(g, i, uses):
@@ -591,7 +636,7 @@ def _plan_for(model, x):
         raise ValueError("expected (N, 3, H, W) images")
     cache = model.__dict__.setdefault("_plans", {})
     key = (n, h, w, x.device.index, os.environ.get("MVAL_FORCE_DIRECT") == "1", _conv_mode(), os.environ.get("MVAL_FUSE_BLOCKS", "1"),
-           os.environ.get("MVAL_P2_BLOCKS", "32"), os.environ.get("MVAL_P2", "1"), os.environ.get("MVAL_P2_BNECK", "1"), os.environ.get("MVAL_P2_STEM", "1"))
+           os.environ.get("MVAL_P2_BLOCKS", "32"), os.environ.get("MVAL_P2", "1"), os.environ.get("MVAL_P2_BNECK", "1"), os.environ.get("MVAL_P2_STEM", "1"), os.environ.get("MVAL_P2_FUSE_UP", "1"))
     plan = cache.get(key)
     if plan is None:
         if len(cache) >= 4:  # keep the arena footprint bounded

@@ -450,3 +450,67 @@ def fused_stem_p2(x, w1, scale1, shift1, w2, scale2, shift2):
     fused_stem_p2.last = b
     return b.result()
 
+
+class P2FuseUp:
+    """The up-sampling terms of one HRNet fuse-layer output in one launch (MVAL_OP_FUSE_UP, csrc/conv_fuse_up_p2.hip):
+    act(((res + up(bn(conv1x1(x_0)))) + up(bn(conv1x1(x_1)))) [+ ...]); res fp32 NHWC (n, h, w, c) with c in {32, 64}; terms = two or
+    three (x NHWC at (h >> up, w >> up), weight (c, cin, 1, 1), scale, shift, up)."""
+
+    def __init__(self, res, terms, relu=True):
+        dev = res.device
+        n, h, w, c = res.shape
+        self.shape = (n, h, w, c)
+        parts = [to_p2(res)] + [to_p2(t[0]) for t in terms]
+        offs_a, top = [], 0
+        for pl, _ in parts:
+            offs_a.append(top)
+            top += _align(pl.numel())
+        out_off = top
+        top += _align(n * h * w * c)
+        row_off = top
+        self.arena = torch.zeros(top + _align((len(parts) + 1) * n * P2_ROW), dtype=torch.float32, device=dev)
+        for i, (pl, rows) in enumerate(parts):
+            self.arena[offs_a[i] : offs_a[i] + pl.numel()] = pl
+            self.arena[row_off + i * n * P2_ROW : row_off + (i + 1) * n * P2_ROW] = rows.view(torch.float32)
+        chunks = []
+        for x, wt, sc, sh, up in terms:
+            chunks += [pack_weights(wt, ALGO_MFMA_H2), sc, sh, p2_bound(wt, sc, sh)]
+        offs, ptop = [], 0
+        for t in chunks:
+            offs.append(ptop)
+            ptop += _align(t.numel())
+        self.params = torch.zeros(ptop, dtype=torch.float32, device=dev)
+        for o, t in zip(offs, chunks):
+            self.params[o : o + t.numel()] = t.to(dev, torch.float32).reshape(-1)
+        m = MvalOp()
+        m.kind, m.algo = 7, 4  # MVAL_OP_FUSE_UP, MVAL_ALGO_MFMA_P2
+        m.k, m.stride, m.pad, m.cin, m.cout = 1, 1, 0, terms[0][0].shape[-1], c
+        m.hin, m.win, m.hout, m.wout = h, w, h, w
+        m.up, m.relu, m.in_nchw, m.out_nchw = 0, int(relu), 0, 0
+        m.in_off, m.out_off, m.res1_off, m.res2_off = offs_a[1], out_off, 0, -1
+        m.res1_amax_off = row_off
+        m.out_amax_off = row_off + len(parts) * n * P2_ROW
+        m.n_terms = len(terms)
+        for j, (x, wt, sc, sh, up) in enumerate(terms):
+            m.t_cin[j], m.t_up[j] = x.shape[-1], up
+            m.t_in_off[j], m.t_in_amax_off[j] = offs_a[1 + j], row_off + (1 + j) * n * P2_ROW
+            m.t_w_off[j], m.t_scale_off[j], m.t_shift_off[j], m.t_bound_off[j] = offs[4 * j : 4 * j + 4]
+        self.op, self.out_off, self.n = m, out_off, n
+        if not _lib.lib().mval_op_algo_supported(C.byref(m), C.c_int(n), C.c_int(4)):
+            raise _lib.MvalError("no fused up-path kernel for this geometry")
+
+    launch = P2Conv.launch
+    out_rows = P2Conv.out_rows
+    kept_amax = P2Conv.kept_amax
+
+    def result(self):
+        n, h, w, c = self.shape
+        return from_p2(self.arena[self.out_off : self.out_off + n * h * w * c], self.out_rows().reshape(-1), n, h, w, c)
+
+
+def fused_up_terms_p2(res, terms, relu=True):
+    b = P2FuseUp(res, terms, relu)
+    b.launch()
+    fused_up_terms_p2.last = b
+    return b.result()
+

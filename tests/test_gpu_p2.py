@@ -209,6 +209,47 @@ def test_p2_stem_vs_float64(dev, shape):
     assert torch.equal(alone[0], got[0])
 
 
+@pytest.mark.parametrize("case", [(2, 32, 64, 64, 3), (2, 32, 64, 64, 2), (3, 64, 32, 32, 2), (1, 32, 96, 72, 3), (2, 32, 24, 40, 2), (1, 64, 16, 8, 2)],
+                         ids=lambda c: "n%d_c%d_%dx%d_t%d" % c)
+def test_p2_fuse_up_terms_vs_float64(dev, case):
+    """MVAL_OP_FUSE_UP (hrnet.py:424-447: the up-sampling 1x1 terms of one fuse-layer output added to the partial sum in one
+    launch) against float64, against the chain of P2 conv launches it replaces (not less accurate: the chain rounds every
+    partial sum to the pair format), kept max |x|, and image 0 alone gives the same bits."""
+    from multi_view_active_learning_amd import _lib, ops
+
+    n, c, h, w, nt = case
+    rng = np.random.default_rng(3 + h + nt)
+    res = torch.from_numpy(np.maximum(rng.standard_normal((n, c, h, w)), 0).astype(np.float32) * 1.5)
+    terms = []
+    for j in range(nt):
+        up, cin = j + 1, c << (j + 1)
+        x = torch.from_numpy(np.maximum(rng.standard_normal((n, cin, h >> up, w >> up)), 0).astype(np.float32))
+        wt = torch.from_numpy((rng.standard_normal((c, cin, 1, 1)) * np.sqrt(2.0 / cin)).astype(np.float32))
+        terms.append((x, wt, torch.from_numpy(rng.uniform(0.5, 1.5, c).astype(np.float32)), torch.from_numpy(rng.standard_normal(c).astype(np.float32) * 0.1), up))
+    d = torch.float64
+    want = res.to(d)
+    for j, (x, wt, sc, sh, up) in enumerate(terms):
+        want = _ref_conv(x.to(d), wt.to(d), sc.to(d), sh.to(d), 1, j == nt - 1, want, None, up)
+    nhwc = lambda v: v.permute(0, 2, 3, 1).contiguous().to(dev)
+    td = [(nhwc(x), wt.to(dev), sc.to(dev), sh.to(dev), up) for x, wt, sc, sh, up in terms]
+    got = ops.fused_up_terms_p2(nhwc(res), td, relu=True)
+    kept = ops.fused_up_terms_p2.last.kept_amax().cpu()
+    got = got.permute(0, 3, 1, 2).cpu()
+    np.testing.assert_allclose(got.numpy(), want.float().numpy(), rtol=1e-4, atol=3e-5)
+    assert torch.allclose(kept, got.abs().amax(dim=(1, 2, 3)), rtol=2.0**-21, atol=0)
+    try:  # (the one-term kernels need 8-pixel-wide low-resolution maps: the smallest cases have no chain to compare with)
+        acc = nhwc(res)
+        for j, (x, wt, sc, sh, up) in enumerate(td):
+            acc = ops.fused_conv_p2(x, wt, sc, sh, relu=(j == nt - 1), res1=acc, up=up)
+        chain = acc.permute(0, 3, 1, 2).cpu()
+        rms = lambda y: (y.double() - want).pow(2).mean().sqrt().item()
+        assert rms(got) <= 1.25 * rms(chain) + 1e-8, (rms(got), rms(chain))
+    except _lib.MvalError:
+        assert min(h, w) >> nt < 8
+    alone = ops.fused_up_terms_p2(nhwc(res[:1]), [(x[:1].contiguous(), wt, sc, sh, up) for x, wt, sc, sh, up in td], relu=True).permute(0, 3, 1, 2).cpu()
+    assert torch.equal(alone[0], got[0])
+
+
 def test_p2_format(dev):
     """The planes hold h = RNE_fp16(x 2^s), l = RNE_fp16(x 2^s - h) with 2^s a power of two that puts the image's bound in
     [2^13, 2^14): (h + l) 2^-s reproduces x to 2^-22 relative (or 2^-25 of the scaled unit for tiny values), the row keeps
@@ -301,6 +342,9 @@ def test_p2_plan_structure(dev, monkeypatch):
     assert plan.ops[bn[0] - 1].kind == engine.OP_CONV and plan.ops[bn[0] - 1].cout == 256 and plan.ops[bn[0]].res1_off == plan.ops[bn[0] - 1].out_off
     assert all(plan.ops[i].res1_off == plan.ops[i].in_off for i in bn[1:])
     assert sum(o.kind == engine.OP_BLOCK for o in plan.ops) == 32
+    # fuse layers: the up-sampling terms of an output are one launch where there are two or three of them
+    fu = [o for o in plan.ops if o.kind == engine.OP_FUSE_UP]
+    assert sorted((o.cout, o.n_terms) for o in fu) == sorted([(32, 2)] * 4 + [(32, 3)] * 3 + [(64, 2)] * 2)
     r = cases.model_cases()["r50"]
     mr, _ = _load(r, dev)
     xr = torch.from_numpy(cases.model_input(r)).to(dev)

@@ -17,7 +17,8 @@ import sys
 
 def fam(n):
     return ("conv_block_p2_kernel" if "conv_block_p2" in n else "conv_bneck_p2_kernel" if "conv_bneck_p2" in n else
-            "conv_stem_p2_kernel" if "conv_stem_p2" in n else "conv_p2_kernel" if "conv_p2" in n else
+            "conv_stem_p2_kernel" if "conv_stem_p2" in n else "conv_fuse_up_p2_kernel" if "conv_fuse_up_p2" in n else
+            "conv_p2_kernel" if "conv_p2" in n else
             "conv_block_kernel" if "conv_block" in n else "conv_split_kernel" if "conv_split" in n else
             "conv_bf3_kernel" if "conv_bf3" in n else "conv_mfma_kernel" if "conv_mfma" in n else
             "conv_stem_kernel" if "conv_stem" in n else n.split("(")[0][:48])
@@ -54,7 +55,7 @@ out = {"kernel_stats": [dict(kernel=n, calls=c, avg_us=round(t / c / 1e3, 2), to
                              pct=round(100 * t / tot, 2)) for n, (c, t) in sorted(k.items(), key=lambda kv: -kv[1][1])[:10]]}
 f, w = agg(fetch, "FETCH_SIZE"), agg(write, "WRITE_SIZE")
 out["hbm_traffic_per_launch"] = []
-for n in ("conv_p2_kernel", "conv_block_p2_kernel", "conv_bneck_p2_kernel", "conv_stem_p2_kernel", "conv_split_kernel", "conv_block_kernel", "conv_bf3_kernel", "conv_mfma_kernel", "conv_stem_kernel"):
+for n in ("conv_p2_kernel", "conv_block_p2_kernel", "conv_bneck_p2_kernel", "conv_stem_p2_kernel", "conv_fuse_up_p2_kernel", "conv_split_kernel", "conv_block_kernel", "conv_bf3_kernel", "conv_mfma_kernel", "conv_stem_kernel"):
     if n in f and n in w:
         nf, fs, tf = f[n]
         nw, ws, _ = w[n]
