@@ -9,9 +9,10 @@
 // ~135 us at the ~4 TB/s those launches reach).  Fused: r is read once and out written once (0.19 GB).  The additions keep
 // the reference's left-to-right order in fp32 (the chain rounds each partial sum to the 22-bit pair format in between).
 //
-// Workgroup = 4 waves on a 16 x 32 output tile:
+// Workgroup = 4 waves on an 8 x 32 output tile (16 x 32 tiles: 1 024 workgroups of 140 registers = 1.33 rounds of the chip; 8 x 32:
+// 2 048 of ~90):
 //   1.  the 1x1 convs of the terms on the matrix cores (conv_p2.hip arithmetic), B fragments straight from global memory
-//       (no halo, no reuse between pixels): term j covers (16 >> u_j) x (32 >> u_j) low-resolution pixels in sixteen-pixel
+//       (no halo, no reuse between pixels): term j covers (8 >> u_j) x (32 >> u_j) low-resolution pixels in sixteen-pixel
 //       fragments; BN_j in registers, fp32 results into LDS [term][pixel][C];
 //   2.  every thread finishes whole 8-channel granules of the output: r's (h, l) granules from global, the terms' values of
 //       its low-resolution parents from LDS (lanes of a 2^u block read the same address), sum, act, max |x|, split, two
@@ -27,6 +28,9 @@ typedef p2_u32x4 u32x4;
 typedef p2_u32x2 u32x2;
 
 #define FU_MAX_TERMS 3
+#ifndef FU_TH
+#define FU_TH 8  // rows of the output tile (x 32 columns)
+#endif
 
 struct FuseUpTerm {
   const _Float16* in;
@@ -53,7 +57,7 @@ __device__ __forceinline__ f32x4 fu_mfma(const u32x4 a, const u32x4 b, const f32
 template <int COUT>
 __global__ __launch_bounds__(256) void conv_fuse_up_p2_kernel(FuseUpArgs a) {
   static_assert(COUT == 32 || COUT == 64, "fuse-layer outputs of 32 or 64 channels");
-  constexpr int TH = 16, TW = 32, NCT = COUT / 16, NH = 4 / NCT, C8 = COUT / 8;
+  constexpr int TH = FU_TH, TW = 32, NCT = COUT / 16, NH = 4 / NCT, C8 = COUT / 8;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ unsigned wgmax;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -206,10 +210,10 @@ int mval_launch_conv_fuse_up_p2(int cout, int n_terms, int relu, const void* res
     a.t[j].w = (unsigned)w[j] * 4u; a.t[j].w_unscale = (unsigned)w_unscale[j] * 4u; a.t[j].scale = (unsigned)scale[j] * 4u;
     a.t[j].shift = (unsigned)shift[j] * 4u; a.t[j].bound = (unsigned)bound[j] * 4u;
     a.t[j].cin = cin[j]; a.t[j].up = up[j];
-    lds += (size_t)(16 >> up[j]) * (32 >> up[j]) * cout * 4;
+    lds += (size_t)(FU_TH >> up[j]) * (32 >> up[j]) * cout * 4;
   }
   a.tiles_x = (W + 31) / 32;
-  a.tiles_y = (H + 15) / 16;
+  a.tiles_y = (H + FU_TH - 1) / FU_TH;
   const int tiles_img = a.tiles_x * a.tiles_y;
   if (tiles_img > P2_SLOTS) mval_launch_zero_rows(out_row, (int64_t)N * P2_ROW, s);
   const dim3 grid((unsigned)(tiles_img * N));
