@@ -308,7 +308,8 @@ void* mval_net_create(const mval_op* ops, int n_ops);
 void mval_net_destroy(void* net);
 /* Branch concurrency of mval_net_forward: -1 = decided by the MVAL_STREAMS environment variable (default:
  * on), 0 = every op on the caller's stream, 1 = fork / join over private streams.  Both forms can be
- * captured into a hipGraph (the fork / join uses events recorded on the capturing stream). */
+ * captured into a hipGraph (the fork / join uses events recorded on the capturing stream).  The side streams and
+ * events are per device and shared by all nets: ONE forward (or training pass) in flight per device at a time. */
 int mval_net_set_multi_stream(void* net, int mode);
 int mval_net_forward(void* net, int n_images, float* workspace, const float* params,
                      const float* input_nchw, float* output_nchw, void* stream);

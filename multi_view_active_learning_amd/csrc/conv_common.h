@@ -93,7 +93,7 @@ __device__ __forceinline__ void conv_amax_commit(unsigned* row, int slot, int co
 }
 // Consumer side: max |x| bits of an image.  Lanes read the partial slots, one wave reduction (uniform result).
 __device__ __forceinline__ unsigned conv_amax_read(const unsigned* row) {
-  const int count = (int)row[0];
+  const int count = min((int)row[0], MVAL_AMAX_ROW - 1);  // (never past the row, whatever the header holds)
   unsigned m = 0;
   for (int i = (int)(threadIdx.x & 63); i < count; i += 64) m = max(m, row[1 + i]);
 #pragma unroll

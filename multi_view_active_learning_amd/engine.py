@@ -240,8 +240,9 @@ class InferencePlan:
         self.arena_floats = _align(self._amax_top)
         self.param_floats = max(ptop, 64)
         self.arena = torch.empty(self.arena_floats, dtype=torch.float32, device=device)
-        if self.p2:  # P2 rows: a partial slot belongs to ONE producing workgroup, the others must read as zero
-            self.arena[self.amax_base :].zero_()
+        # rows behind the activations start as zeros: P2 rows need it (a partial slot belongs to ONE producing workgroup, the others
+        # must read as zero); the [count, partials ...] rows of the h2 kernels then read "no partials" until their producer has run
+        self.arena[self.amax_base :].zero_()
         self.params = torch.zeros(self.param_floats, dtype=torch.float32, device=device)
         self.param_sig = None
         self._graph, self._graph_failed = None, False
