@@ -402,14 +402,14 @@ def main():
             hm = model(images[: nb * v]).reshape(nb, v, j, h // 4, w // 4)
             preds.append(triangulate_batch(hm, proj[:nb], 4, valid[:nb])["keypoints_3d"].to(torch.float32))
         local = torch.cat(preds) if preds else torch.zeros((0, j, 3), device=dev)
-        pool = parallel.all_gather_cat(local)  # ONE collective: (pool, J, 3) fp32 over xGMI
+        pool = parallel.all_gather_cat(local)  # one size exchange + one data gather: (pool, J, 3) fp32 over xGMI
         cs = CoreSet.from_tensors(pool, labeled_pose, 2)
         picks = cs.select_batch(wl["picks"])
         return {"keypoints_3d": pool, "picks": picks}
 
     def scoring_pass():
         """BASELINE configs[3]: the entropy-scoring pass over the whole fixed pool.  Each rank scores its shard batch
-        by batch (heat-maps, triangulation, MPE -- the per-batch body of _compute_sal_dict), then ONE packed
+        by batch (heat-maps, triangulation, MPE -- the per-batch body of _compute_sal_dict), then one size exchange and ONE packed
         all_gather of the (frames, 6 + 3J) result tables and the nlargest selection on every rank."""
         from multi_view_active_learning_amd import parallel
         from multi_view_active_learning_amd.strategy import score_decode_heatmaps_batch
@@ -428,7 +428,7 @@ def main():
                                      r["inlier_count"].to(torch.float64)[:, None], torch.zeros_like(fid)[:, None],
                                      r["keypoints_3d"].to(torch.float32).to(torch.float64).reshape(nb, 3 * j)], dim=1))
         local = torch.cat(tables) if tables else torch.zeros((0, 6 + 3 * j), dtype=torch.float64, device=dev)
-        table = parallel.all_gather_cat(local)  # ONE collective for the pass (12.6 MB at 50 k frames)
+        table = parallel.all_gather_cat(local)  # the pass's two collectives: sizes (3 int64 per rank), then the data (12.6 MB at 50 k frames)
         top = torch.topk(table[:, 2], min(100, table.shape[0])).indices  # AL.ITER_AMOUNT = 100 (config.py:44)
         return {"keypoints_3d": table[:, 6:], "picks": top}
 
@@ -634,7 +634,7 @@ def main():
             "config": ({"workload": wl["desc"].replace("256-frame pool", f"{wl['pool']}-frame pool")
                                    + ("" if wl.get("picks") else f"; one step = one pass over a {wl['pool']}-frame pool sharded over the ranks"),
                         "pool_frames": wl["pool"], "frames_per_batch": frames, "views": v,
-                        "parallelism": f"pool sharded x{world} by frames, ONE packed all_gather per pass (RCCL), selection replicated"}
+                        "parallelism": f"pool sharded x{world} by frames, one size exchange + one data gather per pass (RCCL), selection replicated"}
                        if wl.get("pool") else
                        {"workload": wl["desc"], "frames_per_step_per_gpu": frames, "views": v,
                         "images_per_step_per_gpu": frames * v, "parallelism": f"frame-sharded x{world}, no collective"}),

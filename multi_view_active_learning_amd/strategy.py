@@ -9,7 +9,7 @@ Same names, arguments and result types, so that the reference's orchestration co
 (experiment dirs, checkpoints, TensorBoard -- out of scope here) can call them unchanged.
 What changes is the execution model: a batch of frames is scored by a handful of HIP
 launches with NO per-sample device->host synchronisation and NO per-sample collective;
-ranks exchange ONE packed table per scoring pass (RCCL all_gather) instead of the
+ranks exchange ONE packed table per scoring pass (two RCCL collectives: a size exchange, then the data gather) instead of the
 reference's 8 tiny all_gathers per sample (strategy.py:1106-1114).
 """
 from __future__ import annotations
@@ -327,7 +327,7 @@ class ActiveLearningStrategy:
     # ---- evaluation core (strategy.py:597-636) ----------------------------------------
     def evaluate_mkpe(self, data_loader, pose_estimator):
         """_evaluate_all's MKPE path: heat-maps -> hard arg-max triangulation -> MPJPE over the
-        whole loader (one packed gather instead of 3 all_gathers per sample)."""
+        whole loader (one size exchange + one packed data gather instead of 3 all_gathers per sample)."""
         preds, gts, valids, sizes = [], [], [], []
         with torch.no_grad():
             for dp in data_loader:

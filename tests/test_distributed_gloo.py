@@ -1,4 +1,4 @@
-"""CPU, world_size 2 over gloo: the N>1 glue (frame sharding + ONE packed gather per pass) through the
+"""CPU, world_size 2 over gloo: the N>1 glue (frame sharding + one size exchange and ONE packed data gather per pass) through the
 real entry points ``_compute_sal_dict`` / ``evaluate_mkpe``-style gathers / ``select_al_guids``.
 
 No GPU here, so the two device stages of a pass are stood in for by deterministic fakes
