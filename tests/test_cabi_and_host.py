@@ -89,6 +89,51 @@ def test_plan_geometry_and_arena(lib, name):
         engine.InferencePlan(cases.product_model(cases.model_cases()["w32"]), 1, 100, 100, torch.device("cpu"))
 
 
+def test_p2_launch_list_structure(lib, monkeypatch):
+    """The launch list of a P2 plan (built on the host, no kernel runs): HRNet-W32 at 256 x 256 becomes fused stem + downsample conv
+    + 4 fused Bottlenecks + 32 fused BasicBlocks + 9 fused up-path launches + single convs; every fused op points at the graph's
+    tensors (same arena offsets as the ops it replaces); each switch restores the op-by-op form; W48 / PoseResNet keep the h2 plan."""
+    from multi_view_active_learning_amd import engine
+
+    monkeypatch.setenv("MVAL_CONV", "p2")
+    c = cases.model_cases()["w32"]
+    m = cases.product_model(c)
+    g = m._graph
+
+    def plan():
+        return engine.InferencePlan(m, 4, 256, 256, torch.device("cpu"))
+
+    p = plan()
+    assert p.p2
+    kinds = [o.kind for o in p.ops]
+    assert kinds[0] == engine.OP_STEM_P2 and kinds[1] == engine.OP_CONV and kinds[2] == engine.OP_BNECK
+    assert (kinds.count(engine.OP_BNECK), kinds.count(engine.OP_BLOCK), kinds.count(engine.OP_FUSE_UP), kinds.count(engine.OP_TO_P2)) == (4, 32, 9, 0)
+    # launches = graph ops - (stem pair: 1) - (bottlenecks: 2 each) - (blocks: 1 each) - (up-path chains: terms - 1 each)
+    fu = [o for o in p.ops if o.kind == engine.OP_FUSE_UP]
+    assert len(p.ops) == len(g.ops) - 1 - 8 - 32 - sum(o.n_terms - 1 for o in fu)
+    # every fused op has rows for its output; an up-path launch holds consecutive terms (factors 2, 4[, 8] for branch 0; 2, 4 for
+    # branch 1), each from the branch with cout << up channels, and carries the fuse output's ReLU
+    for o in p.ops:
+        if o.kind in (engine.OP_BNECK, engine.OP_BLOCK, engine.OP_FUSE_UP, engine.OP_STEM_P2):
+            assert o.out_off >= 0 and o.out_amax_off > 0
+        if o.kind == engine.OP_FUSE_UP:
+            ups = [o.t_up[j] for j in range(o.n_terms)]
+            assert ups == list(range(1, 1 + o.n_terms)) and o.relu == 1 and o.res1_off >= 0 and o.res1_amax_off > 0
+            assert [o.t_cin[j] for j in range(o.n_terms)] == [o.cout << u for u in ups]
+            assert all(o.t_in_off[j] >= 0 and o.t_in_amax_off[j] > 0 and o.t_bound_off[j] > 0 for j in range(o.n_terms))
+    assert sorted((o.cout, o.n_terms) for o in fu) == sorted([(32, 2)] * 4 + [(32, 3)] * 3 + [(64, 2)] * 2)
+    for var, kind in (("MVAL_P2_STEM", engine.OP_STEM_P2), ("MVAL_P2_BNECK", engine.OP_BNECK), ("MVAL_P2_FUSE_UP", engine.OP_FUSE_UP)):
+        monkeypatch.setenv(var, "0")
+        assert kind not in [o.kind for o in plan().ops]
+        monkeypatch.delenv(var)
+    monkeypatch.setenv("MVAL_FUSE_BLOCKS", "0")
+    assert {o.kind for o in plan().ops} == {engine.OP_CONV, engine.OP_TO_P2}
+    monkeypatch.delenv("MVAL_FUSE_BLOCKS")
+    for name in ("w48", "r50"):
+        cc = cases.model_cases()[name]
+        assert not engine.InferencePlan(cases.product_model(cc), 2, cc["h"], cc["w"], torch.device("cpu")).p2
+
+
 def test_config_tree_and_factory():
     from multi_view_active_learning_amd.config import get_default_configs
     from multi_view_active_learning_amd.pose_estimators import get_pose_net, PoseResNet, PoseHighResolutionNet
