@@ -84,7 +84,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
   static_assert(XS % 16 == 0 && MSL % 16 == 0 && MSL >= MPX, "256-byte aligned 8-channel blocks");
   constexpr int MS1 = (MSL / 16) / WM;  // conv1 sub-tiles per wave: 6 (C = 32), 12 (C = 64)
   // (C = 32 with both 16-channel sub-tiles per wave and 3 pixel sub-tiles -- half the LDS fragment reads, twice the weight
-  // stream -- measured 83.6 us against 77: the weight stream costs more than the fragment reads save)
+  // stream -- measured 83.6 us against 77: the weight stream costs more than the fragment reads save.  Also measured on C = 32, each
+  // without effect on the 68 us kernel span: row sharing for conv1 (10 row fragments + one gathered fragment for columns 16 / 17:
+  // 20 instead of 36 fragment reads per column tap; conv1 phase 28.0 -> 25.2 us per wave), one ring of three weight columns for
+  // both convs requested two columns ahead (-> 23.7 us), no scheduling barriers in the vector phases.  Per SIMD a tile pair
+  // needs 3.6 us of MFMA issue and ~5 us of vector phases that run 3-4x below their instruction count: the phases do not overlap)
   constexpr int MS2 = TH / WM;          // conv2 rows per wave: 4, 8
   constexpr bool OVERLAY = C > 32;      // M overlays X
   constexpr int XB = NCH * 8 * XS * 16, MB = NCH * 8 * MSL * 16;
