@@ -147,3 +147,7 @@ int mval_launch_conv_fuse_up_p2(int cout, int n_terms, int relu, const void* res
                                 const void* const* in, const unsigned* const* in_row, const int* cin, const int* up, const int64_t* w,
                                 const int64_t* w_unscale, const int64_t* scale, const int64_t* shift, const int64_t* bound, int N, int H, int W,
                                 hipStream_t s);
+// conv_p2w.hip: the 3x3 stride-1 conv on v_mfma_f32_32x32x16_f16 (maps at least 32 wide, cout a multiple of 32 and >= 64, at most one
+// residual); 1 = unsupported
+int mval_conv_p2w_supported(const P2Args& a);
+int mval_launch_conv_p2w(const P2Args& a, hipStream_t s);

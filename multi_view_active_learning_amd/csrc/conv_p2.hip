@@ -677,6 +677,10 @@ int mval_launch_conv_p2(const P2Args& a0, hipStream_t s) {
   p2_override(oms, ont, og);
   const int64_t px = (int64_t)a.N * a.Hout * a.Wout;
   if (a.k == 3 && a.stride == 1) {
+    // MVAL_P2_WIDE=1: the v_mfma_f32_32x32x16_f16 form (conv_p2w.hip) where it applies.  Measured equal or slower (64 -> 64 on 32x32:
+    // 33.1 vs 31.5 us; on 64x64: 115 vs 112.5): kept as the on-device cross-check of the kernels' arithmetic, not used by default
+    const char* we = getenv("MVAL_P2_WIDE");
+    if (we && we[0] == '1' && !g_p2_dry && mval_conv_p2w_supported(a)) return mval_launch_conv_p2w(a, s);
     if (a.Wout >= 16 && a.Hout >= 4) {
       if (a.NS_total <= 2) return launch_p2<3, 1, 1, 2, 2, 1, 4, 16, true>(a, s);  // 32 couts: 2 x 2 waves, 4 rows each
       // 64-pixel tiles: measured faster than 128-pixel ones on every HRNet shape (128 -> 128 on 16x16: 28.8 vs 30.6 us,
