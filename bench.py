@@ -51,7 +51,8 @@ PEAK_FP32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, dense f
 PEAK_HBM_GBPS = 8000.0  # same guide: HBM3E
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # same guide: dense bf16 / fp16 MFMA (the 5 PF headline includes 2:1 sparsity)
 SPLIT_PRODUCTS = {"p2": 3, "h2": 3, "bf3": 6}  # MFMA products per algorithmic product of the 16-bit splits
-PARITY_UNPINNED = ["soft_argmax (kornia absent)", "MPE peak_local_max (skimage absent)", "BSB peak_local_max (skimage absent)"]
+PARITY_UNPINNED = ["soft_argmax (kornia absent)", "MPE / BSB peak_local_max: pinned on scikit-image 0.18.3 vectors except the order among equal intensities "
+                   "(numpy's unstable argsort)"]
 FLOP_PER_IMAGE = {"hrnet_w32_256": 20.387e9}  # conv FLOPs (2*MAC) per frame x view
 
 WORKLOADS = {

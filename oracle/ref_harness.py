@@ -13,12 +13,13 @@ that are never on an arithmetic path, with two documented exceptions that the
 caller may opt into:
 
 * ``skimage.feature.peak_local_max`` -> ``oracle.scoring.peak_local_max``
-  (our restatement of scikit-image 0.18/0.19 semantics).  This lets the
+  (our restatement of scikit-image 0.18/0.19 semantics, itself pinned on vectors of the
+  real scikit-image 0.18.3: tests/golden/make_peaks_golden.py).  This lets the
   reference's own ``_compute_mpe`` / ``_compute_bsb`` arithmetic run
-  (``strategy.py:1149-1215``) around a third-party routine we cannot execute.
+  (``strategy.py:1149-1215``) under the interpreter that has torch but no scikit-image.
 * ``kornia.spatial_soft_argmax2d`` -> ``oracle.geometry.spatial_soft_argmax2d``.
 
-Both are flagged "parity unpinned" in DESIGN.md.
+The second is flagged "parity unpinned" in DESIGN.md (kornia is nowhere in the image).
 """
 from __future__ import annotations
 

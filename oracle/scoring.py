@@ -4,11 +4,21 @@ scorers (reference strategy.py:1149-1215) and top-N selection (strategy.py:932-9
 Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s cpu_baseline leg
 may import this; the product path never does.
 
-``peak_local_max`` is third-party arithmetic (scikit-image, absent from the image
-and from /root/reference; the reference's ``indices=True`` keyword pins it to
-< 0.20).  PARITY UNPINNED for that routine: it restates the published 0.18/0.19
-algorithm (skimage/feature/peak.py of those releases) and is checked only by
-known-answer tests.  The arithmetic *around* it (softmax over peak values,
+``peak_local_max`` is third-party arithmetic (scikit-image; absent from
+/root/reference and from the interpreter the tests run on; the reference's
+``indices=True`` keyword pins it to < 0.20).  It is restated here and PINNED
+against the real library: the build container carries scikit-image 0.18.3 in its
+Anaconda python3.9 tree, ``tests/golden/make_peaks_golden.py`` runs it there and
+stores, for 122 maps (noise, quantised, sparse, smooth, plateaus, constant, and
+their row-soft-maxed forms), the library's candidate list, the order its argsort
+gave them, and its results; ``tests/test_oracle_golden.py`` holds the restatement
+to them stage by stage -- candidates equal on all maps, the spacing pass equal on
+all maps when fed the library's order, whole results (order included) equal on
+every map without tied candidates.  What cannot be pinned is the library's order
+among EQUAL intensities: ``np.argsort(-intensities)`` is numpy's unstable
+quicksort, so for tied candidates which of two adjacent equal maxima survives
+differs between numpy releases; this restatement (and the device kernel) breaks
+ties in row-major order.  The arithmetic *around* it (softmax over peak values,
 entropy, AVG/STD) is pinned against the real reference by running the reference's
 own ``_compute_mpe`` / ``_compute_bsb`` with this function installed as the
 ``skimage.feature.peak_local_max`` stand-in (oracle/ref_harness.py).
@@ -36,19 +46,11 @@ def _maximum_filter_constant0(img: np.ndarray, r: int) -> np.ndarray:
     return out
 
 
-def peak_local_max(image, min_distance=1, indices=True, num_peaks=np.inf, **unused):
-    """skimage.feature.peak_local_max as called at strategy.py:1168-1170,1204-1206.
-
-    threshold_abs=None, threshold_rel=None -> threshold = image.min();
-    exclude_border=True -> border of width min_distance removed;
-    candidates = (image == max_filter(image, (2*md+1)^2, constant 0)) & (image > thr),
-    all-candidate ("trivial") image -> none; sorted by descending intensity
-    (ties: ascending flat index -- the reference's argsort is unstable there);
-    ensure_spacing: walking in that order, a kept peak rejects later peaks at
-    Chebyshev distance < min_distance; truncated to num_peaks.
-    Returns (K, 2) int array of (row, col).
-    """
-    assert indices
+def peak_candidates(image, min_distance=1):
+    """Candidate maxima in np.nonzero (row-major) order: skimage's _get_peak_mask + _exclude_border for the reference's
+    call (threshold_abs = threshold_rel = None -> threshold = image.min(); exclude_border=True -> a border of width
+    min_distance removed; footprint ones((2 md + 1,) * 2), maximum filter with constant 0 outside; an all-candidate
+    ("trivial") image has none).  Returns (K, 2) int64 (row, col)."""
     image = np.asarray(image)
     r = int(min_distance)
     thr = image.min()
@@ -63,9 +65,13 @@ def peak_local_max(image, min_distance=1, indices=True, num_peaks=np.inf, **unus
         mask[:, :r] = False
         mask[:, -r:] = False
     rows, cols = np.nonzero(mask)
-    vals = image[rows, cols]
-    order = np.argsort(-vals, kind="stable")
-    coord = np.stack([rows, cols], axis=1)[order]
+    return np.stack([rows, cols], axis=1).astype(np.int64).reshape(-1, 2)
+
+
+def ensure_spacing(coord, spacing):
+    """skimage._shared.coord.ensure_spacing(coord, spacing, p_norm=inf) on an ORDERED list: walking in that order, a kept
+    point rejects every later point at Chebyshev distance < spacing (the library's k-d tree batches give the same set)."""
+    coord = np.asarray(coord, dtype=np.int64).reshape(-1, 2)
     keep = []
     rejected = np.zeros(len(coord), dtype=bool)
     for i in range(len(coord)):
@@ -74,8 +80,19 @@ def peak_local_max(image, min_distance=1, indices=True, num_peaks=np.inf, **unus
         keep.append(i)
         if i + 1 < len(coord):
             d = np.max(np.abs(coord[i + 1 :] - coord[i]), axis=1)
-            rejected[i + 1 :] |= d < r
-    coord = coord[keep]
+            rejected[i + 1 :] |= d < spacing
+    return coord[keep]
+
+
+def peak_local_max(image, min_distance=1, indices=True, num_peaks=np.inf, **unused):
+    """skimage.feature.peak_local_max as called at strategy.py:1168-1170,1204-1206: candidates (peak_candidates), sorted by
+    descending intensity (the library: np.argsort(-intensities), unstable among ties; here ties keep row-major order),
+    thinned by ensure_spacing(min_distance), truncated to num_peaks.  Returns (K, 2) int array of (row, col)."""
+    assert indices
+    image = np.asarray(image)
+    coord = peak_candidates(image, min_distance)
+    vals = image[coord[:, 0], coord[:, 1]]
+    coord = ensure_spacing(coord[np.argsort(-vals, kind="stable")], int(min_distance))
     if np.isfinite(num_peaks) and len(coord) > num_peaks:
         coord = coord[: int(num_peaks)]
     return coord.astype(np.int64).reshape(-1, 2)

@@ -2,6 +2,7 @@
 C-ABI via ctypes, against (a) the golden vectors captured from the real reference and
 (b) the CPU oracle restatement on the same seeded inputs."""
 import json
+import math
 import os
 
 import numpy as np
@@ -213,6 +214,54 @@ def test_mpe_bsb_fuzz_vs_oracle(dev, hw):
                 np.testing.assert_allclose(bsb[i], abs(p[pk[0][0], pk[0][1]] - p[pk[1][0], pk[1][1]]), rtol=3e-6, atol=4e-7, err_msg=str(specs[i]))
 
     run()
+
+
+def test_mpe_bsb_vs_real_scikit_image_goldens(dev):
+    """The device MPE / BSB statistics against peaks found by the REAL scikit-image 0.18.3 (tests/golden/peaks_skimage.npz):
+    on every golden map whose candidates have no equal intensities (with ties the library's own order is numpy's unstable
+    argsort) the device's peak count equals the library's and its entropy equals the reference's formula over the library's
+    peaks; BSB likewise from the library's top two peaks of the row-soft-maxed map."""
+    from multi_view_active_learning_amd import _lib
+
+    z = np.load(os.path.join(G, "peaks_skimage.npz"))
+    names = [str(v) for v in z["names"]]
+    idx = {nm: i for i, nm in enumerate(names)}
+
+    def tie_free(i):
+        m, c = z[f"map{i}"], z[f"cand{i}"]
+        v = m[c[:, 0], c[:, 1]]
+        return len(np.unique(v)) == len(v)
+
+    by_shape = {}
+    for i, nm in enumerate(names):
+        if nm.endswith("_rowsoftmax") or not tie_free(i):
+            continue
+        by_shape.setdefault(z[f"map{i}"].shape, []).append(i)
+    checked_mpe = checked_bsb = 0
+    for (hh, wh), ids in by_shape.items():
+        if hh < 8 or wh < 8:
+            continue
+        maps = np.stack([z[f"map{i}"] for i in ids])
+        t = torch.from_numpy(maps).to(dev)
+        mpe, cnt = _lib.score_maps(_lib.SCORE_MPE, t, len(ids), hh, wh)
+        bsb, cnt2 = _lib.score_maps(_lib.SCORE_BSB, t, len(ids), hh, wh)
+        mpe, cnt, bsb, cnt2 = mpe.cpu().numpy(), cnt.cpu().numpy(), bsb.cpu().numpy(), cnt2.cpu().numpy()
+        for k, i in enumerate(ids):
+            m, full = z[f"map{i}"], z[f"full{i}"]
+            assert cnt[k] == len(full), (names[i], cnt[k], len(full))
+            if len(full):  # strategy.py:1171-1175 over the library's peaks, in its order
+                peaks = [m[r][c] for r, c in full]
+                probs = np.exp(peaks) / sum(np.exp(peaks))
+                want = sum(-p * math.log(p) for p in probs)
+                np.testing.assert_allclose(mpe[k], want, rtol=3e-6, atol=2e-7, err_msg=names[i])
+                checked_mpe += 1
+            j = idx[names[i] + "_rowsoftmax"]
+            if tie_free(j) and len(z[f"top2_{j}"]) == 2:  # strategy.py:1202-1208 over the library's two highest peaks
+                p, (a, b) = z[f"map{j}"], z[f"top2_{j}"]
+                np.testing.assert_allclose(bsb[k], abs(p[a[0]][a[1]] - p[b[0]][b[1]]), rtol=3e-5, atol=4e-7, err_msg=names[i])
+                assert cnt2[k] >= 2
+                checked_bsb += 1
+    assert checked_mpe >= 20 and checked_bsb >= 10, (checked_mpe, checked_bsb)
 
 
 def test_peak_known_answers_on_device(dev):

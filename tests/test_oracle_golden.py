@@ -275,3 +275,31 @@ def test_sal_filter_restatement_vs_reference_golden(name):
     got = selection.sal_pseudo_label_guids(sal, want["al_guids"], done, c["pseudo_num"], c["thr"], 2,
                                            want["centers"] if c["use_clusters"] else None, c["clusters"])
     assert got == want["sal_guids"]
+
+
+def test_peak_local_max_vs_real_scikit_image():
+    """The peak_local_max restatement against the REAL scikit-image 0.18.3 (tests/golden/peaks_skimage.npz, written by
+    tests/golden/make_peaks_golden.py under the build container's Anaconda python3.9), stage by stage on 122 maps: the
+    candidate list equals the library's on every map; the spacing pass equals the library's on every map when fed the
+    library's own order; the whole result (order included, also with num_peaks=2) equals it on every map whose candidates
+    have no equal intensities.  With ties the library's order is numpy's unstable argsort (differs between numpy
+    releases); the restatement's row-major tie order still yields the same NUMBER of peaks wherever no two tied
+    candidates are closer than the spacing."""
+    z = np.load(os.path.join(G, "peaks_skimage.npz"))
+    names = [str(v) for v in z["names"]]
+    assert str(z["skimage_version"]).startswith("0.18") and len(names) >= 100
+    tie_free = 0
+    for i, nm in enumerate(names):
+        m = z[f"map{i}"]
+        cand = scoring.peak_candidates(m, 2)
+        np.testing.assert_array_equal(cand, z[f"cand{i}"], err_msg=nm)
+        lib = scoring.ensure_spacing(z[f"cand{i}"][z[f"order{i}"]], 2)
+        np.testing.assert_array_equal(lib, z[f"full{i}"], err_msg=nm)
+        np.testing.assert_array_equal(lib[:2], z[f"top2_{i}"], err_msg=nm)
+        vals = m[cand[:, 0], cand[:, 1]]
+        if len(np.unique(vals)) == len(vals):
+            tie_free += 1
+            np.testing.assert_array_equal(scoring.peak_local_max(m, min_distance=2), z[f"full{i}"], err_msg=nm)
+            np.testing.assert_array_equal(scoring.peak_local_max(m, min_distance=2, num_peaks=2), z[f"top2_{i}"], err_msg=nm)
+    assert tie_free >= 60  # every noise / smooth map and their soft-maxed forms without underflow plateaus
+
