@@ -150,6 +150,23 @@ def test_soft_argmax_independent_formulation():
     np.testing.assert_allclose(a, [10, 12], atol=1e-4)
 
 
+def test_soft_argmax_vs_scipy_center_of_mass():
+    """A third-party implementation of the same expectation: scipy.ndimage.center_of_mass of the soft-maxed map is
+    (sum y p, sum x p) / sum p -- the soft-arg-max in (row, col) order; kornia returns (x, y) in pixels (unverified: kornia
+    itself is nowhere in the image)."""
+    from scipy import ndimage
+    from scipy.special import softmax
+
+    rng = np.random.default_rng(2)
+    x = (rng.standard_normal((2, 3, 20, 28)) * 4).astype(np.float32)
+    got = geometry.spatial_soft_argmax2d(x)
+    for b in range(2):
+        for j in range(3):
+            p = softmax(x[b, j].astype(np.float64).ravel()).reshape(20, 28)
+            cy, cx = ndimage.center_of_mass(p)
+            np.testing.assert_allclose(got[b, j], [cx, cy], rtol=0, atol=2e-4)
+
+
 def test_soft_argmax_known_answers():
     m = np.full((1, 1, 8, 12), -1e4, dtype=np.float32)
     m[0, 0, 5, 9] = 0
