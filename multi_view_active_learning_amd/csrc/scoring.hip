@@ -224,29 +224,37 @@ __global__ __launch_bounds__(SC_THREADS) void score_maps_kernel(const float* __r
       __syncthreads();
     }
   }
-  // ensure_spacing: in sorted order a kept peak rejects later peaks at Chebyshev distance < 2.
-  // Two 5x5 maxima can only be that close when their values are equal (plateaus), so the
-  // common case has nothing to do; ties are resolved sequentially by one thread.
-  if (tid == 0) {
+  // ensure_spacing: in sorted order a kept peak rejects later peaks at Chebyshev distance < 2.  Two 5x5 maxima can only be that
+  // close when their values are equal (plateaus), and among equal values the order is row-major: a candidate is rejected iff one
+  // of its four row-major-earlier neighbours (up-left, up, up-right, left) was kept.  The staged map is not needed any more (the
+  // values live in cval): its memory becomes the "kept" map, and the pass is O(candidates) whatever the plateaus -- a final layer
+  // whose inputs are all zero over the background writes its bias there, thousands of equal candidates per map.
+  // No two equal values among the sorted candidates (what network outputs look like away from such plateaus): nothing can be
+  // rejected, no serial pass at all.
+  for (int i = tid; i + 1 < n; i += SC_THREADS)
+    if (cval[i] == cval[i + 1]) sm->overflow = 1;  // (0 here: an overflowed list has returned above)
+  __syncthreads();
+  const bool ties = sm->overflow != 0;
+  if (ties)
+    for (int i = tid; i < hh * ld; i += SC_THREADS) tile[i] = 0.f;
+  __syncthreads();
+  if (ties && tid == 0) {
     int kept = 0;
     for (int i = 0; i < n; i++) {
-      bool rej = false;
-      float v = cval[i];
-      int yi = cidx[i] / wh, xi = cidx[i] % wh;
-      for (int k = kept - 1; k >= 0 && cval[k] == v; k--) {
-        int yk = cidx[k] / wh, xk = cidx[k] % wh;
-        if (max(abs(yi - yk), abs(xi - xk)) < 2) { rej = true; break; }
-      }
-      if (!rej) {
-        cval[kept] = v;
-        cidx[kept] = cidx[i];
+      const int idx = cidx[i];
+      const int yi = idx / wh, xi = idx - yi * wh;
+      float* t = tile + yi * ld + xi;  // (candidates are interior pixels: the neighbours exist)
+      if (t[-ld - 1] == 0.f && t[-ld] == 0.f && t[-ld + 1] == 0.f && t[-1] == 0.f) {
+        *t = 1.f;
+        cval[kept] = cval[i];
+        cidx[kept] = idx;
         kept++;
       }
     }
     sm->n_cand = kept;
   }
   __syncthreads();
-  n = sm->n_cand;
+  n = sm->n_cand;  // (unchanged without ties)
 
   if (KIND == MVAL_SCORE_BSB) {
     if (tid == 0) {
