@@ -83,9 +83,13 @@ enum { MVAL_REDUCE_AVG_F64 = 0, MVAL_REDUCE_AVG_F32 = 1, MVAL_REDUCE_STD_F64 = 2
  *   HP  (strategy.py:1185-1187)  1 - max(row_softmax(map))           (row-wise softmax: SURVEY A.9)
  *   MPE (strategy.py:1168-1175)  entropy of softmax over the local peaks
  *        (skimage.feature.peak_local_max(map, min_distance=2): 5x5 maxima strictly above
- *        map.min(), 2-px border excluded, sorted by descending value, plateau spacing)
+ *        map.min(), 2-px border excluded, sorted by descending value -- equal values in row-major
+ *        order, where the library's order is numpy's unstable argsort --, plateau spacing; equal to
+ *        scikit-image 0.18.3 on every map without tied candidates: tests/golden/peaks_skimage.npz)
  *   BSB (strategy.py:1202-1208)  |p0 - p1| of the two highest local peaks of row_softmax(map)
- *   heatmaps [n_maps,hh,wh] f32 ; stat [n_maps] f32 ; n_peaks [n_maps] i32 (MPE/BSB; 0 for HP). */
+ *   heatmaps [n_maps,hh,wh] f32 ; stat [n_maps] f32 ; n_peaks [n_maps] i32 (MPE/BSB: peaks after the spacing pass, any number
+ *   of candidates -- maps with more than 2048 are redone by a second pass; 0 for HP).  BSB with fewer than two peaks: NaN
+ *   (the reference raises IndexError). */
 int mval_score_maps(int kind, const float* heatmaps, float* stat, int32_t* n_peaks,
                     int64_t n_maps, int hh, int wh, void* stream);
 

@@ -76,7 +76,7 @@ __global__ __launch_bounds__(SC_THREADS) void score_maps_kernel(const float* __r
   const int tid = threadIdx.x;
   const int64_t map = blockIdx.x;
   // second pass (candidate list as large as the map's interior, one workgroup per CU): only the maps whose list
-  // overflowed SC_MAX_PEAKS in the first pass -- wide plateaus, which network outputs do not have -- are redone
+  // overflowed SC_MAX_PEAKS in the first pass -- wide plateaus: flat backgrounds -- are redone
   if (rescue && n_peaks[map] != -1) return;
   const float* p = hm + map * (int64_t)hh * wh;
   const int npix = hh * wh;
