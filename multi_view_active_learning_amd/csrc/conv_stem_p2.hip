@@ -9,11 +9,15 @@
 //
 // Workgroup = 4 waves on a 2 x 16 tile of `out`, persistent over an XCD-contiguous range of tiles; 51 KB of LDS, three
 // workgroups per CU:
-//   P   the 11 x 67 input patch, 3 planes of fp32 (zero outside the image), the next tile's travelling in registers;
-//   1.  conv1 on the vector ALUs (K = 27 is one ragged MFMA step; the arithmetic stays exact fp32 like the stand-alone
-//       stem): lane = (cout quad, run of 11 pixels of one of the 5 x 33 intermediate rows), packed FMAs, weights
-//       [tap][cin][cout] read through L1 (6.9 KB, the same for every lane of the chip); BN1 + ReLU + zero outside y1 -> scaled by the per-IMAGE bound A1 max|x| + B1, split,
-//       8-byte half-granules into Y1 = [chunk][plane h,l][8-ch block][column parity, row, column / 2][16 B];
+//   P   the 11 x 67 input patch (zero outside the image) as the (h, l) fp16 planes of x * 2^sx, sx from the image's max |x|;
+//       the next tile's travels in registers;
+//   1.  conv1 on the matrix cores too: K = 27 taps padded to ONE 32-deep MFMA step.  The B fragment of sixteen intermediate
+//       pixels is an im2col gather (a lane reads its eight taps' halves out of the patch), the A fragments (4 sub-tiles x
+//       (h, l) of the scaled weights) are built once per workgroup from the [27][64] table.  11 fragments cover the 5 x 33
+//       intermediate; a wave takes every fourth.  BN1 + ReLU + zero outside y1 -> scaled by the per-IMAGE bound A1 max|x| +
+//       B1, split, 16-byte granules into Y1 = [chunk][plane h,l][8-ch block][column parity, row, column / 2][16 B].
+//       (The first form did conv1 on the vector ALUs in exact fp32 -- 594 packed FMAs per lane and tile, 41 % of the
+//       kernel: 388 us against 297 us now; -DST_VALU_CONV1 still builds it.)
 //   2.  conv2 on the matrix cores from Y1 (conv_p2.hip arithmetic: three fp16 MFMA products per fp32 product): wave =
 //       16 output channels x 2 rows, a row fragment = 16 consecutive slots of one column parity;
 //       BN2 + ReLU + max |x| + split in registers, 16-byte stores into the output planes.
@@ -24,6 +28,9 @@
 
 #ifndef P2_VALU_PRIO
 #define P2_VALU_PRIO 2
+#endif
+#ifndef ST_VALU_CONV1  // -DST_VALU_CONV1: conv1 on the vector ALUs in exact fp32 (the first form of this kernel: 388 vs 297 us)
+#define ST_MFMA1 1
 #endif
 
 typedef p2_f32x4 f32x4;
@@ -149,7 +156,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
       pre[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, ok ? (unsigned)(((n * 3 + c) * a.H + iy) * a.W + ix) * 4u : 0x80000000u, 0, 0));
     }
   };
-  auto store_patch = [&]() {
+#ifdef ST_MFMA1
+  // conv1 on the matrix cores: the patch is kept as the (h, l) fp16 planes of x * 2^sx (sx from the image's max |x|), 2 bytes each
+  constexpr int PLB = 3 * IH * IWP * 2;
+  auto store_patch = [&](float xmul) {
+    const int T = st_fresh(tid);
+#pragma unroll
+    for (int i = 0; i < NP; i++) {
+      const int e = T + 256 * i;
+      const int c = e / (IH * IW), r = e - c * (IH * IW);
+      const int py = r / IW, px = r - py * IW;
+      if (e < 3 * IH * IW) {
+        const float xs = pre[i] * xmul;
+        const _Float16 h = (_Float16)xs, l = (_Float16)(xs - (float)h);
+        *reinterpret_cast<_Float16*>(smem + P0 + ((c * IH + py) * IWP + px) * 2) = h;
+        *reinterpret_cast<_Float16*>(smem + P0 + PLB + ((c * IH + py) * IWP + px) * 2) = l;
+      }
+    }
+  };
+#else
+  auto store_patch = [&](float) {
     const int T = st_fresh(tid);
 #pragma unroll
     for (int i = 0; i < NP; i++) {
@@ -159,6 +185,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
       if (e < 3 * IH * IW) *reinterpret_cast<float*>(smem + P0 + ((c * IH + py) * IWP + px) * 4) = pre[i];
     }
   };
+#endif
 
   // ---- prologue ----------------------------------------------------------------------------------------------------------
   int tn, toy, tox;
@@ -172,7 +199,49 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
   const f32x4 sc2 = *reinterpret_cast<const f32x4*>(a.scale2 + c0_2), sh2v = *reinterpret_cast<const f32x4*>(a.shift2 + c0_2);
   P2RowRegs row_in;
   p2_row_request(a.in_row, tn, row_in);
-  store_patch();
+  float x_amax_cur = p2_row_amax(row_in), x_mul_cur, x_inv_cur;
+  p2_scale_of(x_amax_cur, x_mul_cur, x_inv_cur);
+#ifdef ST_MFMA1
+  // conv1's weights as A fragments [cout sub-tile][plane]: K = 27 taps (k = tap * 3 + c, the [27][64] table's rows) padded to one
+  // 32-deep step; rows 4..7 <-> 8..11 permuted as in conv_p2.hip; scaled by a power of two from max |w1|, split (h, l)
+  float* bn1 = reinterpret_cast<float*>(smem + W0 + 16);  // scale1[64], shift1[64]
+  if (tid < 64) { bn1[tid] = a.scale1[tid]; bn1[64 + tid] = a.shift1[tid]; }
+  if (tid == 0) wgred[2] = 0u;
+  __syncthreads();
+  {
+    float wm = 0.f;
+    for (int i = tid; i < 27 * 64; i += 256) wm = fmaxf(wm, fabsf(a.w1[i]));
+    const unsigned wb = p2_wave_umax(__float_as_uint(wm));
+    if (lane == 0) atomicMax(&wgred[2], wb);
+  }
+  __syncthreads();
+  float w1_mul, w1_inv;
+  p2_scale_of(__uint_as_float(wgred[2]), w1_mul, w1_inv);
+  u32x4 WA[4][2];
+  int toff[8];  // byte offset (inside a plane of the patch) of the lane's eight taps: k octet lane >> 4
+  {
+    const int wr_ = lane & 15, prow = (wr_ & 3) | ((wr_ & 4) << 1) | ((wr_ & 8) >> 1), g = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const int k = g * 8 + i, tap = k / 3, c = k - tap * 3, ky = tap / 3, kx = tap - ky * 3;
+      toff[i] = k < 27 ? ((c * IH + ky) * IWP + kx) * 2 : 0;  // (k >= 27: any finite value, its weight is zero)
+    }
+#pragma unroll
+    for (int ct = 0; ct < 4; ct++) {
+      _Float16 h[8], l[8];
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        const int k = g * 8 + i;
+        const float w = k < 27 ? a.w1[k * 64 + ct * 16 + prow] * w1_mul : 0.f;
+        h[i] = (_Float16)w;
+        l[i] = (_Float16)(w - (float)h[i]);
+      }
+      WA[ct][0] = __builtin_bit_cast(u32x4, *reinterpret_cast<f16x8*>(h));
+      WA[ct][1] = __builtin_bit_cast(u32x4, *reinterpret_cast<f16x8*>(l));
+    }
+  }
+#endif
+  store_patch(x_mul_cur);
   __syncthreads();
 #ifdef P2_STAMP
   unsigned long long* g_dbg = a.dbg;
@@ -184,7 +253,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
     const int next_tile = tile + wgx;
     const bool have_next = next_tile < tile_end;
     if (have_next) decode(next_tile, tn, toy, tox);
-    const float x_amax = p2_row_amax(row_in);
+    const float x_amax = x_amax_cur, x_inv = x_inv_cur;
+    (void)x_inv;
     if (have_next) p2_row_request(a.in_row, tn, row_in);  // (the next tile's image: requested a tile ahead)
     const float y1_bound = b1a * x_amax + b1b;
     float m1_mul, m1_inv, out_mul, out_inv;
@@ -192,6 +262,54 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
     p2_scale_of(b2a * y1_bound + b2b, out_mul, out_inv);
     if (oy0 == 0 && ox0 == 0 && tid == 0) a.out_row[(int64_t)n * P2_ROW + P2_INV_SLOT] = __float_as_uint(out_inv);
 
+#ifdef ST_MFMA1
+    // ---- 1. conv1 on the matrix cores: one 32-deep step per sixteen-pixel fragment of the 5 x 33 intermediate (11 fragments, a
+    // wave takes every fourth) x four 16-channel sub-tiles; the B fragment is an im2col gather of the lane's eight taps ------------
+    {
+      const int L = st_fresh(lane);
+      const float k1 = x_inv * w1_inv * m1_mul;  // (powers of two: exact)
+      const int cq1 = ((L >> 4) & 1) * 8 + (L >> 5) * 4;
+#pragma unroll
+      for (int fi = 0; fi < 3; fi++) {
+        const int f = wave + 4 * fi;
+        if (f >= 11) break;
+        const int praw = f * 16 + (L & 15), p = praw < PH * PW ? praw : PH * PW - 1;
+        const int py = p / PW, px = p - py * PW;
+        const char* b0 = smem + P0 + ((2 * py) * IWP + 2 * px) * 2;
+        u32x4 xh, xl;
+#pragma unroll
+        for (int i2 = 0; i2 < 4; i2++) {
+          const unsigned h0 = *reinterpret_cast<const unsigned short*>(b0 + toff[2 * i2]), h1 = *reinterpret_cast<const unsigned short*>(b0 + toff[2 * i2 + 1]);
+          const unsigned l0 = *reinterpret_cast<const unsigned short*>(b0 + PLB + toff[2 * i2]), l1 = *reinterpret_cast<const unsigned short*>(b0 + PLB + toff[2 * i2 + 1]);
+          xh[i2] = h0 | (h1 << 16);
+          xl[i2] = l0 | (l1 << 16);
+        }
+        const int yy = 2 * oy0 - 1 + py, xx = 2 * ox0 - 1 + px;
+        const bool inside = praw < PH * PW && yy >= 0 && yy < a.H1 && xx >= 0 && xx < a.W1;
+        const int slot = ((px & 1) * PH + py) * PWh + (px >> 1);
+#pragma unroll
+        for (int ct = 0; ct < 4; ct++) {
+          f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+          acc = st_mfma(WA[ct][1], xh, acc);
+          acc = st_mfma(WA[ct][0], xl, acc);
+          acc = st_mfma(WA[ct][0], xh, acc);
+          const int c0 = ct * 16 + cq1;
+          const f32x4 s1 = *reinterpret_cast<const f32x4*>(bn1 + c0) * k1, h1 = *reinterpret_cast<const f32x4*>(bn1 + 64 + c0) * m1_mul;
+          f32x4 v = acc * s1 + h1;
+          v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+          if (!inside) v = (f32x4){0.f, 0.f, 0.f, 0.f};
+          f16x4 h, l;
+          p2_split(v, h, l);
+          const u32x2 hu = __builtin_bit_cast(u32x2, h), lu = __builtin_bit_cast(u32x2, l);
+          const auto s0 = __builtin_amdgcn_permlane32_swap(hu.x, lu.x, false, false);
+          const auto s1_ = __builtin_amdgcn_permlane32_swap(hu.y, lu.y, false, false);
+          if (praw < PH * PW)
+            *reinterpret_cast<u32x4*>(smem + (ct >> 1) * YCH + (L >> 5) * YPL + ((ct & 1) * 2 + ((L >> 4) & 1)) * SL * 16 + slot * 16) =
+                (u32x4){s0[0], s1_[0], s0[1], s1_[1]};
+        }
+      }
+    }
+#else
     // ---- 1. conv1 on the vector ALUs: lane = (cout quad q, run g of 11 pixels of intermediate row g / 3) -----------------------
     __builtin_amdgcn_s_setprio(P2_VALU_PRIO);
     {
@@ -250,6 +368,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
         }
       }
     }
+#endif
     ST_ACC(1);
     __builtin_amdgcn_s_setprio(0);
     __syncthreads();  // Y1 is complete, the patch is free
@@ -334,7 +453,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
     __builtin_amdgcn_s_setprio(0);
     ST_ACC(4);
     if (!have_next) break;
-    store_patch();    // (every wave passed the barrier behind conv1: the patch buffer is free)
+    x_amax_cur = p2_row_amax(row_in);  // (the next tile's image)
+    p2_scale_of(x_amax_cur, x_mul_cur, x_inv_cur);
+    store_patch(x_mul_cur);  // (every wave passed the barrier behind conv1: the patch buffer is free)
     ST_ACC(5);
     __syncthreads();  // every wave is done with Y1, the next patch is visible
     ST_ACC(6);
@@ -369,7 +490,7 @@ int mval_launch_conv_stem_p2(const float* in, void* out, const float* w1, const 
   a.tiles_x_magic = a.tiles_x > 1 ? (unsigned)(((uint64_t)1 << 32) / (unsigned)a.tiles_x + 1) : 0u;
   // max |x| per image: 64 partial slots of the input's rows
   hipLaunchKernelGGL(image_amax_rows_kernel, dim3(64, (unsigned)N), dim3(256), 0, s, in, (int64_t)3 * H * W, in_row);
-  constexpr size_t smem = 2 * 8 * 170 * 16 + 3 * 11 * 68 * 4 + 16;
+  constexpr size_t smem = 2 * 8 * 170 * 16 + 3 * 11 * 68 * 4 + 16 + 512;
   static int occ = 0;
   if (!occ) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_stem_p2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
