@@ -562,8 +562,8 @@ def main():
                                      + (" + conv_block_kernel<C> (whole BasicBlocks: two 3x3 convs, BNs, residual, ReLUs in one launch)"
                                         if any(o.kind == 3 for o in plan.ops) and pl == "h2" else "")
                                      + f" (fused 3x3 stride-1 conv+BN+residual+ReLU; {what}, fp32 accumulate)", peak, note),
-                family(m_ & stem2, "conv_stem_p2_kernel (both stride-2 stem convs in one launch: 3 -> 64 on the vector ALUs in exact fp32, 64 -> 64 on "
-                                   "the matrix cores from LDS; fp32 NCHW image in, P2 planes out; FLOPs of both convs against the split-MFMA peak)", peak, note),
+                family(m_ & stem2, "conv_stem_p2_kernel (both stride-2 stem convs in one launch, both on the matrix cores: 3 -> 64 as one 32-deep step over an im2col "
+                                   "gather, 64 -> 64 from LDS; fp32 NCHW image in, P2 planes out; FLOPs of both convs against the split-MFMA peak)", peak, note),
                 family(m_ & k3 & ~s1 & ~stem2, ("conv_p2_kernel<3, 2, ...>" if pl == "p2" else f"conv_split_kernel<{2 if pl == 'h2' else 3}, 3, 2, ...>") + " (same, stride 2)", peak, note),
                 hbm_family(m_ & bneck, "conv_bneck_p2_kernel<CIN> (whole Bottlenecks of layer1 in one launch: 1x1 -> 3x3 -> 1x1 convs, BNs, residual, "
                                        "ReLUs; the 64-channel intermediates never leave the CU; HBM is the tighter of its two bounds: "
