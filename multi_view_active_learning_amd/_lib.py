@@ -11,6 +11,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 import threading
+import weakref
 
 import torch
 
@@ -88,7 +89,46 @@ def _req(t, dtype, name):
 # --------------------------------------------------------------------------
 # keypoint decode / triangulation
 # --------------------------------------------------------------------------
+# Decode from the heat-map layer's epilogue: a forward whose final kernel kept the arg-max key of every map
+# (mval_net_forward_keys) remembers them for the tensor it returned; argmax_decode of THAT tensor (any reshape of it,
+# unmodified) then needs no second read of the heat-maps.  MVAL_EPILOGUE_DECODE=0 switches the mechanism off.
+_ARGMAX_KEYS = {}  # id(network output) -> (weak reference to it, keys [n_images * joints] int64 bit patterns)
+
+
+def epilogue_decode_enabled():
+    return os.environ.get("MVAL_EPILOGUE_DECODE", "1") != "0"
+
+
+def remember_argmax_keys(out, keys):
+    k = id(out)
+    _ARGMAX_KEYS[k] = (weakref.ref(out, lambda _r, k=k: _ARGMAX_KEYS.pop(k, None)), keys)
+
+
+def argmax_keys_of(hm):
+    """The keys of the network output `hm` is (a full view of), or None: unknown tensor, a slice, or written to since."""
+    base = hm._base if hm._base is not None else hm
+    e = _ARGMAX_KEYS.get(id(base))
+    if e is None or e[0]() is not base or base._version != 0:
+        return None
+    if hm.numel() != base.numel() or hm.data_ptr() != base.data_ptr() or not hm.is_contiguous() or hm.dtype != torch.float32:
+        return None
+    return e[1]
+
+
+def argmax_from_keys(keys, valid, b, v, j, stride, split_width):
+    out = torch.empty((b, v, j, 2), dtype=torch.int64, device=keys.device)
+    _check(
+        lib().mval_argmax_from_keys(_p(_req(keys, torch.int64, "argmax keys")), _p(valid), _p(out), C.c_int(b), C.c_int(v), C.c_int(j),
+                                    C.c_int(stride), C.c_int(split_width), _stream()),
+        "mval_argmax_from_keys",
+    )
+    return out
+
+
 def argmax_decode(hm, valid, b, v, j, hh, wh, stride, split_width):
+    keys = argmax_keys_of(hm) if epilogue_decode_enabled() else None
+    if keys is not None and keys.numel() == b * v * j and hm.numel() == b * v * j * hh * wh:
+        return argmax_from_keys(keys, valid, b, v, j, stride, split_width)
     out = torch.empty((b, v, j, 2), dtype=torch.int64, device=hm.device)
     _check(
         lib().mval_argmax_decode(

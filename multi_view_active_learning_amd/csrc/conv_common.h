@@ -39,6 +39,9 @@ struct ConvArgs {
   // group (filled by the launcher)
   unsigned* out_amax;
   int amax_tiles;
+  // NCHW heat-map layer (1x1, stride 1, out_nchw, up == 0) on conv_mfma.hip's kernels (KEYS instantiations of
+  // conv_tile_store): != nullptr = also keep the arg-max key of every map [N][Cout] (mval_common.h: decode from the epilogue)
+  unsigned long long* argmax_keys;
   // MFMA tiling (filled by the launcher)
   int th, tw, tn, tw_log2, thw_log2;
   int tiles_x, tiles_y;
@@ -150,7 +153,7 @@ __device__ __forceinline__ void conv_tile_amax(const ConvArgs& a, unsigned* scra
   if (t < a.tn && n0 + t < a.N) conv_amax_put(a.out_amax + (int64_t)(n0 + t) * MVAL_AMAX_ROW, slot, count, scratch[t]);
 }
 
-template <int MT, int NTILE, int NTH = 256>
+template <int MT, int NTILE, int NTH = 256, bool KEYS = false>
 __device__ __forceinline__ void conv_tile_store(const ConvArgs& a, const float* ot, int tid, int n0, int oy0, int ox0,
                                                 int cbase) {
   constexpr int LDW = NTILE + 4;
@@ -245,6 +248,40 @@ __device__ __forceinline__ void conv_tile_store(const ConvArgs& a, const float* 
   }
   // scalar path (NCHW heat-map output, odd channel counts): pixel-fastest so that NCHW rows are
   // written in contiguous runs
+  if constexpr (KEYS) if (a.argmax_keys && a.out_nchw && a.up == 0) {
+    // the heat-map layer with decode from the epilogue (hrnet.py:344-350,500 -> utils/evaluation.py:13-30): every wave
+    // folds the keys of what it stores -- a wave's 64 elements are 64 pixels of ONE map when MT is a multiple of 64 and the
+    // tile holds one image; otherwise per 16-lane group, or per lane
+    static_assert(NTH % 64 == 0, "whole waves");
+    for (int e0 = 0; e0 < MT * NTILE; e0 += NTH) {  // (uniform trip count: the shuffles below need every lane)
+      const int e = e0 + tid;
+      const int cl = e / MT, p = e % MT;
+      const int c = cbase + cl;
+      int tni = 0, ty = 0, tx = 0;
+      const bool inside = conv_tile_decode(a, p, tni, ty, tx);
+      const int y = oy0 + ty, x = ox0 + tx;
+      const int n = n0 + tni;
+      const bool ok = e < MT * NTILE && inside && c < a.Cout && n < a.N && y < a.Hout && x < a.Wout;
+      unsigned long long key = 0ull;
+      const int64_t map = (int64_t)n * a.Cout + c;
+      if (ok) {
+        float r = ot[p * LDW + cl];
+        const int64_t o = (((int64_t)n * a.Hout + y) * a.Wout + x) * a.Cout + c;
+        if (a.res1) r += a.res1[o];
+        if (a.res2) r += a.res2[o];
+        if (a.relu) r = fmaxf(r, 0.f);
+        a.out[(map * a.Hout + y) * a.Wout + x] = r;
+        key = mval_argmax_key(r, (unsigned)(y * a.Wout + x));
+      }
+      if ((MT & 63) == 0 && a.tn == 1) {  // the wave's lanes share (n, c): one atomic per wave
+        key = mval_key_group_max(key, 32);
+        if ((tid & 63) == 0 && key) atomicMax(a.argmax_keys + map, key);
+      } else if (key) {
+        atomicMax(a.argmax_keys + map, key);
+      }
+    }
+    return;
+  }
   for (int e = tid; e < MT * NTILE; e += NTH) {
     const int cl = e / MT, p = e % MT;
     const int c = cbase + cl;

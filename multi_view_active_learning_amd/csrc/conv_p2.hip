@@ -505,6 +505,7 @@ __global__ __launch_bounds__(64 * WN * WM) __attribute__((amdgpu_waves_per_eu(P2
 #pragma unroll
         for (int nt = 0; nt < NT; nt++) {
           const int c0 = (ns0 + nt) * 16 + cq;
+          unsigned long long key[4] = {0ull, 0ull, 0ull, 0ull};  // arg-max keys of the lane's pixels, per cout
 #pragma unroll
           for (int ms = 0; ms < MS; ms++) {
             const f32x4 v = acc[ms][nt] * scu[nt] + sh[nt];
@@ -512,7 +513,23 @@ __global__ __launch_bounds__(64 * WN * WM) __attribute__((amdgpu_waves_per_eu(P2
             if (y < a.Hout && x < a.Wout) {
 #pragma unroll
               for (int j = 0; j < 4; j++)
-                if (c0 + j < a.Cout) a.out_f32[(((int64_t)n * a.Cout + c0 + j) * Ho + y) * Wo + x] = fmaxf(v[j], floor_);
+                if (c0 + j < a.Cout) {
+                  const float o = fmaxf(v[j], floor_);
+                  a.out_f32[(((int64_t)n * a.Cout + c0 + j) * Ho + y) * Wo + x] = o;
+                  if (a.argmax_keys) {
+                    const unsigned long long kk = mval_argmax_key(o, (unsigned)(y * Wo + x));
+                    key[j] = kk > key[j] ? kk : key[j];
+                  }
+                }
+            }
+          }
+          // decode from the epilogue (hrnet.py:344-350,500 -> utils/evaluation.py:13-30): the 16 pixel lanes of a cout
+          // quarter fold their keys, one 64-bit atomicMax per (wave, cout) and tile
+          if (a.argmax_keys) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+              const unsigned long long kk = mval_key_group_max(key[j], 8);
+              if ((lane & 15) == 0 && kk && c0 + j < a.Cout) atomicMax(a.argmax_keys + (int64_t)n * a.Cout + c0 + j, kk);
             }
           }
         }

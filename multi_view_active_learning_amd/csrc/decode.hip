@@ -68,6 +68,32 @@ extern "C" int mval_argmax_decode(const float* heatmaps, const uint8_t* valid, i
   return 0;
 }
 
+// ---- key-points from the arg-max keys the heat-map layer's epilogue kept (mval_common.h) ------------------------------------
+__global__ __launch_bounds__(256) void argmax_from_keys_kernel(const unsigned long long* __restrict__ keys, const uint8_t* __restrict__ valid,
+                                                               int64_t* __restrict__ kp2d, int64_t n_maps, int V, int J, int stride,
+                                                               int split_width) {
+  const int64_t map = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (map >= n_maps) return;
+  const int j = (int)(map % J);
+  const int64_t b = map / ((int64_t)V * J);
+  const unsigned long long k = keys[map];
+  const unsigned bi = (valid && !valid[b * J + j]) || k == 0ull ? 0u : 0xffffffffu - (unsigned)k;
+  const bool inval = valid && !valid[b * J + j];
+  kp2d[map * 2] = inval ? 0 : (int64_t)(bi % (unsigned)split_width) * stride;
+  kp2d[map * 2 + 1] = inval ? 0 : (int64_t)(bi / (unsigned)split_width) * stride;
+}
+
+extern "C" int mval_argmax_from_keys(const uint64_t* keys, const uint8_t* valid, int64_t* kp2d, int B, int V, int J, int stride,
+                                     int split_width, void* stream) {
+  MVAL_REQUIRE(keys && kp2d && B >= 0 && V > 0 && J > 0 && split_width > 0, "mval_argmax_from_keys: bad arguments");
+  const int64_t n_maps = (int64_t)B * V * J;
+  if (n_maps == 0) return 0;
+  hipLaunchKernelGGL(argmax_from_keys_kernel, dim3((unsigned)((n_maps + 255) / 256)), dim3(256), 0, mval_stream(stream),
+                     reinterpret_cast<const unsigned long long*>(keys), valid, kp2d, n_maps, V, J, stride, split_width);
+  MVAL_CHECK_LAUNCH("mval_argmax_from_keys");
+  return 0;
+}
+
 // ---- soft-argmax ----------------------------------------------------------------------
 __global__ __launch_bounds__(256) void soft_argmax_kernel(const float* __restrict__ hm, float* __restrict__ out,
                                                           int64_t n_maps, int hh, int wh, float scale) {

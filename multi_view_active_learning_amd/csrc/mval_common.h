@@ -51,3 +51,23 @@ __device__ __forceinline__ float wave_min(float v) {
   for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
   return v;
 }
+
+// ---- arg-max keys (decode from the heat-map layer's epilogue) ---------------------------------------------------------
+// One 64-bit key per heat-map, kept with atomicMax by the workgroups that STORE the map (csrc/conv_p2.hip,
+// conv_common.h): high word = the value as an order-preserving unsigned (NaN above +inf, -0 == +0: torch.argmax's
+// order, utils/evaluation.py:13-30), low word = ~flat index, so among equal values the FIRST index wins.  The keys are
+// zeroed before the layer runs (every stored value maps to a key > 0); mval_argmax_from_keys turns them into key-points.
+__device__ __forceinline__ unsigned long long mval_argmax_key(float v, unsigned flat_index) {
+  const unsigned b = __float_as_uint(v);
+  const unsigned o = (v != v) ? 0xffffffffu : (b == 0x80000000u) ? b : (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+  return ((unsigned long long)o << 32) | (unsigned long long)(0xffffffffu - flat_index);
+}
+// max over the 2^steps-lane groups of a wave (xor butterfly from `first` down to 1)
+__device__ __forceinline__ unsigned long long mval_key_group_max(unsigned long long k, int first) {
+  for (int o = first; o > 0; o >>= 1) {
+    const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)k, o, 64), hi = (unsigned)__shfl_xor((int)(unsigned)(k >> 32), o, 64);
+    const unsigned long long other = ((unsigned long long)hi << 32) | lo;
+    k = other > k ? other : k;
+  }
+  return k;
+}

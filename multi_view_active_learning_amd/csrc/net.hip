@@ -369,10 +369,26 @@ extern "C" int mval_op_algo_supported(const mval_op* op, int n_images, int algo)
   return mval_conv_split_supported(a);
 }
 
+// 1 when the kernel this op runs on keeps arg-max keys next to an NCHW heat-map output (the P2 and MFMA families)
+static int op_keeps_argmax_keys(const mval_op* op) {
+  if (!op || op->kind != MVAL_OP_CONV || !op->out_nchw || op->up || op->out_off >= 0 || op->k != 1 || op->stride != 1) return 0;
+  if (op->algo == MVAL_ALGO_MFMA_P2) return 1;
+  return op->algo == MVAL_ALGO_MFMA && !force_direct();  // (conv_mfma.hip's 1x1 kernels: the heat-map layer of the h2 / bf3 / fp32 plans)
+}
+
+static int op_launch(const mval_op* op, int n_images, float* workspace, const float* params, const float* net_input,
+                     float* net_output, unsigned long long* argmax_keys, void* stream);
+
 extern "C" int mval_op_launch(const mval_op* op, int n_images, float* workspace, const float* params,
                               const float* net_input, float* net_output, void* stream) {
+  return op_launch(op, n_images, workspace, params, net_input, net_output, nullptr, stream);
+}
+
+static int op_launch(const mval_op* op, int n_images, float* workspace, const float* params, const float* net_input,
+                     float* net_output, unsigned long long* argmax_keys, void* stream) {
   MVAL_REQUIRE(op && n_images > 0, "mval_op_launch: bad arguments");
   ConvArgs a = {};
+  a.argmax_keys = argmax_keys;
   a.in = op->in_off >= 0 ? workspace + op->in_off : net_input;
   a.out = op->out_off >= 0 ? workspace + op->out_off : net_output;
   a.res1 = op->res1_off >= 0 ? workspace + op->res1_off : nullptr;
@@ -495,6 +511,7 @@ extern "C" int mval_op_launch(const mval_op* op, int n_images, float* workspace,
     p.res2_row = a.res2 ? reinterpret_cast<const unsigned*>(workspace + op->res2_amax_off) : nullptr;
     if (op->out_nchw) {
       p.out_f32 = a.out;
+      p.argmax_keys = argmax_keys;
     } else {
       p.out = reinterpret_cast<_Float16*>(a.out);
       p.out_row = reinterpret_cast<unsigned*>(workspace + op->out_amax_off);
@@ -615,8 +632,44 @@ MvalLanes* mval_device_lanes() {
   return L;
 }
 
+extern "C" int mval_net_keeps_argmax_keys(void* net) {
+  if (!net) return 0;
+  MvalNet* n = reinterpret_cast<MvalNet*>(net);
+  int writers = 0, keepers = 0;
+  for (const auto& o : n->ops)
+    if (o.out_off < 0) {  // the op(s) that write the network output
+      writers++;
+      keepers += op_keeps_argmax_keys(&o);
+    }
+  return writers == 1 && keepers == 1;
+}
+
+static int net_forward(void* net, int n_images, float* workspace, const float* params, const float* input_nchw,
+                       float* output_nchw, unsigned long long* argmax_keys, void* stream);
+
 extern "C" int mval_net_forward(void* net, int n_images, float* workspace, const float* params,
                                 const float* input_nchw, float* output_nchw, void* stream) {
+  return net_forward(net, n_images, workspace, params, input_nchw, output_nchw, nullptr, stream);
+}
+
+extern "C" int mval_net_forward_keys(void* net, int n_images, float* workspace, const float* params, const float* input_nchw,
+                                     float* output_nchw, uint64_t* argmax_keys, void* stream) {
+  MVAL_REQUIRE(net && argmax_keys, "mval_net_forward_keys: null argument");
+  MVAL_REQUIRE(mval_net_keeps_argmax_keys(net), "mval_net_forward_keys: the plan's heat-map layer does not run on a kernel that keeps arg-max keys");
+  MvalNet* n = reinterpret_cast<MvalNet*>(net);
+  int64_t maps = 0;
+  for (const auto& o : n->ops)
+    if (o.out_off < 0) maps = (int64_t)n_images * o.cout;
+  // every stored value has a key > 0: zero = "nothing stored yet" (a memset node when captured)
+  if (hipMemsetAsync(argmax_keys, 0, (size_t)maps * 8, mval_stream(stream)) != hipSuccess) {
+    mval_set_error("mval_net_forward_keys: hipMemsetAsync failed");
+    return -2;
+  }
+  return net_forward(net, n_images, workspace, params, input_nchw, output_nchw, reinterpret_cast<unsigned long long*>(argmax_keys), stream);
+}
+
+static int net_forward(void* net, int n_images, float* workspace, const float* params, const float* input_nchw,
+                       float* output_nchw, unsigned long long* argmax_keys, void* stream) {
   MVAL_REQUIRE(net, "mval_net_forward: null net");
   MvalNet* n = reinterpret_cast<MvalNet*>(net);
   hipStream_t main_s = mval_stream(stream);
@@ -627,7 +680,7 @@ extern "C" int mval_net_forward(void* net, int n_images, float* workspace, const
   for (size_t i = 0; i < n->ops.size(); i++) {
     const mval_op& op = n->ops[i];
     hipStream_t s = walk.stream_for(op.phase, op.lane < n->n_lanes ? op.lane : 0);
-    int rc = mval_op_launch(&n->ops[i], n_images, workspace, params, input_nchw, output_nchw, s);
+    int rc = op_launch(&n->ops[i], n_images, workspace, params, input_nchw, output_nchw, op.out_off < 0 ? argmax_keys : nullptr, s);
     if (rc) return rc;
   }
   walk.finish();

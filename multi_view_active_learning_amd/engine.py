@@ -557,13 +557,29 @@ class InferencePlan:
         self.param_sig = sig
 
     # ---- run ---------------------------------------------------------------------------------
-    def _launch(self, x, out):
+    def _keys_wanted(self):
+        """Decode from the heat-map layer's epilogue: the plan's last kernel also keeps the arg-max key of every
+        map it stores (mval_net_forward_keys), unless it runs on a generic kernel or MVAL_EPILOGUE_DECODE=0."""
+        return _lib.epilogue_decode_enabled() and bool(_lib.lib().mval_net_keeps_argmax_keys(C.c_void_p(self.net)))
+
+    def _launch(self, x, out, keys=None):
+        if keys is not None:
+            _lib._check(
+                _lib.lib().mval_net_forward_keys(
+                    C.c_void_p(self.net), C.c_int(self.n), C.c_void_p(self.arena.data_ptr()),
+                    C.c_void_p(self.params.data_ptr()), C.c_void_p(x.data_ptr()), C.c_void_p(out.data_ptr()),
+                    C.c_void_p(keys.data_ptr()), _lib._stream()),
+                "mval_net_forward_keys")
+            return
         _lib._check(
             _lib.lib().mval_net_forward(
                 C.c_void_p(self.net), C.c_int(self.n), C.c_void_p(self.arena.data_ptr()),
                 C.c_void_p(self.params.data_ptr()), C.c_void_p(x.data_ptr()), C.c_void_p(out.data_ptr()),
                 _lib._stream()),
             "mval_net_forward")
+
+    def _new_keys(self):
+        return torch.empty((self.n * self.out_channels,), dtype=torch.int64, device=self.device) if self._keys_wanted() else None
 
     def _graph_wanted(self):
         """The reference's default batches are 2 frames (config.py:67,87): ~300 launches of a few microseconds
@@ -577,15 +593,16 @@ class InferencePlan:
     def _capture(self, x):
         self._gx = torch.empty_like(x)
         self._gout = torch.empty((self.n, self.out_channels) + tuple(self.out_hw), dtype=torch.float32, device=self.device)
+        self._gkeys = self._new_keys()
         self._gx.copy_(x)
         side = torch.cuda.Stream(device=self.device)
         side.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(side):  # warm-up outside the capture (lazy stream / event creation)
-            self._launch(self._gx, self._gout)
+            self._launch(self._gx, self._gout, self._gkeys)
         torch.cuda.current_stream(self.device).wait_stream(side)
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
-            self._launch(self._gx, self._gout)
+            self._launch(self._gx, self._gout, self._gkeys)
         self._graph = graph
 
     def forward(self, x):
@@ -600,9 +617,15 @@ class InferencePlan:
             if self._graph is not None:
                 self._gx.copy_(x)
                 self._graph.replay()
-                return self._gout.clone()
+                out = self._gout.clone()
+                if self._gkeys is not None:
+                    _lib.remember_argmax_keys(out, self._gkeys.clone())
+                return out
         out = torch.empty((self.n, self.out_channels) + tuple(self.out_hw), dtype=torch.float32, device=self.device)
-        self._launch(x, out)
+        keys = self._new_keys()
+        self._launch(x, out, keys)
+        if keys is not None:
+            _lib.remember_argmax_keys(out, keys)
         return out
 
     def forward_timed(self, x):
@@ -637,7 +660,8 @@ def _plan_for(model, x):
         raise ValueError("expected (N, 3, H, W) images")
     cache = model.__dict__.setdefault("_plans", {})
     key = (n, h, w, x.device.index, os.environ.get("MVAL_FORCE_DIRECT") == "1", _conv_mode(), os.environ.get("MVAL_FUSE_BLOCKS", "1"),
-           os.environ.get("MVAL_P2_BLOCKS", "32"), os.environ.get("MVAL_P2", "1"), os.environ.get("MVAL_P2_BNECK", "1"), os.environ.get("MVAL_P2_STEM", "1"), os.environ.get("MVAL_P2_FUSE_UP", "1"))
+           os.environ.get("MVAL_P2_BLOCKS", "32"), os.environ.get("MVAL_P2", "1"), os.environ.get("MVAL_P2_BNECK", "1"), os.environ.get("MVAL_P2_STEM", "1"), os.environ.get("MVAL_P2_FUSE_UP", "1"),
+           os.environ.get("MVAL_EPILOGUE_DECODE", "1"))
     plan = cache.get(key)
     if plan is None:
         if len(cache) >= 4:  # keep the arena footprint bounded

@@ -345,3 +345,30 @@ def test_al_dict_for_coreset_layout():
     d = get_al_dict_for_coreset(labeled)
     assert list(d) == [0, 1, 2] and d[1].shape == (19, 4) and d[1].dtype == np.float64
     assert np.array_equal(d[2], np.array(labeled[2]["3d_keypoints"]).T)
+
+
+def test_argmax_key_stash_follows_the_network_output():
+    """Decode from the heat-map layer's epilogue: the keys a forward kept are found for the tensor it returned
+    and for full views of it, not for slices, copies or tensors written to since, and die with the tensor."""
+    import gc
+
+    import torch
+
+    from multi_view_active_learning_amd import _lib
+
+    out = torch.zeros(8, 17, 4, 4)
+    keys = torch.zeros(8 * 17, dtype=torch.int64)
+    _lib.remember_argmax_keys(out, keys)
+    assert _lib.argmax_keys_of(out) is keys
+    assert _lib.argmax_keys_of(out.reshape(2, 4, 17, 4, 4)) is keys
+    assert _lib.argmax_keys_of(out.reshape(2, 4, 17, 4, 4).to(torch.float32).contiguous()) is keys
+    assert _lib.argmax_keys_of(out[:4]) is None and _lib.argmax_keys_of(out[4:]) is None
+    assert _lib.argmax_keys_of(out.clone()) is None
+    assert _lib.argmax_keys_of(out.permute(0, 1, 3, 2)) is None
+    view = out.reshape(2, 4, 17, 4, 4)
+    view[0, 0, 0, 0, 0] = 1.0  # written through a view: the keys no longer describe the tensor
+    assert _lib.argmax_keys_of(out) is None and _lib.argmax_keys_of(view) is None
+    n = len(_lib._ARGMAX_KEYS)
+    del out, view
+    gc.collect()
+    assert len(_lib._ARGMAX_KEYS) == n - 1

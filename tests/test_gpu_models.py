@@ -425,3 +425,66 @@ def test_magnitude_row_overflow_falls_back_to_atomics(dev):
     assert torch.equal(kept, got.abs().amax(dim=(1, 2, 3)).cpu())
     want = F.relu(F.conv2d(x, wt, None, 2, 1) * sc[None, :, None, None] + sh[None, :, None, None])
     np.testing.assert_allclose(got.permute(0, 3, 1, 2).cpu().numpy(), want.numpy(), rtol=1e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("graph", ["0", "1"])
+@pytest.mark.parametrize("mode", ["p2", "h2", "fp32"])
+@pytest.mark.parametrize("name", ["w32", "w48", "r50"])
+def test_decode_from_heatmap_layer_epilogue(dev, name, mode, graph, monkeypatch):
+    """SURVEY 8(f1) (hrnet.py:344-350,500 -> utils/evaluation.py:13-30): the kernel that stores the NCHW heat-maps keeps one
+    arg-max key per map, and the decode of the tensor the network returned reads those keys instead of the maps.  Bit-equal
+    to argmax_decode_kernel on the same maps (MVAL_EPILOGUE_DECODE=0) and to numpy's first-index arg-max, for the P2 final
+    layer and the fp32-MFMA 1x1 final layer (h2 / fp32 plans, PoseResNet), eager launches and hipGraph replays."""
+    from multi_view_active_learning_amd import _lib, engine
+
+    monkeypatch.setenv("MVAL_CONV", mode)
+    monkeypatch.setenv("MVAL_GRAPH", graph)
+    c = cases.model_cases()[name]
+    m, _ = _load(c, dev)
+    x = torch.from_numpy(cases.model_input(c)).to(dev)
+    n, j, hh, wh = c["n"], c["j"], c["h"] // 4, c["w"] // 4
+    valid = torch.ones((1, j), dtype=torch.uint8, device=dev)
+    valid[0, 1] = 0
+    with torch.no_grad():
+        for rep in range(2):  # (second pass: the replay of a captured graph / the cached plan)
+            hm = m(x)
+            plan = engine._plan_for(m, x)
+            assert plan._keys_wanted(), "the heat-map layer of every MFMA plan keeps arg-max keys"
+            keys = _lib.argmax_keys_of(hm.reshape(1, n, j, hh, wh))
+            assert keys is not None and keys.shape == (n * j,)
+            got = _lib.argmax_decode(hm.reshape(1, n, j, hh, wh), valid, 1, n, j, hh, wh, 4, hh)
+            monkeypatch.setenv("MVAL_EPILOGUE_DECODE", "0")
+            want = _lib.argmax_decode(hm.reshape(1, n, j, hh, wh), valid, 1, n, j, hh, wh, 4, hh)
+            monkeypatch.delenv("MVAL_EPILOGUE_DECODE")
+            assert torch.equal(got, want)
+            idx = hm.reshape(n, j, -1).cpu().numpy().argmax(-1)
+            kp = np.stack([(idx % hh) * 4, (idx // hh) * 4], axis=-1)
+            kp[:, 1] = 0
+            assert np.array_equal(got[0].cpu().numpy(), kp)
+    # a slice, or a tensor written to since, is decoded from the maps
+    assert _lib.argmax_keys_of(hm[:, :1]) is None
+    hm.mul_(1.0)
+    assert _lib.argmax_keys_of(hm) is None
+
+
+def test_decode_from_epilogue_ties_and_constant_maps(dev, monkeypatch):
+    """Equal values: the FIRST flat index wins (torch.argmax), across tiles and waves -- constant maps (zero weights,
+    per-joint bias incl. -0.0, negative and huge) decode to index 0 on both final-layer kernels."""
+    from multi_view_active_learning_amd import _lib
+
+    c = cases.model_cases()["w32"]
+    for mode in ("p2", "h2"):
+        monkeypatch.setenv("MVAL_CONV", mode)
+        m, _ = _load(c, dev)
+        with torch.no_grad():
+            m.final_layer.weight.zero_()
+            b = torch.linspace(-1.0, 1.0, c["j"])
+            b[0], b[1], b[2] = -0.0, 1e30, 0.0
+            m.final_layer.bias.copy_(b)
+            x = torch.from_numpy(cases.model_input(c)).to(dev)
+            hm = m(x)
+        n, j, hh, wh = c["n"], c["j"], c["h"] // 4, c["w"] // 4
+        assert torch.equal(hm[:, j - 1], torch.full_like(hm[:, j - 1], float(b[j - 1])))
+        assert _lib.argmax_keys_of(hm) is not None
+        got = _lib.argmax_decode(hm, None, 1, n, j, hh, wh, 4, hh)
+        assert int(got.abs().max()) == 0
