@@ -274,14 +274,12 @@ def path_kernels(dev, frames, v, j, hh, wh):
     hm = torch.rand(frames, v, j, hh, wh, device=dev)
     valid = torch.ones(frames, j, dtype=torch.uint8, device=dev)
     n_maps, map_bytes = frames * v * j, frames * v * j * hh * wh * 4.0
-    t = timed(lambda: _lib.argmax_decode(hm, valid, frames, v, j, hh, wh, 4, hh))
-    out.append(hbm("argmax_decode_kernel (hard arg-max of every heat-map from a read of the maps: what the decode of a tensor "
-                   "that is NOT the network's own output costs; the step itself decodes from the heat-map layer's epilogue)",
-                   t, map_bytes, "one read of the heat-maps"))
     keys = torch.zeros(n_maps, dtype=torch.int64, device=dev)
     t = timed(lambda: _lib.argmax_from_keys(keys, valid, frames, v, j, 4, hh))
     out.append(hbm("argmax_from_keys_kernel (key-points from the arg-max keys the heat-map layer's epilogue kept: the step's "
-                   "decode, SURVEY 8(f1))", t, n_maps * 24.0, "8-byte key in, two int64 out per map: launch-latency bound"))
+                   "decode, SURVEY 8(f1); argmax_decode_kernel, the decode from a read of the maps, serves tensors that are not the network's "
+                   "own output and is not on this path any more)", t, n_maps * 24.0,
+                   "8-byte key in, two int64 out per map: launch-latency bound"))
     for kind, name in ((_lib.SCORE_HP, "HP"), (_lib.SCORE_MPE, "MPE"), (_lib.SCORE_BSB, "BSB")):
         t = timed(lambda: _lib.score_decode_maps(kind, hm, valid, frames, v, j, hh, wh, 4, hh))
         out.append(hbm(f"score_maps_kernel<{name}, decode> (per-map uncertainty statistic AND hard arg-max key-point from one "
@@ -289,7 +287,7 @@ def path_kernels(dev, frames, v, j, hh, wh):
                        "one read of the heat-maps (uniform-noise maps: ~160 local maxima each to sort for MPE / BSB; "
                        "trained heat-maps have a handful)"))
     proj = torch.from_numpy(np.stack([synth.ring_cameras(v, hh * 4, wh * 4, seed=s) for s in range(frames)])).to(dev)
-    kp = _lib.argmax_decode(hm, valid, frames, v, j, hh, wh, 4, hh)
+    kp = _lib.score_decode_maps(_lib.SCORE_HP, hm, valid, frames, v, j, hh, wh, 4, hh)[2]
     t = timed(lambda: _lib.triangulate_ransac(kp, proj, valid, frames, v, j, 4.0))
     out.append(dict(bound="latency", achieved=round(frames * j / t), peak=None, unit="problems/s", frac=None, traffic=None,
                     kernel="ransac_dlt_kernel (pairwise RANSAC + DLT + reprojection error, float64)",
