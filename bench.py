@@ -274,12 +274,12 @@ def path_kernels(dev, frames, v, j, hh, wh):
     hm = torch.rand(frames, v, j, hh, wh, device=dev)
     valid = torch.ones(frames, j, dtype=torch.uint8, device=dev)
     n_maps, map_bytes = frames * v * j, frames * v * j * hh * wh * 4.0
-    keys = torch.zeros(n_maps, dtype=torch.int64, device=dev)
+    keys = torch.zeros((frames * v, _lib.ARGMAX_SLOTS, j), dtype=torch.int64, device=dev)
     t = timed(lambda: _lib.argmax_from_keys(keys, valid, frames, v, j, 4, hh))
     out.append(hbm("argmax_from_keys_kernel (key-points from the arg-max keys the heat-map layer's epilogue kept: the step's "
                    "decode, SURVEY 8(f1); argmax_decode_kernel, the decode from a read of the maps, serves tensors that are not the network's "
-                   "own output and is not on this path any more)", t, n_maps * 24.0,
-                   "8-byte key in, two int64 out per map: launch-latency bound"))
+                   "own output and is not on this path any more)", t, n_maps * (8.0 * _lib.ARGMAX_SLOTS + 16.0),
+                   "the maps' rows of partial keys in, two int64 out per map: launch-latency bound"))
     for kind, name in ((_lib.SCORE_HP, "HP"), (_lib.SCORE_MPE, "MPE"), (_lib.SCORE_BSB, "BSB")):
         t = timed(lambda: _lib.score_decode_maps(kind, hm, valid, frames, v, j, hh, wh, 4, hh))
         out.append(hbm(f"score_maps_kernel<{name}, decode> (per-map uncertainty statistic AND hard arg-max key-point from one "

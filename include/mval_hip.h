@@ -43,7 +43,7 @@ const char* mval_last_error(void);
 int mval_argmax_decode(const float* heatmaps, const uint8_t* valid, int64_t* kp2d,
                        int B, int V, int J, int hh, int wh, int stride, int split_width, void* stream);
 /* The same key-points from the arg-max keys of mval_net_forward_keys (no read of the heat-maps):
- *   keys [B*V*J] u64 ; valid [B,J] u8 or NULL ; kp2d [B,V,J,2] i64 (x,y). */
+ *   keys [B*V][MVAL_ARGMAX_SLOTS][J] u64 ; valid [B,J] u8 or NULL ; kp2d [B,V,J,2] i64 (x,y). */
 int mval_argmax_from_keys(const uint64_t* keys, const uint8_t* valid, int64_t* kp2d, int B, int V, int J,
                           int stride, int split_width, void* stream);
 
@@ -322,12 +322,15 @@ int mval_net_set_multi_stream(void* net, int mode);
 int mval_net_forward(void* net, int n_images, float* workspace, const float* params,
                      const float* input_nchw, float* output_nchw, void* stream);
 /* Decode from the heat-map layer's epilogue (hrnet.py:344-350,500 / pose_resnet.py final_layer -> utils/evaluation.py:13-30):
- * the same forward, and the kernel that stores the NCHW heat-maps also keeps ONE 64-bit arg-max key per map in
- * argmax_keys [n_images * joints] (device; zeroed here first): high word = the stored value as an order-preserving
- * unsigned (NaN highest, -0 == +0), low word = ~flat index -- torch.argmax's choice, first index on ties.
- * mval_argmax_from_keys turns the keys into the key-points mval_argmax_decode would compute from a second read of the
- * maps (bit-equal).  mval_net_keeps_argmax_keys: 1 when the plan's heat-map layer runs on a kernel that does this
+ * the same forward, and the kernel that stores the NCHW heat-maps also keeps 64-bit arg-max keys of what it stores in
+ * argmax_keys [n_images][MVAL_ARGMAX_SLOTS][joints] (device; zeroed here first): every wave leaves the best key of its
+ * part of a map in its own slot of the map (plain stores; more partials per map than slots -- maps above ~8 000
+ * pixels -- fold with atomicMax).  key: high word = the stored value as an order-preserving unsigned (NaN highest,
+ * -0 == +0), low word = ~flat index, so the largest key is torch.argmax's choice, first index on ties.
+ * mval_argmax_from_keys reduces them and yields the key-points mval_argmax_decode would compute from a second read of
+ * the maps (bit-equal).  mval_net_keeps_argmax_keys: 1 when the plan's heat-map layer runs on a kernel that does this
  * (the MFMA families; not the generic direct kernels), else mval_net_forward_keys fails. */
+#define MVAL_ARGMAX_SLOTS 128
 int mval_net_keeps_argmax_keys(void* net);
 int mval_net_forward_keys(void* net, int n_images, float* workspace, const float* params,
                           const float* input_nchw, float* output_nchw, uint64_t* argmax_keys, void* stream);

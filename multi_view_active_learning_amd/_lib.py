@@ -89,10 +89,11 @@ def _req(t, dtype, name):
 # --------------------------------------------------------------------------
 # keypoint decode / triangulation
 # --------------------------------------------------------------------------
-# Decode from the heat-map layer's epilogue: a forward whose final kernel kept the arg-max key of every map
+# Decode from the heat-map layer's epilogue: a forward whose final kernel kept arg-max keys of every map
 # (mval_net_forward_keys) remembers them for the tensor it returned; argmax_decode of THAT tensor (any reshape of it,
 # unmodified) then needs no second read of the heat-maps.  MVAL_EPILOGUE_DECODE=0 switches the mechanism off.
-_ARGMAX_KEYS = {}  # id(network output) -> (weak reference to it, keys [n_images * joints] int64 bit patterns)
+ARGMAX_SLOTS = 128  # MVAL_ARGMAX_SLOTS (include/mval_hip.h): partial keys per map
+_ARGMAX_KEYS = {}  # id(network output) -> (weak reference to it, keys [n_images, ARGMAX_SLOTS, joints] int64 bit patterns)
 
 
 def epilogue_decode_enabled():
@@ -127,7 +128,7 @@ def argmax_from_keys(keys, valid, b, v, j, stride, split_width):
 
 def argmax_decode(hm, valid, b, v, j, hh, wh, stride, split_width):
     keys = argmax_keys_of(hm) if epilogue_decode_enabled() else None
-    if keys is not None and keys.numel() == b * v * j and hm.numel() == b * v * j * hh * wh:
+    if keys is not None and keys.numel() == b * v * j * ARGMAX_SLOTS and hm.numel() == b * v * j * hh * wh:
         return argmax_from_keys(keys, valid, b, v, j, stride, split_width)
     out = torch.empty((b, v, j, 2), dtype=torch.int64, device=hm.device)
     _check(

@@ -40,7 +40,7 @@ struct ConvArgs {
   unsigned* out_amax;
   int amax_tiles;
   // NCHW heat-map layer (1x1, stride 1, out_nchw, up == 0) on conv_mfma.hip's kernels (KEYS instantiations of
-  // conv_tile_store): != nullptr = also keep the arg-max key of every map [N][Cout] (mval_common.h: decode from the epilogue)
+  // conv_tile_store): != nullptr = also keep the arg-max keys of every map, [N][MVAL_ARGMAX_SLOTS][Cout] (mval_common.h: decode from the epilogue)
   unsigned long long* argmax_keys;
   // MFMA tiling (filled by the launcher)
   int th, tw, tn, tw_log2, thw_log2;
@@ -251,7 +251,7 @@ __device__ __forceinline__ void conv_tile_store(const ConvArgs& a, const float* 
   if constexpr (KEYS) if (a.argmax_keys && a.out_nchw && a.up == 0) {
     // the heat-map layer with decode from the epilogue (hrnet.py:344-350,500 -> utils/evaluation.py:13-30): every wave
     // folds the keys of what it stores -- a wave's 64 elements are 64 pixels of ONE map when MT is a multiple of 64 and the
-    // tile holds one image; otherwise per 16-lane group, or per lane
+    // tile holds one image; otherwise per lane
     static_assert(NTH % 64 == 0, "whole waves");
     for (int e0 = 0; e0 < MT * NTILE; e0 += NTH) {  // (uniform trip count: the shuffles below need every lane)
       const int e = e0 + tid;
@@ -273,11 +273,19 @@ __device__ __forceinline__ void conv_tile_store(const ConvArgs& a, const float* 
         a.out[(map * a.Hout + y) * a.Wout + x] = r;
         key = mval_argmax_key(r, (unsigned)(y * a.Wout + x));
       }
-      if ((MT & 63) == 0 && a.tn == 1) {  // the wave's lanes share (n, c): one atomic per wave
-        key = mval_key_group_max(key, 32);
-        if ((tid & 63) == 0 && key) atomicMax(a.argmax_keys + map, key);
-      } else if (key) {
-        atomicMax(a.argmax_keys + map, key);
+      if ((MT & 63) == 0 && a.tn == 1) {  // the wave's lanes share (n, c): its key goes to its slot of the map's row
+        key = mval_key_row16_max(key);
+        {  // rows 0..3 -> lane 0 (two xor steps across the rows)
+          const unsigned long long k16 = ((unsigned long long)(unsigned)__shfl_xor((int)(unsigned)(key >> 32), 16, 64) << 32) | (unsigned)__shfl_xor((int)(unsigned)key, 16, 64);
+          key = k16 > key ? k16 : key;
+          const unsigned long long k32 = ((unsigned long long)(unsigned)__shfl_xor((int)(unsigned)(key >> 32), 32, 64) << 32) | (unsigned)__shfl_xor((int)(unsigned)key, 32, 64);
+          key = k32 > key ? k32 : key;
+        }
+        if ((tid & 63) == 0 && c < a.Cout && n < a.N)
+          mval_argmax_key_put(a.argmax_keys, n, c, a.Cout, (int)(blockIdx.x % (unsigned)a.amax_tiles) * (MT / 64) + p / 64,
+                              a.amax_tiles * (MT / 64), key);
+      } else if (key) {  // (several images per tile -- maps under 8 rows -- or 16-pixel groups: a few atomics per map)
+        atomicMax(a.argmax_keys + (int64_t)n * MVAL_ARGMAX_SLOTS * a.Cout + c, key);
       }
     }
     return;

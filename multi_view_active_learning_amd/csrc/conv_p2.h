@@ -128,7 +128,7 @@ struct P2Args {
   unsigned* out_row;
   _Float16* out;    // P2 planes ...
   float* out_f32;   // ... or fp32 NCHW (the heat-map layer)
-  unsigned long long* argmax_keys;  // heat-map layer: != nullptr = also keep the arg-max key of every map [N][Cout] (mval_common.h)
+  unsigned long long* argmax_keys;  // heat-map layer: != nullptr = also keep the arg-max keys of every map, [N][MVAL_ARGMAX_SLOTS][Cout] (mval_common.h)
   int N, Hin, Win, Cin, Hout, Wout, Cout;  // Hout / Wout before the fused upsample
   int k, stride;
   int up, relu;

@@ -505,7 +505,10 @@ __global__ __launch_bounds__(64 * WN * WM) __attribute__((amdgpu_waves_per_eu(P2
 #pragma unroll
         for (int nt = 0; nt < NT; nt++) {
           const int c0 = (ns0 + nt) * 16 + cq;
-          unsigned long long key[4] = {0ull, 0ull, 0ull, 0ull};  // arg-max keys of the lane's pixels, per cout
+          // arg-max of the lane's pixels per cout: (value, flat index); the pixels come in increasing flat index, so a strict
+          // "better" keeps the first of equal values (NaN beats everything but an earlier NaN: torch.argmax)
+          float bv[4] = {0.f, 0.f, 0.f, 0.f};
+          unsigned bi[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
 #pragma unroll
           for (int ms = 0; ms < MS; ms++) {
             const f32x4 v = acc[ms][nt] * scu[nt] + sh[nt];
@@ -516,20 +519,22 @@ __global__ __launch_bounds__(64 * WN * WM) __attribute__((amdgpu_waves_per_eu(P2
                 if (c0 + j < a.Cout) {
                   const float o = fmaxf(v[j], floor_);
                   a.out_f32[(((int64_t)n * a.Cout + c0 + j) * Ho + y) * Wo + x] = o;
-                  if (a.argmax_keys) {
-                    const unsigned long long kk = mval_argmax_key(o, (unsigned)(y * Wo + x));
-                    key[j] = kk > key[j] ? kk : key[j];
+                  if (bi[j] == 0xffffffffu || o > bv[j] || (o != o && bv[j] == bv[j])) {
+                    bv[j] = o;
+                    bi[j] = (unsigned)(y * Wo + x);
                   }
                 }
             }
           }
           // decode from the epilogue (hrnet.py:344-350,500 -> utils/evaluation.py:13-30): the 16 pixel lanes of a cout
-          // quarter fold their keys, one 64-bit atomicMax per (wave, cout) and tile
+          // quarter fold their keys; the wave's key of (tile, cout) goes to its slot of the map's row
           if (a.argmax_keys) {
+            const int timg = (oy0 / TH) * a.tiles_x + ox0 / TW;
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-              const unsigned long long kk = mval_key_group_max(key[j], 8);
-              if ((lane & 15) == 0 && kk && c0 + j < a.Cout) atomicMax(a.argmax_keys + (int64_t)n * a.Cout + c0 + j, kk);
+              const unsigned long long kk = mval_key_row16_max(bi[j] == 0xffffffffu ? 0ull : mval_argmax_key(bv[j], bi[j]));
+              if ((lane & 15) == 0 && c0 + j < a.Cout)
+                mval_argmax_key_put(a.argmax_keys, n, c0 + j, a.Cout, timg * WM + wm, tiles_img * WM, kk);
             }
           }
         }

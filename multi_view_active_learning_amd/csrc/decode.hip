@@ -69,16 +69,26 @@ extern "C" int mval_argmax_decode(const float* heatmaps, const uint8_t* valid, i
 }
 
 // ---- key-points from the arg-max keys the heat-map layer's epilogue kept (mval_common.h) ------------------------------------
+// one wave per map: its MVAL_ARGMAX_SLOTS partial keys -> the largest
 __global__ __launch_bounds__(256) void argmax_from_keys_kernel(const unsigned long long* __restrict__ keys, const uint8_t* __restrict__ valid,
                                                                int64_t* __restrict__ kp2d, int64_t n_maps, int V, int J, int stride,
                                                                int split_width) {
-  const int64_t map = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int64_t map = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (map >= n_maps) return;
   const int j = (int)(map % J);
   const int64_t b = map / ((int64_t)V * J);
-  const unsigned long long k = keys[map];
-  const unsigned bi = (valid && !valid[b * J + j]) || k == 0ull ? 0u : 0xffffffffu - (unsigned)k;
+  unsigned long long k = 0ull;
+  static_assert(MVAL_ARGMAX_SLOTS % 64 == 0, "whole waves over a row");
+#pragma unroll
+  for (int i = 0; i < MVAL_ARGMAX_SLOTS / 64; i++) {
+    const unsigned long long v = keys[((map / J) * MVAL_ARGMAX_SLOTS + i * 64 + lane) * J + j];  // [image][slot][joint]
+    k = v > k ? v : k;
+  }
+  k = mval_key_group_max(k, 32);
+  if (lane != 0) return;
   const bool inval = valid && !valid[b * J + j];
+  const unsigned bi = k == 0ull ? 0u : 0xffffffffu - (unsigned)k;
   kp2d[map * 2] = inval ? 0 : (int64_t)(bi % (unsigned)split_width) * stride;
   kp2d[map * 2 + 1] = inval ? 0 : (int64_t)(bi / (unsigned)split_width) * stride;
 }
@@ -88,7 +98,7 @@ extern "C" int mval_argmax_from_keys(const uint64_t* keys, const uint8_t* valid,
   MVAL_REQUIRE(keys && kp2d && B >= 0 && V > 0 && J > 0 && split_width > 0, "mval_argmax_from_keys: bad arguments");
   const int64_t n_maps = (int64_t)B * V * J;
   if (n_maps == 0) return 0;
-  hipLaunchKernelGGL(argmax_from_keys_kernel, dim3((unsigned)((n_maps + 255) / 256)), dim3(256), 0, mval_stream(stream),
+  hipLaunchKernelGGL(argmax_from_keys_kernel, dim3((unsigned)((n_maps + 3) / 4)), dim3(256), 0, mval_stream(stream),
                      reinterpret_cast<const unsigned long long*>(keys), valid, kp2d, n_maps, V, J, stride, split_width);
   MVAL_CHECK_LAUNCH("mval_argmax_from_keys");
   return 0;

@@ -661,7 +661,7 @@ extern "C" int mval_net_forward_keys(void* net, int n_images, float* workspace, 
   for (const auto& o : n->ops)
     if (o.out_off < 0) maps = (int64_t)n_images * o.cout;
   // every stored value has a key > 0: zero = "nothing stored yet" (a memset node when captured)
-  if (hipMemsetAsync(argmax_keys, 0, (size_t)maps * 8, mval_stream(stream)) != hipSuccess) {
+  if (hipMemsetAsync(argmax_keys, 0, (size_t)maps * MVAL_ARGMAX_SLOTS * 8, mval_stream(stream)) != hipSuccess) {
     mval_set_error("mval_net_forward_keys: hipMemsetAsync failed");
     return -2;
   }

@@ -558,7 +558,7 @@ class InferencePlan:
 
     # ---- run ---------------------------------------------------------------------------------
     def _keys_wanted(self):
-        """Decode from the heat-map layer's epilogue: the plan's last kernel also keeps the arg-max key of every
+        """Decode from the heat-map layer's epilogue: the plan's last kernel also keeps arg-max keys of every
         map it stores (mval_net_forward_keys), unless it runs on a generic kernel or MVAL_EPILOGUE_DECODE=0."""
         return _lib.epilogue_decode_enabled() and bool(_lib.lib().mval_net_keeps_argmax_keys(C.c_void_p(self.net)))
 
@@ -579,7 +579,7 @@ class InferencePlan:
             "mval_net_forward")
 
     def _new_keys(self):
-        return torch.empty((self.n * self.out_channels,), dtype=torch.int64, device=self.device) if self._keys_wanted() else None
+        return torch.empty((self.n, _lib.ARGMAX_SLOTS, self.out_channels), dtype=torch.int64, device=self.device) if self._keys_wanted() else None
 
     def _graph_wanted(self):
         """The reference's default batches are 2 frames (config.py:67,87): ~300 launches of a few microseconds

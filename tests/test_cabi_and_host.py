@@ -357,7 +357,7 @@ def test_argmax_key_stash_follows_the_network_output():
     from multi_view_active_learning_amd import _lib
 
     out = torch.zeros(8, 17, 4, 4)
-    keys = torch.zeros(8 * 17, dtype=torch.int64)
+    keys = torch.zeros((8 * 17, _lib.ARGMAX_SLOTS), dtype=torch.int64)
     _lib.remember_argmax_keys(out, keys)
     assert _lib.argmax_keys_of(out) is keys
     assert _lib.argmax_keys_of(out.reshape(2, 4, 17, 4, 4)) is keys

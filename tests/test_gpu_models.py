@@ -431,8 +431,8 @@ def test_magnitude_row_overflow_falls_back_to_atomics(dev):
 @pytest.mark.parametrize("mode", ["p2", "h2", "fp32"])
 @pytest.mark.parametrize("name", ["w32", "w48", "r50"])
 def test_decode_from_heatmap_layer_epilogue(dev, name, mode, graph, monkeypatch):
-    """SURVEY 8(f1) (hrnet.py:344-350,500 -> utils/evaluation.py:13-30): the kernel that stores the NCHW heat-maps keeps one
-    arg-max key per map, and the decode of the tensor the network returned reads those keys instead of the maps.  Bit-equal
+    """SURVEY 8(f1) (hrnet.py:344-350,500 -> utils/evaluation.py:13-30): the kernel that stores the NCHW heat-maps keeps
+    arg-max keys of every map (one per wave and map), and the decode of the tensor the network returned reads those keys instead of the maps.  Bit-equal
     to argmax_decode_kernel on the same maps (MVAL_EPILOGUE_DECODE=0) and to numpy's first-index arg-max, for the P2 final
     layer and the fp32-MFMA 1x1 final layer (h2 / fp32 plans, PoseResNet), eager launches and hipGraph replays."""
     from multi_view_active_learning_amd import _lib, engine
@@ -451,7 +451,7 @@ def test_decode_from_heatmap_layer_epilogue(dev, name, mode, graph, monkeypatch)
             plan = engine._plan_for(m, x)
             assert plan._keys_wanted(), "the heat-map layer of every MFMA plan keeps arg-max keys"
             keys = _lib.argmax_keys_of(hm.reshape(1, n, j, hh, wh))
-            assert keys is not None and keys.shape == (n * j,)
+            assert keys is not None and keys.shape == (n, _lib.ARGMAX_SLOTS, j)
             got = _lib.argmax_decode(hm.reshape(1, n, j, hh, wh), valid, 1, n, j, hh, wh, 4, hh)
             monkeypatch.setenv("MVAL_EPILOGUE_DECODE", "0")
             want = _lib.argmax_decode(hm.reshape(1, n, j, hh, wh), valid, 1, n, j, hh, wh, 4, hh)
@@ -488,3 +488,25 @@ def test_decode_from_epilogue_ties_and_constant_maps(dev, monkeypatch):
         assert _lib.argmax_keys_of(hm) is not None
         got = _lib.argmax_decode(hm, None, 1, n, j, hh, wh, 4, hh)
         assert int(got.abs().max()) == 0
+
+
+@pytest.mark.parametrize("mode", ["p2", "h2"])
+def test_decode_from_epilogue_large_maps_fold_with_atomics(dev, mode, monkeypatch):
+    """Heat-maps of 128 x 96 pixels: more partial keys per map than MVAL_ARGMAX_SLOTS, so the waves fold into the rows with
+    atomicMax -- still bit-equal to the decode from the maps."""
+    from multi_view_active_learning_amd import _lib
+
+    monkeypatch.setenv("MVAL_CONV", mode)
+    c = cases.model_cases()["w32"]
+    m, _ = _load(c, dev)
+    x = torch.randn(2, 3, 512, 384, device=dev, generator=torch.Generator(device=dev).manual_seed(3))
+    with torch.no_grad():
+        hm = m(x)
+    n, j, hh, wh = hm.shape
+    assert (hh, wh) == (128, 96) and _lib.argmax_keys_of(hm) is not None
+    got = _lib.argmax_decode(hm, None, 1, n, j, hh, wh, 4, hh)
+    monkeypatch.setenv("MVAL_EPILOGUE_DECODE", "0")
+    want = _lib.argmax_decode(hm, None, 1, n, j, hh, wh, 4, hh)
+    assert torch.equal(got, want)
+    idx = hm.reshape(n, j, -1).cpu().numpy().argmax(-1)
+    assert np.array_equal(got[0].cpu().numpy(), np.stack([(idx % hh) * 4, (idx // hh) * 4], axis=-1))
