@@ -109,7 +109,12 @@ def argmax_keys_of(hm):
     """The keys of the network output `hm` is (a full view of), or None: unknown tensor, a slice, or written to since."""
     base = hm._base if hm._base is not None else hm
     e = _ARGMAX_KEYS.get(id(base))
-    if e is None or e[0]() is not base or base._version != 0:
+    if e is None or e[0]() is not base:
+        return None
+    try:
+        if base._version != 0:
+            return None
+    except RuntimeError:  # inference-mode tensors track no version: nothing tells whether the maps were written to since
         return None
     if hm.numel() != base.numel() or hm.data_ptr() != base.data_ptr() or not hm.is_contiguous() or hm.dtype != torch.float32:
         return None

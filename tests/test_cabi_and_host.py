@@ -368,6 +368,11 @@ def test_argmax_key_stash_follows_the_network_output():
     view = out.reshape(2, 4, 17, 4, 4)
     view[0, 0, 0, 0, 0] = 1.0  # written through a view: the keys no longer describe the tensor
     assert _lib.argmax_keys_of(out) is None and _lib.argmax_keys_of(view) is None
+    with torch.inference_mode():  # no version counter to trust: decoded from the maps
+        inf = torch.zeros(8, 17, 4, 4)
+        _lib.remember_argmax_keys(inf, keys)
+        assert _lib.argmax_keys_of(inf) is None
+    del inf
     n = len(_lib._ARGMAX_KEYS)
     del out, view
     gc.collect()
