@@ -377,3 +377,25 @@ def test_argmax_key_stash_follows_the_network_output():
     del out, view
     gc.collect()
     assert len(_lib._ARGMAX_KEYS) == n - 1
+
+
+def test_python_constants_match_the_header():
+    """The ctypes mirror restates a few #defines / enum values of include/mval_hip.h: they must agree."""
+    import os
+    import re
+
+    from multi_view_active_learning_amd import _lib, engine
+
+    text = open(os.path.join(os.path.dirname(__file__), "..", "include", "mval_hip.h")).read()
+
+    def define(name):
+        return int(re.search(r"#define\s+%s\s+(\d+)" % name, text).group(1))
+
+    def enum(name):
+        return int(re.search(r"\b%s\s*=\s*(\d+)" % name, text).group(1))
+
+    assert define("MVAL_ARGMAX_SLOTS") == _lib.ARGMAX_SLOTS
+    assert define("MVAL_AMAX_ROW") == engine.AMAX_ROW
+    for name, val in (("MVAL_OP_BNECK", engine.OP_BNECK), ("MVAL_OP_STEM_P2", engine.OP_STEM_P2), ("MVAL_OP_FUSE_UP", engine.OP_FUSE_UP),
+                      ("MVAL_OP_BLOCK", engine.OP_BLOCK)):
+        assert enum(name) == val, name
