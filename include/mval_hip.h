@@ -352,6 +352,10 @@ double mval_op_flops(const mval_op* op, int n_images);
  * ws >= 512 * C * 2 doubles. */
 int mval_bn_batch_stats(const float* z, int64_t M, int C, float eps, float momentum, float* mean, float* invstd,
                         float* running_mean, float* running_var, double* ws, void* stream);
+/* The same statistics from per-(channel, conv workgroup) partials part[C][tiles][2] (float64 sum, sum of squares) that the
+ * training forward's conv epilogues keep while they store z (mval_train_forward): no second pass over z. */
+int mval_bn_finalize_stats(const double* part, int tiles, int64_t M, int C, float eps, float momentum, float* mean,
+                           float* invstd, float* running_mean, float* running_var, void* stream);
 /* out = act(((z*alpha + (beta - mean*alpha)) nearest-upsampled 2^up) + res1 + res2), alpha = invstd*gamma. */
 int mval_bn_apply_fwd(const float* z, const float* mean, const float* invstd, const float* gamma, const float* beta,
                       const float* res1, const float* res2, float* out, int N, int H, int W, int C, int up, int relu,
@@ -374,6 +378,14 @@ int mval_bn_bwd_amax(const float* gout, const float* out, const float* z, const 
                      const float* gamma, float* gres1, float* gres2, float* gz, float* dgamma, float* dbeta, double* ws,
                      float* sums, int N, int H, int W, int C, int up, int relu, int has_bn, int overwrite,
                      uint32_t* gz_amax_row, void* stream);
+/* Backward of out = act(bn(z) + res1 + res2) without upsample, BatchNorm present, C % 4 == 0: the results of
+ * mval_bn_bwd_amax with one tensor write and one to two tensor reads fewer -- the reduction pass does not write the
+ * masked gradient (the apply pass re-reads it from the residual slot this op wrote first, or from gout with the mask
+ * re-derived), and a ReLU without residuals takes its mask from z (`out` may be NULL then; beta is needed for it). */
+int mval_bn_bwd_fused(const float* gout, const float* out, const float* z, const float* mean, const float* invstd,
+                      const float* gamma, const float* beta, float* gres1, float* gres2, float* gz, float* dgamma,
+                      float* dbeta, double* ws, float* sums, int N, int H, int W, int C, int relu, int overwrite,
+                      uint32_t* gz_amax_row, void* stream);
 /* Weight gradient dw [cout][cin][k][k] of a conv: x NHWC (NCHW when x_nchw), dz NHWC.
  * ws >= mval_conv_wgrad_workspace_floats(cin, cout, k) floats. */
 size_t mval_conv_wgrad_workspace_floats(int cin, int cout, int k);
@@ -430,10 +442,12 @@ typedef struct mval_train_op {
 } mval_train_op;
 
 /* ones_off / zeros_off: params offsets of >= max(cout) floats of 1.0 / 0.0.
- * ws: >= 512*maxC*2 doubles. */
+ * ws: ws_doubles >= 512*maxC*2 doubles.  With room for cout * (conv workgroups) * 2 doubles of an op (about
+ * n_images*hout*wout*cout / 16 for the 32-pixel tiles, less for larger ones) that op's batch statistics come from its
+ * conv epilogue; ops whose partials do not fit run the separate statistics pass. */
 int mval_train_forward(const mval_train_op* ops, int n_ops, int n_images, float* arena, const float* params,
                        int64_t ones_off, int64_t zeros_off, const float* input_nchw, float* output_nchw,
-                       double* ws, float momentum, float eps, void* stream);
+                       double* ws, int64_t ws_doubles, float momentum, float eps, void* stream);
 /* gz: scratch >= max over ops of N*hout*wout*cout floats; wsf: >= max wgrad workspace;
  * sums: >= 2*maxC floats.  The gradient w.r.t. the network output must already be in garena at
  * the last op's gout_off (NHWC). */
@@ -446,6 +460,10 @@ int mval_train_backward(const mval_train_op* ops, int n_ops, int n_images, float
  * milliseconds per kernel family -- [conv forward, BN statistics, BN apply, BN backward, weight gradient, data
  * gradient] -- synchronising the stream at the end of the call; NULL switches it off again. */
 int mval_train_timing(float* ms_per_family);
+/* The same plus a per-operator breakdown into a HOST array [n_ops][6]; mval_train_timing_base(first_op) tells a
+ * mval_train_backward call on a sub-range of the op list where that range starts. */
+int mval_train_timing_ops(float* ms_per_family, float* ms_per_op_family, int n_ops);
+int mval_train_timing_base(int first_op);
 
 #ifdef __cplusplus
 }

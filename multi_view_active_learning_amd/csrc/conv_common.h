@@ -42,6 +42,15 @@ struct ConvArgs {
   // NCHW heat-map layer (1x1, stride 1, out_nchw, up == 0) on conv_mfma.hip's kernels (KEYS instantiations of
   // conv_tile_store): != nullptr = also keep the arg-max keys of every map, [N][MVAL_ARGMAX_SLOTS][Cout] (mval_common.h: decode from the epilogue)
   unsigned long long* argmax_keys;
+  // Training forward (raw z out, no residual / ReLU / upsample; net_train.hip): != nullptr = every workgroup also leaves
+  // the per-channel (sum, sum of squares) of the pixels it stored, float64 [cout][bn_tiles][2] -- train-mode BatchNorm's
+  // batch statistics (hrnet.py:16 nn.BatchNorm2d under model.train()) without a second pass over z.  The launcher
+  // fills bn_tiles (workgroups along x) and reports it in *bn_tiles_host; a kernel / tile shape that cannot keep them
+  // leaves *bn_tiles_host untouched (the caller then runs the separate statistics pass).  bn_part_cap: doubles at bn_part
+  double* bn_part;
+  int64_t bn_part_cap;
+  int* bn_tiles_host;
+  int bn_tiles;
   // MFMA tiling (filled by the launcher)
   int th, tw, tn, tw_log2, thw_log2;
   int tiles_x, tiles_y;
@@ -186,11 +195,18 @@ __device__ __forceinline__ void conv_tile_store(const ConvArgs& a, const float* 
         r2[i] = (ok && a.res2) ? *reinterpret_cast<const conv_f32x4*>(a.res2 + off[i]) : (conv_f32x4){0.f, 0.f, 0.f, 0.f};
       }
       float amax = 0.f;
+      conv_f32x4 bsum = (conv_f32x4){0.f, 0.f, 0.f, 0.f}, bsq = (conv_f32x4){0.f, 0.f, 0.f, 0.f};  // (a.bn_part)
 #pragma unroll
       for (int i = 0; i < IT; i++) {
         if (off[i] < 0) continue;
         const int e = tid + NTH * i;
         conv_f32x4 r = *reinterpret_cast<const conv_f32x4*>(ot + (e / Q) * LDW + (e % Q) * 4);
+        if constexpr (NTH % Q == 0) {  // a thread's granules are all of ONE channel quad (e % Q == tid % Q)
+          if (a.bn_part) {
+            bsum += r;
+            bsq += r * r;
+          }
+        }
         if (a.res1) r += r1[i];
         if (a.res2) r += r2[i];
         if (a.relu) {
@@ -201,6 +217,29 @@ __device__ __forceinline__ void conv_tile_store(const ConvArgs& a, const float* 
         if (a.out_amax && a.tn != 1) {  // several images per tile (maps under 8 rows): per image through LDS
           atomicMax(scratch + ((e / Q) >> a.thw_log2), __float_as_uint(amax));
           amax = 0.f;
+        }
+      }
+      if constexpr (NTH % Q == 0 && MT * LDW >= NTH * 8) {
+        if (a.bn_part) {
+          // batch-statistics partials of the tile: thread sums (a few pixels of one channel quad, float32) -> LDS ->
+          // one thread per channel adds the NTH / Q partials of its channel in float64, fixed order (deterministic)
+          __syncthreads();  // every thread is done with the tile in `ot`
+          float* sc = const_cast<float*>(ot);
+          *reinterpret_cast<conv_f32x4*>(sc + tid * 8) = bsum;
+          *reinterpret_cast<conv_f32x4*>(sc + tid * 8 + 4) = bsq;
+          __syncthreads();
+          if (tid < NTILE && cbase + tid < a.Cout) {
+            const int c4 = tid >> 2, k = tid & 3;
+            double s1 = 0.0, s2 = 0.0;
+#pragma unroll 4
+            for (int j = 0; j < NTH / Q; j++) {
+              s1 += (double)sc[(j * Q + c4) * 8 + k];
+              s2 += (double)sc[(j * Q + c4) * 8 + 4 + k];
+            }
+            double* dst = a.bn_part + ((int64_t)(cbase + tid) * a.bn_tiles + blockIdx.x) * 2;
+            dst[0] = s1;
+            dst[1] = s2;
+          }
         }
       }
       conv_tile_amax<MT>(a, scratch, amax, n0);
@@ -310,6 +349,23 @@ static inline void conv_amax_prepare(ConvArgs& a, int tiles_per_image, int group
   a.amax_tiles = tiles_per_image;
   if (a.out_amax && (int64_t)tiles_per_image * groups * 4 > MVAL_AMAX_ROW - 1)  // (up to 4 waves per workgroup)
     mval_launch_zero_rows(a.out_amax, (int64_t)a.N * MVAL_AMAX_ROW, s);
+}
+
+// Launcher side of the batch-statistics partials (a.bn_part): keeps them when the tile shape can (conv_tile_store's
+// float4 path with NTH % (NTILE / 4) == 0 and room for the NTH x 8 float scratch in the output tile) and the buffer
+// holds cout x tiles x 2 doubles; otherwise switches them off for this launch.
+template <int MT, int NTILE, int NTH>
+static inline void conv_bn_part_prepare(ConvArgs& a, unsigned grid_x, unsigned grid_z) {
+  if (!a.bn_part) return;
+  constexpr int Q = NTILE / 4;
+  const bool ok = NTH % Q == 0 && MT * (NTILE + 4) >= NTH * 8 && grid_z == 1 && a.up == 0 && !a.out_nchw && (a.Cout & 3) == 0 &&
+                  !a.res1 && !a.res2 && !a.relu && (int64_t)a.Cout * grid_x * 2 <= a.bn_part_cap;
+  if (!ok) {
+    a.bn_part = nullptr;
+    return;
+  }
+  a.bn_tiles = (int)grid_x;
+  if (a.bn_tiles_host) *a.bn_tiles_host = (int)grid_x;
 }
 
 int mval_launch_conv_mfma(const ConvArgs& a, hipStream_t s);  // conv_mfma.hip; returns 1 if unsupported

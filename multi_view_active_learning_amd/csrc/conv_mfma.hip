@@ -250,6 +250,7 @@ static int launch_cfg(ConvArgs a, int th, int tw, int tn, hipStream_t s) {
   if (g_dry_run) return 0;
   dim3 grid((unsigned)(a.tiles_x * a.tiles_y * ngroups), (unsigned)((a.NS_total + WN * NT - 1) / (WN * NT)));
   conv_amax_prepare(a, a.tiles_x * a.tiles_y, (int)grid.y, s);
+  conv_bn_part_prepare<MT, NTILE, 256>(a, grid.x, 1);
   // staging registers are sized at compile time (runtime-indexed arrays would go to scratch)
   if (ne <= 4)
     hipLaunchKernelGGL((conv_mfma_kernel<KS, S, KC, WN, WM, NT, MS, 4>), grid, dim3(256), smem, s, a);

@@ -413,6 +413,7 @@ static int launch_split(ConvArgs a, int th, int tw, int tn, hipStream_t s) {
   dim3 grid((unsigned)(a.tiles_x * a.tiles_y * ngroups), (unsigned)((a.NS_total + WN * NT - 1) / (WN * NT)),
             (KS == 2 && a.par_w_stride) ? 4u : 1u);
   conv_amax_prepare(a, a.tiles_x * a.tiles_y, (int)(grid.y * grid.z), s);
+  conv_bn_part_prepare<MT, NTILE, NTH>(a, grid.x, grid.z);
   if constexpr (G > 1) {
     constexpr int NEG = (G * MT * 8 + NTH - 1) / NTH;
     if constexpr (PAOK)

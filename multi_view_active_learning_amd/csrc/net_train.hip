@@ -20,6 +20,18 @@ extern "C" int mval_bn_batch_stats(const float*, int64_t, int, float, float, flo
                                    void*);
 extern "C" int mval_bn_apply_fwd(const float*, const float*, const float*, const float*, const float*, const float*,
                                  const float*, float*, int, int, int, int, int, int, void*);
+extern "C" int mval_bn_finalize_stats(const double*, int, int64_t, int, float, float, float*, float*, float*, float*, void*);
+extern "C" int mval_bn_bwd_fused(const float*, const float*, const float*, const float*, const float*, const float*, const float*,
+                                 float*, float*, float*, float*, float*, double*, float*, int, int, int, int, int, int, uint32_t*,
+                                 void*);
+#include <stdlib.h>
+// A/B switches of round 4's BatchNorm restructuring (measurement and the tests' cross-checks; read per call):
+//   MVAL_TRAIN_EPI_STATS=0  batch statistics by the separate pass over z instead of the forward conv's epilogue partials
+//   MVAL_TRAIN_BWD_FUSED=0  round 3's backward pair (masked copy to gz, dz in place) instead of mval_bn_bwd_fused
+static bool env_on(const char* name) {
+  const char* v = getenv(name);
+  return !(v && v[0] == '0');
+}
 
 // ---- measurement mode (bench.py, the c3 line's per-kernel roofline): hipEvents around every launch group of a
 // training step, summed per kernel family.  Off unless mval_train_timing() armed it; the events are resolved (one
@@ -27,7 +39,9 @@ extern "C" int mval_bn_apply_fwd(const float*, const float*, const float*, const
 #include <vector>
 enum { TT_CONV_FWD = 0, TT_BN_STATS, TT_BN_APPLY, TT_BN_BWD, TT_WGRAD, TT_DGRAD, TT_N };
 static float* g_tt_out = nullptr;
-struct TtSpan { int cat; hipEvent_t a, b; };
+static float* g_tt_ops = nullptr;  // optional [n_ops][TT_N] per-operator breakdown (tools/train_op_times.py)
+static int g_tt_n_ops = 0, g_tt_op = -1;
+struct TtSpan { int cat, op; hipEvent_t a, b; };
 static std::vector<TtSpan> g_tt_spans;
 struct TtScope {
   int cat; hipStream_t s; hipEvent_t a = nullptr, b = nullptr;
@@ -40,7 +54,7 @@ struct TtScope {
   ~TtScope() {
     if (!a) return;
     (void)hipEventRecord(b, s);
-    g_tt_spans.push_back({cat, a, b});
+    g_tt_spans.push_back({cat, g_tt_op, a, b});
   }
 };
 static void tt_flush() {
@@ -50,6 +64,7 @@ static void tt_flush() {
     float ms = 0.f;
     (void)hipEventElapsedTime(&ms, sp.a, sp.b);
     g_tt_out[sp.cat] += ms;
+    if (g_tt_ops && sp.op >= 0 && sp.op < g_tt_n_ops) g_tt_ops[sp.op * TT_N + sp.cat] += ms;
     (void)hipEventDestroy(sp.a);
     (void)hipEventDestroy(sp.b);
   }
@@ -57,8 +72,24 @@ static void tt_flush() {
 }
 extern "C" int mval_train_timing(float* ms_per_family) {
   g_tt_out = ms_per_family;
+  g_tt_ops = nullptr;
+  g_tt_n_ops = 0;
   if (ms_per_family)
     for (int i = 0; i < TT_N; i++) ms_per_family[i] = 0.f;
+  return 0;
+}
+// The same with a per-operator breakdown: ms_per_op_family is a HOST array [n_ops][6], indexed by the op's position in
+// the list handed to mval_train_forward (segmented backward calls must pass the op base, mval_train_timing_base).
+static int g_tt_base = 0;
+extern "C" int mval_train_timing_ops(float* ms_per_family, float* ms_per_op_family, int n_ops) {
+  mval_train_timing(ms_per_family);
+  g_tt_ops = ms_per_family ? ms_per_op_family : nullptr;
+  g_tt_n_ops = g_tt_ops ? n_ops : 0;
+  for (int i = 0; i < g_tt_n_ops * TT_N; i++) g_tt_ops[i] = 0.f;
+  return 0;
+}
+extern "C" int mval_train_timing_base(int first_op) {
+  g_tt_base = first_op;
   return 0;
 }
 
@@ -117,10 +148,12 @@ static int run_conv(const ConvArgs& a0, int algo, hipStream_t s, const char* wha
 
 extern "C" int mval_train_forward(const mval_train_op* ops, int n_ops, int n_images, float* arena, const float* params,
                                   int64_t ones_off, int64_t zeros_off, const float* input_nchw, float* output_nchw,
-                                  double* ws, float momentum, float eps, void* stream) {
+                                  double* ws, int64_t ws_doubles, float momentum, float eps, void* stream) {
   MVAL_REQUIRE(ops && n_ops > 0 && n_images > 0, "mval_train_forward: bad arguments");
   hipStream_t s = mval_stream(stream);
+  const bool epi_stats = env_on("MVAL_TRAIN_EPI_STATS");
   for (int i = 0; i < n_ops; i++) {
+    g_tt_op = i;
     const mval_train_op& t = ops[i];
     const mval_op& op = t.op;
     ConvArgs a = {};
@@ -151,6 +184,14 @@ extern "C" int mval_train_forward(const mval_train_op* ops, int n_ops, int n_ima
       a.scale = params + ones_off;
       a.shift = params + zeros_off;
       int rc;
+      // batch statistics: (sum, sum of squares) partials per conv workgroup from the epilogue that stores z, where the
+      // kernel the launcher picks can keep them (tiles > 0 afterwards); else the separate pass over z
+      int tiles = 0;
+      if (epi_stats && op.kind == MVAL_OP_CONV) {
+        a.bn_part = ws;
+        a.bn_part_cap = ws_doubles;
+        a.bn_tiles_host = &tiles;
+      }
       {
         TtScope tt(TT_CONV_FWD, s);
         rc = run_conv(a, op.algo, s, "mval_train_forward/conv");
@@ -159,8 +200,12 @@ extern "C" int mval_train_forward(const mval_train_op* ops, int n_ops, int n_ima
       const int64_t M = (int64_t)n_images * op.hout * op.wout;
       {
         TtScope tt(TT_BN_STATS, s);
-        rc = mval_bn_batch_stats(a.out, M, op.cout, eps, momentum, t.mean, t.invstd, t.running_mean, t.running_var, ws,
-                                 stream);
+        if (tiles > 0)
+          rc = mval_bn_finalize_stats(ws, tiles, M, op.cout, eps, momentum, t.mean, t.invstd, t.running_mean, t.running_var,
+                                      stream);
+        else
+          rc = mval_bn_batch_stats(a.out, M, op.cout, eps, momentum, t.mean, t.invstd, t.running_mean, t.running_var, ws,
+                                   stream);
       }
       if (rc) return rc;
       TtScope tt(TT_BN_APPLY, s);
@@ -193,7 +238,9 @@ extern "C" int mval_train_backward(const mval_train_op* ops, int n_ops, int n_im
   MVAL_REQUIRE(ops && n_ops > 0 && n_images > 0 && garena && gz && wsf && ws && sums,
                "mval_train_backward: bad arguments");
   hipStream_t s = mval_stream(stream);
+  const bool bwd_fused = env_on("MVAL_TRAIN_BWD_FUSED");
   for (int i = n_ops - 1; i >= 0; i--) {
+    g_tt_op = g_tt_base + i;
     const mval_train_op& t = ops[i];
     const mval_op& op = t.op;
     MVAL_REQUIRE(t.gout_off >= 0, "mval_train_backward: op %d has no output gradient slot", i);
@@ -212,6 +259,12 @@ extern "C" int mval_train_backward(const mval_train_op* ops, int n_ops, int n_im
     int rc;
     {
     TtScope tt(TT_BN_BWD, s);
+    if (bwd_fused && t.has_bn && op.up == 0 && (op.cout & 3) == 0)
+      rc = mval_bn_bwd_fused(garena + t.gout_off, outp, arena + t.z_off, t.mean, t.invstd, t.gamma, t.beta,
+                             t.gres1_off >= 0 ? garena + t.gres1_off : nullptr, t.gres2_off >= 0 ? garena + t.gres2_off : nullptr, gz,
+                             t.dgamma, t.dbeta, ws, sums, n_images, op.hout, op.wout, op.cout, op.relu, t.first_touch >> 1, gz_row,
+                             stream);
+    else
     rc = mval_bn_bwd_amax(garena + t.gout_off, outp, t.has_bn ? arena + t.z_off : nullptr, t.mean, t.invstd, t.gamma,
                               t.gres1_off >= 0 ? garena + t.gres1_off : nullptr,
                               t.gres2_off >= 0 ? garena + t.gres2_off : nullptr, gz, t.dgamma, t.dbeta, ws, sums, n_images,

@@ -33,6 +33,19 @@ __device__ __forceinline__ void tr_amax_store(unsigned* row, float m) {
 #define TR_UNROLL 8
 #define TR_EW 4  // pixels per thread and pass in the backward reduction
 
+// Train-mode normalisation of one float4 of z: alpha = invstd * gamma, beta' = beta - mean * alpha, r = z * alpha + beta'
+// (torch's batch_norm elementwise formula).  Explicit FMAs: the forward apply and the backward kernels that RECOMPUTE
+// the ReLU mask from z (no residual: out > 0 <=> r > 0) must round identically whatever the compiler contracts.
+__device__ __forceinline__ f32x4 bn_affine(const f32x4 zv, const f32x4 mu, const f32x4 is, const f32x4 g, const f32x4 b) {
+  f32x4 r;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const float alpha = is[k] * g[k];
+    r[k] = __builtin_fmaf(zv[k], alpha, __builtin_fmaf(-mu[k], alpha, b[k]));
+  }
+  return r;
+}
+
 // ---- batch statistics -----------------------------------------------------------------
 // partial[block][c][2] = (sum, sum of squares) over the block's pixel slice
 __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __restrict__ z, double* __restrict__ part,
@@ -116,6 +129,52 @@ __global__ __launch_bounds__(64) void bn_stats_finalize_kernel(const double* __r
   }
 }
 
+// The same from the partials the forward conv's epilogue kept (ConvArgs.bn_part, conv_common.h): part[c][tiles][2]
+// float64 (sum, sum of squares) per (channel, conv workgroup).  One 256-thread workgroup per channel, contiguous reads.
+__global__ __launch_bounds__(256) void bn_stats_finalize_tiles_kernel(const double* __restrict__ part, int tiles, int64_t M,
+                                                                      float eps, float momentum, float* __restrict__ mean,
+                                                                      float* __restrict__ invstd,
+                                                                      float* __restrict__ running_mean,
+                                                                      float* __restrict__ running_var) {
+  __shared__ double red[2][4];
+  const int c = blockIdx.x;
+  const double* p = part + (int64_t)c * tiles * 2;
+  double s = 0, ss = 0;
+  for (int b = threadIdx.x; b < tiles; b += 256) {
+    s += p[2 * b];
+    ss += p[2 * b + 1];
+  }
+  s = wave_sum(s);
+  ss = wave_sum(ss);
+  if ((threadIdx.x & 63) == 0) {
+    red[0][threadIdx.x >> 6] = s;
+    red[1][threadIdx.x >> 6] = ss;
+  }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  s = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+  ss = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+  const double mu = s / (double)M;
+  double var = ss / (double)M - mu * mu;
+  if (var < 0) var = 0;
+  mean[c] = (float)mu;
+  invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+  if (running_mean) {
+    const double unbiased = M > 1 ? var * (double)M / (double)(M - 1) : var;
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mu;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+  }
+}
+
+extern "C" int mval_bn_finalize_stats(const double* part, int tiles, int64_t M, int C, float eps, float momentum, float* mean,
+                                      float* invstd, float* running_mean, float* running_var, void* stream) {
+  MVAL_REQUIRE(part && tiles > 0 && M > 0 && C > 0 && mean && invstd, "mval_bn_finalize_stats: bad arguments");
+  hipLaunchKernelGGL(bn_stats_finalize_tiles_kernel, dim3(C), dim3(256), 0, mval_stream(stream), part, tiles, M, eps, momentum,
+                     mean, invstd, running_mean, running_var);
+  MVAL_CHECK_LAUNCH("mval_bn_finalize_stats");
+  return 0;
+}
+
 extern "C" int mval_bn_batch_stats(const float* z, int64_t M, int C, float eps, float momentum, float* mean,
                                    float* invstd, float* running_mean, float* running_var, double* ws, void* stream) {
   MVAL_REQUIRE(M > 0 && C > 0 && (C & 3) == 0, "mval_bn_batch_stats: bad dims (C must be a multiple of 4)");
@@ -158,8 +217,7 @@ __global__ __launch_bounds__(TR_APPLY_THREADS) void bn_apply_fwd_kernel(const fl
     const f32x4 is = *reinterpret_cast<const f32x4*>(invstd + q * 4);
     const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + q * 4);
     const f32x4 b = *reinterpret_cast<const f32x4*>(beta + q * 4);
-    const f32x4 alpha = is * g;  // torch: alpha = invstd * weight ; beta' = bias - mean * alpha
-    f32x4 r = zv * alpha + (b - mu * alpha);
+    f32x4 r = bn_affine(zv, mu, is, g, b);  // torch: alpha = invstd * weight ; beta' = bias - mean * alpha
     const int64_t o = p * C + q * 4;
     if (res1) r += *reinterpret_cast<const f32x4*>(res1 + o);
     if (res2) r += *reinterpret_cast<const f32x4*>(res2 + o);
@@ -441,6 +499,177 @@ extern "C" int mval_bn_bwd_amax(const float* gout, const float* out, const float
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(nb2), dim3(TR_APPLY_THREADS), 0, s, gz, z, mean, invstd, gamma, sums, M, C, gz_amax_row);
     MVAL_CHECK_LAUNCH("mval_bn_bwd/apply");
   }
+  return 0;
+}
+
+// ---- backward, round 4 form (no upsample, BatchNorm): the masked gradient is NOT written by the reduction -------
+// Round 3's pair moved gout -> gz (masked copy) -> gz (dz in place): one write and one read more than needed, and the
+// mask always came from a read of `out`.  Here the reduction only reads (gout, z, and `out` when a residual makes the
+// mask unrecoverable from z) and scatters the residual gradients; the apply pass re-reads its gradient source -- the
+// residual slot this op stored the masked gradient in (first writer), else gout with the mask re-derived -- and writes
+// dz once.  mask_mode: 0 none, 1 out > 0, 2 bn_affine(z) > 0 (ReLU without residual: out = max(bn_affine(z), 0)).
+__device__ __forceinline__ f32x4 bwd_mask(f32x4 g, const int mask_mode, const f32x4 ov, const f32x4 zv, const f32x4 mu,
+                                          const f32x4 is, const f32x4 gm, const f32x4 bt) {
+  if (mask_mode == 1) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) g[k] = ov[k] > 0.f ? g[k] : 0.f;
+  } else if (mask_mode == 2) {
+    const f32x4 r = bn_affine(zv, mu, is, gm, bt);
+#pragma unroll
+    for (int k = 0; k < 4; k++) g[k] = r[k] > 0.f ? g[k] : 0.f;
+  }
+  return g;
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_reduce2_kernel(const float* __restrict__ gout, const float* __restrict__ out,
+                                                             const float* __restrict__ z, const float* __restrict__ mean,
+                                                             const float* __restrict__ invstd,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             float* __restrict__ gres1, float* __restrict__ gres2,
+                                                             double* __restrict__ part, int M, int C, int mask_mode,
+                                                             int overwrite) {
+  extern __shared__ double sh[];
+  const int c4n = C >> 2;
+  const int lanes = min(c4n, 256);
+  const int rows = 256 / lanes;
+  const int col = threadIdx.x % lanes, row = threadIdx.x / lanes;
+  const f32x4 zero = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int cb = 0; cb < c4n; cb += lanes) {
+    const int q = cb + col;
+    double sb[4] = {0, 0, 0, 0}, sg[4] = {0, 0, 0, 0};
+    if (q < c4n && row < rows) {
+      const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + q * 4);
+      const f32x4 is = *reinterpret_cast<const f32x4*>(invstd + q * 4);
+      f32x4 gm = zero, bt = zero;
+      if (mask_mode == 2) {
+        gm = *reinterpret_cast<const f32x4*>(gamma + q * 4);
+        bt = *reinterpret_cast<const f32x4*>(beta + q * 4);
+      }
+      const int G = gridDim.x * rows;
+      for (int p0 = blockIdx.x * rows + row; p0 < M; p0 += TR_EW * G) {
+        f32x4 g[TR_EW], ov[TR_EW], zv[TR_EW], a1[TR_EW], a2[TR_EW];
+#pragma unroll
+        for (int u = 0; u < TR_EW; u++) {
+          const int p = p0 + u * G;
+          const bool ok = p < M;
+          const int64_t o = (int64_t)p * C + q * 4;
+          g[u] = ok ? *reinterpret_cast<const f32x4*>(gout + o) : zero;
+          ov[u] = (ok && mask_mode == 1) ? *reinterpret_cast<const f32x4*>(out + o) : zero;
+          zv[u] = ok ? *reinterpret_cast<const f32x4*>(z + o) : zero;
+          a1[u] = (ok && gres1 && !(overwrite & 1)) ? *reinterpret_cast<const f32x4*>(gres1 + o) : zero;
+          a2[u] = (ok && gres2 && !(overwrite & 2)) ? *reinterpret_cast<const f32x4*>(gres2 + o) : zero;
+        }
+#pragma unroll
+        for (int u = 0; u < TR_EW; u++) {
+          const int p = p0 + u * G;
+          if (p >= M) break;
+          const int64_t o = (int64_t)p * C + q * 4;
+          const f32x4 gv = bwd_mask(g[u], mask_mode, ov[u], zv[u], mu, is, gm, bt);
+          if (gres1) *reinterpret_cast<f32x4*>(gres1 + o) = a1[u] + gv;
+          if (gres2) *reinterpret_cast<f32x4*>(gres2 + o) = a2[u] + gv;
+          const f32x4 xh = (zv[u] - mu) * is;
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            sb[k] += (double)gv[k];
+            sg[k] += (double)gv[k] * (double)xh[k];
+          }
+        }
+      }
+    }
+    __syncthreads();
+    if (q < c4n && row < rows)
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        sh[((row * lanes + col) * 4 + k) * 2] = sb[k];
+        sh[((row * lanes + col) * 4 + k) * 2 + 1] = sg[k];
+      }
+    __syncthreads();
+    if (row == 0 && q < c4n) {
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        double a = 0, b = 0;
+        for (int r = 0; r < rows; r++) {
+          a += sh[((r * lanes + col) * 4 + k) * 2];
+          b += sh[((r * lanes + col) * 4 + k) * 2 + 1];
+        }
+        part[((int64_t)blockIdx.x * C + q * 4 + k) * 2] = a;
+        part[((int64_t)blockIdx.x * C + q * 4 + k) * 2 + 1] = b;
+      }
+    }
+  }
+}
+
+// dz = gamma * invstd * (g - dbeta / M - xhat * dgamma / M), g = gsrc masked as the reduction masked it
+// (gsrc = a residual slot holding the masked gradient: mask_mode 0)
+__global__ __launch_bounds__(TR_APPLY_THREADS) void bn_bwd_apply2_kernel(const float* __restrict__ gsrc, const float* __restrict__ out,
+                                                           const float* __restrict__ z, const float* __restrict__ mean,
+                                                           const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, const float* __restrict__ sums,
+                                                           float* __restrict__ gz, int64_t M, int C, int mask_mode,
+                                                           unsigned* __restrict__ amax_row) {
+  const int c4n = C >> 2;
+  const int64_t total = M * c4n;
+  const float invM = 1.0f / (float)M;
+  const f32x4 zero = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float amax = 0.f;
+  for (int64_t t = (int64_t)blockIdx.x * TR_APPLY_THREADS + threadIdx.x; t < total; t += (int64_t)gridDim.x * TR_APPLY_THREADS) {
+    const int q = (int)(t % c4n);
+    const int64_t i = (t / c4n) * C + q * 4;
+    const f32x4 gv0 = *reinterpret_cast<const f32x4*>(gsrc + i);
+    const f32x4 zv = *reinterpret_cast<const f32x4*>(z + i);
+    const f32x4 ov = mask_mode == 1 ? *reinterpret_cast<const f32x4*>(out + i) : zero;
+    const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + q * 4);
+    const f32x4 is = *reinterpret_cast<const f32x4*>(invstd + q * 4);
+    const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + q * 4);
+    const f32x4 bt = mask_mode == 2 ? *reinterpret_cast<const f32x4*>(beta + q * 4) : zero;
+    const f32x4 db = *reinterpret_cast<const f32x4*>(sums + q * 4);
+    const f32x4 dg = *reinterpret_cast<const f32x4*>(sums + C + q * 4);
+    const f32x4 gv = bwd_mask(gv0, mask_mode, ov, zv, mu, is, g, bt);
+    const f32x4 xh = (zv - mu) * is;
+    const f32x4 r = (g * is) * (gv - db * invM - xh * (dg * invM));
+    *reinterpret_cast<f32x4*>(gz + i) = r;
+    amax = fmaxf(fmaxf(amax, fmaxf(fabsf(r.x), fabsf(r.y))), fmaxf(fabsf(r.z), fabsf(r.w)));
+  }
+  if (amax_row) tr_amax_store(amax_row, amax);
+}
+
+// Backward of out = act(bn(z) + res1 + res2) at the conv resolution (no upsample): same results as mval_bn_bwd_amax
+// (dz in gz, dgamma, dbeta, residual gradients scattered), one tensor write and one to two tensor reads fewer.
+extern "C" int mval_bn_bwd_fused(const float* gout, const float* out, const float* z, const float* mean, const float* invstd,
+                                 const float* gamma, const float* beta, float* gres1, float* gres2, float* gz, float* dgamma,
+                                 float* dbeta, double* ws, float* sums, int N, int H, int W, int C, int relu, int overwrite,
+                                 uint32_t* gz_amax_row, void* stream) {
+  MVAL_REQUIRE(gout && z && mean && invstd && gamma && beta && gz && ws && sums && N > 0 && H > 0 && W > 0 && C > 0 && (C & 3) == 0,
+               "mval_bn_bwd_fused: bad arguments (C must be a multiple of 4)");
+  MVAL_REQUIRE((int64_t)N * H * W * C < ((int64_t)1 << 33) && (int64_t)N * H * W < ((int64_t)1 << 31), "mval_bn_bwd_fused: more than 2^31 float4 elements");
+  MVAL_REQUIRE(!gres1 || gres1 != gres2, "mval_bn_bwd_fused: the two residual gradients must be distinct buffers");
+  MVAL_REQUIRE(!relu || out || (!gres1 && !gres2), "mval_bn_bwd_fused: ReLU with residuals needs the output activation for the mask");
+  const int64_t M = (int64_t)N * H * W;
+  const int c4n = C >> 2;
+  const int lanes = c4n < 256 ? c4n : 256;
+  const int rows = 256 / lanes;
+  int nb = (int)((M + rows - 1) / rows);
+  if (nb > TR_BLOCKS) nb = TR_BLOCKS;
+  const size_t sh = (size_t)rows * lanes * 4 * 2 * sizeof(double);
+  hipStream_t s = mval_stream(stream);
+  const int mask_mode = !relu ? 0 : (gres1 || gres2) ? 1 : 2;
+  hipLaunchKernelGGL(bn_bwd_reduce2_kernel, dim3(nb), dim3(256), sh, s, gout, out, z, mean, invstd, gamma, beta, gres1, gres2, ws,
+                     (int)M, C, mask_mode, overwrite);
+  MVAL_CHECK_LAUNCH("mval_bn_bwd_fused/reduce");
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, s, ws, nb, C, dbeta, dgamma, sums);
+  MVAL_CHECK_LAUNCH("mval_bn_bwd_fused/finalize");
+  // the masked gradient again: from the residual slot this op was the first to write (it holds exactly that), else
+  // from gout with the mask re-derived
+  const float* gsrc = gout;
+  int apply_mask = mask_mode;
+  if (gres1 && (overwrite & 1)) { gsrc = gres1; apply_mask = 0; }
+  else if (gres2 && (overwrite & 2)) { gsrc = gres2; apply_mask = 0; }
+  const int64_t total = M * c4n;
+  int nb2 = (int)((total + TR_APPLY_THREADS - 1) / TR_APPLY_THREADS);
+  if (nb2 > TR_APPLY_BLOCKS) nb2 = TR_APPLY_BLOCKS;
+  hipLaunchKernelGGL(bn_bwd_apply2_kernel, dim3(nb2), dim3(TR_APPLY_THREADS), 0, s, gsrc, out, z, mean, invstd, gamma, beta, sums, gz, M,
+                     C, apply_mask, gz_amax_row);
+  MVAL_CHECK_LAUNCH("mval_bn_bwd_fused/apply");
   return 0;
 }
 

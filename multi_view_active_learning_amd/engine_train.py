@@ -231,7 +231,10 @@ class TrainPlan:
         self.stats = torch.zeros(max(stat_top, 64), **f32)
         self.gz = torch.empty(max(gz_max, 64), **f32)
         self.wsf = torch.empty(max(wsf_max, 64), **f32)
-        self.ws = torch.empty(512 * maxc * 2 + 64, dtype=torch.float64, device=device)
+        # float64 scratch of the BatchNorm reductions; sized so that the forward conv epilogues' per-workgroup statistics
+        # partials fit (cout x workgroups x 2, workgroups <= pixels / 32 for every tile the large layers use)
+        epi = max((op.cout * ((n * geo[i][2] * geo[i][3] + 31) // 32 + 64) * 2 for i, op in enumerate(g.ops) if op.bn), default=0)
+        self.ws = torch.empty(max(512 * maxc * 2, epi) + 64, dtype=torch.float64, device=device)
         self.sums = torch.empty(2 * maxc + 64, **f32)
         self.param_sig = None
         self._pack_ptrs, self._pack_jobs = None, None
@@ -381,7 +384,7 @@ class TrainPlan:
                 self.ops, C.c_int(len(self.ops)), C.c_int(self.n), C.c_void_p(self.arena.data_ptr()),
                 C.c_void_p(self.params.data_ptr()), C.c_int64(self.ones_off), C.c_int64(self.zeros_off),
                 C.c_void_p(x.data_ptr()), C.c_void_p(out.data_ptr()), C.c_void_p(self.ws.data_ptr()),
-                C.c_float(BN_MOMENTUM), C.c_float(BN_EPS), _lib._stream()),
+                C.c_int64(self.ws.numel()), C.c_float(BN_MOMENTUM), C.c_float(BN_EPS), _lib._stream()),
             "mval_train_forward")
         if self.bn_counters:
             torch._foreach_add_(self.bn_counters, 1)
@@ -420,6 +423,7 @@ class TrainPlan:
         lo, hi = self.segments[k]
         grads = self._grads
         sub = (MvalTrainOp * (hi - lo)).from_address(C.addressof(self.ops) + lo * C.sizeof(MvalTrainOp))
+        _lib.lib().mval_train_timing_base(C.c_int(lo))  # (measurement mode's per-operator breakdown)
         _lib._check(
             _lib.lib().mval_train_backward(
                 sub, C.c_int(hi - lo), C.c_int(self.n), C.c_void_p(self.arena.data_ptr()),
