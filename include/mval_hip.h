@@ -409,6 +409,14 @@ int mval_maxpool_bwd(const float* gout, const float* x, float* gin, int N, int H
 int mval_conv_dgrad(const float* dz, const float* w_packed, const float* ones, const float* zeros, float* dx,
                     int accumulate, int N, int hin, int win, int cin, int hout, int wout, int cout, int k,
                     int stride, int pad, int algo, void* stream);
+/* Data gradient of Conv2d(k3, s2, p1) with even hin / win as four 2x2 stride-1 convs over dz, one per parity of dx, in ONE
+ * launch (16 tap-pixels per dz pixel instead of the zero-dilated form's 36; the fp16 split applies).  algo: MVAL_ALGO_MFMA_BF3
+ * or _H2 (then dz_amax_row); w_packed: mval_pack_conv_weights(pack, transposed = 4, w, ..., cout' = cin, cin' = cout, k = 4)
+ * from the conv's own [cout][cin][3][3] weight.  _supported: 1 when a kernel exists for the shape. */
+int mval_conv_dgrad_parity_supported(int N, int hin, int win, int cin, int hout, int wout, int cout, int algo);
+int mval_conv_dgrad_parity(const float* dz, const float* w_packed, const float* ones, const float* zeros, float* dx,
+                           int accumulate, int N, int hin, int win, int cin, int hout, int wout, int cout, int algo,
+                           const uint32_t* dz_amax_row, void* stream);
 /* The same with algo = MVAL_ALGO_MFMA_H2 allowed (stride 1): dz_amax_row = the magnitude row of dz (one row for the
  * tensor), w_packed in MVAL_PACK_MFMA16_H2 form (with its trailer). */
 int mval_conv_dgrad_scaled(const float* dz, const float* w_packed, const float* ones, const float* zeros, float* dx,
@@ -429,7 +437,9 @@ typedef struct mval_train_op {
   int64_t z_off;      /* raw conv output at conv resolution (arena); unused when has_bn == 0 */
   int64_t gin_off, gout_off, gres1_off, gres2_off; /* garena; -1 = no gradient needed */
   int64_t wd_off;     /* params: weights packed for the data-gradient conv (-1: none) */
-  int32_t has_bn, dgrad_algo, first_touch, reserved1;
+  int32_t has_bn, dgrad_algo, first_touch;
+  int32_t dgrad_form; /* 0: plain (stride 2: dz read zero-dilated); 1: Conv2d(k3, s2, p1) on even sizes as four 2x2 parity convs
+                       * (mval_conv_dgrad_parity; wd_off packed with transposed = 4, k = 4) */
   float* gamma; float* beta; float* running_mean; float* running_var; /* device pointers */
   float* mean; float* invstd;            /* saved batch statistics [cout] */
   float* dweight; float* dgamma; float* dbeta; /* gradient outputs (dbeta = bias grad w/o BN) */

@@ -605,6 +605,16 @@ int mval_conv_split_supported(const ConvArgs& a) {
 // Source element of packed position (tap t, cin ci, cout co) for the `mode`s of mval_pack_conv_weights.
 __device__ __forceinline__ float split_w_at(const float* __restrict__ w, int mode, int cout, int cin, int k, int t, int ci, int co) {
   const int T = k * k;
+  if (mode == 4) {
+    // data gradient of Conv2d(k3, s2, p1) as four 2x2 stride-1 convs over dz, one per parity (py, px) of dx (packed with
+    // k = 4: t = parity * 4 + (dy * 2 + dx); the SOURCE is the conv's own [cin' = cout][cout' = cin][3][3] weight).
+    // dx[2a] = dz[a] W[1]; dx[2a + 1] = dz[a] W[2] + dz[a + 1] W[0].  The parity kernel's window is rows (a - 1, a) for
+    // py = 0 and (a, a + 1) for py = 1 (as the transposed conv's, mode 3): py = 0 uses its second row only.
+    const int pp = t >> 2, dy = (t >> 1) & 1, dx = t & 1;
+    const int ky = (pp >> 1) ? (dy ? 0 : 2) : (dy ? 1 : -1), kx = (pp & 1) ? (dx ? 0 : 2) : (dx ? 1 : -1);
+    if (ky < 0 || kx < 0) return 0.f;
+    return w[((int64_t)ci * cout + co) * 9 + ky * 3 + kx];
+  }
   if (mode == 3) {
     // ConvTranspose2d(k4, s2, p1) as four 2x2 stride-1 convs, one per output parity (py, px):
     // t = parity * 4 + (dy * 2 + dx); window row dy of parity py reads kernel row 3 - 2 dy (py = 0:
@@ -711,7 +721,7 @@ __global__ __launch_bounds__(256) void pack_amax_batch_kernel(const PackBf3Job* 
   const PackBf3Job jb = jobs[blockIdx.x];
   if (!(jb.mode & 0x100)) return;
   __shared__ float red[4];
-  const int64_t n = (int64_t)jb.cout * jb.cin * jb.k * jb.k;
+  const int64_t n = (int64_t)jb.cout * jb.cin * ((jb.mode & 0xff) == 4 ? 9 : jb.k * jb.k);  // (mode 4: a 3x3 source packed as k = 4)
   float m = 0.f;
   for (int64_t i = threadIdx.x; i < n; i += 256) m = fmaxf(m, fabsf(jb.w[i]));
   m = wave_max(m);
@@ -777,7 +787,7 @@ int mval_pack_h2(int mode, const float* w, float* packed, int cout, int cin, int
   const int64_t total = (int64_t)k * k * G * NS * 512;
   float* trailer = packed + total;  // 2 planes x 512 halves = 512 floats per block
   (void)hipMemsetAsync(trailer, 0, 4 * sizeof(float), s);
-  const int64_t nw = (int64_t)cout * cin * k * k;
+  const int64_t nw = (int64_t)cout * cin * (mode == 4 ? 9 : k * k);
   hipLaunchKernelGGL(weight_amax_kernel, dim3((unsigned)((nw + 1023) / 1024 > 256 ? 256 : (nw + 1023) / 1024)), dim3(256), 0, s, w, nw,
                      reinterpret_cast<unsigned*>(trailer) + 1);
   hipLaunchKernelGGL(pack_h2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w,

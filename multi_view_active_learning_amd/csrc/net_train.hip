@@ -315,6 +315,11 @@ extern "C" int mval_train_backward(const mval_train_op* ops, int n_ops, int n_im
     if (t.gin_off >= 0) {
       MVAL_REQUIRE(t.dgrad_algo != MVAL_ALGO_MFMA_H2 || gz_row, "mval_train_backward: op %d: fp16-split data gradient without dz's magnitude row", i);
       TtScope tt(TT_DGRAD, s);
+      if (t.dgrad_form == 1)  // (dgrad_form: the four-parity form of a stride-2 3x3 data gradient)
+        rc = mval_conv_dgrad_parity(gz, params + t.wd_off, params + ones_off, params + zeros_off, garena + t.gin_off,
+                                    !(t.first_touch & 1), n_images, op.hin, op.win, op.cin, op.hout, op.wout, op.cout, t.dgrad_algo,
+                                    gz_row, stream);
+      else
       rc = mval_conv_dgrad_scaled(gz, params + t.wd_off, params + ones_off, params + zeros_off, garena + t.gin_off,
                                   !(t.first_touch & 1), n_images,
                                   op.hin, op.win, op.cin, op.hout, op.wout, op.cout, op.k, op.stride, op.pad, t.dgrad_algo,
@@ -334,6 +339,52 @@ extern "C" int mval_conv_dgrad(const float* dz, const float* w_packed, const flo
   MVAL_REQUIRE(algo != MVAL_ALGO_MFMA_H2, "mval_conv_dgrad: the fp16-split form needs dz's magnitude row (mval_conv_dgrad_scaled)");
   return mval_conv_dgrad_scaled(dz, w_packed, ones, zeros, dx, accumulate, N, hin, win, cin, hout, wout, cout, k, stride, pad,
                                 algo, nullptr, stream);
+}
+
+// Data gradient of Conv2d(k3, s2, p1) on even-sized inputs as FOUR 2x2 stride-1 convs over dz, one per parity of dx, in
+// one launch (the split kernels' parity form, as the inference plans run transposed convs): 16 tap-pixels per dz pixel
+// instead of the 36 of the zero-dilated form (three of four staged values zero), and the fp16 split applies (stride 1).
+// w_packed: mval_pack_conv_weights(pack, 4, w, ..., cout' = cin, cin' = cout, k = 4).
+static void dgrad_parity_args(ConvArgs& a, int N, int hin, int win, int cin, int hout, int wout, int cout, int algo) {
+  a.N = N;
+  a.Hin = hout; a.Win = wout; a.Cin = cout;
+  a.Hout = hout; a.Wout = wout; a.Cout = cin;  // the parity grid; dx is (hout << 1) x (wout << 1)
+  a.k = 2; a.stride = 1; a.pad = 1; a.dil = 1;
+  a.os_log2 = 1;
+  a.G_total = (cout + 15) / 16;
+  a.NS_total = (cin + 15) / 16;
+  a.planes = algo == MVAL_ALGO_MFMA_H2 ? 2 : 3;
+  const int pack = algo == MVAL_ALGO_MFMA_H2 ? MVAL_PACK_MFMA16_H2 : MVAL_PACK_MFMA16_BF3;
+  a.par_w_stride = (int)((mval_packed_weight_floats(pack, cin, cout, 4) & ~(size_t)7) / 4);
+}
+extern "C" int mval_conv_dgrad_parity_supported(int N, int hin, int win, int cin, int hout, int wout, int cout, int algo) {
+  if ((algo != MVAL_ALGO_MFMA_BF3 && algo != MVAL_ALGO_MFMA_H2) || N <= 0 || (hin & 1) || (win & 1) || hout * 2 != hin || wout * 2 != win ||
+      (cin & 3) || (cout % 32 != 0 && cout != 48))
+    return 0;
+  ConvArgs a = {};
+  dgrad_parity_args(a, N, hin, win, cin, hout, wout, cout, algo);
+  return mval_conv_split_supported(a);
+}
+extern "C" int mval_conv_dgrad_parity(const float* dz, const float* w_packed, const float* ones, const float* zeros, float* dx,
+                                      int accumulate, int N, int hin, int win, int cin, int hout, int wout, int cout, int algo,
+                                      const uint32_t* dz_amax_row, void* stream) {
+  MVAL_REQUIRE(dz && w_packed && ones && zeros && dx, "mval_conv_dgrad_parity: bad arguments");
+  MVAL_REQUIRE(mval_conv_dgrad_parity_supported(N, hin, win, cin, hout, wout, cout, algo),
+               "mval_conv_dgrad_parity: k3 s2 p1 on even input sizes, cin %% 4 == 0, cout %% 32 == 0 (or 48), split algos only");
+  MVAL_REQUIRE(algo != MVAL_ALGO_MFMA_H2 || dz_amax_row, "mval_conv_dgrad_parity: the fp16 split needs dz's magnitude row");
+  ConvArgs a = {};
+  dgrad_parity_args(a, N, hin, win, cin, hout, wout, cout, algo);
+  a.in = dz;
+  a.w = w_packed;
+  if (algo == MVAL_ALGO_MFMA_H2) {
+    a.in_amax = dz_amax_row;
+    a.w_unscale = w_packed + mval_packed_weight_floats(MVAL_PACK_MFMA16_H2, cin, cout, 4) - 4;
+  }
+  a.scale = ones;
+  a.shift = zeros;
+  a.out = dx;
+  a.res1 = accumulate ? dx : nullptr;
+  return run_conv(a, algo, mval_stream(stream), "mval_conv_dgrad_parity");
 }
 
 extern "C" int mval_conv_dgrad_scaled(const float* dz, const float* w_packed, const float* ones, const float* zeros, float* dx,

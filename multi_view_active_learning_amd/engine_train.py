@@ -41,7 +41,7 @@ class MvalTrainOp(C.Structure):
         ("z_off", C.c_int64),
         ("gin_off", C.c_int64), ("gout_off", C.c_int64), ("gres1_off", C.c_int64), ("gres2_off", C.c_int64),
         ("wd_off", C.c_int64),
-        ("has_bn", C.c_int32), ("dgrad_algo", C.c_int32), ("first_touch", C.c_int32), ("reserved1", C.c_int32),
+        ("has_bn", C.c_int32), ("dgrad_algo", C.c_int32), ("first_touch", C.c_int32), ("dgrad_form", C.c_int32),
         ("gamma", C.c_void_p), ("beta", C.c_void_p), ("running_mean", C.c_void_p), ("running_var", C.c_void_p),
         ("mean", C.c_void_p), ("invstd", C.c_void_p),
         ("dweight", C.c_void_p), ("dgamma", C.c_void_p), ("dbeta", C.c_void_p),
@@ -187,9 +187,19 @@ class TrainPlan:
                         if lib.mval_op_algo_supported(C.byref(d), C.c_int(n), C.c_int(ALGO_MFMA_H2)):
                             t.dgrad_algo = ALGO_MFMA_H2
                             t.gz_amax_off = self.gz_amax_off
+                # stride-2 3x3 on even sizes: four 2x2 parity convs over dz instead of a 3x3 conv over the zero-dilated dz
+                # (2.25x fewer tap-pixels, and the fp16 split applies); weights packed with mode 4 as k = 4
+                if bf3 and op.k == 3 and op.stride == 2 and op.pad == 1 and os.environ.get("MVAL_TRAIN_DGRAD_PARITY", "1") != "0":
+                    for cand in ((ALGO_MFMA_H2, ALGO_MFMA_BF3) if (h2 and op.bn) else (ALGO_MFMA_BF3,)):
+                        if lib.mval_conv_dgrad_parity_supported(C.c_int(n), C.c_int(hin), C.c_int(win), C.c_int(op.cin), C.c_int(hout),
+                                                                C.c_int(wout), C.c_int(op.cout), C.c_int(cand)):
+                            t.dgrad_algo, t.dgrad_form = cand, 1
+                            if cand == ALGO_MFMA_H2:
+                                t.gz_amax_off = self.gz_amax_off
+                            break
                 dpack = _PACK_OF[t.dgrad_algo]
                 # the data-gradient conv has cin' = cout, cout' = cin
-                nd = int(lib.mval_packed_weight_floats(C.c_int(dpack), C.c_int(op.cin), C.c_int(op.cout), C.c_int(op.k)))
+                nd = int(lib.mval_packed_weight_floats(C.c_int(dpack), C.c_int(op.cin), C.c_int(op.cout), C.c_int(4 if t.dgrad_form == 1 else op.k)))
                 t.wd_off = ptop
                 ptop += _align(nd)
             self.jobs.append((i, fpack, dpack))
@@ -307,14 +317,17 @@ class TrainPlan:
                 self._pack_jobs = None
                 return
             fmode, dmode = (2, 0) if op.kind == "deconv" else (0, 2)
+            dk = op.k
+            if t.dgrad_form == 1:  # four-parity form of a stride-2 data gradient: mode 4, packed as k = 4
+                dmode, dk = 4, 4
             todo = []
             if fpack in (PACK_MFMA16_BF3, PACK_MFMA16_H2):  # (bit 8 of the mode: fp16-split packing, mval_pack_split_jobs)
-                todo.append((base + 4 * t.op.w_off, fmode | (0x100 if fpack == PACK_MFMA16_H2 else 0), op.cout, op.cin))
+                todo.append((base + 4 * t.op.w_off, fmode | (0x100 if fpack == PACK_MFMA16_H2 else 0), op.cout, op.cin, op.k))
             if dpack in (PACK_MFMA16_BF3, PACK_MFMA16_H2):
-                todo.append((base + 4 * t.wd_off, dmode | (0x100 if dpack == PACK_MFMA16_H2 else 0), op.cin, op.cout))
-            for dst, mode, cout, cin in todo:
-                total = op.k * op.k * ((cin + 31) // 32) * ((cout + 15) // 16) * 512
-                rows.append((w.data_ptr(), dst, mode, cout, cin, op.k))
+                todo.append((base + 4 * t.wd_off, dmode | (0x100 if dpack == PACK_MFMA16_H2 else 0), op.cin, op.cout, dk))
+            for dst, mode, cout, cin, kk in todo:
+                total = kk * kk * ((cin + 31) // 32) * ((cout + 15) // 16) * 512
+                rows.append((w.data_ptr(), dst, mode, cout, cin, kk))
                 first.append(blocks)
                 blocks += (total + 255) // 256
         if not rows:
@@ -357,12 +370,15 @@ class TrainPlan:
                 # Conv2d: forward as stored (0), data gradient tap-flipped / channel-swapped (2);
                 # ConvTranspose2d: the other way round (forward = conv over the zero-dilated input)
                 fmode, dmode = (2, 0) if op.kind == "deconv" else (0, 2)
+                dk = op.k
+                if t.dgrad_form == 1:
+                    dmode, dk = 4, 4
                 if not (batched and fpack in (PACK_MFMA16_BF3, PACK_MFMA16_H2)):
                     _lib._check(lib.mval_pack_conv_weights(C.c_int(fpack), C.c_int(fmode), wp, C.c_void_p(base + 4 * t.op.w_off),
                                                            C.c_int(op.cout), C.c_int(op.cin), C.c_int(op.k), st), "pack fwd")
                 if dpack is not None and not (batched and dpack in (PACK_MFMA16_BF3, PACK_MFMA16_H2)):
                     _lib._check(lib.mval_pack_conv_weights(C.c_int(dpack), C.c_int(dmode), wp, C.c_void_p(base + 4 * t.wd_off),
-                                                           C.c_int(op.cin), C.c_int(op.cout), C.c_int(op.k), st), "pack dgrad")
+                                                           C.c_int(op.cin), C.c_int(op.cout), C.c_int(dk), st), "pack dgrad")
                 if getattr(conv, "bias", None) is not None:
                     self.params[t.op.shift_off : t.op.shift_off + op.cout] = conv.bias.detach()
             if op.bn:

@@ -171,6 +171,34 @@ def conv_dgrad(dz, weight, in_hw, stride=1, algo=ALGO_MFMA, accumulate_into=None
     return dx
 
 
+def conv_dgrad_parity(dz, weight, in_hw, algo=ALGO_MFMA_BF3, accumulate_into=None, dz_amax_row=None):
+    """Data gradient of ``F.conv2d(x, weight, stride=2, padding=1)`` with a 3x3 weight and even input sizes as four 2x2
+    parity convs over dz in one launch (mval_conv_dgrad_parity): dz NHWC (N,Ho,Wo,Cout) -> dx NHWC (N,H,W,Cin)."""
+    lib = _lib.lib()
+    cout, cin, k, _ = weight.shape
+    n, ho, wo, _ = dz.shape
+    h, w = in_hw
+    if k != 3 or not lib.mval_conv_dgrad_parity_supported(C.c_int(n), C.c_int(h), C.c_int(w), C.c_int(cin), C.c_int(ho), C.c_int(wo),
+                                                          C.c_int(cout), C.c_int(algo)):
+        raise _lib.MvalError(f"conv_dgrad_parity: no parity form for {tuple(weight.shape)} on {h}x{w}")
+    pack = _PACK_OF[algo]
+    nw = int(lib.mval_packed_weight_floats(C.c_int(pack), C.c_int(cin), C.c_int(cout), C.c_int(4)))
+    wp = torch.empty(nw, dtype=torch.float32, device=dz.device)
+    wt = weight.detach().contiguous()
+    _lib._check(lib.mval_pack_conv_weights(C.c_int(pack), C.c_int(4), _lib._p(wt), _lib._p(wp), C.c_int(cin), C.c_int(cout),
+                                           C.c_int(4), _lib._stream()), "mval_pack_conv_weights")
+    ones = torch.ones(max(cin, cout), dtype=torch.float32, device=dz.device)
+    zeros = torch.zeros_like(ones)
+    dx = accumulate_into if accumulate_into is not None else torch.empty((n, h, w, cin), dtype=torch.float32, device=dz.device)
+    _lib._check(
+        lib.mval_conv_dgrad_parity(_lib._p(dz.contiguous()), _lib._p(wp), _lib._p(ones), _lib._p(zeros), _lib._p(dx),
+                                   C.c_int(int(accumulate_into is not None)), C.c_int(n), C.c_int(h), C.c_int(w), C.c_int(cin),
+                                   C.c_int(ho), C.c_int(wo), C.c_int(cout), C.c_int(algo),
+                                   _lib._p(dz_amax_row) if dz_amax_row is not None else C.c_void_p(None), _lib._stream()),
+        "mval_conv_dgrad_parity")
+    return dx
+
+
 def p2_bound(weight, scale, shift):
     """[A, B] of csrc/conv_p2.h: |bn(conv(x))| <= A * max|x| + B with A = max_c |scale_c| * sum |w_c|, B = max_c |shift_c|
     (one float32 rounding of slack each: the kernel's scale leaves a factor 2)."""

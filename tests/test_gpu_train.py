@@ -37,7 +37,7 @@ def test_bn_train_ops_vs_torch(dev):
 
     rng = np.random.default_rng(0)
     for (n, h, w, c, up, relu, nres) in [(3, 8, 6, 32, 0, True, 1), (2, 4, 4, 64, 1, True, 1), (2, 4, 3, 48, 2, False, 2),
-                                         (4, 16, 16, 32, 0, True, 0)]:
+                                         (4, 16, 16, 32, 0, True, 0), (2, 6, 5, 64, 0, True, 2), (2, 9, 7, 16, 0, False, 0)]:
         z = torch.from_numpy(rng.standard_normal((n, c, h, w)).astype(np.float32) * 2 + 0.5).requires_grad_(True)
         gamma = torch.from_numpy(rng.uniform(0.5, 1.5, c).astype(np.float32)).requires_grad_(True)
         beta = torch.from_numpy(rng.standard_normal(c).astype(np.float32)).requires_grad_(True)
@@ -89,6 +89,31 @@ def test_bn_train_ops_vs_torch(dev):
                                     C.c_int(h), C.c_int(w), C.c_int(c), C.c_int(up), C.c_int(int(relu)), C.c_int(1), C.c_int(3), st), "bwd")
         for r, gr in zip(res, stale):
             np.testing.assert_allclose(gr.permute(0, 3, 1, 2).cpu().numpy(), r.grad.numpy(), rtol=1e-6, atol=1e-6)
+        if up == 0:
+            # round 4: the backward that does not write the masked gradient in its reduction pass (mask from z without a
+            # residual, the apply pass re-reading the residual slot it stored first, or gout): same results, both modes
+            for overwrite, fill in ((0, 0.0), (3, 7.0)):
+                gr2 = [torch.full_like(r, fill) for r in resd]
+                gz2, dg2, db2 = torch.full_like(gz, 9.0), torch.empty(c, device=dev), torch.empty(c, device=dev)
+                _lib._check(lib.mval_bn_bwd_fused(p(goutd), p(outd) if nres else p(None), p(zd), p(mean), p(invstd), p(gd), p(bd),
+                                                  p(gr2[0]) if nres > 0 else p(None), p(gr2[1]) if nres > 1 else p(None), p(gz2), p(dg2),
+                                                  p(db2), p(ws), p(sums), C.c_int(n), C.c_int(h), C.c_int(w), C.c_int(c),
+                                                  C.c_int(int(relu)), C.c_int(overwrite), p(None), st), "bwd fused")
+                assert torch.equal(gz2, gz) and torch.equal(dg2, dg) and torch.equal(db2, db)
+                for r, gr in zip(res, gr2):
+                    np.testing.assert_allclose(gr.permute(0, 3, 1, 2).cpu().numpy(), r.grad.numpy(), rtol=1e-6, atol=1e-6)
+            # batch statistics from per-tile partials, as the forward conv epilogues leave them ([C][tiles][2] float64)
+            tiles = 5
+            zt = zd.reshape(-1, c).double()
+            chunks = torch.tensor_split(zt, tiles, dim=0)
+            part = torch.stack([torch.stack([ch.sum(0), (ch * ch).sum(0)], dim=-1) for ch in chunks], dim=1).contiguous()  # (C, tiles, 2)
+            mean2, invstd2 = torch.empty(c, device=dev), torch.empty(c, device=dev)
+            rm2, rv2 = torch.zeros(c, device=dev), torch.ones(c, device=dev)
+            _lib._check(lib.mval_bn_finalize_stats(p(part), C.c_int(tiles), C.c_int64(n * h * w), C.c_int(c), C.c_float(1e-5),
+                                                   C.c_float(0.1), p(mean2), p(invstd2), p(rm2), p(rv2), st), "finalize")
+            np.testing.assert_allclose(mean2.cpu().numpy(), mean.cpu().numpy(), rtol=1e-6, atol=1e-7)
+            np.testing.assert_allclose(invstd2.cpu().numpy(), invstd.cpu().numpy(), rtol=1e-6)
+            np.testing.assert_allclose(rv2.cpu().numpy(), rvd.cpu().numpy(), rtol=1e-6)
 
 
 WG_CASES = [(2, 32, 32, 16, 16, 3, 1), (2, 64, 32, 16, 16, 3, 2), (3, 32, 64, 8, 8, 1, 1), (2, 128, 128, 8, 8, 3, 1),
@@ -128,6 +153,18 @@ def test_conv_wgrad_and_dgrad_vs_torch(dev, case):
         assert _rel(got.permute(0, 3, 1, 2).cpu().numpy(), x.grad.numpy()) < 2e-5
     if (cout % 32 == 0 or cout == 48) and (k == 3 or s == 1):  # split-bf16 kernel (stride 2: dz read zero-dilated)
         got = ops.conv_dgrad(dzd, wt.detach().to(dev), (h, w), stride=s, algo=ops.ALGO_MFMA_BF3)
+        assert _rel(got.permute(0, 3, 1, 2).cpu().numpy(), x.grad.numpy()) < 2e-5
+    if k == 3 and s == 2 and h % 2 == 0 and w % 2 == 0 and cin % 4 == 0 and (cout % 32 == 0 or cout == 48):
+        # round 4: the stride-2 data gradient as four 2x2 parity convs over dz (store and accumulate forms, both splits)
+        got = ops.conv_dgrad_parity(dzd, wt.detach().to(dev), (h, w))
+        assert _rel(got.permute(0, 3, 1, 2).cpu().numpy(), x.grad.numpy()) < 2e-5
+        base = torch.from_numpy(rng.standard_normal((n, h, w, cin)).astype(np.float32)).to(dev)
+        got = ops.conv_dgrad_parity(dzd, wt.detach().to(dev), (h, w), accumulate_into=base.clone())
+        assert _rel((got - base).permute(0, 3, 1, 2).cpu().numpy(), x.grad.numpy()) < 2e-5
+        row = torch.zeros(576, dtype=torch.int32, device=dev)  # [count, partial maxima]: one partial = max |dz|
+        row[0] = 1
+        row[1] = int(np.float32(np.abs(dz.numpy()).max()).view(np.int32))
+        got = ops.conv_dgrad_parity(dzd, wt.detach().to(dev), (h, w), algo=ops.ALGO_MFMA_H2, dz_amax_row=row)
         assert _rel(got.permute(0, 3, 1, 2).cpu().numpy(), x.grad.numpy()) < 2e-5
 
 
