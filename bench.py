@@ -27,6 +27,9 @@ Prints ONE JSON line on rank 0 with the driver's contract fields plus
   exact_modes  ms per step of the same workload with the bit-faithful conv kernels (MVAL_CONV=bf3: exact 3-way bf16
                split, six MFMA products; fp32: v_mfma_f32_16x16x4_f32) and with round 2's fp32-activation fp16 split
                (h2), 20 steps each, outside the headline's timed region;
+  companions   (default c2 run at one GPU only) BASELINE configs[2] and [3] under the same driver clock: the C3 training step and
+               the C4 scoring slice, each run by a child process of this command after the headline (>= 2 s timed each), with
+               their own rooflines (and C3's cpu_baseline);
   cpu_baseline the CPU oracle (stock torch fp32 HRNet-W32 + numpy RANSAC-DLT restatement,
                oracle/) timed on the host on a bounded sample of the same workload; its "parity_sample" compares
                the HIP path with the oracle on that sample's first frames (the metric's "MPJPE vs ref": heat-map max
@@ -142,7 +145,8 @@ def cpu_baseline(wl, sd_np, seconds_target=20.0):
                 break
     return dict(
         _check=dict(images=imgs, proj=proj, **first),
-        value=done * v / el, unit="frames*views/s", cores=torch.get_num_threads(), kind="port",
+        value=done * v / el, unit="frames*views/s", cores=torch.get_num_threads(), kind="port", host_cpu=host_cpu_model(),
+        host_logical_cpus=os.cpu_count(),
         sample=f"{done} frames x {v} views ({done * v} images) of the same workload, {el:.1f} s, "
                f"stock torch fp32 {wl['arch']} + numpy RANSAC-DLT (oracle/), {torch.get_num_threads()} threads "
                f"(best of {sorted(tried)}; {frames_per_call * v} images per call)",
@@ -185,7 +189,8 @@ def cpu_baseline_train(wl, sd_np, seconds_target=20.0):
         el = time.perf_counter() - t0
         if el > seconds_target or done >= 16:
             break
-    return dict(value=done * v / el, unit="frames*views/s", cores=best, kind="port",
+    return dict(value=done * v / el, unit="frames*views/s", cores=best, kind="port", host_cpu=host_cpu_model(),
+                host_logical_cpus=os.cpu_count(),
                 sample=f"{done} frames x {v} views of the same shapes, {el:.1f} s, stock torch fp32 train-mode forward + masked MSE + "
                        f"autograd backward (oracle/), {best} threads (best of {sorted(tried)}); no optimizer step",
                 threads_tried={str(k): round(frames_per_call * v / t, 2) for k, t in tried.items()})
@@ -247,6 +252,17 @@ def train_rooflines(model, step, frames, v, mode):
     return top
 
 
+def host_cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def path_kernels(dev, frames, v, j, hh, wh):
     """The non-conv kernels of the path at this workload's sizes, each against its own bound: events
     on torch's current stream, which is the stream the wrappers launch on."""
@@ -286,6 +302,14 @@ def path_kernels(dev, frames, v, j, hh, wh):
                        "staged read: the scoring pass's only pass over the heat-maps)", t, map_bytes,
                        "one read of the heat-maps (uniform-noise maps: ~160 local maxima each to sort for MPE / BSB; "
                        "trained heat-maps have a handful)"))
+    # soft-arg-max (utils/triangulation.py:191-200 use_soft_argmax=True, utils/evaluation.py:38): one read of the maps; at this
+    # workload's map size and at C4's (8 frames x 8 views x 19 maps of 96 x 72)
+    for (f_, v_, h_, w_, tag) in ((frames, v, hh, wh, "this workload"), (8, 8, 96, 72, "C4 slice: 8 frames x 8 views, 96x72 maps")):
+        hm_s = hm if (f_, v_, h_, w_) == (frames, v, hh, wh) else torch.rand(f_, v_, j, h_, w_, device=dev)
+        n_s = f_ * v_ * j
+        t = timed(lambda: _lib.soft_argmax(hm_s, n_s, h_, w_, 4.0))
+        out.append(hbm(f"soft_argmax_kernel ({n_s} maps of {h_}x{w_}; {tag}; parity unpinned: kornia absent)", t, n_s * h_ * w_ * 4.0,
+                       "one read of the heat-maps (soft-max over the whole map, expectation of the pixel grid), two floats out per map"))
     proj = torch.from_numpy(np.stack([synth.ring_cameras(v, hh * 4, wh * 4, seed=s) for s in range(frames)])).to(dev)
     kp = _lib.score_decode_maps(_lib.SCORE_HP, hm, valid, frames, v, j, hh, wh, 4, hh)[2]
     t = timed(lambda: _lib.triangulate_ransac(kp, proj, valid, frames, v, j, 4.0))
@@ -323,6 +347,8 @@ def main():
                          "collectives on (MVAL_DIST_NO_SHORTCUT=1): the single-GPU rehearsal of the multi-GPU pass")
     ap.add_argument("--no-exact-modes", action="store_true", help="skip the companion timings of the other conv kernel families")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    ap.add_argument("--no-companions", action="store_true",
+                    help="default c2 run: skip the C3 / C4 companion lines (child processes after the headline)")
     args = ap.parse_args()
     pool_pass = args.pool is not None or WORKLOADS[args.workload].get("pool") is not None
     if args.steps is None:
@@ -387,7 +413,7 @@ def main():
 
         model.train()
         net = model
-        if world > 1:
+        if world > 1 or args.rccl_world_1:
             net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], broadcast_buffers=True)
         opt = torch.optim.Adam(model.parameters(), lr=1e-3)
         loss_fn = Pose2DMeanSquaredError()
@@ -401,15 +427,24 @@ def main():
         from multi_view_active_learning_amd.utils.coreset import CoreSet
 
         lo, hi = parallel.shard_range(wl["pool"], rank, world)
+        if pass_t.get("on"):
+            pass_t["_t0"] = time.perf_counter()
         preds = []
         for f0 in range(lo, hi, frames):
             nb = min(frames, hi - f0)
             hm = model(images[: nb * v]).reshape(nb, v, j, h // 4, w // 4)
             preds.append(triangulate_batch(hm, proj[:nb], 4, valid[:nb])["keypoints_3d"].to(torch.float32))
         local = torch.cat(preds) if preds else torch.zeros((0, j, 3), device=dev)
+        if pass_t.get("on"):
+            torch.cuda.synchronize()  # (the shard's compute is done here: what follows is gather + selection)
+            pass_t["compute_s"] += time.perf_counter() - pass_t.pop("_t0")
         pool = parallel.all_gather_cat(local)  # one size exchange + one data gather: (pool, J, 3) fp32 over xGMI
+        ts = time.perf_counter()
         cs = CoreSet.from_tensors(pool, labeled_pose, 2)
         picks = cs.select_batch(wl["picks"])
+        if pass_t.get("on"):
+            torch.cuda.synchronize()
+            pass_t["select_s"] += time.perf_counter() - ts
         return {"keypoints_3d": pool, "picks": picks}
 
     def scoring_pass():
@@ -420,6 +455,8 @@ def main():
         from multi_view_active_learning_amd.strategy import score_decode_heatmaps_batch
 
         lo, hi = parallel.shard_range(wl["pool"], rank, world)
+        if pass_t.get("on"):
+            pass_t["_t0"] = time.perf_counter()
         tables = []
         for f0 in range(lo, hi, frames):
             nb = min(frames, hi - f0)
@@ -433,10 +470,20 @@ def main():
                                      r["inlier_count"].to(torch.float64)[:, None], torch.zeros_like(fid)[:, None],
                                      r["keypoints_3d"].to(torch.float32).to(torch.float64).reshape(nb, 3 * j)], dim=1))
         local = torch.cat(tables) if tables else torch.zeros((0, 6 + 3 * j), dtype=torch.float64, device=dev)
+        if pass_t.get("on"):
+            torch.cuda.synchronize()  # (the shard's compute is done here: what follows is gather + selection)
+            pass_t["compute_s"] += time.perf_counter() - pass_t.pop("_t0")
         table = parallel.all_gather_cat(local)  # the pass's two collectives: sizes (3 int64 per rank), then the data (12.6 MB at 50 k frames)
+        ts = time.perf_counter()
         top = torch.topk(table[:, 2], min(100, table.shape[0])).indices  # AL.ITER_AMOUNT = 100 (config.py:44)
+        if pass_t.get("on"):
+            torch.cuda.synchronize()
+            pass_t["select_s"] += time.perf_counter() - ts
         return {"keypoints_3d": table[:, 6:], "picks": top}
 
+    # attribution of a pool pass (N >= 1): this rank's compute, the collectives (parallel.timers()), the selection -- host
+    # wall clock with a device synchronisation at the three boundaries of every pass (three syncs per 20 - 150 s pass)
+    pass_t = {"on": bool(wl.get("pool")), "compute_s": 0.0, "select_s": 0.0}
     if wl.get("picks"):
         labeled_pose = torch.from_numpy(np.random.default_rng(5).standard_normal((wl["labeled"], j, 3)) * 300.0).to(dev)
 
@@ -483,15 +530,58 @@ def main():
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 repeats = int(t.item())
         sync()
+        from multi_view_active_learning_amd import parallel as _par
+
+        _par.reset_timers(on=bool(wl.get("pool")))
+        pass_t.update(compute_s=0.0, select_s=0.0)
         t0 = time.perf_counter()
         for _ in range(args.steps * repeats):
             r = step()
+        torch.cuda.synchronize()
+        el_rank = (time.perf_counter() - t0) / repeats  # this rank's own time, before it waits for the others
         sync()
         el = (time.perf_counter() - t0) / repeats
+        _par.reset_timers(on=False)
+    attribution = None
+    if world > 1 or args.rccl_world_1:
+        # every rank reports before rank 0 prints: per-rank time of the timed region, and for the pool passes its split
+        mine = torch.tensor([el_rank, pass_t["compute_s"] / repeats, _par.timers()["gather_s"] / repeats, pass_t["select_s"] / repeats],
+                            dtype=torch.float64, device=dev)
+        allr = torch.empty(world * 4, dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(allr, mine)
+        allr = allr.cpu().reshape(world, 4).numpy()
+        attribution = {"per_rank_s": {"min": round(float(allr[:, 0].min()), 4), "mean": round(float(allr[:, 0].mean()), 4),
+                                      "max": round(float(allr[:, 0].max()), 4), "all": [round(float(x), 4) for x in allr[:, 0]]},
+                       "note": "seconds of the K-step timed region per rank (before the closing barrier); value uses the max over ranks incl. the barrier"}
+        if wl.get("pool"):
+            attribution.update(compute_s={"min": round(float(allr[:, 1].min()), 4), "max": round(float(allr[:, 1].max()), 4)},
+                               gather_s=round(float(allr[:, 2].max()), 4), select_s=round(float(allr[:, 3].max()), 4),
+                               split_note="per pass-set: shard compute (heat-maps + decode + triangulation [+ scoring]) / the two collectives "
+                                          "(incl. waiting for the slowest rank) / selection (k-center or top-k, replicated)")
     if world > 1:
         t = torch.tensor([el], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
+    if train and (world > 1 or args.rccl_world_1) and isinstance(net, torch.nn.parallel.DistributedDataParallel):
+        # exposed all-reduce: the same step with the gradient synchronisation switched off (no_sync) against the normal one
+        def timed_steps(k, ctx):
+            sync()
+            t1 = time.perf_counter()
+            with ctx():
+                for _ in range(k):
+                    step()
+            sync()
+            return (time.perf_counter() - t1) / k
+        import contextlib
+
+        with torch.enable_grad():
+            t_sync = timed_steps(10, contextlib.nullcontext)
+            t_nosync = timed_steps(10, net.no_sync)
+        tt = torch.tensor([t_sync, t_nosync], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        attribution["allreduce_exposed_s"] = round(float(tt[0] - tt[1]), 5)
+        attribution["allreduce_note"] = (f"step with DDP's bucketed RCCL all-reduce {float(tt[0]) * 1e3:.2f} ms vs under no_sync() {float(tt[1]) * 1e3:.2f} ms "
+                                         "(10 steps each, max over ranks): what the segmented backward does not hide")
     assert torch.isfinite(r["keypoints_3d"]).all()
 
     # ---- roofline of the dominant kernel family (outside the timed region) ------------------------
@@ -607,6 +697,10 @@ def main():
                              "achieved rate against round 1's 416.7 TFLOP/s, for comparison across rounds")
         roof["all_conv_tflops"] = round(float(flops[allc].sum()) / (float(ms[allc].sum()) * 1e-3) / 1e12, 2)
         roof["all_conv_frac_of_fp32_mfma_peak"] = round(roof["all_conv_tflops"] / PEAK_FP32_MFMA_TFLOPS, 4)
+        if getattr(plan, "p2", False):
+            roof["p2_bound_slack_log2"] = round(plan.p2_slack_log2(), 2)
+            roof["p2_bound_slack_note"] = ("log2 of the largest (a-priori output bound / actual max |x|) over the plan's P2 activations and images; "
+                                           "above 15 the engine hands over to the h2 plan (engine.P2_MAX_SLACK_LOG2)")
         roof["whole_forward_ms"] = round(float(ms.sum()), 3)
         roof["non_mfma_ms"] = round(float(ms[~allc].sum()), 3)
 
@@ -646,24 +740,39 @@ def main():
             "roofline": roof,
             "parity_unpinned": PARITY_UNPINNED,
         }
+        if attribution is not None:
+            out["attribution"] = attribution
         if not train and not wl.get("pool") and world == 1 and not args.no_exact_modes:
             # the same step with the other conv kernel families (plans are cached per mode), outside the timed region
             exact = {}
             headline_mode = _conv_mode()
-            for mode_ in ("h2", "bf3", "fp32"):
-                if mode_ == headline_mode:
-                    continue
-                os.environ["MVAL_CONV"] = mode_
-                with torch.no_grad():
-                    for _ in range(3):
-                        step()
-                    sync()
-                    t0 = time.perf_counter()
-                    for _ in range(20):
-                        step()
-                    sync()
-                exact[mode_] = round((time.perf_counter() - t0) / 20 * 1e3, 3)
-            os.environ["MVAL_CONV"] = headline_mode
+            had_env = "MVAL_CONV" in os.environ
+            try:  # (a failure here must neither leave the mode changed nor lose the headline measured above)
+                for mode_ in ("h2", "bf3", "fp32"):
+                    if mode_ == headline_mode:
+                        continue
+                    os.environ["MVAL_CONV"] = mode_
+                    try:
+                        with torch.no_grad():
+                            for _ in range(3):
+                                step()
+                            sync()
+                            t0 = time.perf_counter()
+                            for _ in range(20):
+                                step()
+                            sync()
+                        exact[mode_] = round((time.perf_counter() - t0) / 20 * 1e3, 3)
+                    except Exception as e:  # noqa: BLE001
+                        exact[mode_] = f"failed: {type(e).__name__}: {e}"
+                    # this companion's plan (and its arena) is not needed again
+                    for key in [k for k in getattr(model, "_plans", {}) if mode_ in k]:
+                        model._plans.pop(key, None)
+                    torch.cuda.empty_cache()
+            finally:
+                if had_env:
+                    os.environ["MVAL_CONV"] = headline_mode
+                else:
+                    os.environ.pop("MVAL_CONV", None)
             exact["note"] = ("ms per step; h2 = round 2's kernels (fp32 NHWC activations, split while staging), bf3 = exact 3-way "
                              "bf16 split (six MFMA products), fp32 = exact-fp32 MFMA (v_mfma_f32_16x16x4_f32) everywhere")
             out["exact_modes"] = exact
@@ -686,6 +795,41 @@ def main():
                 "max_joint_delta_mm": float(delta.max()),
             }
             out["cpu_baseline"] = cpu
+        if args.workload == "c2" and world == 1 and not args.no_companions and not args.rccl_world_1:
+            # BASELINE configs[2] / [3] under the same (driver) clock: child processes of this command, run after the headline's
+            # timed region and measurements; each times >= 2 s of its own step.  A failure is recorded, not raised.
+            import subprocess
+
+            comp = {}
+            for name, extra in (("c3", ["--steps", "20", "--warmup", "3", "--cpu-seconds", str(min(args.cpu_seconds, 12.0))]),
+                                ("c4", ["--steps", "40", "--warmup", "3", "--no-cpu-baseline"])):
+                cmd = [sys.executable, os.path.abspath(__file__), "--workload", name, "--no-companions", "--no-exact-modes"] + extra
+                if args.no_cpu_baseline and "--no-cpu-baseline" not in cmd:
+                    cmd.append("--no-cpu-baseline")
+                t0 = time.perf_counter()
+                try:
+                    pr = subprocess.run(cmd, capture_output=True, text=True, timeout=240)
+                    line = [ln for ln in pr.stdout.splitlines() if ln.startswith("{")]
+                    d = json.loads(line[-1]) if line else None
+                    if d is None:
+                        comp[name] = {"error": f"rc {pr.returncode}: {pr.stderr[-300:]}"}
+                    else:
+                        roof_c = d.get("roofline") or {}
+                        comp[name] = {"metric": d["metric"], "ms_per_step": d["ms_per_step"], "value": d["value"], "unit": d["unit"],
+                                      "steps": d["steps"], "timed_repeats": d["timed_repeats"],
+                                      "timed_s": round(d["ms_per_step"] * d["steps"] * d["timed_repeats"] * 1e-3, 2),
+                                      "config": d["config"], "dtype": d["dtype"],
+                                      "roofline": {k: roof_c.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "seconds_in_kernel_per_step")},
+                                      "families": [{k: f.get(k) for k in ("kernel", "bound", "achieved", "unit", "frac", "seconds_in_kernel_per_step")}
+                                                   for f in (roof_c.get("other_kernels") or [])[:6]]}
+                        if "cpu_baseline" in d:
+                            comp[name]["cpu_baseline"] = {k: v_ for k, v_ in d["cpu_baseline"].items() if k != "threads_tried_note"}
+                except Exception as e:  # noqa: BLE001
+                    comp[name] = {"error": f"{type(e).__name__}: {e}"}
+                comp[name]["wall_s"] = round(time.perf_counter() - t0, 1)
+            comp["note"] = ("BASELINE configs[2] (C3 training step) and configs[3]'s per-GPU slice (C4: HRNet-W48, 8 views, 384x288, 8 frames + MPE "
+                            "scoring) run by this command as child processes after the headline: same box, same driver clock")
+            out["companions"] = comp
         print(json.dumps(out))
     if world > 1 or args.rccl_world_1:
         dist.barrier()

@@ -100,6 +100,13 @@ def epilogue_decode_enabled():
     return os.environ.get("MVAL_EPILOGUE_DECODE", "1") != "0"
 
 
+def forget_argmax_keys(t):
+    """Drop the remembered keys of a network output: for callers that write into it through its data pointer (any kernel of
+    this package launched on it in place) -- torch's version counter, which argmax_keys_of relies on, does not see such writes."""
+    base = t._base if t._base is not None else t
+    _ARGMAX_KEYS.pop(id(base), None)
+
+
 def remember_argmax_keys(out, keys):
     k = id(out)
     _ARGMAX_KEYS[k] = (weakref.ref(out, lambda _r, k=k: _ARGMAX_KEYS.pop(k, None)), keys)
@@ -133,7 +140,9 @@ def argmax_from_keys(keys, valid, b, v, j, stride, split_width):
 
 def argmax_decode(hm, valid, b, v, j, hh, wh, stride, split_width):
     keys = argmax_keys_of(hm) if epilogue_decode_enabled() else None
-    if keys is not None and keys.numel() == b * v * j * ARGMAX_SLOTS and hm.numel() == b * v * j * hh * wh:
+    # the keys are laid out [image][slot][joint of the PLAN]: only the caller's factorisation that matches it may use them
+    # (b = n * J, v = 1, j = 1 has the same element count and would index them wrongly: ADVICE round 3)
+    if keys is not None and tuple(keys.shape) == (b * v, ARGMAX_SLOTS, j) and hm.numel() == b * v * j * hh * wh:
         return argmax_from_keys(keys, valid, b, v, j, stride, split_width)
     out = torch.empty((b, v, j, 2), dtype=torch.int64, device=hm.device)
     _check(

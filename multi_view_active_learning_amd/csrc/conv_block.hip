@@ -219,10 +219,10 @@ __global__ __launch_bounds__(32 * TH) __attribute__((amdgpu_waves_per_eu(C == 32
 #pragma unroll
     for (int ns = 0; ns < NS; ns++) {
       f32x4 v = acc1[ms][ns] * (bn_sc[ns] * u1) + bn_sh[ns];
-      v.x = inside ? fmaxf(v.x, 0.f) : 0.f;
-      v.y = inside ? fmaxf(v.y, 0.f) : 0.f;
-      v.z = inside ? fmaxf(v.z, 0.f) : 0.f;
-      v.w = inside ? fmaxf(v.w, 0.f) : 0.f;
+      v.x = inside ? mval_relu(v.x) : 0.f;
+      v.y = inside ? mval_relu(v.y) : 0.f;
+      v.z = inside ? mval_relu(v.z) : 0.f;
+      v.w = inside ? mval_relu(v.w) : 0.f;
       acc1[ms][ns] = v;
       tmax = fmaxf(fmaxf(tmax, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
     }
@@ -316,7 +316,7 @@ __global__ __launch_bounds__(32 * TH) __attribute__((amdgpu_waves_per_eu(C == 32
     for (int ns = 0; ns < NS; ns++) {
       f32x4 v = acc2[ms][ns] * (bn_sc[ns] * u2) + bn_sh[ns];
       v += res[ms][ns];
-      v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+      v.x = mval_relu(v.x); v.y = mval_relu(v.y); v.z = mval_relu(v.z); v.w = mval_relu(v.w);
       *reinterpret_cast<f32x4*>(a.out + ooff[ms] + ns * 16) = v;
       amax = fmaxf(fmaxf(amax, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
     }

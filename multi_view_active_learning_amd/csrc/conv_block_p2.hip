@@ -293,10 +293,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
         const int gy = oy0 - 1 + my, gx = ox0 - 1 + mx;
         const bool inside = p < MPX && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
         f32x4 v = acc1[ms] * s1u + h1u;
-        v.x = inside ? fmaxf(v.x, 0.f) : 0.f;
-        v.y = inside ? fmaxf(v.y, 0.f) : 0.f;
-        v.z = inside ? fmaxf(v.z, 0.f) : 0.f;
-        v.w = inside ? fmaxf(v.w, 0.f) : 0.f;
+        v.x = inside ? p2_max_nan(v.x, 0.f) : 0.f;
+        v.y = inside ? p2_max_nan(v.y, 0.f) : 0.f;
+        v.z = inside ? p2_max_nan(v.z, 0.f) : 0.f;
+        v.w = inside ? p2_max_nan(v.w, 0.f) : 0.f;
         f16x4 h, l;
         p2_split(v, h, l);
         const u32x2 hu = __builtin_bit_cast(u32x2, h), lu = __builtin_bit_cast(u32x2, l);
@@ -379,7 +379,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
         const auto r1 = __builtin_amdgcn_permlane32_swap(RX[ms].y, RX[ms].w, false, false);
         const u32x2 rh = {r0[0], r1[0]}, rl = {r0[1], r1[1]};
         f32x4 r = acc2[ms] * s2u + sh2 + p2_join(__builtin_bit_cast(f16x4, rh), __builtin_bit_cast(f16x4, rl)) * in_inv;
-        r.x = fmaxf(r.x, 0.f); r.y = fmaxf(r.y, 0.f); r.z = fmaxf(r.z, 0.f); r.w = fmaxf(r.w, 0.f);
+        r.x = p2_max_nan(r.x, 0.f); r.y = p2_max_nan(r.y, 0.f); r.z = p2_max_nan(r.z, 0.f); r.w = p2_max_nan(r.w, 0.f);
         const bool ok = oy0 + wm * MS2 + ms < a.H;
         if (ok) amax = conv_amax4(amax, r.x, r.y, r.z, r.w);
         f16x4 h, l;
@@ -438,26 +438,11 @@ static int launch_block_p2(P2BlockArgs a, hipStream_t s) {
 #ifdef P2_STAMP
   a.dbg = g_p2_dbg_shared;
 #endif
-  static int occ = 0;
-  if (!occ) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_block_p2_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    // resident workgroups per CU: LDS, and registers (allocation granule 8, 512 per SIMD lane; the occupancy API's
-    // answer was not usable here: with it the 32-channel block kernel ran 20x slower)
-    hipFuncAttributes fa;
-    int nb = (int)((160 * 1024) / smem);
-    if (hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&conv_block_p2_kernel<C>)) == hipSuccess && fa.numRegs > 0) {
-      const int waves_simd = 512 / ((fa.numRegs + 7) / 8 * 8);
-      nb = min(nb, max(1, waves_simd * 4 / (256 / 64)));
-    } else {
-      nb = min(nb, 2);
-    }
-    if (nb < 1) nb = 1;
-    occ = nb;
-  }
-  int per_cu = occ;
+  static std::atomic<int> occ{0};
+  int per_cu = p2_resident_wgs(&conv_block_p2_kernel<C>, occ, smem, 4);
   const char* pe = getenv("MVAL_P2_WGS");
   if (pe && atoi(pe) > 0) per_cu = atoi(pe);
-  int wgs = 256 * per_cu;
+  int wgs = mval_cu_count() * per_cu;
   if (wgs >= a.tiles_total) wgs = a.tiles_total;
   else {
     const int per = (a.tiles_total + 7) / 8, rounds = (per + wgs / 8 - 1) / (wgs / 8);

@@ -72,7 +72,7 @@ __device__ __forceinline__ f32x4 bn_mfma3(const u32x4 wh, const u32x4 wl, const 
   return bn_mfma(wh, xh, c);
 }
 __device__ __forceinline__ f32x4 bn_relu(f32x4 v) {
-  v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+  v.x = p2_max_nan(v.x, 0.f); v.y = p2_max_nan(v.y, 0.f); v.z = p2_max_nan(v.z, 0.f); v.w = p2_max_nan(v.w, 0.f);
   return v;
 }
 // scaled fp32 x4 of a lane's four channels -> the 16-byte granule the lane pair (l, l + 32) stores: lanes below 32 get the
@@ -529,23 +529,11 @@ static int launch_bneck_p2(P2BneckArgs a, hipStream_t s) {
 #ifdef P2_STAMP
   a.dbg = g_p2_dbg_shared;
 #endif
-  static int occ = 0;
-  if (!occ) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bneck_p2_kernel<CIN>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipFuncAttributes fa;  // resident workgroups per CU from LDS and registers (conv_p2.hip)
-    int nb = (int)((160 * 1024) / smem);
-    if (hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&conv_bneck_p2_kernel<CIN>)) == hipSuccess && fa.numRegs > 0) {
-      const int waves_simd = 512 / ((fa.numRegs + 7) / 8 * 8);
-      nb = min(nb, max(1, waves_simd));
-    } else {
-      nb = min(nb, 2);
-    }
-    occ = nb < 1 ? 1 : nb;
-  }
-  int per_cu = occ;
+  static std::atomic<int> occ{0};
+  int per_cu = p2_resident_wgs(&conv_bneck_p2_kernel<CIN>, occ, smem, 4);
   const char* pe = getenv("MVAL_P2_WGS");
   if (pe && atoi(pe) > 0) per_cu = atoi(pe);
-  int wgs = 256 * per_cu;
+  int wgs = mval_cu_count() * per_cu;
   if (wgs >= a.tiles_total) wgs = a.tiles_total;
   else {
     const int per = (a.tiles_total + 7) / 8, rounds = (per + wgs / 8 - 1) / (wgs / 8);

@@ -70,7 +70,7 @@ __device__ __forceinline__ void conv_store(const ConvArgs& a, int n, int y, int 
       float r = v;
       if (a.res1) r += a.res1[o];
       if (a.res2) r += a.res2[o];
-      if (a.relu) r = fmaxf(r, 0.f);
+      if (a.relu) r = mval_relu(r);
       if (a.out_nchw)
         a.out[(((int64_t)n * a.Cout + c) * Ho + Y) * Wo + X] = r;
       else
@@ -210,7 +210,7 @@ __device__ __forceinline__ void conv_tile_store(const ConvArgs& a, const float* 
         if (a.res1) r += r1[i];
         if (a.res2) r += r2[i];
         if (a.relu) {
-          r.x = fmaxf(r.x, 0.f); r.y = fmaxf(r.y, 0.f); r.z = fmaxf(r.z, 0.f); r.w = fmaxf(r.w, 0.f);
+          r.x = mval_relu(r.x); r.y = mval_relu(r.y); r.z = mval_relu(r.z); r.w = mval_relu(r.w);
         }
         *reinterpret_cast<conv_f32x4*>(a.out + off[i]) = r;
         amax = conv_amax4(amax, r.x, r.y, r.z, r.w);
@@ -271,7 +271,7 @@ __device__ __forceinline__ void conv_tile_store(const ConvArgs& a, const float* 
         for (int u = 0; u < 4; u++) {
           conv_f32x4 r = v + r1[u] + r2[u];
           if (a.relu) {
-            r.x = fmaxf(r.x, 0.f); r.y = fmaxf(r.y, 0.f); r.z = fmaxf(r.z, 0.f); r.w = fmaxf(r.w, 0.f);
+            r.x = mval_relu(r.x); r.y = mval_relu(r.y); r.z = mval_relu(r.z); r.w = mval_relu(r.w);
           }
           *reinterpret_cast<conv_f32x4*>(a.out + o[u]) = r;
           amax = conv_amax4(amax, r.x, r.y, r.z, r.w);
@@ -308,7 +308,7 @@ __device__ __forceinline__ void conv_tile_store(const ConvArgs& a, const float* 
         const int64_t o = (((int64_t)n * a.Hout + y) * a.Wout + x) * a.Cout + c;
         if (a.res1) r += a.res1[o];
         if (a.res2) r += a.res2[o];
-        if (a.relu) r = fmaxf(r, 0.f);
+        if (a.relu) r = mval_relu(r);
         a.out[(map * a.Hout + y) * a.Wout + x] = r;
         key = mval_argmax_key(r, (unsigned)(y * a.Wout + x));
       }

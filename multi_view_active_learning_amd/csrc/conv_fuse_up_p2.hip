@@ -166,7 +166,7 @@ __global__ __launch_bounds__(256) void conv_fuse_up_p2_kernel(FuseUpArgs a) {
     f16x8 ho, lo;
 #pragma unroll
     for (int k = 0; k < 8; k++) {
-      if (a.relu) v[k] = fmaxf(v[k], 0.f);
+      if (a.relu) v[k] = p2_max_nan(v[k], 0.f);
       if (ok) amax = fmaxf(amax, fabsf(v[k]));
       const float sv = v[k] * out_mul;
       ho[k] = (_Float16)sv;

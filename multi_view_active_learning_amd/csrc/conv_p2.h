@@ -45,6 +45,11 @@ __device__ __forceinline__ void p2_scale_of(float bound, float& mul, float& inv)
   inv = __uint_as_float((unsigned)(127 - s) << 23);
 }
 
+// max(v, floor) that PROPAGATES NaN (IEEE 754-2019 maximum: one v_maximum3_f32 on gfx950), for the ReLU / "no activation"
+// clamps of the epilogues: fmaxf returns the other operand for a NaN, which turned a diverged model's NaNs into 0 (ReLU) or
+// -inf where torch -- and the h2 / bf3 / fp32 plans -- hand them on.
+__device__ __forceinline__ float p2_max_nan(float v, float floor_) { return __builtin_elementwise_maximum(v, floor_); }
+
 __device__ __forceinline__ void p2_split(const p2_f32x4 v, p2_f16x4& h, p2_f16x4& l) {
   h = __builtin_convertvector(v, p2_f16x4);
 #ifdef P2_NO_FMA_MIX
@@ -111,6 +116,30 @@ __device__ __forceinline__ float p2_row_amax(const P2RowRegs& r) {
 #pragma unroll
   for (int i = 1; i < P2_SLOTS / 64; i++) m = max(m, r.v[i]);
   return __uint_as_float(p2_wave_umax(m));
+}
+
+// Launcher side of the persistent kernels: resident workgroups per CU of one kernel instantiation, from its LDS size and its
+// register count (allocation granule 8, 512 per SIMD lane; hipOccupancyMaxActiveBlocksPerMultiprocessor's answer was not
+// usable: with it the 32-channel block kernel ran 20x slower).  `slot` is the instantiation's own static std::atomic<int>
+// (0 = not computed yet): threads racing on the first launch compute the same value, so no lock is needed.
+#include <atomic>
+int mval_cu_count();  // common.hip: compute units of the CURRENT device (hipDeviceProp_t::multiProcessorCount), cached per device
+template <typename K>
+static inline int p2_resident_wgs(K kernel, std::atomic<int>& slot, size_t smem, int waves_per_wg) {
+  int nb = slot.load(std::memory_order_relaxed);
+  if (nb) return nb;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  hipFuncAttributes fa;
+  nb = (int)((160 * 1024) / smem);
+  if (hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(kernel)) == hipSuccess && fa.numRegs > 0) {
+    const int waves_simd = 512 / ((fa.numRegs + 7) / 8 * 8);
+    nb = min(nb, max(1, waves_simd * 4 / waves_per_wg));
+  } else {
+    nb = min(nb, 2);
+  }
+  if (nb < 1) nb = 1;
+  slot.store(nb, std::memory_order_relaxed);
+  return nb;
 }
 
 struct P2Args {

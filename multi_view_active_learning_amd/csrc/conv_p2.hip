@@ -465,7 +465,7 @@ __global__ __launch_bounds__(64 * WN * WM) __attribute__((amdgpu_waves_per_eu(P2
       // four finished values -> scaled, split, the halves exchanged with the partner lane, ONE 16-byte store
       const float floor_ = a.relu ? 0.f : -INFINITY;  // (ReLU without a branch)
       auto put = [&](f32x4 r, unsigned vo, int so) {
-        r.x = fmaxf(r.x, floor_); r.y = fmaxf(r.y, floor_); r.z = fmaxf(r.z, floor_); r.w = fmaxf(r.w, floor_);
+        r.x = p2_max_nan(r.x, floor_); r.y = p2_max_nan(r.y, floor_); r.z = p2_max_nan(r.z, floor_); r.w = p2_max_nan(r.w, floor_);
         amax = conv_amax4(amax, r.x, r.y, r.z, r.w);
         f16x4 h, l;
         p2_split(r * out_mul, h, l);
@@ -517,7 +517,7 @@ __global__ __launch_bounds__(64 * WN * WM) __attribute__((amdgpu_waves_per_eu(P2
 #pragma unroll
               for (int j = 0; j < 4; j++)
                 if (c0 + j < a.Cout) {
-                  const float o = fmaxf(v[j], floor_);
+                  const float o = p2_max_nan(v[j], floor_);
                   a.out_f32[(((int64_t)n * a.Cout + c0 + j) * Ho + y) * Wo + x] = o;
                   if (bi[j] == 0xffffffffu || o > bv[j] || (o != o && bv[j] == bv[j])) {
                     bv[j] = o;
@@ -634,27 +634,11 @@ static int launch_p2e(P2Args a, hipStream_t s) {
   // persistent workgroups: as many as stay resident (the runtime's occupancy answer for this instantiation: LDS and
   // registers), a multiple of 8 per cout group so that every XCD walks its own contiguous tile range; fewer tiles than
   // that: one tile each.  (No workgroup waits for another one: an optimistic answer only costs a second round.)
-  static int occ = 0;
-  if (!occ) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_p2_kernel<KS, S, G, WN, WM, NT, MS, TW, RS, EPI>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    // resident workgroups per CU: LDS, and registers (allocation granule 8, 512 per SIMD lane; the occupancy API's
-    // answer was not usable here: with it the 32-channel block kernel ran 20x slower)
-    hipFuncAttributes fa;
-    int nb = (int)((160 * 1024) / smem);
-    if (hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&conv_p2_kernel<KS, S, G, WN, WM, NT, MS, TW, RS, EPI>)) == hipSuccess && fa.numRegs > 0) {
-      const int waves_simd = 512 / ((fa.numRegs + 7) / 8 * 8);
-      nb = min(nb, max(1, waves_simd * 4 / (NTH / 64)));
-    } else {
-      nb = min(nb, 2);
-    }
-    if (nb < 1) nb = 1;
-    occ = nb;
-  }
-  int per_cu = occ;
+  static std::atomic<int> occ{0};
+  int per_cu = p2_resident_wgs(&conv_p2_kernel<KS, S, G, WN, WM, NT, MS, TW, RS, EPI>, occ, smem, NTH / 64);
   const char* pe = getenv("MVAL_P2_WGS");  // measurement override: workgroups per CU
   if (pe && atoi(pe) > 0) per_cu = atoi(pe);
-  int wgs = (256 * per_cu / (int)groups) & ~7;
+  int wgs = (mval_cu_count() * per_cu / (int)groups) & ~7;
   if (wgs < 8) wgs = 8;
   if (wgs >= a.tiles_total) wgs = a.tiles_total;
   else {  // equal shares: the XCD groups' ranges are walked in steps of wgs / 8

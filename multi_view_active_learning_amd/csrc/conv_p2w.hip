@@ -255,7 +255,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
             const u32x2 h = {s0[0], s1[0]}, l = {s0[1], s1[1]};
             r += p2_join(__builtin_bit_cast(f16x4, h), __builtin_bit_cast(f16x4, l)) * r1_inv;
           }
-          r.x = fmaxf(r.x, floor_); r.y = fmaxf(r.y, floor_); r.z = fmaxf(r.z, floor_); r.w = fmaxf(r.w, floor_);
+          r.x = p2_max_nan(r.x, floor_); r.y = p2_max_nan(r.y, floor_); r.z = p2_max_nan(r.z, floor_); r.w = p2_max_nan(r.w, floor_);
           if (yo + ms < a.Hout && xo < a.Wout) amax = conv_amax4(amax, r.x, r.y, r.z, r.w);
           f16x4 h, l;
           p2_split(r * out_mul, h, l);
@@ -307,21 +307,11 @@ int mval_launch_conv_p2w(const P2Args& a0, hipStream_t s) {
   a.tiles_img_magic = a.amax_tiles > 1 ? (unsigned)(((uint64_t)1 << 32) / (unsigned)a.amax_tiles + 1) : 0u;
   a.tiles_x_magic = a.tiles_x > 1 ? (unsigned)(((uint64_t)1 << 32) / (unsigned)a.tiles_x + 1) : 0u;
   const unsigned groups = (unsigned)((a.Cout + 63) / 64);
-  static int occ = 0;
-  if (!occ) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_p2w_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipFuncAttributes fa;
-    int nb = (int)((160 * 1024) / smem);
-    if (hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&conv_p2w_kernel)) == hipSuccess && fa.numRegs > 0)
-      nb = min(nb, max(1, 512 / ((fa.numRegs + 7) / 8 * 8)));
-    else
-      nb = min(nb, 2);
-    occ = nb < 1 ? 1 : nb;
-  }
-  int per_cu = occ;
+  static std::atomic<int> occ{0};
+  int per_cu = p2_resident_wgs(&conv_p2w_kernel, occ, smem, 4);
   const char* pe = getenv("MVAL_P2_WGS");
   if (pe && atoi(pe) > 0) per_cu = atoi(pe);
-  int wgs = (256 * per_cu / (int)groups) & ~7;
+  int wgs = (mval_cu_count() * per_cu / (int)groups) & ~7;
   if (wgs < 8) wgs = 8;
   if (wgs >= a.tiles_total) wgs = a.tiles_total;
   else {

@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
         if (x >= a.Wout) continue;
         f32x4 r = acc[p] * sc + sh;
         if (a.relu) {
-          r.x = fmaxf(r.x, 0.f); r.y = fmaxf(r.y, 0.f); r.z = fmaxf(r.z, 0.f); r.w = fmaxf(r.w, 0.f);
+          r.x = mval_relu(r.x); r.y = mval_relu(r.y); r.z = mval_relu(r.z); r.w = mval_relu(r.w);
         }
         *reinterpret_cast<f32x4*>(a.out + (((int64_t)n * a.Hout + y) * a.Wout + x) * a.Cout + q * 4) = r;
         amax = conv_amax4(amax, r.x, r.y, r.z, r.w);

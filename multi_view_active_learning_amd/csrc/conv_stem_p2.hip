@@ -296,7 +296,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
           const int c0 = ct * 16 + cq1;
           const f32x4 s1 = *reinterpret_cast<const f32x4*>(bn1 + c0) * k1, h1 = *reinterpret_cast<const f32x4*>(bn1 + 64 + c0) * m1_mul;
           f32x4 v = acc * s1 + h1;
-          v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+          v.x = p2_max_nan(v.x, 0.f); v.y = p2_max_nan(v.y, 0.f); v.z = p2_max_nan(v.z, 0.f); v.w = p2_max_nan(v.w, 0.f);
           if (!inside) v = (f32x4){0.f, 0.f, 0.f, 0.f};
           f16x4 h, l;
           p2_split(v, h, l);
@@ -358,7 +358,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
         for (int p = 0; p < RUN; p++) {
           const int px = px0 + p, xx = 2 * ox0 - 1 + px;
           f32x4 v = acc[p] * s1 + h1;
-          v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+          v.x = p2_max_nan(v.x, 0.f); v.y = p2_max_nan(v.y, 0.f); v.z = p2_max_nan(v.z, 0.f); v.w = p2_max_nan(v.w, 0.f);
           if (!(row_in_img && xx >= 0 && xx < a.W1)) v = (f32x4){0.f, 0.f, 0.f, 0.f};
           f16x4 h, l;
           p2_split(v, h, l);
@@ -426,7 +426,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
       for (int ms = 0; ms < TH; ms++) {
         const bool ok = oy0 + ms < a.H2;  // (uniform)
         f32x4 r = acc2[ms] * s2u + sh2;
-        r.x = fmaxf(r.x, 0.f); r.y = fmaxf(r.y, 0.f); r.z = fmaxf(r.z, 0.f); r.w = fmaxf(r.w, 0.f);
+        r.x = p2_max_nan(r.x, 0.f); r.y = p2_max_nan(r.y, 0.f); r.z = p2_max_nan(r.z, 0.f); r.w = p2_max_nan(r.w, 0.f);
         if (ok && xo < a.W2) amax = conv_amax4(amax, r.x, r.y, r.z, r.w);
         f16x4 h, l;
         p2_split(r * out_mul, h, l);
@@ -491,21 +491,11 @@ int mval_launch_conv_stem_p2(const float* in, void* out, const float* w1, const 
   // max |x| per image: 64 partial slots of the input's rows
   hipLaunchKernelGGL(image_amax_rows_kernel, dim3(64, (unsigned)N), dim3(256), 0, s, in, (int64_t)3 * H * W, in_row);
   constexpr size_t smem = 2 * 8 * 170 * 16 + 3 * 11 * 68 * 4 + 16 + 512;
-  static int occ = 0;
-  if (!occ) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_stem_p2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipFuncAttributes fa;  // resident workgroups per CU from LDS and registers (conv_p2.hip)
-    int nb = (int)((160 * 1024) / smem);
-    if (hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&conv_stem_p2_kernel)) == hipSuccess && fa.numRegs > 0)
-      nb = min(nb, max(1, 512 / ((fa.numRegs + 7) / 8 * 8)));
-    else
-      nb = min(nb, 2);
-    occ = nb < 1 ? 1 : nb;
-  }
-  int per_cu = occ;
+  static std::atomic<int> occ{0};
+  int per_cu = p2_resident_wgs(&conv_stem_p2_kernel, occ, smem, 4);
   const char* pe = getenv("MVAL_P2_WGS");
   if (pe && atoi(pe) > 0) per_cu = atoi(pe);
-  int wgs = 256 * per_cu;
+  int wgs = mval_cu_count() * per_cu;
   if (wgs >= a.tiles_total) wgs = a.tiles_total;
   else {
     const int per = (a.tiles_total + 7) / 8, rounds = (per + wgs / 8 - 1) / (wgs / 8);

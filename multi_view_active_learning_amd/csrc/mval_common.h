@@ -99,3 +99,7 @@ __device__ __forceinline__ unsigned long long mval_key_group_max(unsigned long l
   }
   return k;
 }
+
+// ReLU that hands a NaN on, as torch.relu does (fmaxf returns the OTHER operand for a NaN and would turn a diverged model's
+// NaNs into zeros): IEEE 754-2019 maximum, one v_maximum3_f32 on gfx950.
+__device__ __forceinline__ float mval_relu(float v) { return __builtin_elementwise_maximum(v, 0.f); }

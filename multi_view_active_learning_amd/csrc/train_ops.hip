@@ -222,7 +222,7 @@ __global__ __launch_bounds__(TR_APPLY_THREADS) void bn_apply_fwd_kernel(const fl
     if (res1) r += *reinterpret_cast<const f32x4*>(res1 + o);
     if (res2) r += *reinterpret_cast<const f32x4*>(res2 + o);
     if (relu) {
-      r.x = fmaxf(r.x, 0.f); r.y = fmaxf(r.y, 0.f); r.z = fmaxf(r.z, 0.f); r.w = fmaxf(r.w, 0.f);
+      r.x = mval_relu(r.x); r.y = mval_relu(r.y); r.z = mval_relu(r.z); r.w = mval_relu(r.w);
     }
     *reinterpret_cast<f32x4*>(out + o) = r;
     amax = fmaxf(fmaxf(amax, fmaxf(fabsf(r.x), fabsf(r.y))), fmaxf(fabsf(r.z), fabsf(r.w)));

@@ -246,6 +246,9 @@ class InferencePlan:
         self.params = torch.zeros(self.param_floats, dtype=torch.float32, device=device)
         self.param_sig = None
         self._graph, self._graph_failed = None, False
+        # P2 plans: (offset of the n rows) of every activation kept in HBM, for the bound-vs-actual check (p2_slack)
+        self._p2_rows = sorted(set(row_of.values())) if self.p2 else []
+        self._slack_pending, self.p2_slack = False, None
         self.net = lib.mval_net_create(self.ops, C.c_int(len(self.ops)))
         if not self.net:
             raise _lib.MvalError("mval_net_create failed: " + lib.mval_last_error().decode())
@@ -508,10 +511,7 @@ class InferencePlan:
 
     # ---- parameters ---------------------------------------------------------------------
     def _signature(self):
-        holders = self.model._holders
-        return tuple(t._version for h in holders.values() for t in list(h.parameters()) + list(h.buffers())) + tuple(
-            t.data_ptr() for h in holders.values() for t in h.parameters()
-        )
+        return _param_signature(self.model)
 
     def refresh_params(self, force=False):
         sig = self._signature()
@@ -555,6 +555,31 @@ class InferencePlan:
                 b_ = self.params[b_off : b_off + op.cout].abs().double().max()
                 self.params[gm.bound_off : gm.bound_off + 2] = torch.stack([a_, b_]).to(torch.float32)
         self.param_sig = sig
+        self._slack_pending = self.p2 and os.environ.get("MVAL_P2_SLACK_CHECK", "1") != "0"
+
+    def p2_slack_log2(self):
+        """log2 of the largest (output bound / actual max |x|) over the P2 activations of the LAST forward and its images
+        (csrc/conv_p2.h: the scale of a P2 tensor comes from an a-priori bound; values more than ~2^16 below the bound lose
+        low-part bits).  Synthetic variance-preserving weights: <= 8 except the fused Bottlenecks' outputs (11 .. 12.6: three
+        chained bounds); folded BatchNorm statistics with a wide per-channel spread can compound it further.
+        One device -> host copy."""
+        if not self._p2_rows:
+            return 0.0
+        idx = torch.tensor(self._p2_rows, dtype=torch.int64, device=self.device)
+        rows = self.arena.view(torch.int32)[(idx[:, None] + torch.arange(self.n * P2_ROW, device=self.device)[None, :])].reshape(-1, P2_ROW)
+        amax = rows[:, : P2_ROW // 2].view(torch.float32).max(dim=1).values
+        inv = rows[:, P2_ROW - 1 : P2_ROW].view(torch.float32)[:, 0]
+        ok = (amax > 0) & (inv > 0) & torch.isfinite(amax)
+        if not bool(ok.any()):
+            return 0.0
+        slack = torch.log2(8192.0 * inv[ok] / amax[ok])  # the bound sits in [2^13, 2^14) of the scaled range
+        return float(slack.max())
+
+    def _check_p2_slack(self):
+        self._slack_pending = False
+        self.p2_slack = self.p2_slack_log2()
+        if self.p2_slack > P2_MAX_SLACK_LOG2 and os.environ.get("MVAL_P2", "1") != "force":
+            raise P2SlackError(self.p2_slack)
 
     # ---- run ---------------------------------------------------------------------------------
     def _keys_wanted(self):
@@ -617,6 +642,8 @@ class InferencePlan:
             if self._graph is not None:
                 self._gx.copy_(x)
                 self._graph.replay()
+                if self._slack_pending:
+                    self._check_p2_slack()
                 out = self._gout.clone()
                 if self._gkeys is not None:
                     _lib.remember_argmax_keys(out, self._gkeys.clone())
@@ -624,6 +651,8 @@ class InferencePlan:
         out = torch.empty((self.n, self.out_channels) + tuple(self.out_hw), dtype=torch.float32, device=self.device)
         keys = self._new_keys()
         self._launch(x, out, keys)
+        if self._slack_pending:  # first forward with these parameters: is the a-priori bound close enough to the activations?
+            self._check_p2_slack()
         if keys is not None:
             _lib.remember_argmax_keys(out, keys)
         return out
@@ -652,6 +681,48 @@ class InferencePlan:
                 C.c_void_p(self.params.data_ptr()), C.c_void_p(x.data_ptr()), C.c_void_p(out.data_ptr()),
                 _lib._stream()),
             "mval_op_launch")
+
+
+def _param_signature(model):
+    holders = model._holders
+    return tuple(t._version for h in holders.values() for t in list(h.parameters()) + list(h.buffers())) + tuple(
+        t.data_ptr() for h in holders.values() for t in h.parameters()
+    )
+
+
+# bound / actual maximum above which a P2 plan hands over to h2.  The pair (h, l) keeps all 22 significand bits of a value whose
+# SCALED magnitude is at least 2^-2 (below, l runs into fp16's subnormal spacing: absolute error 2^-25 scaled); the bound is put
+# at 2^13.5, so values a decade below a tensor's maximum keep 22 bits up to a slack of ~2^12 and lose one bit per further
+# factor of two: 19 bits (relative 2^-20, the size of the fp32 accumulation error of a 3x3x64 dot product) at 2^15.  Measured on
+# the synthetic BASELINE weights (tools/p2_slack.py, 128 images): the fused Bottlenecks' outputs 2^11.3 .. 2^12.6 (three chained
+# per-layer bounds), every other tensor <= 2^8.1 -- the arg-max census and the goldens hold there with margin.
+P2_MAX_SLACK_LOG2 = 15.0
+
+
+class P2SlackError(_lib.MvalError):
+    """The a-priori output bounds of a P2 plan sit too far above the activations of these parameters (run_network then uses
+    the h2 plan: same arithmetic, scales from the exact per-image maxima)."""
+
+    def __init__(self, slack):
+        super().__init__(f"P2 plan: output bound 2^{slack:.1f} above the activations' maximum (limit 2^{P2_MAX_SLACK_LOG2:.0f})")
+        self.slack = slack
+
+
+class _conv_mode_as:
+    """Temporarily select a conv kernel family (the plan cache is keyed by it).  Not thread-safe: os.environ."""
+
+    def __init__(self, mode):
+        self.mode = mode
+
+    def __enter__(self):
+        self.old = os.environ.get("MVAL_CONV")
+        os.environ["MVAL_CONV"] = self.mode
+
+    def __exit__(self, *exc):
+        if self.old is None:
+            os.environ.pop("MVAL_CONV", None)
+        else:
+            os.environ["MVAL_CONV"] = self.old
 
 
 def _plan_for(model, x):
@@ -684,9 +755,10 @@ def _max_images_per_launch(model, h, w):
             hout, wout = (hin + 2 * op.pad - op.k) // op.stride + 1, (win + 2 * op.pad - op.k) // op.stride + 1
         dims[op.dst] = (hout << op.up, wout << op.up)
         biggest = max(biggest, hin * win * op.cin, (hout << op.up) * (wout << op.up) * op.cout)
-    # (P2 plans address their planes with byte offsets below 2^31: 2^29 elements)
-    p2_candidate = _conv_mode() == "p2" and all(op.kind == "conv" and (op.src == g.input or op.cin % 32 == 0) for op in g.ops)  # (InferencePlan._p2_covers)
-    limit = 2**29 if p2_candidate else 2**31
+    # P2 plans address their planes with byte offsets below 2^31: 2^29 elements.  Whether a plan ends up on the P2 kernels is
+    # InferencePlan._p2_covers' decision (and MVAL_P2=force's): the conservative limit applies whenever the mode allows them
+    # (a graph with max-pool / transposed convs -- PoseResNet -- never runs on them)
+    limit = 2**29 if (_conv_mode() == "p2" and all(op.kind == "conv" for op in g.ops)) else 2**31
     return max(1, (limit - 1) // biggest)
 
 
@@ -702,6 +774,27 @@ def run_network(model, x):
 
         return run_network_train(model, x)
     cap = _max_images_per_launch(model, x.shape[2], x.shape[3])
-    if x.shape[0] > cap:  # very large batches run as equal slices of one plan size (plus a remainder plan)
-        return torch.cat([_plan_for(model, xs).forward(xs) for xs in x.split(cap)])
-    return _plan_for(model, x).forward(x)
+
+    def run():
+        if x.shape[0] > cap:  # very large batches run as equal slices of one plan size (plus a remainder plan)
+            return torch.cat([_plan_for(model, xs).forward(xs) for xs in x.split(cap)])
+        return _plan_for(model, x).forward(x)
+
+    # P2 plans whose a-priori bounds sit too far above the activations of the CURRENT parameters (checked on the first
+    # forward after every parameter change) hand over to the h2 plan until the parameters change again
+    fb = model.__dict__.get("_p2_fallback_sig")
+    if fb is not None and _conv_mode() == "p2":
+        if _param_signature(model) == fb:
+            with _conv_mode_as("h2"):
+                return run()
+        model.__dict__["_p2_fallback_sig"] = None
+    try:
+        return run()
+    except P2SlackError as e:
+        import warnings
+
+        warnings.warn(f"{e}; using the h2 kernels (fp32 activations, exact per-image scales) for these parameters. "
+                      "MVAL_P2=force keeps the P2 plan, MVAL_P2_SLACK_CHECK=0 skips the check.", RuntimeWarning, stacklevel=3)
+        model.__dict__["_p2_fallback_sig"] = _param_signature(model)
+        with _conv_mode_as("h2"):
+            return run()

@@ -37,30 +37,61 @@ def _collectives_on():
     return dist.get_world_size() > 1 or os.environ.get("MVAL_DIST_NO_SHORTCUT") == "1"
 
 
+# Seconds spent inside the collectives of the passes since the last reset_timers() (host wall clock around each
+# _gather_packed call, device synchronised on both sides when timing is on): bench.py's N > 1 line reports them so that a
+# multi-GPU number can be attributed (per-rank compute vs gather vs selection).
+_TIMERS = {"gather_s": 0.0, "gather_calls": 0, "on": False}
+
+
+def reset_timers(on: bool = True):
+    _TIMERS.update(gather_s=0.0, gather_calls=0, on=bool(on))
+
+
+def timers():
+    return dict(_TIMERS)
+
+
 def _gather_packed(t: torch.Tensor, extra=None, flag: int = 0):
-    """The two collectives of a pass: ONE exchange of three int64 per rank ([rows of t, len(extra), flag]) and ONE padded
-    all_gather of bytes carrying t's rows AND the int64 list ``extra`` (a rank's batch sizes) behind them.
-    Returns (per-rank tensors shaped like t, per-rank int64 lists, per-rank flags)."""
+    """The two collectives of a pass: ONE ``all_gather_into_tensor`` of three int64 per rank ([rows of t, len(extra), flag])
+    and ONE ``all_gather_into_tensor`` of bytes, padded to the largest rank, carrying t's rows AND the int64 list ``extra``
+    (a rank's batch sizes) behind them.  One host copy (the stacked headers); the per-rank tables are VIEWS of the
+    gathered buffer.  Returns (per-rank tensors shaped like t, per-rank int64 lists, per-rank flags)."""
+    import time
+
+    timed = _TIMERS["on"]
+    if timed:
+        if t.is_cuda:
+            torch.cuda.synchronize(t.device)
+        t0 = time.perf_counter()
     ws = dist.get_world_size()
     dev = t.device
     t = t.contiguous()
     ex = torch.as_tensor(list(extra) if extra is not None else [], dtype=torch.int64, device=dev).reshape(-1)
     head = torch.tensor([t.shape[0], ex.shape[0], int(flag)], dtype=torch.int64, device=dev)
-    heads = [torch.zeros_like(head) for _ in range(ws)]
-    dist.all_gather(heads, head)
-    heads = [h.cpu().tolist() for h in heads]
+    heads_t = torch.empty(ws * 3, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(heads_t, head)
+    heads = heads_t.cpu().reshape(ws, 3).tolist()  # the pass's one device -> host copy before the data gather
     row_bytes = t.element_size() * int(np.prod(t.shape[1:], dtype=np.int64)) if t.dim() > 1 else t.element_size()
     need = [h[0] * row_bytes + h[1] * 8 for h in heads]
-    pad = torch.zeros(max(max(need), 8), dtype=torch.uint8, device=dev)
+    cap = (max(max(need), 8) + 7) // 8 * 8  # (8-byte slots: every rank's table and int64 list stay aligned for the views below)
+    pad = torch.zeros(cap, dtype=torch.uint8, device=dev)
     mine = torch.cat([t.reshape(-1).view(torch.uint8), ex.view(torch.uint8)])
     pad[: mine.shape[0]] = mine
-    bufs = [torch.empty_like(pad) for _ in range(ws)]
-    dist.all_gather(bufs, pad)
-    tabs, lists = [], []
-    for r in range(ws):
-        nb = heads[r][0] * row_bytes
-        tabs.append(bufs[r][:nb].clone().view(t.dtype).reshape((heads[r][0],) + tuple(t.shape[1:])))
-        lists.append(bufs[r][nb : nb + heads[r][1] * 8].clone().view(torch.int64).cpu().tolist())
+    buf = torch.empty(ws * cap, dtype=torch.uint8, device=dev)
+    dist.all_gather_into_tensor(buf, pad)
+    tabs = [buf[r * cap : r * cap + heads[r][0] * row_bytes].view(t.dtype).reshape((heads[r][0],) + tuple(t.shape[1:])) for r in range(ws)]
+    lists = [[] for _ in range(ws)]
+    if any(h[1] for h in heads):  # every rank's batch-size list: one device-side concatenation, one host copy
+        ex_host = torch.cat([buf[r * cap + heads[r][0] * row_bytes : r * cap + need[r]] for r in range(ws)]).cpu().view(torch.int64).tolist()
+        pos = 0
+        for r in range(ws):
+            lists[r] = ex_host[pos : pos + heads[r][1]]
+            pos += heads[r][1]
+    if timed:
+        if t.is_cuda:
+            torch.cuda.synchronize(t.device)
+        _TIMERS["gather_s"] += time.perf_counter() - t0
+        _TIMERS["gather_calls"] += 1
     return tabs, lists, [h[2] for h in heads]
 
 

@@ -379,6 +379,38 @@ def test_argmax_key_stash_follows_the_network_output():
     assert len(_lib._ARGMAX_KEYS) == n - 1
 
 
+def test_argmax_keys_serve_only_the_plans_factorisation(monkeypatch):
+    """The keys are [image][slot][joint of the plan]: a caller that factors the same heat-maps differently (b = n * J, v = 1,
+    j = 1 has the same element count) must be decoded from the maps, not from mis-indexed keys; and
+    forget_argmax_keys drops them for callers that write into the output through its data pointer."""
+    import torch
+
+    from multi_view_active_learning_amd import _lib
+
+    used = []
+    monkeypatch.setattr(_lib, "argmax_from_keys", lambda *a, **k: used.append("keys") or "from-keys")
+
+    class _FakeLib:
+        def mval_argmax_decode(self, *a):
+            used.append("maps")
+            return 0
+
+    monkeypatch.setattr(_lib, "lib", lambda: _FakeLib())
+    monkeypatch.setattr(_lib, "_p", lambda t: None)
+    monkeypatch.setattr(_lib, "_stream", lambda: None)
+    n, J, h, w = 8, 17, 4, 4
+    out = torch.zeros(n, J, h, w)
+    keys = torch.zeros((n, _lib.ARGMAX_SLOTS, J), dtype=torch.int64)
+    _lib.remember_argmax_keys(out, keys)
+    valid = torch.ones(2, J, dtype=torch.uint8)
+    assert _lib.argmax_decode(out.reshape(2, 4, J, h, w), valid, 2, 4, J, h, w, 4, h) == "from-keys"
+    _lib.argmax_decode(out.reshape(n * J, 1, 1, h, w), torch.ones(n * J, 1, dtype=torch.uint8), n * J, 1, 1, h, w, 4, h)
+    _lib.argmax_decode(out.reshape(1, n, J, h, w), valid, 1, n, J, h, w, 4, h)  # (b * v = n, j = J: same layout -> keys)
+    assert used == ["keys", "maps", "keys"]
+    _lib.forget_argmax_keys(out.reshape(2, 4, J, h, w))
+    assert _lib.argmax_keys_of(out) is None
+
+
 def test_python_constants_match_the_header():
     """The ctypes mirror restates a few #defines / enum values of include/mval_hip.h: they must agree."""
     import os

@@ -163,8 +163,9 @@ def _worker_counts(rank, world, path, out):
     from multi_view_active_learning_amd import parallel
 
     calls = []
-    real = dist.all_gather
-    dist.all_gather = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+    real, real_list = dist.all_gather_into_tensor, dist.all_gather
+    dist.all_gather_into_tensor = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+    dist.all_gather = lambda *a, **k: (calls.append(1), real_list(*a, **k))[1]  # (the list form would count as well)
     st = _strategy()
     mine = ALL[rank::world]
     st._compute_sal_dict(_loader(mine, 2), None)
@@ -184,7 +185,7 @@ def _worker_counts(rank, world, path, out):
         err = None
     except Exception as e:  # noqa: BLE001
         err = type(e).__name__
-    dist.all_gather = real
+    dist.all_gather_into_tensor, dist.all_gather = real, real_list
     torch.save({"n_pass": n_pass, "n_eval": n_eval, "err": err}, out + ".%d" % rank)
     dist.barrier()
     dist.destroy_process_group()

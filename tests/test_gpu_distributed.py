@@ -118,8 +118,9 @@ def test_rccl_world_1_carries_the_collectives(tmp_path, monkeypatch):
     dist.init_process_group("nccl", rank=0, world_size=1, init_method="file://" + str(tmp_path / "rccl"), device_id=dev)
     try:
         calls = []
-        real = dist.all_gather
-        monkeypatch.setattr(dist, "all_gather", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+        real = dist.all_gather_into_tensor  # (a pass = one header exchange + one data gather, both all_gather_into_tensor)
+        monkeypatch.setattr(dist, "all_gather_into_tensor", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+        monkeypatch.setattr(dist, "all_gather", lambda *a, **k: (_ for _ in ()).throw(AssertionError("the list all_gather is not used")))
         t = torch.arange(7 * 5, dtype=torch.float64, device=dev).reshape(7, 5)
         tabs, sizes = parallel.gather_tables(t, [3, 3, 1])
         assert len(calls) == 2 and sizes == [[3, 3, 1]]
@@ -139,3 +140,25 @@ def test_rccl_world_1_carries_the_collectives(tmp_path, monkeypatch):
     # (RCCL prints its version banner to stdout when the process exits: the line is the last one that is JSON)
     line = json.loads([l for l in r.stdout.strip().splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 1 and line["config"]["pool_frames"] == 16 and line["value"] > 0
+    # the N > 1 line is attributable: per-rank time of the timed region and its split into compute / collectives / selection
+    at = line["attribution"]
+    assert at["per_rank_s"]["max"] > 0 and at["compute_s"]["max"] > 0 and at["gather_s"] >= 0 and at["select_s"] > 0
+    assert at["compute_s"]["max"] + at["gather_s"] + at["select_s"] <= at["per_rank_s"]["max"] * 1.05
+
+
+def test_rccl_world_1_training_step_under_ddp():
+    """bench.py --workload c3 --rccl-world-1: the training step through DistributedDataParallel (segmented backward, bucketed
+    all-reduce) over the "nccl" backend (= RCCL) at world size 1 -- the single-GPU rehearsal of the multi-GPU C3 line, with
+    the exposed all-reduce time (step vs the same step under no_sync) in the line."""
+    import json
+    import subprocess
+    import sys
+
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29643")
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--workload", "c3", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+                        "--rccl-world-1"], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.strip().splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["value"] > 0 and line["ms_per_step"] < 200
+    at = line["attribution"]
+    assert at["per_rank_s"]["max"] > 0 and "allreduce_exposed_s" in at and abs(at["allreduce_exposed_s"]) < 0.05

@@ -461,6 +461,11 @@ def test_decode_from_heatmap_layer_epilogue(dev, name, mode, graph, monkeypatch)
             kp = np.stack([(idx % hh) * 4, (idx // hh) * 4], axis=-1)
             kp[:, 1] = 0
             assert np.array_equal(got[0].cpu().numpy(), kp)
+            # another factorisation of the same maps (every map its own "frame": b = n * j, v = 1, j = 1) has the same
+            # element count but not the keys' [image][slot][joint] layout: it must come out of the maps, correctly
+            flat = _lib.argmax_decode(hm.reshape(n * j, 1, 1, hh, wh), torch.ones((n * j, 1), dtype=torch.uint8, device=dev), n * j, 1, 1, hh, wh, 4, hh)
+            kp_all = np.stack([(idx % hh) * 4, (idx // hh) * 4], axis=-1)
+            assert np.array_equal(flat.reshape(n, j, 2).cpu().numpy(), kp_all)
     # a slice, or a tensor written to since, is decoded from the maps
     assert _lib.argmax_keys_of(hm[:, :1]) is None
     hm.mul_(1.0)
@@ -510,3 +515,37 @@ def test_decode_from_epilogue_large_maps_fold_with_atomics(dev, mode, monkeypatc
     assert torch.equal(got, want)
     idx = hm.reshape(n, j, -1).cpu().numpy().argmax(-1)
     assert np.array_equal(got[0].cpu().numpy(), np.stack([(idx % hh) * 4, (idx // hh) * 4], axis=-1))
+
+
+def test_w48_argmax_census_headline_plan_vs_exact_fp32(dev, monkeypatch):
+    """BASELINE configs[3] / [4] decode parity: HRNet-W48 at 384 x 288, 64 frames x 8 views (9 728 heat-maps), the plan the
+    pool passes run (MVAL_CONV default: HRNet-W48's 48-channel branches keep it on the h2 kernels) against the exact-fp32 MFMA
+    plan.  No map whose top-2 margin exceeds twice the heat-map tolerance may change its arg-max."""
+    from multi_view_active_learning_amd import engine, synth
+
+    c = dict(arch="hrnet_w48", seed=0, n=64, h=384, w=288, j=19)
+    m, _ = _load(c, dev)
+    frames, v, nb = 64, 8, 64
+    flips, flips_above, maps, worst_err = 0, 0, 0, 0.0
+    monkeypatch.delenv("MVAL_CONV", raising=False)
+    with torch.no_grad():
+        for b in range(frames * v // nb):
+            x = torch.from_numpy(synth.images(900 + b, nb // v, v, 384, 288)).reshape(nb, 3, 384, 288).to(dev)
+            monkeypatch.delenv("MVAL_CONV", raising=False)
+            y = m(x)
+            headline = "p2" if engine._plan_for(m, x).p2 else "h2"
+            monkeypatch.setenv("MVAL_CONV", "fp32")
+            z = m(x)
+            tol = 2e-4 * float(z.abs().max())
+            worst_err = max(worst_err, float((y - z).abs().max()))
+            fy, fz = y.reshape(nb, 19, -1), z.reshape(nb, 19, -1)
+            top2 = torch.topk(fz, 2, dim=-1).values
+            margin = top2[..., 0] - top2[..., 1]
+            differ = fy.argmax(-1) != fz.argmax(-1)
+            flips += int(differ.sum())
+            flips_above += int((differ & (margin > 2 * tol)).sum())
+            maps += differ.numel()
+            assert worst_err <= tol, (worst_err, tol)
+    print(f"\nW48 arg-max census, {headline} plan vs exact-fp32: {maps} maps, {flips} flips ({flips_above} above margin 2*tol), "
+          f"max |heat-map difference| {worst_err:.2e}")
+    assert maps == 64 * 8 * 19 and flips_above == 0

@@ -415,3 +415,70 @@ def test_p2_argmax_census_vs_exact_fp32(dev, monkeypatch):
     print(f"\narg-max census, P2 vs exact-fp32 plans: {maps} maps, {flips} flips ({flips_above} above margin 2*tol), "
           f"max |heat-map difference| {worst_err:.2e}, smallest top-2 margin among agreeing maps {min_margin_agree:.2e}")
     assert flips_above == 0
+
+
+def test_p2_nan_propagates_like_the_other_plans(dev, monkeypatch):
+    """A NaN in one image reaches that image's heat-maps in the P2 plan as it does in torch and in the h2 / fp32 plans (the P2
+    epilogues clamped with fmaxf, which returns the OTHER operand for a NaN: a diverged model looked finite; ADVICE round 3);
+    the other images of the batch are untouched."""
+    c = cases.model_cases()["w32"]
+    m, _ = _load(c, dev)
+    x = torch.from_numpy(cases.model_input(c)).to(dev)
+    assert x.shape[0] >= 2
+    clean = {}
+    for mode in ("p2", "h2"):
+        monkeypatch.setenv("MVAL_CONV", mode)
+        with torch.no_grad():
+            clean[mode] = m(x).clone()
+    xn = x.clone()
+    xn[0, 1, 100, 80] = float("nan")
+    for mode in ("p2", "h2"):
+        monkeypatch.setenv("MVAL_CONV", mode)
+        with torch.no_grad():
+            y = m(xn)
+        assert torch.isnan(y[0]).any(), mode
+        assert torch.equal(y[1:], clean[mode][1:]), mode  # per-image scales: the NaN stays in its image
+
+
+def test_p2_bound_slack_check_and_h2_fallback(dev, monkeypatch):
+    """P2 scales come from a-priori bounds that compound inside fused operators; parameters with a wide
+    per-channel spread can put the bound 2^12+ above the activations, where the fp16 pair loses precision.  The plan measures
+    bound / actual maximum on the first forward after every parameter change (p2_slack) and run_network hands over to the
+    h2 plan (exact per-image scales) above 2^15 (engine.P2_MAX_SLACK_LOG2)."""
+    import warnings
+
+    from multi_view_active_learning_amd import engine
+
+    monkeypatch.setenv("MVAL_CONV", "p2")
+    c = cases.model_cases()["w32"]
+    m, sd = _load(c, dev)
+    x = torch.from_numpy(cases.model_input(c)).to(dev)
+    with torch.no_grad(), warnings.catch_warnings():
+        warnings.simplefilter("error")  # synthetic variance-preserving weights: no fallback
+        y0 = m(x)
+    plan = engine._plan_for(m, x)
+    assert plan.p2 and plan.p2_slack is not None and 8.0 < plan.p2_slack < 13.5, plan.p2_slack  # (the fused Bottlenecks' chained bounds)
+    # trained-like spread: one BatchNorm channel with a huge gain whose output the next conv ignores -- the activations stay
+    # as they were, the bound A * max|x| + B of every operator downstream of that channel explodes
+    sd2 = {k: v.clone() for k, v in sd.items()}
+    sd2["stage2.0.branches.0.0.bn1.weight"][0] *= 2.0**18
+    sd2["stage2.0.branches.0.0.bn1.bias"][0] = 2.0**17
+    sd2["stage2.0.branches.0.0.conv2.weight"][:, 0] = 0.0
+    m.load_state_dict(sd2, strict=True)
+    monkeypatch.setenv("MVAL_CONV", "h2")
+    with torch.no_grad():
+        want = m(x).clone()
+    monkeypatch.setenv("MVAL_CONV", "p2")
+    with torch.no_grad(), warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        got = m(x)
+        again = m(x)  # (second call: straight to the h2 plan, no second warning)
+    assert any("h2 kernels" in str(i.message) for i in w) and sum("h2 kernels" in str(i.message) for i in w) == 1
+    assert torch.equal(got, want) and torch.equal(again, want)
+    # MVAL_P2=force keeps the P2 plan (measurement): finite, but it may be less accurate than the tolerance
+    # new parameters: P2 again
+    m.load_state_dict(sd, strict=True)
+    with torch.no_grad(), warnings.catch_warnings():
+        warnings.simplefilter("error")
+        y1 = m(x)
+    assert torch.equal(y1, y0)
