@@ -341,6 +341,8 @@ def main():
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--pool", type=int, default=None,
                     help="c4 / c5: frames of the fixed pool sharded over the ranks (BASELINE: 50000); one step = one whole pass")
+    ap.add_argument("--frames-per-batch", type=int, default=None,
+                    help="c4 / c5 pool passes: frames (x 8 views) per network launch (default 8: 64 images)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--rccl-world-1", action="store_true",
                     help="with --gpus 1: initialise the nccl (= RCCL) process group at world size 1 and keep the pool passes' "
@@ -401,6 +403,10 @@ def main():
         if args.workload not in ("c4", "c5"):
             sys.exit("--pool applies to the pool passes c4 / c5")
         wl["pool"] = args.pool
+    if args.frames_per_batch:
+        if not (args.pool is not None or wl.get("pool")):
+            sys.exit("--frames-per-batch applies to the pool passes")
+        wl["frames"] = args.frames_per_batch
     v, h, w, j, frames = wl["v"], wl["h"], wl["w"], wl["j"], wl["frames"]
     model, sd_np = build_model(wl["arch"], j, dev)
     images = torch.from_numpy(synth.images(1000 + rank, frames, v, h, w)).to(dev).reshape(frames * v, 3, h, w)
@@ -516,7 +522,10 @@ def main():
     # workload: clocks and caches have not settled); every repeat runs exactly K steps, all of them are timed.
     repeats = 1
     with torch.set_grad_enabled(train):
-        for _ in range(max(args.warmup, 1)):
+        if args.warmup == 0 and wl.get("pool"):  # (--warmup 0 on a pool pass: build the plan on one batch instead of a whole pass)
+            model(images)
+            r = None
+        for _ in range(args.warmup if wl.get("pool") else max(args.warmup, 1)):
             r = step()
         sync()
         if not wl.get("pool"):
@@ -802,7 +811,7 @@ def main():
 
             comp = {}
             for name, extra in (("c3", ["--steps", "20", "--warmup", "3", "--cpu-seconds", str(min(args.cpu_seconds, 12.0))]),
-                                ("c4", ["--steps", "40", "--warmup", "3", "--no-cpu-baseline"])):
+                                ("c4", ["--steps", "100", "--warmup", "3", "--no-cpu-baseline"])):
                 cmd = [sys.executable, os.path.abspath(__file__), "--workload", name, "--no-companions", "--no-exact-modes"] + extra
                 if args.no_cpu_baseline and "--no-cpu-baseline" not in cmd:
                     cmd.append("--no-cpu-baseline")
