@@ -2,7 +2,7 @@
 //
 //     out = act( ((r + up_{u1}(bn1(conv1x1(x_1)))) + up_{u2}(bn2(conv1x1(x_2)))) [+ up_{u3}(bn3(conv1x1(x_3)))] )
 //           r: the partial sum so far (the branch's own activation, or the output of the down-sampling terms), C = 32 / 64
-//           channels at H x W;  x_j: C * 2^u_j ... channels at (H >> u_j) x (W >> u_j);  up_u = nearest neighbour, 2^u
+//           (HRNet-W32) or 48 / 96 (HRNet-W48, round 4: 8 x 24 / 4 x 36 tiles for its 72- / 36-pixel-wide maps) channels at H x W;  x_j: C * 2^u_j ... channels at (H >> u_j) x (W >> u_j);  up_u = nearest neighbour, 2^u
 //
 // Op by op every term reads the full-resolution partial sum and writes it again (the 1x1 convs at the low resolutions are
 // nothing next to that: 134 MB per link for the 32-channel 64x64 branch of 128 images, 3 links = 0.40 GB + 0.06 GB of inputs,
@@ -54,10 +54,12 @@ __device__ __forceinline__ f32x4 fu_mfma(const u32x4 a, const u32x4 b, const f32
   return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
 
-template <int COUT>
+template <int COUT, int TH = FU_TH, int TW = 32>
 __global__ __launch_bounds__(256) void conv_fuse_up_p2_kernel(FuseUpArgs a) {
-  static_assert(COUT == 32 || COUT == 64, "fuse-layer outputs of 32 or 64 channels");
-  constexpr int TH = FU_TH, TW = 32, NCT = COUT / 16, NH = 4 / NCT, C8 = COUT / 8;
+  static_assert(COUT == 32 || COUT == 64 || COUT == 48 || COUT == 96, "fuse-layer outputs of 32 / 64 (HRNet-W32) or 48 / 96 (HRNet-W48) channels");
+  constexpr int NCT = COUT / 16, C8 = COUT / 8;
+  constexpr bool EVEN = 4 % NCT == 0;  // cout sub-tiles divide the four waves (32 / 64 channels): wave = (sub-tile, fragment group)
+  constexpr int NH = EVEN ? 4 / NCT : 1;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ unsigned wgmax;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -71,7 +73,7 @@ __global__ __launch_bounds__(256) void conv_fuse_up_p2_kernel(FuseUpArgs a) {
   P2RowRegs row_r;
   p2_row_request(a.res_row, n, row_r);
   // the partial sum's granules of this thread's items travel during the matrix phase
-  constexpr int ITEMS = TH * TW * C8 / 256;
+  constexpr int NITEMS = TH * TW * C8, ITEMS = (NITEMS + 255) / 256;
   const unsigned ohw16 = (unsigned)(a.H * a.W) * 16u, oimg = 2u * C8 * ohw16, oplane = C8 * ohw16;
   const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(a.res), 0, (unsigned)a.N * oimg, 0x00020000);
   const __amdgpu_buffer_rsrc_t orr = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (unsigned)a.N * oimg, 0x00020000);
@@ -83,15 +85,14 @@ __global__ __launch_bounds__(256) void conv_fuse_up_p2_kernel(FuseUpArgs a) {
     const int c8 = e / (TH * TW), q = e - c8 * (TH * TW);
     const int ly = q / TW, lx = q - ly * TW;
     const int y = oy0 + ly, x = ox0 + lx;
-    go[i] = (y < a.H && x < a.W) ? (unsigned)n * oimg + (unsigned)((c8 * a.H + y) * a.W + x) * 16u : 0x80000000u;
+    go[i] = (e < NITEMS && y < a.H && x < a.W) ? (unsigned)n * oimg + (unsigned)((c8 * a.H + y) * a.W + x) * 16u : 0x80000000u;
     R[i][0] = __builtin_amdgcn_raw_buffer_load_b128(rr, go[i], 0, 0);
     R[i][1] = __builtin_amdgcn_raw_buffer_load_b128(rr, __builtin_elementwise_add_sat(go[i], oplane), 0, 0);
   }
 
   // ---- 1. the terms' 1x1 convs: wave = cout sub-tile ct, every NH-th sixteen-pixel fragment ---------------------------------
-  const int ct = wave % NCT, hgrp = wave / NCT;
   const int wrow = lane & 15, wsrc = (lane & 48) | ((wrow & 3) | ((wrow & 4) << 1) | ((wrow & 8) >> 1));
-  const int cq = ((lane >> 4) & 1) * 8 + (lane >> 5) * 4, c0 = ct * 16 + cq;  // the lane's four output channels
+  const int cq = ((lane >> 4) & 1) * 8 + (lane >> 5) * 4;  // the lane's four output channels inside a cout sub-tile
   float bound = 0.f;
   int lds_base = 0;
 #pragma unroll
@@ -104,11 +105,16 @@ __global__ __launch_bounds__(256) void conv_fuse_up_p2_kernel(FuseUpArgs a) {
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(t.in), 0, (unsigned)a.N * img, 0x00020000);
     P2RowRegs row_j;
     p2_row_request(t.in_row, n, row_j);
-    const f32x4 sc = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(pr, c0 * 4, t.scale, 0));
-    const f32x4 sh = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(pr, c0 * 4, t.shift, 0));
-    const unsigned wv = t.w + (unsigned)((ct * 128 + wsrc) * 16);
     const int blk = NCT * 2048;  // bytes per 32-channel step of the packed weights
-    for (int f = hgrp; f < nfrag; f += NH) {
+    // work item = (cout sub-tile ct, sixteen-pixel fragment f): 32 / 64 channels -- a wave keeps its sub-tile and walks every
+    // NH-th fragment; 48 / 96 channels (3 / 6 sub-tiles) -- the items are dealt to the four waves in turn
+    for (int wi = wave; wi < (EVEN ? 4 * ((nfrag + NH - 1) / NH) : NCT * nfrag); wi += 4) {
+      const int ct = EVEN ? wave % NCT : wi % NCT, f = EVEN ? (wave / NCT) + NH * (wi >> 2) : wi / NCT;
+      if (f >= nfrag) break;
+      const int c0 = ct * 16 + cq;
+      const f32x4 sc = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(pr, c0 * 4, t.scale, 0));
+      const f32x4 sh = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(pr, c0 * 4, t.shift, 0));
+      const unsigned wv = t.w + (unsigned)((ct * 128 + wsrc) * 16);
       // the lane's pixel of the fragment (MFMA column lane & 15), its k octet = 8-channel block lane >> 4 of a step
       const int p = f * 16 + (lane & 15);
       const int ly = p / tw, lx = p - ly * tw;
@@ -181,8 +187,21 @@ __global__ __launch_bounds__(256) void conv_fuse_up_p2_kernel(FuseUpArgs a) {
   if (tid == 0) p2_slot_put(a.out_row + (int64_t)n * P2_ROW, tr, tiles_img, wgmax);
 }
 
+// tile of the output a workgroup covers: 8 x 32 (32 / 64 / 48 channels), 8 x 24 for 48 channels on widths that 24 divides and 32 does not
+// (HRNet-W48's 96 x 72 branch: 3 tiles of 24 instead of 2.25 of 32), 4 x 36 / 4 x 32 for 96 channels (12 granule blocks per pixel)
+static void fuse_up_tile(int cout, int W, int* th, int* tw) {
+  *th = cout == 96 ? 4 : FU_TH;
+  *tw = 32;
+  if (cout == 48 && W % 24 == 0 && W % 32 != 0) *tw = 24;
+  if (cout == 96 && W % 36 == 0 && W % 32 != 0) *tw = 36;
+}
+
 int mval_conv_fuse_up_p2_supported(int cout, int n_terms, const int* cin, const int* up, int N, int H, int W) {
-  if ((cout != 32 && cout != 64) || n_terms < 2 || n_terms > FU_MAX_TERMS) return 0;
+  if ((cout != 32 && cout != 64 && cout != 48 && cout != 96) || n_terms < 2 || n_terms > FU_MAX_TERMS) return 0;
+  int th, tw;
+  fuse_up_tile(cout, W, &th, &tw);
+  for (int j = 0; j < n_terms; j++)
+    if ((th >> up[j]) < 1 || (tw & ((1 << up[j]) - 1))) return 0;
   for (int j = 0; j < n_terms; j++) {
     if (up[j] < 1 || up[j] > 3 || (cin[j] & 31) || cin[j] > 512) return 0;
     if ((H & ((1 << up[j]) - 1)) || (W & ((1 << up[j]) - 1))) return 0;
@@ -204,20 +223,26 @@ int mval_launch_conv_fuse_up_p2(int cout, int n_terms, int relu, const void* res
   a.n_terms = n_terms; a.relu = relu;
   a.N = N; a.H = H; a.W = W;
   size_t lds = 0;
+  int th, tw;
+  fuse_up_tile(cout, W, &th, &tw);
   for (int j = 0; j < n_terms; j++) {
     if ((w[j] | w_unscale[j] | scale[j] | shift[j] | bound[j]) < 0 || (w[j] | w_unscale[j] | scale[j] | shift[j] | bound[j]) >= ((int64_t)1 << 28)) return 1;
     a.t[j].in = reinterpret_cast<const _Float16*>(in[j]); a.t[j].in_row = in_row[j];
     a.t[j].w = (unsigned)w[j] * 4u; a.t[j].w_unscale = (unsigned)w_unscale[j] * 4u; a.t[j].scale = (unsigned)scale[j] * 4u;
     a.t[j].shift = (unsigned)shift[j] * 4u; a.t[j].bound = (unsigned)bound[j] * 4u;
     a.t[j].cin = cin[j]; a.t[j].up = up[j];
-    lds += (size_t)(FU_TH >> up[j]) * (32 >> up[j]) * cout * 4;
+    lds += (size_t)(th >> up[j]) * (tw >> up[j]) * cout * 4;
   }
-  a.tiles_x = (W + 31) / 32;
-  a.tiles_y = (H + FU_TH - 1) / FU_TH;
+  a.tiles_x = (W + tw - 1) / tw;
+  a.tiles_y = (H + th - 1) / th;
   const int tiles_img = a.tiles_x * a.tiles_y;
   if (tiles_img > P2_SLOTS) mval_launch_zero_rows(out_row, (int64_t)N * P2_ROW, s);
   const dim3 grid((unsigned)(tiles_img * N));
   if (cout == 32) hipLaunchKernelGGL((conv_fuse_up_p2_kernel<32>), grid, dim3(256), lds, s, a);
-  else hipLaunchKernelGGL((conv_fuse_up_p2_kernel<64>), grid, dim3(256), lds, s, a);
+  else if (cout == 64) hipLaunchKernelGGL((conv_fuse_up_p2_kernel<64>), grid, dim3(256), lds, s, a);
+  else if (cout == 48 && tw == 24) hipLaunchKernelGGL((conv_fuse_up_p2_kernel<48, FU_TH, 24>), grid, dim3(256), lds, s, a);
+  else if (cout == 48) hipLaunchKernelGGL((conv_fuse_up_p2_kernel<48, FU_TH, 32>), grid, dim3(256), lds, s, a);
+  else if (tw == 36) hipLaunchKernelGGL((conv_fuse_up_p2_kernel<96, 4, 36>), grid, dim3(256), lds, s, a);
+  else hipLaunchKernelGGL((conv_fuse_up_p2_kernel<96, 4, 32>), grid, dim3(256), lds, s, a);
   return 0;
 }

@@ -93,7 +93,11 @@ __device__ __forceinline__ f32x4 p2_mfma(const u32x4 a, const u32x4 b, const f32
 // EPI: 0 = P2 planes out (residuals at the conv resolution), 1 = P2 planes out through the fused nearest upsample (the 1x1
 // convs of the fuse layers), 2 = fp32 NCHW out (the heat-map layer) -- separate instantiations: one kernel with all three
 // epilogues spilled ~50-100 registers in every hot instantiation.
-template <int KS, int S, int G, int WN, int WM, int NT, int MS, int TW, bool RS, int EPI>
+// OW > 0 ("odd" tiles, round 4: HRNet-W48's 24 x 18 and 12 x 9 maps): the tile is OW = Wout columns wide and
+// floor(16 MS WM / OW) rows high -- full-width rows, pixel slot p -> (p / OW, p % OW), the slots past the last whole row are
+// padding.  On such maps the power-of-two tiles compute 1.33x (24 x 18 in 8 x 8 tiles) to 2.4x (12 x 9) the pixels that exist
+// (HRNet-W48 forced onto P2: 384 -> 384 on 12 x 9 took 134 us against 65 us for the h2 kernel's odd tiles).
+template <int KS, int S, int G, int WN, int WM, int NT, int MS, int TW, bool RS, int EPI, int OW = 0>
 __global__ __launch_bounds__(64 * WN * WM) __attribute__((amdgpu_waves_per_eu(P2_WAVES(MS, NT, EPI), 8))) void conv_p2_kernel(P2Args a) {
   constexpr int NTH = 64 * WN * WM, TAPS = KS * KS, SPN = 8 * G, SPN_LOG2 = G == 1 ? 3 : G == 2 ? 4 : 5;
   constexpr int pad = KS / 2;
@@ -104,10 +108,12 @@ __global__ __launch_bounds__(64 * WN * WM) __attribute__((amdgpu_waves_per_eu(P2
   const int wn = wave % WN, wm = wave / WN;
   // the tile is TH x TW output pixels: every patch / LDS quantity is a compile-time constant (tap offsets become
   // ds_read immediates; with a run-time tile the unrolled loop kept ~60 address registers alive)
-  constexpr int TH = 16 * MS * WM / TW, TW_LOG2 = TW == 8 ? 3 : TW == 16 ? 4 : TW == 32 ? 5 : 6;
-  static_assert(TH * TW == 16 * MS * WM && (TW == 8 || TW == 16 || TW == 32 || TW == 64), "tile shape");
+  constexpr int TWE = OW ? OW : TW;  // tile width in pixels
+  constexpr int TH = 16 * MS * WM / TWE, TW_LOG2 = TW == 8 ? 3 : TW == 16 ? 4 : TW == 32 ? 5 : 6;
+  static_assert(OW || (TH * TW == 16 * MS * WM && (TW == 8 || TW == 16 || TW == 32 || TW == 64)), "tile shape");
   static_assert(!RS || TW == 16, "row sharing: 16-wide tiles");
-  constexpr int PH = (TH - 1) * S + KS, PW = (TW - 1) * S + KS, PWh = (PW + 1) >> 1;
+  static_assert(OW == 0 || (!RS && S == 1 && EPI == 0 && TH >= 1), "odd tiles: stride 1, P2 planes out, no row sharing");
+  constexpr int PH = (TH - 1) * S + KS, PW = (TWE - 1) * S + KS, PWh = (PW + 1) >> 1;
   constexpr int slots = S == 1 ? PH * PW : 2 * PH * PWh;
   constexpr int PPX = (slots + 15) & ~15;  // slots per 8-channel block (256-byte aligned blocks)
   constexpr int buf_bytes = SPN * PPX * 16;
@@ -131,7 +137,7 @@ __global__ __launch_bounds__(64 * WN * WM) __attribute__((amdgpu_waves_per_eu(P2
     const int r = t - n * tiles_img;
     const int tyi = a.tiles_x_magic ? (int)__umulhi((unsigned)r, a.tiles_x_magic) : r;
     oy0 = tyi * TH;
-    ox0 = (r - tyi * a.tiles_x) * TW;
+    ox0 = (r - tyi * a.tiles_x) * TWE;
   };
 
   // ---- staging plan: granule e = tid + NTH * i -> (patch row py, block sp = g*8 + plane*4 + c8, column px) ------
@@ -190,7 +196,8 @@ __global__ __launch_bounds__(64 * WN * WM) __attribute__((amdgpu_waves_per_eu(P2
 #pragma unroll
     for (int ms = 0; ms < MS; ms++) {
       const int p = (wm * MS + ms) * 16 + (lane & 15);
-      const int ty = p >> TW_LOG2, tx = p & (TW - 1);
+      int ty = OW ? p / TWE : p >> TW_LOG2, tx = OW ? p - ty * TWE : p & (TW - 1);
+      if (OW && ty >= TH) ty = tx = 0;  // padding slot of an odd tile: any address inside the patch
       xb[ms] = ((lane >> 4) * PPX + (S == 1 ? ty * PW + tx : 2 * ty * PWh + tx)) * 16;
     }
   }
@@ -220,11 +227,23 @@ __global__ __launch_bounds__(64 * WN * WM) __attribute__((amdgpu_waves_per_eu(P2
   const __amdgpu_buffer_rsrc_t r1r = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(a.res1), 0, a.res1 ? obytes : 0u, 0x00020000);
   const __amdgpu_buffer_rsrc_t r2r = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(a.res2), 0, a.res2 ? obytes : 0u, 0x00020000);
   // lane -> (row, column) inside a 16-pixel sub-tile, and the sub-tile's own (row, column) inside the tile
-  const int ly = TW == 8 ? (lane >> 3) & 1 : 0, lx = TW == 8 ? lane & 7 : lane & 15;
+  const int ly = OW ? 0 : TW == 8 ? (lane >> 3) & 1 : 0, lx = OW ? 0 : TW == 8 ? lane & 7 : lane & 15;
   const float bound_a = a.out_f32 ? 0.f : a.bound[0], bound_b = a.out_f32 ? 0.f : a.bound[1];
   const int Ho = a.Hout << a.up, Wo = a.Wout << a.up, rep = 1 << a.up;
   const int C8o = a.Cout >> 3;
   const int64_t oplane = (int64_t)C8o * Ho * Wo * 8;  // halves per plane of one image
+  // odd tiles: the lane's pixel of sub-tile ms -> its row inside the tile (-1: padding slot) and its byte offset from the
+  // tile's first pixel inside an 8-channel block of the output planes
+  int opty[OW ? MS : 1], opix[OW ? MS : 1];
+  if constexpr (OW > 0) {
+#pragma unroll
+    for (int ms = 0; ms < MS; ms++) {
+      const int p = (wm * MS + ms) * 16 + (lane & 15);
+      const int ty = p / TWE, tx = p - ty * TWE;
+      opty[ms] = ty < TH ? ty : -1;
+      opix[ms] = (ty * Wo + tx) * 16;
+    }
+  }
 
   f32x4 acc[MS][NT];
   constexpr int SB = 0;  // sched_barrier mask: nothing crosses.  Left to itself the compiler sinks every weight load and
@@ -395,8 +414,11 @@ __global__ __launch_bounds__(64 * WN * WM) __attribute__((amdgpu_waves_per_eu(P2
     // pixel sub-tile ms of the wave: its first row / column inside the tile (uniform)
     auto sub_ty = [&](int ms) { return TW == 8 ? 2 * (wm * MS + ms) : ((wm * MS + ms) * 16) >> TW_LOG2; };
     auto sub_tx = [&](int ms) { return TW == 8 ? 0 : ((wm * MS + ms) * 16) & (TW - 1); };
-    auto voff = [&](int nt, int ms) -> unsigned { return (yl + sub_ty(ms) < a.Hout && xl + sub_tx(ms) < a.Wout) ? vb[nt] : 0x80000000u; };
-    auto soff = [&](int ms) -> int { return (sub_ty(ms) * Wo + sub_tx(ms)) * 16; };
+    auto voff = [&](int nt, int ms) -> unsigned {
+      if constexpr (OW > 0) return (opty[ms] >= 0 && oy0 + opty[ms] < a.Hout && vb[nt] != 0x80000000u) ? vb[nt] + (unsigned)opix[ms] : 0x80000000u;
+      else return (yl + sub_ty(ms) < a.Hout && xl + sub_tx(ms) < a.Wout) ? vb[nt] : 0x80000000u;
+    };
+    auto soff = [&](int ms) -> int { return OW ? 0 : (sub_ty(ms) * Wo + sub_tx(ms)) * 16; };
     if (wave_active) {
       p2_row_request(a.in_row, n, row_in);
       if (a.res1) p2_row_request(a.res1_row, n, row_r1);
@@ -610,18 +632,20 @@ __global__ __launch_bounds__(64 * WN * WM) __attribute__((amdgpu_waves_per_eu(P2
 
 static thread_local int g_p2_dry = 0;
 
-template <int KS, int S, int G, int WN, int WM, int NT, int MS, int TW, bool RS, int EPI>
+template <int KS, int S, int G, int WN, int WM, int NT, int MS, int TW, bool RS, int EPI, int OW = 0>
 static int launch_p2e(P2Args a, hipStream_t s) {
-  constexpr int TH = 16 * MS * WM / TW;
-  constexpr int PH = (TH - 1) * S + KS, PW = (TW - 1) * S + KS, PWh = (PW + 1) / 2;
+  constexpr int TWE = OW ? OW : TW;
+  constexpr int TH = 16 * MS * WM / TWE;
+  constexpr int PH = (TH - 1) * S + KS, PW = (TWE - 1) * S + KS, PWh = (PW + 1) / 2;
   constexpr int slots = S == 1 ? PH * PW : 2 * PH * PWh;
   constexpr int PPX = (slots + 15) & ~15;
   constexpr size_t smem = (size_t)2 * 8 * G * PPX * 16 + 16;
   static_assert(smem <= 160 * 1024, "LDS");
   constexpr int NTH = 64 * WN * WM;
-  a.th = TH; a.tw = TW;
-  a.tiles_x = (a.Wout + TW - 1) / TW;
+  a.th = TH; a.tw = TWE;
+  a.tiles_x = (a.Wout + TWE - 1) / TWE;
   a.tiles_y = (a.Hout + TH - 1) / TH;
+  if (OW && a.Wout != OW) return 1;
   const unsigned groups = (unsigned)((a.NS_total + WN * NT - 1) / (WN * NT));
   a.amax_tiles = a.tiles_x * a.tiles_y;
   a.tiles_total = a.amax_tiles * a.N;
@@ -635,7 +659,7 @@ static int launch_p2e(P2Args a, hipStream_t s) {
   // registers), a multiple of 8 per cout group so that every XCD walks its own contiguous tile range; fewer tiles than
   // that: one tile each.  (No workgroup waits for another one: an optimistic answer only costs a second round.)
   static std::atomic<int> occ{0};
-  int per_cu = p2_resident_wgs(&conv_p2_kernel<KS, S, G, WN, WM, NT, MS, TW, RS, EPI>, occ, smem, NTH / 64);
+  int per_cu = p2_resident_wgs(&conv_p2_kernel<KS, S, G, WN, WM, NT, MS, TW, RS, EPI, OW>, occ, smem, NTH / 64);
   const char* pe = getenv("MVAL_P2_WGS");  // measurement override: workgroups per CU
   if (pe && atoi(pe) > 0) per_cu = atoi(pe);
   int wgs = (mval_cu_count() * per_cu / (int)groups) & ~7;
@@ -649,12 +673,16 @@ static int launch_p2e(P2Args a, hipStream_t s) {
   dim3 grid((unsigned)wgs, groups);
   if (!a.out_f32 && (int64_t)a.amax_tiles * groups > P2_SLOTS)
     mval_launch_zero_rows(a.out_row, (int64_t)a.N * P2_ROW, s);  // (the kernel rewrites the scale slots)
-  hipLaunchKernelGGL((conv_p2_kernel<KS, S, G, WN, WM, NT, MS, TW, RS, EPI>), grid, dim3(NTH), smem, s, a);
+  hipLaunchKernelGGL((conv_p2_kernel<KS, S, G, WN, WM, NT, MS, TW, RS, EPI, OW>), grid, dim3(NTH), smem, s, a);
   return 0;
 }
 
-template <int KS, int S, int G, int WN, int WM, int NT, int MS, int TW, bool RS = false>
+template <int KS, int S, int G, int WN, int WM, int NT, int MS, int TW, bool RS = false, int OW = 0>
 static int launch_p2(const P2Args& a, hipStream_t s) {
+  if constexpr (OW > 0) {
+    if (a.out_f32 || a.up) return 1;
+    return launch_p2e<KS, S, G, WN, WM, NT, MS, TW, RS, 0, OW>(a, s);
+  }
   if (a.out_f32) {
     if constexpr (KS == 1 && NT == 1 && MS <= 4) return launch_p2e<KS, S, G, WN, WM, NT, MS, TW, RS, 2>(a, s);
     return 1;
@@ -687,6 +715,12 @@ int mval_launch_conv_p2(const P2Args& a0, hipStream_t s) {
     // 33.1 vs 31.5 us; on 64x64: 115 vs 112.5): kept as the on-device cross-check of the kernels' arithmetic, not used by default
     const char* we = getenv("MVAL_P2_WIDE");
     if (we && we[0] == '1' && !g_p2_dry && mval_conv_p2w_supported(a)) return mval_launch_conv_p2w(a, s);
+    // maps no power-of-two tile fits (HRNet-W48 at 384 x 288: 24 x 18 and 12 x 9): full-width odd tiles, 3 x 18 / 7 x 9 pixels
+    const char* oe = getenv("MVAL_P2_ODD");
+    if (!(oe && oe[0] == '0') && a.NS_total > 2 && !a.up && !a.out_f32) {
+      if (a.Wout == 18) return launch_p2<3, 1, 1, 4, 1, 1, 4, 8, false, 18>(a, s);
+      if (a.Wout == 9) return launch_p2<3, 1, 1, 4, 1, 1, 4, 8, false, 9>(a, s);
+    }
     if (a.Wout >= 16 && a.Hout >= 4) {
       if (a.NS_total <= 2) return launch_p2<3, 1, 1, 2, 2, 1, 4, 16, true>(a, s);  // 32 couts: 2 x 2 waves, 4 rows each
       // 64-pixel tiles: measured faster than 128-pixel ones on every HRNet shape (128 -> 128 on 16x16: 28.8 vs 30.6 us,

@@ -267,9 +267,10 @@ class InferencePlan:
                 continue
             if op.kind != "conv" or g.acts[op.src].layout == "nchw":
                 return False
-            # HRNet-W48's 48- / 96-channel branches (half-empty second K chunk, no fused P2 block yet) measured SLOWER on
-            # P2 than on the h2 kernels with their fused 48-channel block (C4: 26.3 vs 22.7 ms): such plans stay h2
-            if op.cin % 32 and os.environ.get("MVAL_P2") != "force":
+            # HRNet-W48 (48- / 96-channel branches: half-empty second K chunk; 24 x 18 and 12 x 9 maps) ran SLOWER on P2 than on
+            # the h2 kernels through round 3 (C4 24.8 vs 22.4 ms); with round 4's full-width odd tiles (conv_p2.hip OW) and the
+            # 48- / 96-channel fused up-paths it is ahead (21.8 vs 22.1 ms).  MVAL_P2_W48=0 keeps such plans on h2.
+            if op.cin % 32 and os.environ.get("MVAL_P2_W48", "1") == "0" and os.environ.get("MVAL_P2") != "force":
                 return False
             m = MvalOp()
             m.kind, m.algo = OP_CONV, ALGO_MFMA_P2
@@ -422,7 +423,7 @@ class InferencePlan:
         while k < len(g.ops) and len(chain) < 3:
             o = g.ops[k]
             if not (o.kind == "conv" and o.k == 1 and o.stride == 1 and o.up >= 1 and o.bn and o.res1 is not None and o.res2 is None
-                    and o.cin % 32 == 0 and o.cout in (32, 64) and o.dst != g.output):
+                    and o.cin % 32 == 0 and o.cout in (32, 64, 48, 96) and o.dst != g.output):
                 break
             if chain:
                 p = g.ops[chain[-1]]
@@ -731,7 +732,7 @@ def _plan_for(model, x):
         raise ValueError("expected (N, 3, H, W) images")
     cache = model.__dict__.setdefault("_plans", {})
     key = (n, h, w, x.device.index, os.environ.get("MVAL_FORCE_DIRECT") == "1", _conv_mode(), os.environ.get("MVAL_FUSE_BLOCKS", "1"),
-           os.environ.get("MVAL_P2_BLOCKS", "32"), os.environ.get("MVAL_P2", "1"), os.environ.get("MVAL_P2_BNECK", "1"), os.environ.get("MVAL_P2_STEM", "1"), os.environ.get("MVAL_P2_FUSE_UP", "1"),
+           os.environ.get("MVAL_P2_BLOCKS", "32"), os.environ.get("MVAL_P2", "1"), os.environ.get("MVAL_P2_W48", "1"), os.environ.get("MVAL_P2_BNECK", "1"), os.environ.get("MVAL_P2_STEM", "1"), os.environ.get("MVAL_P2_FUSE_UP", "1"),
            os.environ.get("MVAL_EPILOGUE_DECODE", "1"))
     plan = cache.get(key)
     if plan is None:

@@ -519,8 +519,8 @@ def test_decode_from_epilogue_large_maps_fold_with_atomics(dev, mode, monkeypatc
 
 def test_w48_argmax_census_headline_plan_vs_exact_fp32(dev, monkeypatch):
     """BASELINE configs[3] / [4] decode parity: HRNet-W48 at 384 x 288, 64 frames x 8 views (9 728 heat-maps), the plan the
-    pool passes run (MVAL_CONV default: HRNet-W48's 48-channel branches keep it on the h2 kernels) against the exact-fp32 MFMA
-    plan.  No map whose top-2 margin exceeds twice the heat-map tolerance may change its arg-max."""
+    pool passes run (MVAL_CONV default: since round 4 the P2 plan -- full-width odd tiles on its 24 x 18 / 12 x 9 maps, fused
+    48- / 96-channel up-paths, fused stem and Bottlenecks) AND the h2 plan it replaced, each against the exact-fp32 MFMA plan.  No map whose top-2 margin exceeds twice the heat-map tolerance may change its arg-max."""
     from multi_view_active_learning_amd import engine, synth
 
     c = dict(arch="hrnet_w48", seed=0, n=64, h=384, w=288, j=19)
@@ -531,21 +531,28 @@ def test_w48_argmax_census_headline_plan_vs_exact_fp32(dev, monkeypatch):
     with torch.no_grad():
         for b in range(frames * v // nb):
             x = torch.from_numpy(synth.images(900 + b, nb // v, v, 384, 288)).reshape(nb, 3, 384, 288).to(dev)
-            monkeypatch.delenv("MVAL_CONV", raising=False)
-            y = m(x)
-            headline = "p2" if engine._plan_for(m, x).p2 else "h2"
             monkeypatch.setenv("MVAL_CONV", "fp32")
-            z = m(x)
+            z = m(x).clone()
             tol = 2e-4 * float(z.abs().max())
-            worst_err = max(worst_err, float((y - z).abs().max()))
-            fy, fz = y.reshape(nb, 19, -1), z.reshape(nb, 19, -1)
+            fz = z.reshape(nb, 19, -1)
             top2 = torch.topk(fz, 2, dim=-1).values
             margin = top2[..., 0] - top2[..., 1]
-            differ = fy.argmax(-1) != fz.argmax(-1)
-            flips += int(differ.sum())
-            flips_above += int((differ & (margin > 2 * tol)).sum())
-            maps += differ.numel()
-            assert worst_err <= tol, (worst_err, tol)
-    print(f"\nW48 arg-max census, {headline} plan vs exact-fp32: {maps} maps, {flips} flips ({flips_above} above margin 2*tol), "
+            for mode in ("default", "h2"):
+                if mode == "default":
+                    monkeypatch.delenv("MVAL_CONV", raising=False)
+                else:
+                    monkeypatch.setenv("MVAL_CONV", mode)
+                y = m(x)
+                if mode == "default":
+                    headline = "p2" if engine._plan_for(m, x).p2 else "h2"
+                    assert headline == "p2"
+                err = float((y - z).abs().max())
+                worst_err = max(worst_err, err)
+                differ = y.reshape(nb, 19, -1).argmax(-1) != fz.argmax(-1)
+                flips += int(differ.sum())
+                flips_above += int((differ & (margin > 2 * tol)).sum())
+                maps += differ.numel()
+                assert err <= tol, (mode, err, tol)
+    print(f"\nW48 arg-max census, {headline} (default) and h2 plans vs exact-fp32: {maps} maps, {flips} flips ({flips_above} above margin 2*tol), "
           f"max |heat-map difference| {worst_err:.2e}")
-    assert maps == 64 * 8 * 19 and flips_above == 0
+    assert maps == 2 * 64 * 8 * 19 and flips_above == 0

@@ -58,6 +58,10 @@ P2_CASES = [
     (2, 192, 192, 24, 18, 3, 1, True, True, False, 0, False),
     (3, 384, 384, 12, 9, 3, 1, True, True, False, 0, False),
     (2, 48, 96, 96, 72, 3, 2, True, False, False, 0, False),
+    # round 4: full-width odd tiles (3 x 18 / 7 x 9 pixels) -- partial last tiles, two residuals, no ReLU, 96 couts
+    (2, 96, 192, 10, 18, 3, 1, False, True, True, 0, False),
+    (3, 192, 96, 5, 9, 3, 1, True, False, False, 0, False),
+    (1, 64, 64, 23, 9, 3, 1, True, True, False, 0, False),
     (2, 192, 384, 24, 18, 3, 2, True, True, True, 0, False),
     (1, 192, 48, 24, 18, 1, 1, False, True, False, 2, False),
     (2, 64, 256, 96, 72, 1, 1, True, True, False, 0, False),
@@ -239,7 +243,10 @@ def test_p2_stem_vs_float64(dev, shape):
     assert torch.equal(alone[0], got[0])
 
 
-@pytest.mark.parametrize("case", [(2, 32, 64, 64, 3), (2, 32, 64, 64, 2), (3, 64, 32, 32, 2), (1, 32, 96, 72, 3), (2, 32, 24, 40, 2), (1, 64, 16, 8, 2)],
+@pytest.mark.parametrize("case", [(2, 32, 64, 64, 3), (2, 32, 64, 64, 2), (3, 64, 32, 32, 2), (1, 32, 96, 72, 3), (2, 32, 24, 40, 2), (1, 64, 16, 8, 2),
+                                  # round 4: HRNet-W48's fuse outputs (48 / 96 channels: three / six cout sub-tiles over four waves; 8 x 24 and
+                                  # 4 x 36 tiles on the 72- / 36-wide maps, 8 x 32 / 4 x 32 elsewhere)
+                                  (2, 48, 96, 72, 3), (1, 48, 96, 72, 2), (2, 96, 48, 36, 2), (1, 48, 32, 64, 2), (1, 96, 24, 40, 2)],
                          ids=lambda c: "n%d_c%d_%dx%d_t%d" % c)
 def test_p2_fuse_up_terms_vs_float64(dev, case):
     """MVAL_OP_FUSE_UP (hrnet.py:424-447: the up-sampling 1x1 terms of one fuse-layer output added to the partial sum in one
