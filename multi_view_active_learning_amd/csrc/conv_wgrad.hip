@@ -332,6 +332,11 @@ static int wg_splits(int cin, int cout, int target) {
   return ps;
 }
 
+int mval_conv_wgrad_split_streams(const float* x, const float* dz, float* dw, float* ws, int N, int Hin, int Win, int Cin, int Hout,
+                                  int Wout, int Cout, int k, int stride, int pad, int x_nchw, const uint32_t* x_amax_row,
+                                  const uint32_t* dz_amax_row, hipStream_t s, hipStream_t reduce_stream, hipEvent_t ready,
+                                  hipEvent_t done);
+
 extern "C" size_t mval_conv_wgrad_workspace_floats(int cin, int cout, int k) {
   return (size_t)wg_splits(cin, cout, 1024) * k * k * cin * cout;  // PS slabs of [tap][cin][cout]
 }
@@ -345,8 +350,18 @@ extern "C" int mval_conv_wgrad(const float* x, const float* dz, float* dw, float
 extern "C" int mval_conv_wgrad_scaled(const float* x, const float* dz, float* dw, float* ws, int N, int Hin, int Win, int Cin,
                                       int Hout, int Wout, int Cout, int k, int stride, int pad, int x_nchw,
                                       const uint32_t* x_amax_row, const uint32_t* dz_amax_row, void* stream) {
+  return mval_conv_wgrad_split_streams(x, dz, dw, ws, N, Hin, Win, Cin, Hout, Wout, Cout, k, stride, pad, x_nchw, x_amax_row, dz_amax_row,
+                                       mval_stream(stream), nullptr, nullptr, nullptr);
+}
+
+// The same with the slab reduction on a second stream (net_train.hip: it only feeds the optimizer, so it can run beside the
+// op's data gradient and the next op's BatchNorm backward): reduce_stream waits for `ready` (recorded behind the split-K
+// kernel on s) and records `done` behind the reduction; the caller makes s wait for `done` before ws is written again.
+int mval_conv_wgrad_split_streams(const float* x, const float* dz, float* dw, float* ws, int N, int Hin, int Win, int Cin, int Hout,
+                                  int Wout, int Cout, int k, int stride, int pad, int x_nchw, const uint32_t* x_amax_row,
+                                  const uint32_t* dz_amax_row, hipStream_t s, hipStream_t reduce_stream, hipEvent_t ready,
+                                  hipEvent_t done) {
   MVAL_REQUIRE(N > 0 && Cin > 0 && Cout > 0 && k > 0 && stride > 0, "mval_conv_wgrad: bad dims");
-  hipStream_t s = mval_stream(stream);
   const int T = k * k;
   const int64_t n_out = (int64_t)T * Cin * Cout;
   // k = 4, stride 2, pad 1: the weight gradient of ConvTranspose2d(k4, s2, p1) with the roles of the
@@ -428,8 +443,15 @@ extern "C" int mval_conv_wgrad_scaled(const float* x, const float* dz, float* dw
   }
   int parts = PS / 8;  // >= 8 slabs per lane
   parts = parts < 1 ? 1 : parts > 16 ? 16 : parts;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n_out + 63) / 64)), dim3(64 * parts), 0, s, ws, PS, T, Cin,
+  hipStream_t rs = s;
+  if (reduce_stream && ready && done) {
+    (void)hipEventRecord(ready, s);
+    (void)hipStreamWaitEvent(reduce_stream, ready, 0);
+    rs = reduce_stream;
+  }
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n_out + 63) / 64)), dim3(64 * parts), 0, rs, ws, PS, T, Cin,
                      Cout, dw);
   MVAL_CHECK_LAUNCH("mval_conv_wgrad/reduce");
+  if (rs != s) (void)hipEventRecord(done, rs);
   return 0;
 }
