@@ -14,6 +14,60 @@ import torch
 import torch.distributed as dist
 
 
+# ---- overlap of a batch's post-network stage with the next batch's network ---------------------------------------------
+# Per batch the path is network -> decode / scoring / RANSAC-DLT -> a row of the result table; the rows are only read when the
+# pass ends (strategy.py:1004-1147 appends per sample and gathers at the end).  The post-network kernels are latency-bound (a
+# few waves per CU: ransac_dlt 175 us, the MPE / BSB statistics 160 - 200 us per batch) and sit serially behind the network on
+# one stream; on a side stream they run beside the NEXT batch's convolutions.  Tensors created inside the context belong to
+# the side stream; tensors handed in from the main stream are marked with record_stream.
+_POST_STREAMS = {}
+
+
+class PostStream:
+    """``with post.batch(heatmaps): table = score(...)`` per batch, ``post.join()`` before the results are read on the
+    caller's stream.  A no-op for host tensors and with MVAL_POST_OVERLAP=0."""
+
+    def __init__(self, enabled=None):
+        import os
+
+        self.enabled = (os.environ.get("MVAL_POST_OVERLAP", "1") != "0") if enabled is None else bool(enabled)
+        self.side = None
+
+    class _Ctx:
+        def __init__(self, outer, inputs):
+            self.outer, self.inputs, self.cm = outer, inputs, None
+
+        def __enter__(self):
+            o = self.outer
+            t0 = next((t for t in self.inputs if torch.is_tensor(t) and t.is_cuda), None)
+            if not o.enabled or t0 is None:
+                return self
+            key = t0.device.index
+            if key not in _POST_STREAMS:
+                _POST_STREAMS[key] = torch.cuda.Stream(device=t0.device)
+            o.side = _POST_STREAMS[key]
+            o.side.wait_stream(torch.cuda.current_stream(t0.device))  # the batch's heat-maps (and arg-max keys) are complete
+            for t in self.inputs:
+                if torch.is_tensor(t) and t.is_cuda:
+                    t.record_stream(o.side)
+            self.cm = torch.cuda.stream(o.side)
+            self.cm.__enter__()
+            return self
+
+        def __exit__(self, *exc):
+            if self.cm is not None:
+                self.cm.__exit__(*exc)
+            return False
+
+    def batch(self, *inputs):
+        return PostStream._Ctx(self, inputs)
+
+    def join(self):
+        """The caller's current stream waits for everything queued on the side stream."""
+        if self.side is not None:
+            torch.cuda.current_stream(self.side.device).wait_stream(self.side)
+
+
 def world():
     if dist.is_available() and dist.is_initialized():
         return dist.get_rank(), dist.get_world_size()

@@ -229,13 +229,17 @@ class ActiveLearningStrategy:
         }
         self._pending_checks = []
         tables, sizes = [], []
+        from .parallel import PostStream, world
+
+        post = PostStream()  # a batch's decode / scoring / triangulation runs beside the next batch's network
         with torch.no_grad():
             for dp in data_loader:
                 heatmaps = self._compute_batch_heatmap(pose_estimator, dp)
-                t = self.score_batch(heatmaps, dp)
+                with post.batch(heatmaps, _lib.argmax_keys_of(heatmaps) if torch.is_tensor(heatmaps) and heatmaps.is_cuda else None):
+                    t = self.score_batch(heatmaps, dp)
                 tables.append(t)
                 sizes.append(t.shape[0])
-        from .parallel import world
+        post.join()
 
         if not tables:
             from .parallel import _collectives_on
@@ -329,18 +333,23 @@ class ActiveLearningStrategy:
         """_evaluate_all's MKPE path: heat-maps -> hard arg-max triangulation -> MPJPE over the
         whole loader (one size exchange + one packed data gather instead of 3 all_gathers per sample)."""
         preds, gts, valids, sizes = [], [], [], []
+        from .parallel import PostStream
+
+        post = PostStream()  # (decode + triangulation of a batch beside the next batch's network)
         with torch.no_grad():
             for dp in data_loader:
                 hm = self._compute_batch_heatmap(pose_estimator, dp)
                 b = torch.as_tensor(dp["pose"]).reshape(-1).shape[0] if "pose" in dp else dp["images"].shape[0]
                 _, j, hh, wh = hm.shape
                 jv = torch.as_tensor(dp["joint_valid"]).reshape(b, j)
-                r = triangulation.triangulate_batch(hm.reshape(b, -1, j, hh, wh), dp["proj_matrices"],
-                                                    self.al_cfg.POSE_ESTIMATOR.STRIDE, jv)
-                preds.append(r["keypoints_3d"].to(torch.float32))
-                gts.append(torch.as_tensor(dp["3d_keypoints"]).to(hm.device, torch.float32))
-                valids.append(jv.to(hm.device, torch.float32))
+                with post.batch(hm, _lib.argmax_keys_of(hm) if hm.is_cuda else None):
+                    r = triangulation.triangulate_batch(hm.reshape(b, -1, j, hh, wh), dp["proj_matrices"],
+                                                        self.al_cfg.POSE_ESTIMATOR.STRIDE, jv)
+                    preds.append(r["keypoints_3d"].to(torch.float32))
+                    gts.append(torch.as_tensor(dp["3d_keypoints"]).to(hm.device, torch.float32))
+                    valids.append(jv.to(hm.device, torch.float32))
                 sizes.append(b)
+        post.join()
         from .parallel import all_gather_reference_order as gather
 
         j = self.num_joints if not preds else preds[0].shape[1]

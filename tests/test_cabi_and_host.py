@@ -129,9 +129,16 @@ def test_p2_launch_list_structure(lib, monkeypatch):
     monkeypatch.setenv("MVAL_FUSE_BLOCKS", "0")
     assert {o.kind for o in plan().ops} == {engine.OP_CONV, engine.OP_TO_P2}
     monkeypatch.delenv("MVAL_FUSE_BLOCKS")
-    for name in ("w48", "r50"):
-        cc = cases.model_cases()[name]
-        assert not engine.InferencePlan(cases.product_model(cc), 2, cc["h"], cc["w"], torch.device("cpu")).p2
+    # PoseResNet (max-pool, transposed convs) never; HRNet-W48 since round 4 (odd full-width tiles, 48- / 96-channel fused up-paths),
+    # MVAL_P2_W48=0 keeps it on the h2 kernels
+    cc = cases.model_cases()["r50"]
+    assert not engine.InferencePlan(cases.product_model(cc), 2, cc["h"], cc["w"], torch.device("cpu")).p2
+    cc = cases.model_cases()["w48"]
+    p48 = engine.InferencePlan(cases.product_model(cc), 2, cc["h"], cc["w"], torch.device("cpu"))
+    assert p48.p2 and sorted((o.cout, o.n_terms) for o in p48.ops if o.kind == engine.OP_FUSE_UP) == sorted([(48, 2)] * 4 + [(48, 3)] * 3 + [(96, 2)] * 2)
+    assert sum(o.kind == engine.OP_BNECK for o in p48.ops) == 4 and p48.ops[0].kind == engine.OP_STEM_P2
+    monkeypatch.setenv("MVAL_P2_W48", "0")
+    assert not engine.InferencePlan(cases.product_model(cc), 2, cc["h"], cc["w"], torch.device("cpu")).p2
 
 
 def test_config_tree_and_factory():
