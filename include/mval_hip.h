@@ -365,6 +365,11 @@ int mval_bn_apply_fwd(const float* z, const float* mean, const float* invstd, co
 int mval_bn_apply_fwd_amax(const float* z, const float* mean, const float* invstd, const float* gamma, const float* beta,
                            const float* res1, const float* res2, float* out, int N, int H, int W, int C, int up, int relu,
                            uint32_t* amax_row, void* stream);
+/* The same, and (relu_mask != NULL) the bits (out > 0) of every float4 of `out` in one byte each: relu_mask[i / 4] for the float4
+ * that starts at element i (N*Ho*Wo*C/4 bytes) -- what mval_bn_bwd_fused_mask needs of `out`. */
+int mval_bn_apply_fwd_mask(const float* z, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                           const float* res1, const float* res2, float* out, int N, int H, int W, int C, int up, int relu,
+                           uint32_t* amax_row, uint8_t* relu_mask, void* stream);
 /* Backward of the above: masks gout by (out > 0) when relu, adds it into gres1/gres2 (stores it
  * instead where `overwrite` bit 0 / bit 1 is set: the first writer of a gradient slot), window-sums
  * it to the conv resolution, then (has_bn) dgamma/dbeta and dz = gamma*invstd*(g - dbeta/M -
@@ -386,6 +391,12 @@ int mval_bn_bwd_fused(const float* gout, const float* out, const float* z, const
                       const float* gamma, const float* beta, float* gres1, float* gres2, float* gz, float* dgamma,
                       float* dbeta, double* ws, float* sums, int N, int H, int W, int C, int relu, int overwrite,
                       uint32_t* gz_amax_row, void* stream);
+/* The same with the ReLU mask of an op WITH residuals taken from the bytes mval_bn_apply_fwd_mask kept (relu_mask != NULL: `out`
+ * is not read; a sixteenth of its bytes). */
+int mval_bn_bwd_fused_mask(const float* gout, const float* out, const uint8_t* relu_mask, const float* z, const float* mean,
+                           const float* invstd, const float* gamma, const float* beta, float* gres1, float* gres2, float* gz,
+                           float* dgamma, float* dbeta, double* ws, float* sums, int N, int H, int W, int C, int relu, int overwrite,
+                           uint32_t* gz_amax_row, void* stream);
 /* Weight gradient dw [cout][cin][k][k] of a conv: x NHWC (NCHW when x_nchw), dz NHWC.
  * ws >= mval_conv_wgrad_workspace_floats(cin, cout, k) floats. */
 size_t mval_conv_wgrad_workspace_floats(int cin, int cout, int k);
@@ -449,6 +460,10 @@ typedef struct mval_train_op {
    * leaves max |out|; gz_amax_off = the row of the op's dz scratch (written by its BatchNorm backward, read by its
    * data-gradient conv). */
   int64_t out_amax_off, gz_amax_off;
+  /* > 0: float offset into `arena` of N*hout*wout*cout/4 BYTES -- the forward apply keeps (out > 0) of every float4 as four
+   * bits of one byte there and the backward takes the ReLU mask from it instead of reading `out` (ops with relu, a residual
+   * and no upsample; 0 = none). */
+  int64_t mask_off;
 } mval_train_op;
 
 /* ones_off / zeros_off: params offsets of >= max(cout) floats of 1.0 / 0.0.

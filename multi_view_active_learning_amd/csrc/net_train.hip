@@ -20,6 +20,11 @@ extern "C" int mval_bn_batch_stats(const float*, int64_t, int, float, float, flo
                                    void*);
 extern "C" int mval_bn_apply_fwd(const float*, const float*, const float*, const float*, const float*, const float*,
                                  const float*, float*, int, int, int, int, int, int, void*);
+extern "C" int mval_bn_apply_fwd_mask(const float*, const float*, const float*, const float*, const float*, const float*, const float*, float*,
+                                      int, int, int, int, int, int, uint32_t*, uint8_t*, void*);
+extern "C" int mval_bn_bwd_fused_mask(const float*, const float*, const uint8_t*, const float*, const float*, const float*, const float*,
+                                      const float*, float*, float*, float*, float*, float*, double*, float*, int, int, int, int, int, int,
+                                      uint32_t*, void*);
 extern "C" int mval_bn_finalize_stats(const double*, int, int64_t, int, float, float, float*, float*, float*, float*, void*);
 extern "C" int mval_bn_bwd_fused(const float*, const float*, const float*, const float*, const float*, const float*, const float*,
                                  float*, float*, float*, float*, float*, double*, float*, int, int, int, int, int, int, uint32_t*,
@@ -243,10 +248,10 @@ extern "C" int mval_train_forward(const mval_train_op* ops, int n_ops, int n_ima
       }
       if (rc) return rc;
       TtScope tt(TT_BN_APPLY, s);
-      rc = mval_bn_apply_fwd_amax(a.out, t.mean, t.invstd, t.gamma, t.beta, op.res1_off >= 0 ? arena + op.res1_off : nullptr,
+      rc = mval_bn_apply_fwd_mask(a.out, t.mean, t.invstd, t.gamma, t.beta, op.res1_off >= 0 ? arena + op.res1_off : nullptr,
                                   op.res2_off >= 0 ? arena + op.res2_off : nullptr, out, n_images, op.hout, op.wout, op.cout,
                                   op.up, op.relu, t.out_amax_off > 0 ? reinterpret_cast<uint32_t*>(arena + t.out_amax_off) : nullptr,
-                                  stream);
+                                  t.mask_off > 0 ? reinterpret_cast<uint8_t*>(arena + t.mask_off) : nullptr, stream);
       if (rc) return rc;
     } else {
       MVAL_REQUIRE(op.up == 0, "mval_train_forward: op %d: upsample without BatchNorm is not part of any graph", i);
@@ -296,7 +301,8 @@ extern "C" int mval_train_backward(const mval_train_op* ops, int n_ops, int n_im
     {
     TtScope tt(TT_BN_BWD, s);
     if (bwd_fused && t.has_bn && op.up == 0 && (op.cout & 3) == 0)
-      rc = mval_bn_bwd_fused(garena + t.gout_off, outp, arena + t.z_off, t.mean, t.invstd, t.gamma, t.beta,
+      rc = mval_bn_bwd_fused_mask(garena + t.gout_off, outp, t.mask_off > 0 ? reinterpret_cast<const uint8_t*>(arena + t.mask_off) : nullptr,
+                             arena + t.z_off, t.mean, t.invstd, t.gamma, t.beta,
                              t.gres1_off >= 0 ? garena + t.gres1_off : nullptr, t.gres2_off >= 0 ? garena + t.gres2_off : nullptr, gz,
                              t.dgamma, t.dbeta, ws, sums, n_images, op.hout, op.wout, op.cout, op.relu, t.first_touch >> 1, gz_row,
                              stream);

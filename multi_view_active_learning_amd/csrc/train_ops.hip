@@ -9,6 +9,11 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+extern "C" int mval_bn_apply_fwd_mask(const float*, const float*, const float*, const float*, const float*, const float*, const float*, float*,
+                                      int, int, int, int, int, int, uint32_t*, uint8_t*, void*);
+extern "C" int mval_bn_bwd_fused_mask(const float*, const float*, const uint8_t*, const float*, const float*, const float*, const float*,
+                                      const float*, float*, float*, float*, float*, float*, double*, float*, int, int, int, int, int, int,
+                                      uint32_t*, void*);
 #define TR_BLOCKS 512
 // The two elementwise BatchNorm streams run 1024-thread workgroups, at most two per CU: every workgroup leaves ONE
 // partial maximum, and every workgroup of the consuming conv reads them all -- 2048 partials (256-thread workgroups)
@@ -200,7 +205,7 @@ __global__ __launch_bounds__(TR_APPLY_THREADS) void bn_apply_fwd_kernel(const fl
                                                            const float* __restrict__ res1,
                                                            const float* __restrict__ res2, float* __restrict__ out,
                                                            int N, int H, int W, int C, int up, int relu,
-                                                           unsigned* __restrict__ amax_row) {
+                                                           unsigned* __restrict__ amax_row, unsigned char* __restrict__ relu_mask) {
   const int c4n = C >> 2;
   const int Ho = H << up, Wo = W << up;
   const int64_t total = (int64_t)N * Ho * Wo * c4n;
@@ -225,6 +230,9 @@ __global__ __launch_bounds__(TR_APPLY_THREADS) void bn_apply_fwd_kernel(const fl
       r.x = mval_relu(r.x); r.y = mval_relu(r.y); r.z = mval_relu(r.z); r.w = mval_relu(r.w);
     }
     *reinterpret_cast<f32x4*>(out + o) = r;
+    // (out > 0) of the float4 as four bits of one byte: what the backward pass of a ReLU behind residual adds needs of
+    // `out` -- a sixteenth of the bytes (mval_bn_bwd_fused, mask_mode 3)
+    if (relu_mask) relu_mask[o >> 2] = (unsigned char)((r.x > 0.f) | ((r.y > 0.f) << 1) | ((r.z > 0.f) << 2) | ((r.w > 0.f) << 3));
     amax = fmaxf(fmaxf(amax, fmaxf(fabsf(r.x), fabsf(r.y))), fmaxf(fabsf(r.z), fabsf(r.w)));
   }
   if (amax_row) tr_amax_store(amax_row, amax);
@@ -233,12 +241,17 @@ __global__ __launch_bounds__(TR_APPLY_THREADS) void bn_apply_fwd_kernel(const fl
 extern "C" int mval_bn_apply_fwd_amax(const float* z, const float* mean, const float* invstd, const float* gamma,
                                       const float* beta, const float* res1, const float* res2, float* out, int N, int H,
                                       int W, int C, int up, int relu, uint32_t* amax_row, void* stream) {
+  return mval_bn_apply_fwd_mask(z, mean, invstd, gamma, beta, res1, res2, out, N, H, W, C, up, relu, amax_row, nullptr, stream);
+}
+extern "C" int mval_bn_apply_fwd_mask(const float* z, const float* mean, const float* invstd, const float* gamma,
+                                      const float* beta, const float* res1, const float* res2, float* out, int N, int H,
+                                      int W, int C, int up, int relu, uint32_t* amax_row, uint8_t* relu_mask, void* stream) {
   MVAL_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && (C & 3) == 0 && up >= 0, "mval_bn_apply_fwd: bad dims");
   int64_t total = (int64_t)N * (H << up) * (W << up) * (C >> 2);
   int nb = (int)((total + TR_APPLY_THREADS - 1) / TR_APPLY_THREADS);
   if (nb > TR_APPLY_BLOCKS) nb = TR_APPLY_BLOCKS;
   hipLaunchKernelGGL(bn_apply_fwd_kernel, dim3(nb), dim3(TR_APPLY_THREADS), 0, mval_stream(stream), z, mean, invstd, gamma, beta,
-                     res1, res2, out, N, H, W, C, up, relu, amax_row);
+                     res1, res2, out, N, H, W, C, up, relu, amax_row, relu_mask);
   MVAL_CHECK_LAUNCH("mval_bn_apply_fwd");
   return 0;
 }
@@ -507,10 +520,15 @@ extern "C" int mval_bn_bwd_amax(const float* gout, const float* out, const float
 // mask always came from a read of `out`.  Here the reduction only reads (gout, z, and `out` when a residual makes the
 // mask unrecoverable from z) and scatters the residual gradients; the apply pass re-reads its gradient source -- the
 // residual slot this op stored the masked gradient in (first writer), else gout with the mask re-derived -- and writes
-// dz once.  mask_mode: 0 none, 1 out > 0, 2 bn_affine(z) > 0 (ReLU without residual: out = max(bn_affine(z), 0)).
+// dz once.  mask_mode: 0 none, 1 out > 0, 2 bn_affine(z) > 0 (ReLU without residual: out = max(bn_affine(z), 0)), 3 the
+// (out > 0) bits the forward apply kept (one byte per float4; the caller passes it in ov.x's bit pattern).
 __device__ __forceinline__ f32x4 bwd_mask(f32x4 g, const int mask_mode, const f32x4 ov, const f32x4 zv, const f32x4 mu,
                                           const f32x4 is, const f32x4 gm, const f32x4 bt) {
-  if (mask_mode == 1) {
+  if (mask_mode == 3) {
+    const unsigned m = __float_as_uint(ov.x);
+#pragma unroll
+    for (int k = 0; k < 4; k++) g[k] = ((m >> k) & 1u) ? g[k] : 0.f;
+  } else if (mask_mode == 1) {
 #pragma unroll
     for (int k = 0; k < 4; k++) g[k] = ov[k] > 0.f ? g[k] : 0.f;
   } else if (mask_mode == 2) {
@@ -527,7 +545,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce2_kernel(const float* __rest
                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
                                                              float* __restrict__ gres1, float* __restrict__ gres2,
                                                              double* __restrict__ part, int M, int C, int mask_mode,
-                                                             int overwrite) {
+                                                             int overwrite, const unsigned char* __restrict__ relu_mask) {
   extern __shared__ double sh[];
   const int c4n = C >> 2;
   const int lanes = min(c4n, 256);
@@ -555,6 +573,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce2_kernel(const float* __rest
           const int64_t o = (int64_t)p * C + q * 4;
           g[u] = ok ? *reinterpret_cast<const f32x4*>(gout + o) : zero;
           ov[u] = (ok && mask_mode == 1) ? *reinterpret_cast<const f32x4*>(out + o) : zero;
+          if (ok && mask_mode == 3) ov[u].x = __uint_as_float((unsigned)relu_mask[o >> 2]);
           zv[u] = ok ? *reinterpret_cast<const f32x4*>(z + o) : zero;
           a1[u] = (ok && gres1 && !(overwrite & 1)) ? *reinterpret_cast<const f32x4*>(gres1 + o) : zero;
           a2[u] = (ok && gres2 && !(overwrite & 2)) ? *reinterpret_cast<const f32x4*>(gres2 + o) : zero;
@@ -606,7 +625,7 @@ __global__ __launch_bounds__(TR_APPLY_THREADS) void bn_bwd_apply2_kernel(const f
                                                            const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, const float* __restrict__ sums,
                                                            float* __restrict__ gz, int64_t M, int C, int mask_mode,
-                                                           unsigned* __restrict__ amax_row) {
+                                                           unsigned* __restrict__ amax_row, const unsigned char* __restrict__ relu_mask) {
   const int c4n = C >> 2;
   const int64_t total = M * c4n;
   const float invM = 1.0f / (float)M;
@@ -617,7 +636,8 @@ __global__ __launch_bounds__(TR_APPLY_THREADS) void bn_bwd_apply2_kernel(const f
     const int64_t i = (t / c4n) * C + q * 4;
     const f32x4 gv0 = *reinterpret_cast<const f32x4*>(gsrc + i);
     const f32x4 zv = *reinterpret_cast<const f32x4*>(z + i);
-    const f32x4 ov = mask_mode == 1 ? *reinterpret_cast<const f32x4*>(out + i) : zero;
+    f32x4 ov = mask_mode == 1 ? *reinterpret_cast<const f32x4*>(out + i) : zero;
+    if (mask_mode == 3) ov.x = __uint_as_float((unsigned)relu_mask[i >> 2]);
     const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + q * 4);
     const f32x4 is = *reinterpret_cast<const f32x4*>(invstd + q * 4);
     const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + q * 4);
@@ -639,11 +659,19 @@ extern "C" int mval_bn_bwd_fused(const float* gout, const float* out, const floa
                                  const float* gamma, const float* beta, float* gres1, float* gres2, float* gz, float* dgamma,
                                  float* dbeta, double* ws, float* sums, int N, int H, int W, int C, int relu, int overwrite,
                                  uint32_t* gz_amax_row, void* stream) {
+  return mval_bn_bwd_fused_mask(gout, out, nullptr, z, mean, invstd, gamma, beta, gres1, gres2, gz, dgamma, dbeta, ws, sums, N, H, W, C, relu,
+                                overwrite, gz_amax_row, stream);
+}
+// The same with the ReLU mask taken from the bytes mval_bn_apply_fwd_mask kept (relu_mask != NULL: `out` is not read at all).
+extern "C" int mval_bn_bwd_fused_mask(const float* gout, const float* out, const uint8_t* relu_mask, const float* z, const float* mean,
+                                      const float* invstd, const float* gamma, const float* beta, float* gres1, float* gres2, float* gz,
+                                      float* dgamma, float* dbeta, double* ws, float* sums, int N, int H, int W, int C, int relu,
+                                      int overwrite, uint32_t* gz_amax_row, void* stream) {
   MVAL_REQUIRE(gout && z && mean && invstd && gamma && beta && gz && ws && sums && N > 0 && H > 0 && W > 0 && C > 0 && (C & 3) == 0,
                "mval_bn_bwd_fused: bad arguments (C must be a multiple of 4)");
   MVAL_REQUIRE((int64_t)N * H * W * C < ((int64_t)1 << 33) && (int64_t)N * H * W < ((int64_t)1 << 31), "mval_bn_bwd_fused: more than 2^31 float4 elements");
   MVAL_REQUIRE(!gres1 || gres1 != gres2, "mval_bn_bwd_fused: the two residual gradients must be distinct buffers");
-  MVAL_REQUIRE(!relu || out || (!gres1 && !gres2), "mval_bn_bwd_fused: ReLU with residuals needs the output activation for the mask");
+  MVAL_REQUIRE(!relu || out || relu_mask || (!gres1 && !gres2), "mval_bn_bwd_fused: ReLU with residuals needs the output activation (or its mask bytes)");
   const int64_t M = (int64_t)N * H * W;
   const int c4n = C >> 2;
   const int lanes = c4n < 256 ? c4n : 256;
@@ -652,9 +680,9 @@ extern "C" int mval_bn_bwd_fused(const float* gout, const float* out, const floa
   if (nb > TR_BLOCKS) nb = TR_BLOCKS;
   const size_t sh = (size_t)rows * lanes * 4 * 2 * sizeof(double);
   hipStream_t s = mval_stream(stream);
-  const int mask_mode = !relu ? 0 : (gres1 || gres2) ? 1 : 2;
+  const int mask_mode = !relu ? 0 : (gres1 || gres2) ? (relu_mask ? 3 : 1) : 2;
   hipLaunchKernelGGL(bn_bwd_reduce2_kernel, dim3(nb), dim3(256), sh, s, gout, out, z, mean, invstd, gamma, beta, gres1, gres2, ws,
-                     (int)M, C, mask_mode, overwrite);
+                     (int)M, C, mask_mode, overwrite, relu_mask);
   MVAL_CHECK_LAUNCH("mval_bn_bwd_fused/reduce");
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, s, ws, nb, C, dbeta, dgamma, sums);
   MVAL_CHECK_LAUNCH("mval_bn_bwd_fused/finalize");
@@ -668,7 +696,7 @@ extern "C" int mval_bn_bwd_fused(const float* gout, const float* out, const floa
   int nb2 = (int)((total + TR_APPLY_THREADS - 1) / TR_APPLY_THREADS);
   if (nb2 > TR_APPLY_BLOCKS) nb2 = TR_APPLY_BLOCKS;
   hipLaunchKernelGGL(bn_bwd_apply2_kernel, dim3(nb2), dim3(TR_APPLY_THREADS), 0, s, gsrc, out, z, mean, invstd, gamma, beta, sums, gz, M,
-                     C, apply_mask, gz_amax_row);
+                     C, apply_mask, gz_amax_row, relu_mask);
   MVAL_CHECK_LAUNCH("mval_bn_bwd_fused/apply");
   return 0;
 }

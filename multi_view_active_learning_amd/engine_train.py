@@ -46,6 +46,7 @@ class MvalTrainOp(C.Structure):
         ("mean", C.c_void_p), ("invstd", C.c_void_p),
         ("dweight", C.c_void_p), ("dgamma", C.c_void_p), ("dbeta", C.c_void_p),
         ("out_amax_off", C.c_int64), ("gz_amax_off", C.c_int64),
+        ("mask_off", C.c_int64),
     ]
 
 
@@ -209,6 +210,13 @@ class TrainPlan:
             wsf_max = max(wsf_max, int(lib.mval_conv_wgrad_workspace_floats(C.c_int(op.cin), C.c_int(op.cout), C.c_int(op.k))))
         for i, op in enumerate(g.ops):  # producers leave max |out| where a split conv will look for it
             self.ops[i].out_amax_off = amax_row.get(op.dst, 0)
+        # ReLU behind residual adds (BasicBlock / Bottleneck outputs, fuse sums at the conv resolution): the forward apply keeps
+        # (out > 0) as one byte per float4, the backward reads that instead of `out` (a sixteenth of the bytes)
+        if os.environ.get("MVAL_TRAIN_RELU_MASK", "1") != "0":
+            for i, op in enumerate(g.ops):
+                if op.bn and op.relu and op.up == 0 and (op.res1 is not None or op.res2 is not None) and op.cout % 4 == 0:
+                    self.ops[i].mask_off = self._row_top
+                    self._row_top += _align((n * geo[i][2] * geo[i][3] * op.cout // 4 + 3) // 4)
         if g.input in amax_row:
             raise _lib.MvalError("the network input cannot feed an fp16-split conv")
         self.arena_floats = _align(self._row_top)

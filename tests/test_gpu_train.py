@@ -102,6 +102,24 @@ def test_bn_train_ops_vs_torch(dev):
                 assert torch.equal(gz2, gz) and torch.equal(dg2, dg) and torch.equal(db2, db)
                 for r, gr in zip(res, gr2):
                     np.testing.assert_allclose(gr.permute(0, 3, 1, 2).cpu().numpy(), r.grad.numpy(), rtol=1e-6, atol=1e-6)
+            if relu and nres:
+                # the ReLU mask as bytes kept by the forward apply (four bits per float4) instead of a read of `out`
+                out2, mask = torch.empty_like(outd), torch.zeros(n * h * w * c // 4, dtype=torch.uint8, device=dev)
+                _lib._check(lib.mval_bn_apply_fwd_mask(p(zd), p(mean), p(invstd), p(gd), p(bd), p(resd[0]), p(resd[1]) if nres > 1 else p(None),
+                                                       p(out2), C.c_int(n), C.c_int(h), C.c_int(w), C.c_int(c), C.c_int(0), C.c_int(1), p(None),
+                                                       p(mask), st), "apply + mask")
+                assert torch.equal(out2, outd)
+                want_bits = (outd.reshape(-1, 4) > 0).to(torch.uint8)
+                assert torch.equal(mask, want_bits[:, 0] | (want_bits[:, 1] << 1) | (want_bits[:, 2] << 2) | (want_bits[:, 3] << 3))
+                for overwrite in (0, 3):
+                    gr3 = [torch.full_like(r, 7.0 if overwrite else 0.0) for r in resd]
+                    gz3, dg3, db3 = torch.full_like(gz, 9.0), torch.empty(c, device=dev), torch.empty(c, device=dev)
+                    _lib._check(lib.mval_bn_bwd_fused_mask(p(goutd), p(None), p(mask), p(zd), p(mean), p(invstd), p(gd), p(bd), p(gr3[0]),
+                                                           p(gr3[1]) if nres > 1 else p(None), p(gz3), p(dg3), p(db3), p(ws), p(sums), C.c_int(n),
+                                                           C.c_int(h), C.c_int(w), C.c_int(c), C.c_int(1), C.c_int(overwrite), p(None), st), "bwd mask")
+                    assert torch.equal(gz3, gz) and torch.equal(dg3, dg) and torch.equal(db3, db)
+                    for r, gr in zip(res, gr3):
+                        np.testing.assert_allclose(gr.permute(0, 3, 1, 2).cpu().numpy(), r.grad.numpy(), rtol=1e-6, atol=1e-6)
             # batch statistics from per-tile partials, as the forward conv epilogues leave them ([C][tiles][2] float64)
             tiles = 5
             zt = zd.reshape(-1, c).double()

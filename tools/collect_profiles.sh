@@ -10,13 +10,14 @@ for w in c1 c1x16 c4 c5; do
   python3 bench.py --workload $w --no-cpu-baseline --steps 20 2>/dev/null | tail -1 > $out/bench_${w}_$tag.json
 done
 python3 bench.py --workload c3 --steps 20 2>/dev/null | tail -1 > $out/bench_c3_$tag.json   # (with its cpu_baseline)
-python3 bench.py 2>/dev/null | tail -1 > $out/bench_c2_$tag.json
+python3 bench.py 2>/dev/null | tail -1 > $out/bench_c2_$tag.json                            # (the driver's command: headline + exact_modes + companions)
 export MVAL_STREAMS=1
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_c2 -o c2 -- python3 bench.py --no-cpu-baseline --no-exact-modes --steps 30 2>/dev/null | tail -1 > $out/bench_c2_${tag}_under_rocprof.json
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_c2 -o c2 -- python3 bench.py --no-cpu-baseline --no-exact-modes --no-companions --steps 30 2>/dev/null | tail -1 > $out/bench_c2_${tag}_under_rocprof.json
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_c3 -o c3 -- python3 bench.py --workload c3 --no-cpu-baseline --steps 5 > /dev/null 2>&1
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -o c2 -- python3 bench.py --no-cpu-baseline --no-exact-modes --steps 5 > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -o c2 -- python3 bench.py --no-cpu-baseline --no-exact-modes --steps 5 > /dev/null 2>&1
-rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS --output-format csv -d $out/pmc_sq -o c2 -- python3 bench.py --no-cpu-baseline --no-exact-modes --steps 3 > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_c4 -o c4 -- python3 bench.py --workload c4 --no-cpu-baseline --steps 20 > /dev/null 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -o c2 -- python3 bench.py --no-cpu-baseline --no-exact-modes --no-companions --steps 5 > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -o c2 -- python3 bench.py --no-cpu-baseline --no-exact-modes --no-companions --steps 5 > /dev/null 2>&1
+rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS --output-format csv -d $out/pmc_sq -o c2 -- python3 bench.py --no-cpu-baseline --no-exact-modes --no-companions --steps 3 > /dev/null 2>&1
 ks=$(find $out/kt_c2 -name '*kernel_stats.csv' | head -1)
 k3=$(find $out/kt_c3 -name '*kernel_stats.csv' | head -1)
 fe=$(find $out/pmc_fetch -name '*counter_collection.csv' | head -1)
@@ -24,10 +25,12 @@ wr=$(find $out/pmc_write -name '*counter_collection.csv' | head -1)
 sq=$(find $out/pmc_sq -name '*counter_collection.csv' | head -1)
 cp $ks $out/bench_c2_kernel_stats_$tag.csv
 cp $k3 $out/bench_c3_kernel_stats_$tag.csv
+k4=$(find $out/kt_c4 -name '*kernel_stats.csv' | head -1)
+cp $k4 $out/bench_c4_kernel_stats_$tag.csv
 python3 tools/pmc_summary.py $ks $fe $wr $sq > $out/bench_c2_${tag}_summary.json
-rm -rf $out/kt_c2 $out/kt_c3 $out/pmc_fetch $out/pmc_write $out/pmc_sq
+rm -rf $out/kt_c2 $out/kt_c3 $out/kt_c4 $out/pmc_fetch $out/pmc_write $out/pmc_sq
 if [ -n "$POOL50K" ]; then   # the BASELINE-size pool passes (about 140 s each): unedited bench lines
-  python3 bench.py --workload c4 --pool 50000 --no-cpu-baseline 2>/dev/null | tail -1 > $out/bench_c4_pool50000.json
-  python3 bench.py --workload c5 --pool 50000 --no-cpu-baseline 2>/dev/null | tail -1 > $out/bench_c5_pool50000.json
+  python3 bench.py --workload c4 --pool 50000 --no-cpu-baseline --warmup 0 2>/dev/null | tail -1 > $out/bench_c4_pool50000.json
+  python3 bench.py --workload c5 --pool 50000 --no-cpu-baseline --warmup 0 2>/dev/null | tail -1 > $out/bench_c5_pool50000.json
 fi
 ls -la $out
