@@ -237,10 +237,13 @@ def train_rooflines(model, step, frames, v, mode):
                     seconds_in_kernel_per_step=round(tt, 6), bytes_per_step=b)
 
     fams = [
-        mf("conv forward (conv_split_kernel / conv_mfma_kernel, raw z, bias-free accumulate)", fl_fwd, t[0]),
-        hb("BatchNorm statistics (bn_stats_partial + finalize: one read of z, float64 two-stage sums)", zb, t[1]),
-        hb("BatchNorm apply (bn_apply_fwd: z -> normalise + residuals + ReLU (+ upsample) -> out)", zb + ob, t[2]),
-        hb("BatchNorm backward (bn_bwd_reduce + finalize + bn_bwd_apply: gout, out, z -> dz, dgamma, dbeta, residual gradients)",
+        mf("conv forward (conv_split_kernel / conv_mfma_kernel, raw z, bias-free accumulate; since round 4 the epilogue also keeps the "
+           "per-workgroup (sum, sum of squares) partials of BatchNorm's batch statistics)", fl_fwd, t[0]),
+        hb("BatchNorm statistics (bn_stats_finalize_tiles: the conv epilogues' float64 partials -> mean / invstd / running stats; the "
+           "stem conv, whose kernel keeps none, still runs bn_stats_partial over z; bytes = one read of z, as in round 3, for comparison)", zb, t[1]),
+        hb("BatchNorm apply (bn_apply_fwd: z -> normalise + residuals + ReLU (+ upsample) -> out, + the ReLU mask bytes of residual ops)", zb + ob, t[2]),
+        hb("BatchNorm backward (bn_bwd_reduce2 + finalize + bn_bwd_apply2: gout, z [, mask bytes] -> dz, dgamma, dbeta, residual gradients; "
+           "bytes = round 3's count (2 x out-sized + 4 x z-sized tensors), for comparison: the round-4 kernels move 5 - 7 of those 6 - 8)",
            2.0 * ob + 4.0 * zb, t[3]),
         mf("weight gradient (conv_wgrad_bf3_kernel split-K + float64 slab reduction)", fl_fwd, t[4]),
         mf("data gradient (forward kernels on flipped weights)", fl_dgrad, t[5]),
@@ -567,12 +570,15 @@ def main():
         el = (time.perf_counter() - t0) / repeats
         _par.reset_timers(on=False)
     attribution = None
-    if world > 1 or args.rccl_world_1:
+    if world > 1 or args.rccl_world_1 or wl.get("pool"):
         # every rank reports before rank 0 prints: per-rank time of the timed region, and for the pool passes its split
         mine = torch.tensor([el_rank, pass_t["compute_s"] / repeats, _par.timers()["gather_s"] / repeats, pass_t["select_s"] / repeats],
                             dtype=torch.float64, device=dev)
-        allr = torch.empty(world * 4, dtype=torch.float64, device=dev)
-        dist.all_gather_into_tensor(allr, mine)
+        if world > 1 or args.rccl_world_1:
+            allr = torch.empty(world * 4, dtype=torch.float64, device=dev)
+            dist.all_gather_into_tensor(allr, mine)
+        else:
+            allr = mine
         allr = allr.cpu().reshape(world, 4).numpy()
         attribution = {"per_rank_s": {"min": round(float(allr[:, 0].min()), 4), "mean": round(float(allr[:, 0].mean()), 4),
                                       "max": round(float(allr[:, 0].max()), 4), "all": [round(float(x), 4) for x in allr[:, 0]]},
