@@ -69,6 +69,29 @@ class _ViewDesc(C.Structure):
                 ("right", C.c_int32), ("bottom", C.c_int32), ("tmp_off", C.c_int64)]
 
 
+# Descriptor uploads of resize_views: a small ring of pinned host buffers per device, copied with non_blocking=True on the current
+# stream (a pageable copy would stall the host until the stream drains -- a batch pipeline then loses the overlap of the next
+# batch's launches with the GPU's work); a slot is reused only after the event recorded behind its last copy has completed.
+_DESC_RING = {}
+
+
+def _upload_descs(raw: bytes, dev):
+    key = dev.index
+    ring = _DESC_RING.setdefault(key, {"k": 0, "slots": [None] * 4})
+    i = ring["k"] % 4
+    ring["k"] += 1
+    slot = ring["slots"][i]
+    if slot is None or slot[0].numel() < len(raw):
+        slot = [torch.empty(max(len(raw), 16384), dtype=torch.uint8).pin_memory(), torch.cuda.Event()]
+        ring["slots"][i] = slot
+    else:
+        slot[1].synchronize()
+    slot[0][: len(raw)].copy_(torch.frombuffer(bytearray(raw), dtype=torch.uint8))
+    out = slot[0][: len(raw)].to(dev, non_blocking=True)
+    slot[1].record(torch.cuda.current_stream(dev))
+    return out
+
+
 def resize_views(images, boxes, in_w, in_h):
     """Pixel half of prepare_single_view for a list of decoded RGB images (uint8 HIP tensors (h0, w0, 3)) and
     their SQUARE boxes: (V, 3, in_h, in_w) float32 on the device (BGR order, ImageNet-normalised)."""
@@ -90,7 +113,7 @@ def resize_views(images, boxes, in_w, in_h):
     lib.mval_prepare_views_workspace_bytes.restype = C.c_size_t
     ws = torch.empty(int(lib.mval_prepare_views_workspace_bytes(C.c_int(len(images)), C.c_int64(rows), C.c_int(in_w), C.c_int(in_h))),
                      dtype=torch.uint8, device=dev)
-    dd = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).to(dev)
+    dd = _upload_descs(bytes(descs), dev)
     out = torch.empty((len(images), 3, in_h, in_w), dtype=torch.float32, device=dev)
     _lib._check(
         lib.mval_prepare_views(_lib._p(dd), C.c_int(len(images)), C.c_int(max(d.bottom - d.top for d in descs)),
