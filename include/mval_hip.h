@@ -370,6 +370,13 @@ int mval_bn_apply_fwd_amax(const float* z, const float* mean, const float* invst
 int mval_bn_apply_fwd_mask(const float* z, const float* mean, const float* invstd, const float* gamma, const float* beta,
                            const float* res1, const float* res2, float* out, int N, int H, int W, int C, int up, int relu,
                            uint32_t* amax_row, uint8_t* relu_mask, void* stream);
+/* The same, and the output ALSO as P2 planes (csrc/conv_p2.h: [n][plane][C/8][Ho][Wo][8] fp16 pairs, rows p2_rows[n][MVAL_P2_ROW]) for
+ * the P2 convs of the training forward; the tensor's scale comes from the a-priori bound |bn(z)| <= |gamma| sqrt(M - 1) + |beta|
+ * (Samuelson) plus the residuals' exact maxima (res*_row: their magnitude rows, required with a residual).  out may be NULL. */
+int mval_bn_apply_fwd_p2(const float* z, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                         const float* res1, const float* res2, float* out, void* p2_planes, uint32_t* p2_rows, int N, int H, int W,
+                         int C, int up, int relu, uint32_t* amax_row, uint8_t* relu_mask, const uint32_t* res1_row,
+                         const uint32_t* res2_row, void* stream);
 /* Backward of the above: masks gout by (out > 0) when relu, adds it into gres1/gres2 (stores it
  * instead where `overwrite` bit 0 / bit 1 is set: the first writer of a gradient slot), window-sums
  * it to the conv resolution, then (has_bn) dgamma/dbeta and dz = gamma*invstd*(g - dbeta/M -
@@ -464,6 +471,13 @@ typedef struct mval_train_op {
    * bits of one byte there and the backward takes the ReLU mask from it instead of reading `out` (ops with relu, a residual
    * and no upsample; 0 = none). */
   int64_t mask_off;
+  /* Round 4: the training forward's convs on the P2 kernels (csrc/conv_p2.hip, raw fp32 NHWC z out + batch-statistics partials).
+   * fwd_p2 != 0: this op's conv reads its input as P2 planes at in_p2_off with rows at in_p2_rows_off (float offsets into `arena`;
+   * weights packed MVAL_PACK_MFMA16_H2 at op.w_off).  out_p2_off > 0: this op's BatchNorm apply ALSO writes its output as P2 planes
+   * there (rows at out_p2_rows_off, n_images * MVAL_P2_ROW dwords, zero-initialised once by the caller); res1_amax_off /
+   * res2_amax_off: the magnitude rows ([count, partials]) of its residuals, needed for the P2 scale (0: none / no residual). */
+  int32_t fwd_p2, reserved2;
+  int64_t in_p2_off, in_p2_rows_off, out_p2_off, out_p2_rows_off, res1_amax_off, res2_amax_off;
 } mval_train_op;
 
 /* ones_off / zeros_off: params offsets of >= max(cout) floats of 1.0 / 0.0.

@@ -110,6 +110,14 @@ __device__ __forceinline__ unsigned p2_wave_umax(unsigned m) {
   const unsigned c = (unsigned)__builtin_amdgcn_readlane((int)m, 32), d = (unsigned)__builtin_amdgcn_readlane((int)m, 48);
   return max(max(a, b), max(c, d));
 }
+// Sum over each 16-lane row of the wave, in every lane of the row (four DPP steps, fixed order: deterministic)
+__device__ __forceinline__ float p2_row16_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false));   // quad_perm [2,3,0,1]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, false));  // row_half_mirror
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, false));  // row_mirror
+  return v;
+}
 // ... and their maximum (uniform over the wave)
 __device__ __forceinline__ float p2_row_amax(const P2RowRegs& r) {
   unsigned m = r.v[0];
@@ -157,6 +165,14 @@ struct P2Args {
   unsigned* out_row;
   _Float16* out;    // P2 planes ...
   float* out_f32;   // ... or fp32 NCHW (the heat-map layer)
+  // ... or (training forward, round 4: EPI 3) the RAW conv output z = acc * 2^-s as fp32 NHWC, for train-mode BatchNorm; bn_part != nullptr:
+  // every (workgroup, pixel-wave) also leaves the per-channel (sum, sum of squares) of what it stored over its whole tile walk,
+  // float64 [cout][bn_slots][2] (bn_slots = wgs_x * WM, filled by the launcher and reported in *bn_slots_host)
+  float* out_nhwc;
+  double* bn_part;
+  int64_t bn_part_cap;
+  int* bn_slots_host;
+  int bn_slots;
   unsigned long long* argmax_keys;  // heat-map layer: != nullptr = also keep the arg-max keys of every map, [N][MVAL_ARGMAX_SLOTS][Cout] (mval_common.h)
   int N, Hin, Win, Cin, Hout, Wout, Cout;  // Hout / Wout before the fused upsample
   int k, stride;

@@ -91,8 +91,9 @@ __device__ __forceinline__ f32x4 p2_mfma(const u32x4 a, const u32x4 b, const f32
 // (also across tiles), and at the start of a tile's last stage everything its epilogue needs (scale rows, residual
 // granules, BN factors), so the epilogue is arithmetic and stores.
 // EPI: 0 = P2 planes out (residuals at the conv resolution), 1 = P2 planes out through the fused nearest upsample (the 1x1
-// convs of the fuse layers), 2 = fp32 NCHW out (the heat-map layer) -- separate instantiations: one kernel with all three
-// epilogues spilled ~50-100 registers in every hot instantiation.
+// convs of the fuse layers), 2 = fp32 NCHW out (the heat-map layer), 3 = raw fp32 NHWC out + BatchNorm batch-statistics
+// partials (the TRAINING forward, round 4) -- separate instantiations: one kernel with all three epilogues spilled ~50-100
+// registers in every hot instantiation.
 // OW > 0 ("odd" tiles, round 4: HRNet-W48's 24 x 18 and 12 x 9 maps): the tile is OW = Wout columns wide and
 // floor(16 MS WM / OW) rows high -- full-width rows, pixel slot p -> (p / OW, p % OW), the slots past the last whole row are
 // padding.  On such maps the power-of-two tiles compute 1.33x (24 x 18 in 8 x 8 tiles) to 2.4x (12 x 9) the pixels that exist
@@ -112,7 +113,7 @@ __global__ __launch_bounds__(64 * WN * WM) __attribute__((amdgpu_waves_per_eu(P2
   constexpr int TH = 16 * MS * WM / TWE, TW_LOG2 = TW == 8 ? 3 : TW == 16 ? 4 : TW == 32 ? 5 : 6;
   static_assert(OW || (TH * TW == 16 * MS * WM && (TW == 8 || TW == 16 || TW == 32 || TW == 64)), "tile shape");
   static_assert(!RS || TW == 16, "row sharing: 16-wide tiles");
-  static_assert(OW == 0 || (!RS && S == 1 && EPI == 0 && TH >= 1), "odd tiles: stride 1, P2 planes out, no row sharing");
+  static_assert(OW == 0 || (!RS && S == 1 && (EPI == 0 || EPI == 3) && TH >= 1), "odd tiles: stride 1, no fused upsample, no row sharing");
   constexpr int PH = (TH - 1) * S + KS, PW = (TWE - 1) * S + KS, PWh = (PW + 1) >> 1;
   constexpr int slots = S == 1 ? PH * PW : 2 * PH * PWh;
   constexpr int PPX = (slots + 15) & ~15;  // slots per 8-channel block (256-byte aligned blocks)
@@ -129,7 +130,36 @@ __global__ __launch_bounds__(64 * WN * WM) __attribute__((amdgpu_waves_per_eu(P2
   const int xg = (int)blockIdx.x % X;
   int tile = xg * per + (int)blockIdx.x / X;
   const int tile_end = min(a.tiles_total, (xg + 1) * per);
-  if (tile >= tile_end) return;
+  // (EPI 3) batch-statistics sums of the lane's four output channels per cout sub-tile, over the workgroup's whole tile walk
+  float bsum[EPI == 3 ? NT : 1][4], bsq[EPI == 3 ? NT : 1][4];
+  auto stats_put = [&]() {
+    if constexpr (EPI == 3) {
+      if (!a.bn_part || !wave_active) return;
+      const int cqs = ((lane >> 4) & 1) * 8 + (lane >> 5) * 4;
+#pragma unroll
+      for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const float s1 = p2_row16_sum(bsum[nt][j]), s2 = p2_row16_sum(bsq[nt][j]);
+          const int c = (ns0 + nt) * 16 + cqs + j;
+          if ((lane & 15) == 0 && c < a.Cout) {
+            double* d = a.bn_part + ((int64_t)c * a.bn_slots + (int64_t)blockIdx.x * WM + wm) * 2;
+            d[0] = (double)s1;
+            d[1] = (double)s2;
+          }
+        }
+    }
+  };
+  if constexpr (EPI == 3) {
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+      for (int j = 0; j < 4; j++) bsum[nt][j] = bsq[nt][j] = 0.f;
+  }
+  if (tile >= tile_end) {
+    stats_put();  // (a workgroup without tiles still owns its slots of the partials)
+    return;
+  }
   const int tiles_img = a.tiles_x * a.tiles_y;
   int tn, toy, tox;  // the tile being computed: image, first output row / column
   auto decode = [&](int t, int& n, int& oy0, int& ox0) {  // (t / d as a multiply: magic = 2^32 / d + 1, t * d < 2^32)
@@ -222,26 +252,27 @@ __global__ __launch_bounds__(64 * WN * WM) __attribute__((amdgpu_waves_per_eu(P2
   // output / residual planes through buffer descriptors: per tile ONE per-lane 32-bit byte offset (+ a scalar offset per
   // pixel sub-tile); lanes outside the image or past Cout get offset 2^31 and the range check drops them -- the
   // epilogue has no branches and no 64-bit address arithmetic (the tensors are below 2^31 bytes: the launcher checks)
-  const unsigned obytes = a.out_f32 ? 0u : (unsigned)((int64_t)a.N * (a.Cout >> 3) * (a.Hout << a.up) * (a.Wout << a.up) * 32);
+  const unsigned obytes = (a.out_f32 || EPI == 3) ? 0u : (unsigned)((int64_t)a.N * (a.Cout >> 3) * (a.Hout << a.up) * (a.Wout << a.up) * 32);
+  const __amdgpu_buffer_rsrc_t zr = __builtin_amdgcn_make_buffer_rsrc(a.out_nhwc, 0, EPI == 3 ? (unsigned)((int64_t)a.N * a.Hout * a.Wout * a.Cout * 4) : 0u, 0x00020000);
   const __amdgpu_buffer_rsrc_t orr = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, obytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t r1r = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(a.res1), 0, a.res1 ? obytes : 0u, 0x00020000);
   const __amdgpu_buffer_rsrc_t r2r = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(a.res2), 0, a.res2 ? obytes : 0u, 0x00020000);
   // lane -> (row, column) inside a 16-pixel sub-tile, and the sub-tile's own (row, column) inside the tile
   const int ly = OW ? 0 : TW == 8 ? (lane >> 3) & 1 : 0, lx = OW ? 0 : TW == 8 ? lane & 7 : lane & 15;
-  const float bound_a = a.out_f32 ? 0.f : a.bound[0], bound_b = a.out_f32 ? 0.f : a.bound[1];
+  const float bound_a = (a.out_f32 || EPI == 3) ? 0.f : a.bound[0], bound_b = (a.out_f32 || EPI == 3) ? 0.f : a.bound[1];
   const int Ho = a.Hout << a.up, Wo = a.Wout << a.up, rep = 1 << a.up;
   const int C8o = a.Cout >> 3;
   const int64_t oplane = (int64_t)C8o * Ho * Wo * 8;  // halves per plane of one image
   // odd tiles: the lane's pixel of sub-tile ms -> its row inside the tile (-1: padding slot) and its byte offset from the
   // tile's first pixel inside an 8-channel block of the output planes
-  int opty[OW ? MS : 1], opix[OW ? MS : 1];
+  int opty[OW ? MS : 1], opix[OW ? MS : 1];  // (EPI 3: opix holds the column instead)
   if constexpr (OW > 0) {
 #pragma unroll
     for (int ms = 0; ms < MS; ms++) {
       const int p = (wm * MS + ms) * 16 + (lane & 15);
       const int ty = p / TWE, tx = p - ty * TWE;
       opty[ms] = ty < TH ? ty : -1;
-      opix[ms] = (ty * Wo + tx) * 16;
+      opix[ms] = EPI == 3 ? tx : (ty * Wo + tx) * 16;
     }
   }
 
@@ -454,7 +485,7 @@ __global__ __launch_bounds__(64 * WN * WM) __attribute__((amdgpu_waves_per_eu(P2
     if (wave_active) {
       const float in_inv = __uint_as_float(row_in.inv);
       float r1_inv = 0.f, r2_inv = 0.f, out_mul = 1.f, out_inv = 1.f;
-      if constexpr (EPI != 2) {
+      if constexpr (EPI < 2) {
         float bound = bound_a * p2_row_amax(row_in) + bound_b;
         if (a.res1) {
           bound += p2_row_amax(row_r1);
@@ -523,7 +554,40 @@ __global__ __launch_bounds__(64 * WN * WM) __attribute__((amdgpu_waves_per_eu(P2
       };
       using T_ = std::true_type;
       using F_ = std::false_type;
-      if constexpr (EPI == 2) {  // the heat-map layer: fp32 NCHW, no residuals, no upsample
+      if constexpr (EPI == 3) {
+        // training forward: z = acc * 2^-s (no BatchNorm factors, no activation) as fp32 NHWC -- a lane's four couts of a pixel are
+        // 16 contiguous bytes, the four quarters of a 16-cout sub-tile 64 -- and the running (sum, sum of squares) per channel
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++) {
+          const int c0 = (ns0 + nt) * 16 + cq;
+#pragma unroll
+          for (int ms = 0; ms < MS; ms++) {
+            int y, x;
+            bool ok;
+            if constexpr (OW > 0) {
+              y = oy0 + opty[ms];
+              x = opix[ms];
+              ok = opty[ms] >= 0 && y < a.Hout;
+            } else {
+              y = yl + sub_ty(ms);
+              x = xl + sub_tx(ms);
+              ok = y < a.Hout && x < a.Wout;
+            }
+            ok = ok && c0 < a.Cout;
+            const f32x4 v = acc[ms][nt] * unscale;
+            const unsigned zo = ok ? (unsigned)((((unsigned)n * a.Hout + y) * a.Wout + x) * a.Cout + c0) * 4u : 0x80000000u;
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), zr, zo, 0, 0);
+            asm volatile("s_nop 1");
+            if (ok) {
+#pragma unroll
+              for (int j = 0; j < 4; j++) {
+                bsum[nt][j] += v[j];
+                bsq[nt][j] = __builtin_fmaf(v[j], v[j], bsq[nt][j]);
+              }
+            }
+          }
+        }
+      } else if constexpr (EPI == 2) {  // the heat-map layer: fp32 NCHW, no residuals, no upsample
 #pragma unroll
         for (int nt = 0; nt < NT; nt++) {
           const int c0 = (ns0 + nt) * 16 + cq;
@@ -600,7 +664,7 @@ __global__ __launch_bounds__(64 * WN * WM) __attribute__((amdgpu_waves_per_eu(P2
         }
       }
     }
-    if constexpr (EPI != 2) {
+    if constexpr (EPI < 2) {
       // the workgroup's max |x| without a barrier: LDS atomics, the wave that arrives last publishes and re-arms
       const unsigned amax_bits = p2_wave_umax(__float_as_uint(amax));
       if (lane == 0) {
@@ -626,6 +690,7 @@ __global__ __launch_bounds__(64 * WN * WM) __attribute__((amdgpu_waves_per_eu(P2
     buf ^= 1;
     tile = next_tile;
   }
+  stats_put();
   P2_FLUSH;
   P2_MARK(4);
 }
@@ -664,15 +729,22 @@ static int launch_p2e(P2Args a, hipStream_t s) {
   if (pe && atoi(pe) > 0) per_cu = atoi(pe);
   int wgs = (mval_cu_count() * per_cu / (int)groups) & ~7;
   if (wgs < 8) wgs = 8;
-  if (wgs >= a.tiles_total) wgs = a.tiles_total;
+  // (a count >= 8 must be a multiple of 8: the kernel walks 8 XCD groups in steps of wgs / 8 -- with 12 workgroups for 12 tiles the
+  // floor made four tiles run twice: harmless for stored outputs, wrong for the batch-statistics sums of EPI 3)
+  if (wgs >= a.tiles_total) wgs = a.tiles_total < 8 ? a.tiles_total : (a.tiles_total + 7) & ~7;
   else {  // equal shares: the XCD groups' ranges are walked in steps of wgs / 8
     const int per = (a.tiles_total + 7) / 8, rounds = (per + wgs / 8 - 1) / (wgs / 8);
     wgs = 8 * ((per + rounds - 1) / rounds);
   }
   a.wgs_x = wgs;
   dim3 grid((unsigned)wgs, groups);
-  if (!a.out_f32 && (int64_t)a.amax_tiles * groups > P2_SLOTS)
+  if (EPI < 2 && (int64_t)a.amax_tiles * groups > P2_SLOTS)
     mval_launch_zero_rows(a.out_row, (int64_t)a.N * P2_ROW, s);  // (the kernel rewrites the scale slots)
+  if constexpr (EPI == 3) {
+    a.bn_slots = wgs * WM;
+    if (a.bn_part && (int64_t)a.Cout * a.bn_slots * 2 > a.bn_part_cap) a.bn_part = nullptr;  // (no room: the caller runs the separate statistics pass)
+    if (a.bn_part && a.bn_slots_host) *a.bn_slots_host = a.bn_slots;
+  }
   hipLaunchKernelGGL((conv_p2_kernel<KS, S, G, WN, WM, NT, MS, TW, RS, EPI, OW>), grid, dim3(NTH), smem, s, a);
   return 0;
 }
@@ -681,7 +753,13 @@ template <int KS, int S, int G, int WN, int WM, int NT, int MS, int TW, bool RS 
 static int launch_p2(const P2Args& a, hipStream_t s) {
   if constexpr (OW > 0) {
     if (a.out_f32 || a.up) return 1;
+    if (a.out_nhwc) return launch_p2e<KS, S, G, WN, WM, NT, MS, TW, RS, 3, OW>(a, s);
     return launch_p2e<KS, S, G, WN, WM, NT, MS, TW, RS, 0, OW>(a, s);
+  }
+  if (a.out_nhwc) {
+    if (a.up || a.res1 || a.res2 || a.out_f32) return 1;
+    if constexpr (MS <= 4 || KS == 3) return launch_p2e<KS, S, G, WN, WM, NT, MS, TW, RS, 3>(a, s);
+    return 1;
   }
   if (a.out_f32) {
     if constexpr (KS == 1 && NT == 1 && MS <= 4) return launch_p2e<KS, S, G, WN, WM, NT, MS, TW, RS, 2>(a, s);
@@ -703,7 +781,7 @@ static void p2_override(int& ms, int& nt, int& g) {
 int mval_launch_conv_p2(const P2Args& a0, hipStream_t s) {
   P2Args a = a0;
   a.NS_total = (a.Cout + 15) / 16;
-  if ((a.Cin & 7) || (!a.out_f32 && (a.Cout & 7))) return 1;
+  if ((a.Cin & 7) || (!a.out_f32 && !a.out_nhwc && (a.Cout & 7)) || (a.out_nhwc && (a.Cout & 3))) return 1;
   if (a.out_f32 && (a.up || a.res1 || a.res2)) return 1;
   if ((int64_t)a.N * a.Hin * a.Win * a.Cin >= (int64_t)1 << 29) return 1;  // byte offsets into the planes below 2^31
   if ((int64_t)a.N * (a.Hout << a.up) * (a.Wout << a.up) * a.Cout >= (int64_t)1 << 29) return 1;

@@ -14,7 +14,7 @@
 // first writer of every slot (mval_train_op.first_touch: bit 0 data gradient, bit 1 / 2 residual
 // gradients), which stores instead of accumulating, so the arena is never zero-filled and fan-out
 // (residual skips, HRNet fuse layers, transitions) needs no special casing.
-#include "conv_common.h"
+#include "conv_p2.h"
 
 extern "C" int mval_bn_batch_stats(const float*, int64_t, int, float, float, float*, float*, float*, float*, double*,
                                    void*);
@@ -25,6 +25,8 @@ extern "C" int mval_bn_apply_fwd_mask(const float*, const float*, const float*, 
 extern "C" int mval_bn_bwd_fused_mask(const float*, const float*, const uint8_t*, const float*, const float*, const float*, const float*,
                                       const float*, float*, float*, float*, float*, float*, double*, float*, int, int, int, int, int, int,
                                       uint32_t*, void*);
+extern "C" int mval_bn_apply_fwd_p2(const float*, const float*, const float*, const float*, const float*, const float*, const float*, float*,
+                                    void*, uint32_t*, int, int, int, int, int, int, uint32_t*, uint8_t*, const uint32_t*, const uint32_t*, void*);
 extern "C" int mval_bn_finalize_stats(const double*, int, int64_t, int, float, float, float*, float*, float*, float*, void*);
 extern "C" int mval_bn_bwd_fused(const float*, const float*, const float*, const float*, const float*, const float*, const float*,
                                  float*, float*, float*, float*, float*, double*, float*, int, int, int, int, int, int, uint32_t*,
@@ -231,7 +233,32 @@ extern "C" int mval_train_forward(const mval_train_op* ops, int n_ops, int n_ima
         a.bn_part_cap = ws_doubles;
         a.bn_tiles_host = &tiles;
       }
-      {
+      if (t.fwd_p2) {
+        // the conv on the P2 kernels: input planes written by the producer's apply, raw z as fp32 NHWC, statistics partials per
+        // (persistent workgroup, pixel wave)
+        MVAL_REQUIRE(op.kind == MVAL_OP_CONV && t.in_p2_off > 0 && t.in_p2_rows_off > 0, "mval_train_forward: op %d: P2 conv without its input planes", i);
+        P2Args p = {};
+        p.in = reinterpret_cast<const _Float16*>(arena + t.in_p2_off);
+        p.in_row = reinterpret_cast<const unsigned*>(arena + t.in_p2_rows_off);
+        p.w = params + op.w_off;
+        p.w_unscale = p.w + mval_packed_weight_floats(MVAL_PACK_MFMA16_H2, op.cout, op.cin, op.k) - 4;
+        p.scale = params + ones_off;
+        p.shift = params + zeros_off;
+        p.out_nhwc = arena + t.z_off;
+        p.N = n_images; p.Hin = op.hin; p.Win = op.win; p.Cin = op.cin; p.Hout = op.hout; p.Wout = op.wout; p.Cout = op.cout;
+        p.k = op.k; p.stride = op.stride;
+        if (epi_stats) {
+          p.bn_part = ws;
+          p.bn_part_cap = ws_doubles;
+          p.bn_slots_host = &tiles;
+        }
+        TtScope tt(TT_CONV_FWD, s);
+        if (mval_launch_conv_p2(p, s)) {
+          mval_set_error("mval_train_forward: op %d: no P2 kernel (k%d s%d cin%d cout%d %dx%d)", i, op.k, op.stride, op.cin, op.cout, op.hin, op.win);
+          return -1;
+        }
+        rc = 0;
+      } else {
         TtScope tt(TT_CONV_FWD, s);
         rc = run_conv(a, op.algo, s, "mval_train_forward/conv");
       }
@@ -248,6 +275,15 @@ extern "C" int mval_train_forward(const mval_train_op* ops, int n_ops, int n_ima
       }
       if (rc) return rc;
       TtScope tt(TT_BN_APPLY, s);
+      if (t.out_p2_off > 0)
+        rc = mval_bn_apply_fwd_p2(a.out, t.mean, t.invstd, t.gamma, t.beta, op.res1_off >= 0 ? arena + op.res1_off : nullptr,
+                                  op.res2_off >= 0 ? arena + op.res2_off : nullptr, out, arena + t.out_p2_off,
+                                  reinterpret_cast<uint32_t*>(arena + t.out_p2_rows_off), n_images, op.hout, op.wout, op.cout, op.up, op.relu,
+                                  t.out_amax_off > 0 ? reinterpret_cast<uint32_t*>(arena + t.out_amax_off) : nullptr,
+                                  t.mask_off > 0 ? reinterpret_cast<uint8_t*>(arena + t.mask_off) : nullptr,
+                                  t.res1_amax_off > 0 ? reinterpret_cast<const uint32_t*>(arena + t.res1_amax_off) : nullptr,
+                                  t.res2_amax_off > 0 ? reinterpret_cast<const uint32_t*>(arena + t.res2_amax_off) : nullptr, stream);
+      else
       rc = mval_bn_apply_fwd_mask(a.out, t.mean, t.invstd, t.gamma, t.beta, op.res1_off >= 0 ? arena + op.res1_off : nullptr,
                                   op.res2_off >= 0 ? arena + op.res2_off : nullptr, out, n_images, op.hout, op.wout, op.cout,
                                   op.up, op.relu, t.out_amax_off > 0 ? reinterpret_cast<uint32_t*>(arena + t.out_amax_off) : nullptr,

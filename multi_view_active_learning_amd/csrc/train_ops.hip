@@ -5,7 +5,7 @@
 // ``batch_loss.backward()``).  All tensors NHWC fp32; every kernel is an HBM-bound stream with
 // float4 lanes along channels; per-channel reductions accumulate in float64 and are
 // two-stage (per-workgroup partials -> finalize) so results are deterministic.
-#include "mval_common.h"
+#include "conv_p2.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -259,6 +259,122 @@ extern "C" int mval_bn_apply_fwd(const float* z, const float* mean, const float*
                                  const float* beta, const float* res1, const float* res2, float* out, int N, int H,
                                  int W, int C, int up, int relu, void* stream) {
   return mval_bn_apply_fwd_amax(z, mean, invstd, gamma, beta, res1, res2, out, N, H, W, C, up, relu, nullptr, stream);
+}
+
+// ---- forward apply that ALSO writes the activation as P2 planes (round 4: the training forward's convs on conv_p2.hip) ----------
+// out = act(((bn(z) up) + res1) + res2) as fp32 NHWC (residual consumers, weight gradients) AND as the fp16 plane pairs
+// [n][plane][C/8][Ho][Wo][8] the P2 convs stage by copy.  The P2 scale must exist before the first store: it comes from a rigorous
+// a-priori bound of train-mode BatchNorm's output -- Samuelson's inequality: |z_i - mean| <= std * sqrt(M - 1) over the M samples of
+// a channel, so |bn(z)| <= |gamma| sqrt(M - 1) + |beta| -- plus the exact maxima of the residuals (their magnitude rows).  On the
+// BASELINE shapes the bound sits 2^4 .. 2^7 above the actual maximum (|xhat| reaches 4 - 6 of sqrt(M - 1) = 90 .. 724): inside the
+// range where the pair keeps all 22 bits (conv_p2.h).  One scale for the tensor (BatchNorm couples the batch anyway): every image's row
+// gets the same 2^-s.  Thread = 8 channels of one pixel, sixteen consecutive pixels per 8-channel block and half-wave quarter: 128-byte
+// NHWC reads, 256-byte P2 stores.
+__global__ __launch_bounds__(TR_APPLY_THREADS) void bn_apply_fwd_p2_kernel(
+    const float* __restrict__ z, const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
+    const float* __restrict__ beta, const float* __restrict__ res1, const float* __restrict__ res2, float* __restrict__ out,
+    _Float16* __restrict__ planes, unsigned* __restrict__ p2_rows, int N, int H, int W, int C, int up, int relu,
+    unsigned* __restrict__ amax_row, unsigned char* __restrict__ relu_mask, const unsigned* __restrict__ res1_row,
+    const unsigned* __restrict__ res2_row, float sqrt_m1) {
+  // A workgroup handles blocks of 4096 float4 = BP consecutive output pixels x C channels: the NHWC side (z, residuals, fp32 out, mask
+  // bytes) is read and written in float4 order (fully coalesced, as bn_apply_fwd_kernel), the (h, l) halves go through LDS as
+  // [plane][8-channel block][pixel][16 B] and leave as 16-byte granules, BP contiguous pixels per block and plane (>= 1 KiB runs).
+  extern __shared__ __attribute__((aligned(16))) char p2sh[];  // 2 planes x 4096 x 8 bytes = 64 KB
+  const int c4n = C >> 2, C8 = C >> 3;
+  const int BP = 4096 / c4n;  // pixels per block (48-channel multiples: BP * c4n < 4096, the tail items idle)
+  const int Ho = H << up, Wo = W << up;
+  const int HWo = Ho * Wo;
+  const int64_t npx = (int64_t)N * HWo;
+  // the tensor's scale (every wave computes it: a few loads per lane)
+  float bnd = 0.f;
+  for (int c = threadIdx.x & 63; c < C; c += 64) bnd = fmaxf(bnd, __builtin_fmaf(fabsf(gamma[c]), sqrt_m1, fabsf(beta[c])));
+  bnd = __uint_as_float(p2_wave_umax(__float_as_uint(bnd))) * (1.f + 1e-6f);
+  if (res1_row) bnd += __uint_as_float(conv_amax_read(res1_row));
+  if (res2_row) bnd += __uint_as_float(conv_amax_read(res2_row));
+  float out_mul, out_inv;
+  p2_scale_of(bnd, out_mul, out_inv);
+  if (blockIdx.x == 0)
+    for (int n = threadIdx.x; n < N; n += TR_APPLY_THREADS) p2_rows[(int64_t)n * P2_ROW + P2_INV_SLOT] = __float_as_uint(out_inv);
+  const int64_t nblocks = (npx + BP - 1) / BP;
+  const int64_t plane_halves = (int64_t)C8 * HWo * 8;
+  const int lplane = 4096 * 8;  // bytes of one plane's LDS image
+  float amax = 0.f;
+  for (int64_t blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
+    const int64_t p0 = blk * BP;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int e = threadIdx.x + TR_APPLY_THREADS * i;  // float4 of the block: pixel e / c4n, channel quad e % c4n
+      const int pl = e / c4n, q = e - pl * c4n;
+      const int64_t pix = p0 + pl;
+      if (pl < BP && pix < npx) {
+        const int n = (int)(pix / HWo), pin = (int)(pix - (int64_t)n * HWo);
+        const int Y = pin / Wo, X = pin - Y * Wo;
+        const int64_t zi = (((int64_t)n * H + (Y >> up)) * W + (X >> up)) * C + q * 4;
+        const int64_t o = pix * C + q * 4;
+        const f32x4 zv = *reinterpret_cast<const f32x4*>(z + zi);
+        const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + q * 4);
+        const f32x4 is = *reinterpret_cast<const f32x4*>(invstd + q * 4);
+        const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + q * 4);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(beta + q * 4);
+        f32x4 rr = bn_affine(zv, mu, is, g, b);
+        if (res1) rr += *reinterpret_cast<const f32x4*>(res1 + o);
+        if (res2) rr += *reinterpret_cast<const f32x4*>(res2 + o);
+        if (relu) {
+          rr.x = mval_relu(rr.x); rr.y = mval_relu(rr.y); rr.z = mval_relu(rr.z); rr.w = mval_relu(rr.w);
+        }
+        if (out) *reinterpret_cast<f32x4*>(out + o) = rr;
+        if (relu_mask) relu_mask[o >> 2] = (unsigned char)((rr.x > 0.f) | ((rr.y > 0.f) << 1) | ((rr.z > 0.f) << 2) | ((rr.w > 0.f) << 3));
+        amax = fmaxf(fmaxf(amax, fmaxf(fabsf(rr.x), fabsf(rr.y))), fmaxf(fabsf(rr.z), fabsf(rr.w)));
+        p2_f16x4 h, l;
+        p2_split(rr * out_mul, h, l);
+        // LDS image [8-channel block q / 2][pixel pl][half (q & 1)][8 bytes]
+        char* d = p2sh + (((q >> 1) * BP + pl) * 2 + (q & 1)) * 8;
+        *reinterpret_cast<p2_f16x4*>(d) = h;
+        *reinterpret_cast<p2_f16x4*>(d + lplane) = l;
+      }
+    }
+    __syncthreads();
+    // granules out: item = (plane, 8-channel block, pixel), pixel fastest
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int e = threadIdx.x + TR_APPLY_THREADS * i;  // 0 .. 4095 = 2 planes x C8 x BP
+      const int plane = e / (C8 * BP), r = e - plane * (C8 * BP);
+      const int c8 = r / BP, pl = r - c8 * BP;
+      const int64_t pix = p0 + pl;
+      if (plane < 2 && pix < npx) {
+        const int n = (int)(pix / HWo), pin = (int)(pix - (int64_t)n * HWo);
+        const p2_u32x4 gran = *reinterpret_cast<const p2_u32x4*>(p2sh + plane * lplane + (c8 * BP + pl) * 16);
+        *reinterpret_cast<p2_u32x4*>(planes + (((int64_t)n * 2 * C8 + c8) * HWo + pin) * 8 + plane * plane_halves) = gran;
+      }
+    }
+    __syncthreads();
+  }
+  if (amax_row) tr_amax_store(amax_row, amax);
+}
+
+extern "C" int mval_bn_apply_fwd_p2(const float* z, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                                    const float* res1, const float* res2, float* out, void* p2_planes, uint32_t* p2_rows, int N, int H,
+                                    int W, int C, int up, int relu, uint32_t* amax_row, uint8_t* relu_mask, const uint32_t* res1_row,
+                                    const uint32_t* res2_row, void* stream) {
+  MVAL_REQUIRE(z && p2_planes && p2_rows && N > 0 && H > 0 && W > 0 && C > 0 && (C & 7) == 0 && up >= 0, "mval_bn_apply_fwd_p2: bad arguments (C % 8)");
+  MVAL_REQUIRE((!res1 || res1_row) && (!res2 || res2_row), "mval_bn_apply_fwd_p2: a residual needs its magnitude row (the P2 scale is a bound)");
+  MVAL_REQUIRE((int64_t)N * (H << up) * (W << up) * C < ((int64_t)1 << 31), "mval_bn_apply_fwd_p2: tensor too large");
+  MVAL_REQUIRE(C <= 4096, "mval_bn_apply_fwd_p2: more than 4096 channels");
+  const int64_t npx = (int64_t)N * (H << up) * (W << up);
+  const int BP = 4096 / (C >> 2);
+  int nb = (int)((npx + BP - 1) / BP);
+  if (nb > TR_APPLY_BLOCKS) nb = TR_APPLY_BLOCKS;
+  const double M = (double)N * H * W;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bn_apply_fwd_p2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(bn_apply_fwd_p2_kernel, dim3(nb), dim3(TR_APPLY_THREADS), 64 * 1024, mval_stream(stream), z, mean, invstd, gamma, beta, res1,
+                     res2, out, reinterpret_cast<_Float16*>(p2_planes), p2_rows, N, H, W, C, up, relu, amax_row, relu_mask, res1_row, res2_row,
+                     (float)sqrt(M > 1 ? M - 1.0 : 1.0));
+  MVAL_CHECK_LAUNCH("mval_bn_apply_fwd_p2");
+  return 0;
 }
 
 // ---- backward, stage 1 ------------------------------------------------------------------

@@ -47,6 +47,9 @@ class MvalTrainOp(C.Structure):
         ("dweight", C.c_void_p), ("dgamma", C.c_void_p), ("dbeta", C.c_void_p),
         ("out_amax_off", C.c_int64), ("gz_amax_off", C.c_int64),
         ("mask_off", C.c_int64),
+        ("fwd_p2", C.c_int32), ("reserved2", C.c_int32),
+        ("in_p2_off", C.c_int64), ("in_p2_rows_off", C.c_int64), ("out_p2_off", C.c_int64), ("out_p2_rows_off", C.c_int64),
+        ("res1_amax_off", C.c_int64), ("res2_amax_off", C.c_int64),
     ]
 
 
@@ -80,6 +83,7 @@ class TrainPlan:
             # the graph output also gets a slot: its NHWC gradient lives at the same offset of garena
             act_off[a.id] = top
             top += _align(n * dims[a.id][0] * dims[a.id][1] * a.channels)
+        self._act_top = top  # (the gradient arena mirrors the activation slots only)
         z_off = []
         for i, op in enumerate(g.ops):
             if op.bn:
@@ -208,6 +212,45 @@ class TrainPlan:
             stat_top += 2 * _align(op.cout)
             gz_max = max(gz_max, n * hout * wout * op.cout)
             wsf_max = max(wsf_max, int(lib.mval_conv_wgrad_workspace_floats(C.c_int(op.cin), C.c_int(op.cout), C.c_int(op.k))))
+        # Round 4: forward convs on the P2 kernels (conv_p2.hip EPI 3) where the op's fp16-split conv qualifies: the producer's
+        # BatchNorm apply also writes the activation as P2 planes (mval_bn_apply_fwd_p2); the residuals of such producers need
+        # magnitude rows (the P2 scale is an a-priori bound + the residuals' exact maxima).  MVAL_TRAIN_P2=0: round 3's h2 forward.
+        P2_ROW = 512
+        producer = {op.dst: k for k, op in enumerate(g.ops)}
+        p2_act = {}
+        self.p2_rows = []
+        if h2 and os.environ.get("MVAL_TRAIN_P2", "1") != "0":
+            for i, op in enumerate(g.ops):
+                t = self.ops[i]
+                k = producer.get(op.src)
+                if not (op.kind == "conv" and op.bn and t.op.algo == ALGO_MFMA_H2 and k is not None and g.ops[k].bn and g.ops[k].cout % 8 == 0
+                        and op.cout % 4 == 0):
+                    continue
+                hin, win, hout, wout = geo[i]
+                d = MvalOp()
+                d.kind, d.k, d.stride, d.pad, d.cin, d.cout = 0, op.k, op.stride, op.pad, op.cin, op.cout
+                d.hin, d.win, d.hout, d.wout = hin, win, hout, wout
+                if not lib.mval_op_algo_supported(C.byref(d), C.c_int(n), C.c_int(4)):  # (MVAL_ALGO_MFMA_P2)
+                    continue
+                if op.src not in p2_act:
+                    planes = self._row_top
+                    self._row_top += _align(n * hin * win * op.cin)
+                    rows = self._row_top
+                    self._row_top += _align(n * P2_ROW)
+                    p2_act[op.src] = (planes, rows)
+                    self.p2_rows.append((rows, n * P2_ROW))
+                t.fwd_p2 = 1
+                t.in_p2_off, t.in_p2_rows_off = p2_act[op.src]
+            for a_, (planes, rows) in p2_act.items():
+                k = producer[a_]
+                pt, po = self.ops[k], g.ops[k]
+                pt.out_p2_off, pt.out_p2_rows_off = planes, rows
+                for r_, name in ((po.res1, "res1_amax_off"), (po.res2, "res2_amax_off")):
+                    if r_ is not None:
+                        if r_ not in amax_row:
+                            amax_row[r_] = self._row_top
+                            self._row_top += TRAIN_AMAX_ROW
+                        setattr(pt, name, amax_row[r_])
         for i, op in enumerate(g.ops):  # producers leave max |out| where a split conv will look for it
             self.ops[i].out_amax_off = amax_row.get(op.dst, 0)
         # ReLU behind residual adds (BasicBlock / Bottleneck outputs, fuse sums at the conv resolution): the forward apply keeps
@@ -243,7 +286,9 @@ class TrainPlan:
         self.param_floats = ptop
         f32 = dict(dtype=torch.float32, device=device)
         self.arena = torch.empty(self.arena_floats, **f32)
-        self.garena = torch.empty(self.arena_floats, **f32)
+        for off, cnt in self.p2_rows:  # P2 rows: unused partial slots must read as zero (csrc/conv_p2.h); the scale slot is rewritten every forward
+            self.arena[off : off + cnt].zero_()
+        self.garena = torch.empty(max(self._act_top, 64), **f32)
         self.params = torch.zeros(self.param_floats, **f32)
         self.params[self.ones_off : self.ones_off + maxc] = 1.0
         self.stats = torch.zeros(max(stat_top, 64), **f32)
