@@ -431,6 +431,8 @@ int mval_conv_dgrad(const float* dz, const float* w_packed, const float* ones, c
  * launch (16 tap-pixels per dz pixel instead of the zero-dilated form's 36; the fp16 split applies).  algo: MVAL_ALGO_MFMA_BF3
  * or _H2 (then dz_amax_row); w_packed: mval_pack_conv_weights(pack, transposed = 4, w, ..., cout' = cin, cin' = cout, k = 4)
  * from the conv's own [cout][cin][3][3] weight.  _supported: 1 when a kernel exists for the shape. */
+/* 1 when the split weight-gradient kernel that can read x as P2 planes covers the conv (3x3 stride 1 / 2, wide 1x1; cin % 8 == 0). */
+int mval_conv_wgrad_p2_covers(int cin, int cout, int k, int stride);
 int mval_conv_dgrad_parity_supported(int N, int hin, int win, int cin, int hout, int wout, int cout, int algo);
 int mval_conv_dgrad_parity(const float* dz, const float* w_packed, const float* ones, const float* zeros, float* dx,
                            int accumulate, int N, int hin, int win, int cin, int hout, int wout, int cout, int algo,
@@ -476,7 +478,9 @@ typedef struct mval_train_op {
    * weights packed MVAL_PACK_MFMA16_H2 at op.w_off).  out_p2_off > 0: this op's BatchNorm apply ALSO writes its output as P2 planes
    * there (rows at out_p2_rows_off, n_images * MVAL_P2_ROW dwords, zero-initialised once by the caller); res1_amax_off /
    * res2_amax_off: the magnitude rows ([count, partials]) of its residuals, needed for the P2 scale (0: none / no residual). */
-  int32_t fwd_p2, reserved2;
+  int32_t fwd_p2;
+  int32_t p2_flags; /* bit 0: this op's weight gradient reads its input from the P2 planes (mval_conv_wgrad_p2_covers); bit 1: this op's
+                     * apply writes ONLY the P2 planes (every consumer of its output reads those: no fp32 NHWC copy) */
   int64_t in_p2_off, in_p2_rows_off, out_p2_off, out_p2_rows_off, res1_amax_off, res2_amax_off;
 } mval_train_op;
 

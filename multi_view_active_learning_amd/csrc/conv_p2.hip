@@ -29,7 +29,13 @@
 #ifdef P2_W3
 #define P2_WAVES(MS, NT, EPI) (((MS) * (NT) <= 4 && (EPI) == 0) ? 3 : 2)
 #else
+// (EPI 3, the training forward: no residual granules, no output split -- 117 .. 147 registers on the light configurations, so a
+// third wave per SIMD fits; MVAL measured below)
+#ifdef P2_EPI3_W3
+#define P2_WAVES(MS, NT, EPI) (((EPI) == 3 && (MS) * (NT) <= 4) ? 3 : 2)
+#else
 #define P2_WAVES(MS, NT, EPI) 2
+#endif
 #endif
 
 #ifndef P2_VALU_PRIO

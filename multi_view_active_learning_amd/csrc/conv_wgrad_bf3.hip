@@ -46,6 +46,11 @@ struct WgradBf3Args {
   int tiles_x, tiles_y, ntiles, PS;
   const unsigned* x_amax;   // PL = 2: magnitude rows ([count, partials], one row per tensor) of x and dz
   const unsigned* dz_amax;
+  // XP2 (round 4): x as P2 planes [n][plane h,l][Cin/8][Hin][Win][8] with its rows (csrc/conv_p2.h; ONE scale for the tensor in
+  // training: row 0's 2^-s) -- the activation the training forward's P2 convs read; staging is a 16-byte copy per (pixel, 8 channels,
+  // plane) instead of a float4 load + scale + split
+  const _Float16* x_p2;
+  const unsigned* x_p2_rows;
 };
 
 __device__ __forceinline__ void wb_split_pair(const f32x2 x, unsigned& h, unsigned& m, unsigned& l) {
@@ -99,8 +104,10 @@ __device__ __forceinline__ void wb_scale(unsigned amax_bits, float& mul, float& 
 }
 
 // KS x KS taps, stride S, tile TH x TW output pixels, NT cout tiles and MI cin tiles (of 16) per wave
-template <int PL, int KS, int S, int TH, int TW, int NT, int MI>
+typedef unsigned wb_u32x4 __attribute__((ext_vector_type(4)));
+template <int PL, int KS, int S, int TH, int TW, int NT, int MI, bool XP2 = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((KS == 3 && S == 1 && TH == 8 && NT == 2) ? 2 : 1, 8))) void conv_wgrad_bf3_kernel(WgradBf3Args a) {
+  static_assert(!XP2 || PL == 2, "P2 activations are fp16 pairs");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int T = KS * KS, MT = TH * TW;
   constexpr int PH = (TH - 1) * S + KS, PW = (TW - 1) * S + KS, PPX = PH * PW;
@@ -114,7 +121,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((KS == 3 &&
   float x_mul = 1.f, z_mul = 1.f, unscale = 1.f;
   if constexpr (PL == 2) {
     float xi, zi;
-    wb_scale(conv_amax_read(a.x_amax), x_mul, xi);
+    if constexpr (XP2) xi = __uint_as_float(a.x_p2_rows[511]);  // (P2_INV_SLOT of row 0: one scale for the whole tensor in training)
+    else wb_scale(conv_amax_read(a.x_amax), x_mul, xi);
     wb_scale(conv_amax_read(a.dz_amax), z_mul, zi);
     unscale = xi * zi;
   }
@@ -157,6 +165,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((KS == 3 &&
   const bool cx_ok = ci0 + xq4 < a.Cin, cz_ok = co0 + zq4 < a.Cout;
 
   f32x4 xr[NEX], zr[NEZ];
+  // XP2: item j = tid % XQ of a pixel -> plane j / (CI / 8), 8-channel block j % (CI / 8)  (XQ = CI / 4 = 2 planes x CI / 8 blocks)
+  const int xp_plane = (tid % XQ) / (CI / 8), xp_c8 = (tid % XQ) % (CI / 8);
+  const int C8x = a.Cin >> 3;
+  const int64_t xp_hw = (int64_t)a.Hin * a.Win;
   auto load_tile = [&](int t) {
     const int txi = t % a.tiles_x;
     t /= a.tiles_x;
@@ -164,9 +176,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((KS == 3 &&
 #pragma unroll
     for (int i = 0; i < NEX; i++) {
       const int iy = oy0 * S - pad + xrow[i], ix = ox0 * S - pad + xcol[i];
+      if constexpr (XP2) {
+        const bool ok = tid + 256 * i < PPX * XQ && ci0 + xp_c8 * 8 < a.Cin && (unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win;
+        const wb_u32x4 g = ok ? *reinterpret_cast<const wb_u32x4*>(a.x_p2 + ((((int64_t)n * 2 + xp_plane) * C8x + (ci0 >> 3) + xp_c8) * xp_hw + (int64_t)iy * a.Win + ix) * 8)
+                              : (wb_u32x4){0u, 0u, 0u, 0u};
+        xr[i] = __builtin_bit_cast(f32x4, g);
+      } else {
       const bool ok = tid + 256 * i < PPX * XQ && cx_ok && (unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win;
       xr[i] = ok ? *reinterpret_cast<const f32x4*>(a.x + (((int64_t)n * a.Hin + iy) * a.Win + ix) * a.Cin + ci0 + xq4)
                  : (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
     }
 #pragma unroll
     for (int i = 0; i < NEZ; i++) {
@@ -186,7 +205,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((KS == 3 &&
     for (int i = 0; i < NEX; i++) {
       const int e = tid + 256 * i;
       if (e < PPX * XQ) {
-        if constexpr (PL == 3) wb_split_store(xr[i], xl + (e / XQ) * XROW + (e % XQ) * 8, XPLANE);
+        if constexpr (XP2) *reinterpret_cast<wb_u32x4*>(xl + xp_plane * XPLANE + (e / XQ) * XROW + xp_c8 * 16) = __builtin_bit_cast(wb_u32x4, xr[i]);
+        else if constexpr (PL == 3) wb_split_store(xr[i], xl + (e / XQ) * XROW + (e % XQ) * 8, XPLANE);
         else wb_split_store2(xr[i], x_mul, xl + (e / XQ) * XROW + (e % XQ) * 8, XPLANE);
       }
     }
@@ -261,7 +281,9 @@ template <int KS, int S, int TH, int TW, int NT, int MI>
 static void wb_launch(const WgradBf3Args& a, dim3 grid, hipStream_t s) {
   constexpr int PPX = ((TH - 1) * S + KS) * ((TW - 1) * S + KS);
   constexpr size_t plane = (size_t)PPX * (64 * MI + 32) + (size_t)TH * TW * (64 * NT + 32);
-  if (a.x_amax && a.dz_amax)
+  if (a.x_p2 && a.dz_amax)
+    hipLaunchKernelGGL((conv_wgrad_bf3_kernel<2, KS, S, TH, TW, NT, MI, true>), grid, dim3(256), 2 * plane, s, a);
+  else if (a.x_amax && a.dz_amax)
     hipLaunchKernelGGL((conv_wgrad_bf3_kernel<2, KS, S, TH, TW, NT, MI>), grid, dim3(256), 2 * plane, s, a);
   else
     hipLaunchKernelGGL((conv_wgrad_bf3_kernel<3, KS, S, TH, TW, NT, MI>), grid, dim3(256), 3 * plane, s, a);
@@ -272,9 +294,25 @@ static void wb_launch(const WgradBf3Args& a, dim3 grid, hipStream_t s) {
 // 0 when the shape is not covered (the caller then uses the exact-fp32 kernel).  max_slabs bounds PS
 // (workspace size).  x is (N, Hin, Win, Cin), dz (N, Hout, Wout, Cout).
 // x_amax / dz_amax: both non-null = the fp16x2 split with those magnitude rows, else bf16x3.
+int mval_launch_wgrad_bf3_p2(const float* x, const void* x_p2, const unsigned* x_p2_rows, const float* dz, float* slabs, int N, int Hin,
+                             int Win, int Cin, int Hout, int Wout, int Cout, int k, int stride, int max_slabs, const unsigned* x_amax,
+                             const unsigned* dz_amax, hipStream_t s);
+int mval_wgrad_bf3_covers(int Cin, int Cout, int k, int stride) {
+  const char* e = getenv("MVAL_CONV");
+  if ((e && e[0] == 'f') || (Cin & 3) || (Cout & 3) || Cin < 16 || Cout < 16) return 0;
+  return (k == 3 && (stride == 1 || stride == 2)) || (k == 1 && stride == 1 && Cin >= 64 && Cout >= 64);
+}
+
 int mval_launch_wgrad_bf3(const float* x, const float* dz, float* slabs, int N, int Hin, int Win, int Cin, int Hout,
                           int Wout, int Cout, int k, int stride, int max_slabs, const unsigned* x_amax,
                           const unsigned* dz_amax, hipStream_t s) {
+  return mval_launch_wgrad_bf3_p2(x, nullptr, nullptr, dz, slabs, N, Hin, Win, Cin, Hout, Wout, Cout, k, stride, max_slabs, x_amax, dz_amax, s);
+}
+
+// x_p2 != nullptr: x as P2 planes (+ rows) instead of fp32 NHWC (needs dz_amax: the fp16 split; Cin % 8 == 0)
+int mval_launch_wgrad_bf3_p2(const float* x, const void* x_p2, const unsigned* x_p2_rows, const float* dz, float* slabs, int N, int Hin,
+                             int Win, int Cin, int Hout, int Wout, int Cout, int k, int stride, int max_slabs, const unsigned* x_amax,
+                             const unsigned* dz_amax, hipStream_t s) {
   static int enabled = -1;
   if (enabled < 0) {
     const char* e = getenv("MVAL_CONV");
@@ -288,6 +326,9 @@ int mval_launch_wgrad_bf3(const float* x, const float* dz, float* slabs, int N, 
   a.x = x; a.dz = dz; a.slabs = slabs;
   a.N = N; a.Hin = Hin; a.Win = Win; a.H = Hout; a.W = Wout; a.Cin = Cin; a.Cout = Cout;
   a.x_amax = x_amax; a.dz_amax = dz_amax;
+  a.x_p2 = (x_p2 && dz_amax && (Cin & 7) == 0) ? reinterpret_cast<const _Float16*>(x_p2) : nullptr;
+  a.x_p2_rows = x_p2_rows;
+  if (x_p2 && !a.x_p2) return 0;
   // 8-wide tiles also for widths like 72 / 36 / 18 / 24 where they waste fewer (zero-padded) columns than 16-wide ones
   const int tw = (Wout > 8 && ((Wout + 15) / 16) * 16 <= ((Wout + 7) / 8) * 8) ? 16 : 8;
   const int th = (stride == 2 ? 32 : 64) / tw;  // stride-2 patches are ~4x larger per pixel: 32-pixel tiles

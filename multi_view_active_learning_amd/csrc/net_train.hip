@@ -40,6 +40,7 @@ int mval_conv_wgrad_split_streams(const float* x, const float* dz, float* dw, fl
                                   int Wout, int Cout, int k, int stride, int pad, int x_nchw, const uint32_t* x_amax_row,
                                   const uint32_t* dz_amax_row, hipStream_t s, hipStream_t reduce_stream, hipEvent_t ready,
                                   hipEvent_t done);
+void mval_conv_wgrad_set_p2_x(const void* planes, const unsigned* rows);  // conv_wgrad.hip: x as P2 planes for the next weight gradient
 // Side stream of the weight-gradient slab reductions (one per device, created once, never destroyed -- as the branch lanes of
 // net.hip): a reduction only feeds the optimizer, so it runs beside the op's data gradient and the next op's BatchNorm
 // backward; the main stream waits for it before the shared slab workspace is written again and at the end of the call.
@@ -277,7 +278,7 @@ extern "C" int mval_train_forward(const mval_train_op* ops, int n_ops, int n_ima
       TtScope tt(TT_BN_APPLY, s);
       if (t.out_p2_off > 0)
         rc = mval_bn_apply_fwd_p2(a.out, t.mean, t.invstd, t.gamma, t.beta, op.res1_off >= 0 ? arena + op.res1_off : nullptr,
-                                  op.res2_off >= 0 ? arena + op.res2_off : nullptr, out, arena + t.out_p2_off,
+                                  op.res2_off >= 0 ? arena + op.res2_off : nullptr, (t.p2_flags & 2) ? nullptr : out, arena + t.out_p2_off,
                                   reinterpret_cast<uint32_t*>(arena + t.out_p2_rows_off), n_images, op.hout, op.wout, op.cout, op.up, op.relu,
                                   t.out_amax_off > 0 ? reinterpret_cast<uint32_t*>(arena + t.out_amax_off) : nullptr,
                                   t.mask_off > 0 ? reinterpret_cast<uint8_t*>(arena + t.mask_off) : nullptr,
@@ -394,6 +395,8 @@ extern "C" int mval_train_backward(const mval_train_op* ops, int n_ops, int n_im
       (void)hipStreamWaitEvent(s, side->done, 0);
       side_pending = false;
     }
+    if (t.fwd_p2 && (t.p2_flags & 1))  // (wgrad_p2: this op's input exists as P2 planes and its weight gradient reads those)
+      mval_conv_wgrad_set_p2_x(arena + t.in_p2_off, reinterpret_cast<const unsigned*>(arena + t.in_p2_rows_off));
     rc = mval_conv_wgrad_split_streams(x, gz, t.dweight, wsf, n_images, op.hin, op.win, op.cin, op.hout, op.wout, op.cout, op.k,
                                        op.stride, op.pad, op.in_nchw, x_row, x_row ? gz_row : nullptr, s, side ? side->stream : nullptr,
                                        side ? side->ready : nullptr, side ? side->done : nullptr);

@@ -47,7 +47,7 @@ class MvalTrainOp(C.Structure):
         ("dweight", C.c_void_p), ("dgamma", C.c_void_p), ("dbeta", C.c_void_p),
         ("out_amax_off", C.c_int64), ("gz_amax_off", C.c_int64),
         ("mask_off", C.c_int64),
-        ("fwd_p2", C.c_int32), ("reserved2", C.c_int32),
+        ("fwd_p2", C.c_int32), ("p2_flags", C.c_int32),
         ("in_p2_off", C.c_int64), ("in_p2_rows_off", C.c_int64), ("out_p2_off", C.c_int64), ("out_p2_rows_off", C.c_int64),
         ("res1_amax_off", C.c_int64), ("res2_amax_off", C.c_int64),
     ]
@@ -251,6 +251,23 @@ class TrainPlan:
                             amax_row[r_] = self._row_top
                             self._row_top += TRAIN_AMAX_ROW
                         setattr(pt, name, amax_row[r_])
+            # weight gradients read x from the planes where the split kernel covers the conv; an activation whose EVERY consumer reads the
+            # planes (P2 forward conv + P2 weight gradient, no residual use, not the network output) is not written as fp32 at all
+            p2w = os.environ.get("MVAL_TRAIN_P2_WGRAD", "1") != "0"
+            res_used = {r for op in g.ops for r in (op.res1, op.res2) if r is not None}
+            consumers = {}
+            for i, op in enumerate(g.ops):
+                consumers.setdefault(op.src, []).append(i)
+                t = self.ops[i]
+                if p2w and t.fwd_p2 and t.gz_amax_off > 0 and lib.mval_conv_wgrad_p2_covers(C.c_int(op.cin), C.c_int(op.cout), C.c_int(op.k), C.c_int(op.stride)):
+                    t.p2_flags |= 1
+            for a_ in p2_act:
+                cons = consumers.get(a_, [])
+                po = g.ops[producer[a_]]
+                # (its own backward must not need `out` either: a ReLU behind residual adds takes its mask from the mask bytes)
+                own_ok = not (po.relu and (po.res1 is not None or po.res2 is not None)) or (os.environ.get("MVAL_TRAIN_RELU_MASK", "1") != "0" and po.up == 0)
+                if p2w and own_ok and a_ not in res_used and a_ != g.output and cons and all(self.ops[i].fwd_p2 and (self.ops[i].p2_flags & 1) for i in cons):
+                    self.ops[producer[a_]].p2_flags |= 2
         for i, op in enumerate(g.ops):  # producers leave max |out| where a split conv will look for it
             self.ops[i].out_amax_off = amax_row.get(op.dst, 0)
         # ReLU behind residual adds (BasicBlock / Bottleneck outputs, fuse sums at the conv resolution): the forward apply keeps
