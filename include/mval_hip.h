@@ -404,6 +404,12 @@ int mval_bn_bwd_fused_mask(const float* gout, const float* out, const uint8_t* r
                            const float* invstd, const float* gamma, const float* beta, float* gres1, float* gres2, float* gz,
                            float* dgamma, float* dbeta, double* ws, float* sums, int N, int H, int W, int C, int relu, int overwrite,
                            uint32_t* gz_amax_row, void* stream);
+/* mval_bn_bwd_fused_mask, and (dz_planes != NULL) dz ALSO as P2 planes [n][plane][C/8][H][W][8] + rows dz_rows[n][MVAL_P2_ROW] for the
+ * data-gradient conv on the P2 kernels; gmax_ws >= 512 floats, bound_slot one dword of scratch; gz may be NULL then. */
+int mval_bn_bwd_fused_p2(const float* gout, const float* out, const uint8_t* relu_mask, const float* z, const float* mean,
+                         const float* invstd, const float* gamma, const float* beta, float* gres1, float* gres2, float* gz,
+                         float* dgamma, float* dbeta, double* ws, float* sums, int N, int H, int W, int C, int relu, int overwrite,
+                         uint32_t* gz_amax_row, void* dz_planes, uint32_t* dz_rows, float* gmax_ws, uint32_t* bound_slot, void* stream);
 /* Weight gradient dw [cout][cin][k][k] of a conv: x NHWC (NCHW when x_nchw), dz NHWC.
  * ws >= mval_conv_wgrad_workspace_floats(cin, cout, k) floats. */
 size_t mval_conv_wgrad_workspace_floats(int cin, int cout, int k);
@@ -433,6 +439,8 @@ int mval_conv_dgrad(const float* dz, const float* w_packed, const float* ones, c
  * from the conv's own [cout][cin][3][3] weight.  _supported: 1 when a kernel exists for the shape. */
 /* 1 when the split weight-gradient kernel that can read x as P2 planes covers the conv (3x3 stride 1 / 2, wide 1x1; cin % 8 == 0). */
 int mval_conv_wgrad_p2_covers(int cin, int cout, int k, int stride);
+/* 1 when the split weight-gradient kernel covers the conv at all (it can then read dz as P2 planes when cout % 8 == 0). */
+int mval_conv_wgrad_split_covers(int cin, int cout, int k, int stride);
 int mval_conv_dgrad_parity_supported(int N, int hin, int win, int cin, int hout, int wout, int cout, int algo);
 int mval_conv_dgrad_parity(const float* dz, const float* w_packed, const float* ones, const float* zeros, float* dx,
                            int accumulate, int N, int hin, int win, int cin, int hout, int wout, int cout, int algo,
@@ -482,6 +490,11 @@ typedef struct mval_train_op {
   int32_t p2_flags; /* bit 0: this op's weight gradient reads its input from the P2 planes (mval_conv_wgrad_p2_covers); bit 1: this op's
                      * apply writes ONLY the P2 planes (every consumer of its output reads those: no fp32 NHWC copy) */
   int64_t in_p2_off, in_p2_rows_off, out_p2_off, out_p2_rows_off, res1_amax_off, res2_amax_off;
+  /* p2_flags bit 3: with bit 2 -- the weight gradient reads dz from the planes as well, so the BatchNorm backward writes no fp32 dz.
+   * p2_flags bit 2: the op's data gradient runs on the P2 kernels (stride 1): its BatchNorm backward ALSO writes dz as P2 planes into the
+   * scratch at gz_p2_off (float offset into `arena`: planes of the largest dz, then n_images * MVAL_P2_ROW row dwords (zeroed once by the
+   * caller), then 512 floats + 64 dwords of reduction scratch), and mval_conv_p2 reads them with the data-gradient packing at wd_off. */
+  int64_t gz_p2_off, gz_p2_rows_off;
 } mval_train_op;
 
 /* ones_off / zeros_off: params offsets of >= max(cout) floats of 1.0 / 0.0.

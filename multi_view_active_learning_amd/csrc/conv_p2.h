@@ -169,6 +169,7 @@ struct P2Args {
   // every (workgroup, pixel-wave) also leaves the per-channel (sum, sum of squares) of what it stored over its whole tile walk,
   // float64 [cout][bn_slots][2] (bn_slots = wgs_x * WM, filled by the launcher and reported in *bn_slots_host)
   float* out_nhwc;
+  int acc_nhwc;  // (EPI 3) != 0: out_nhwc += the result instead of = (a data gradient accumulating into the producer's gradient slot)
   double* bn_part;
   int64_t bn_part_cap;
   int* bn_slots_host;

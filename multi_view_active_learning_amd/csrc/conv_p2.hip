@@ -561,8 +561,11 @@ __global__ __launch_bounds__(64 * WN * WM) __attribute__((amdgpu_waves_per_eu(P2
       using T_ = std::true_type;
       using F_ = std::false_type;
       if constexpr (EPI == 3) {
-        // training forward: z = acc * 2^-s (no BatchNorm factors, no activation) as fp32 NHWC -- a lane's four couts of a pixel are
-        // 16 contiguous bytes, the four quarters of a 16-cout sub-tile 64 -- and the running (sum, sum of squares) per channel
+        // training: z = acc * 2^-s (no BatchNorm factors, no activation) as fp32 NHWC -- a lane's four couts of a pixel are 16
+        // contiguous bytes, the four quarters of a 16-cout sub-tile 64 -- and, for the forward, the running (sum, sum of squares) per
+        // channel; a data gradient (acc_nhwc) adds to what the slot holds: those loads are all requested before the first store
+        unsigned zo[MS][NT];
+        f32x4 ex[MS][NT];
 #pragma unroll
         for (int nt = 0; nt < NT; nt++) {
           const int c0 = (ns0 + nt) * 16 + cq;
@@ -580,11 +583,19 @@ __global__ __launch_bounds__(64 * WN * WM) __attribute__((amdgpu_waves_per_eu(P2
               ok = y < a.Hout && x < a.Wout;
             }
             ok = ok && c0 < a.Cout;
-            const f32x4 v = acc[ms][nt] * unscale;
-            const unsigned zo = ok ? (unsigned)((((unsigned)n * a.Hout + y) * a.Wout + x) * a.Cout + c0) * 4u : 0x80000000u;
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), zr, zo, 0, 0);
+            zo[ms][nt] = ok ? (unsigned)((((unsigned)n * a.Hout + y) * a.Wout + x) * a.Cout + c0) * 4u : 0x80000000u;
+            if (a.acc_nhwc) ex[ms][nt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(zr, zo[ms][nt], 0, 0));
+          }
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++) {
+#pragma unroll
+          for (int ms = 0; ms < MS; ms++) {
+            f32x4 v = acc[ms][nt] * unscale;
+            if (a.acc_nhwc) v += ex[ms][nt];
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), zr, zo[ms][nt], 0, 0);
             asm volatile("s_nop 1");
-            if (ok) {
+            if (zo[ms][nt] != 0x80000000u) {
 #pragma unroll
               for (int j = 0; j < 4; j++) {
                 bsum[nt][j] += v[j];

@@ -25,8 +25,9 @@ int mval_launch_wgrad_bf3(const float* x, const float* dz, float* slabs, int N, 
                           const unsigned* dz_amax, hipStream_t s);
 int mval_launch_wgrad_bf3_p2(const float* x, const void* x_p2, const unsigned* x_p2_rows, const float* dz, float* slabs, int N, int Hin,
                              int Win, int Cin, int Hout, int Wout, int Cout, int k, int stride, int max_slabs, const unsigned* x_amax,
-                             const unsigned* dz_amax, hipStream_t s);
+                             const unsigned* dz_amax, hipStream_t s, const void* dz_p2 = nullptr, const unsigned* dz_p2_rows = nullptr);
 int mval_wgrad_bf3_covers(int Cin, int Cout, int k, int stride);
+extern "C" int mval_conv_wgrad_split_covers(int cin, int cout, int k, int stride) { return mval_wgrad_bf3_covers(cin, cout, k, stride); }
 extern "C" int mval_conv_wgrad_p2_covers(int cin, int cout, int k, int stride) { return mval_wgrad_bf3_covers(cin, cout, k, stride) && (cin & 7) == 0; }
 // x as P2 planes for the next mval_conv_wgrad_split_streams call of this thread (net_train.hip sets it per operator; nullptr = fp32 x)
 static thread_local const void* g_wgrad_x_p2 = nullptr;
@@ -34,6 +35,12 @@ static thread_local const unsigned* g_wgrad_x_p2_rows = nullptr;
 void mval_conv_wgrad_set_p2_x(const void* planes, const unsigned* rows) {
   g_wgrad_x_p2 = planes;
   g_wgrad_x_p2_rows = rows;
+}
+static thread_local const void* g_wgrad_dz_p2 = nullptr;
+static thread_local const unsigned* g_wgrad_dz_p2_rows = nullptr;
+void mval_conv_wgrad_set_p2_dz(const void* planes, const unsigned* rows) {
+  g_wgrad_dz_p2 = planes;
+  g_wgrad_dz_p2_rows = rows;
 }
   // conv_wgrad_bf3.hip
 
@@ -386,10 +393,14 @@ int mval_conv_wgrad_split_streams(const float* x, const float* dz, float* dw, fl
   const unsigned* xp2_rows = g_wgrad_x_p2_rows;
   g_wgrad_x_p2 = nullptr;
   g_wgrad_x_p2_rows = nullptr;
+  const void* zp2 = g_wgrad_dz_p2;
+  const unsigned* zp2_rows = g_wgrad_dz_p2_rows;
+  g_wgrad_dz_p2 = nullptr;
+  g_wgrad_dz_p2_rows = nullptr;
   if (!x_nchw && pad == k / 2)  // split-bf16 kernel (conv_wgrad_bf3.hip); 0 = shape not covered
     PS = mval_launch_wgrad_bf3_p2(x, xp2, xp2_rows, dz, ws, N, Hin, Win, Cin, Hout, Wout, Cout, k, stride, wg_splits(Cin, Cout, 1024),
-                                  x_amax_row, dz_amax_row, s);
-  MVAL_REQUIRE(!xp2 || PS > 0, "mval_conv_wgrad: the P2 form of x needs the split kernel (k%d s%d cin%d cout%d) and dz's magnitude row", k, stride, Cin, Cout);
+                                  x_amax_row, dz_amax_row, s, zp2, zp2_rows);
+  MVAL_REQUIRE(!(xp2 || zp2) || PS > 0, "mval_conv_wgrad: the P2 form of x needs the split kernel (k%d s%d cin%d cout%d) and dz's magnitude row", k, stride, Cin, Cout);
   if (PS > 0) {
     MVAL_CHECK_LAUNCH("mval_conv_wgrad/bf3");
   } else if (stem) {

@@ -51,6 +51,9 @@ struct WgradBf3Args {
   // plane) instead of a float4 load + scale + split
   const _Float16* x_p2;
   const unsigned* x_p2_rows;
+  // ZP2: dz as P2 planes [n][plane][Cout/8][H][W][8] + rows (written by the BatchNorm backward for the P2 data-gradient conv)
+  const _Float16* dz_p2;
+  const unsigned* dz_p2_rows;
 };
 
 __device__ __forceinline__ void wb_split_pair(const f32x2 x, unsigned& h, unsigned& m, unsigned& l) {
@@ -105,9 +108,9 @@ __device__ __forceinline__ void wb_scale(unsigned amax_bits, float& mul, float& 
 
 // KS x KS taps, stride S, tile TH x TW output pixels, NT cout tiles and MI cin tiles (of 16) per wave
 typedef unsigned wb_u32x4 __attribute__((ext_vector_type(4)));
-template <int PL, int KS, int S, int TH, int TW, int NT, int MI, bool XP2 = false>
+template <int PL, int KS, int S, int TH, int TW, int NT, int MI, bool XP2 = false, bool ZP2 = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((KS == 3 && S == 1 && TH == 8 && NT == 2) ? 2 : 1, 8))) void conv_wgrad_bf3_kernel(WgradBf3Args a) {
-  static_assert(!XP2 || PL == 2, "P2 activations are fp16 pairs");
+  static_assert(!(XP2 || ZP2) || PL == 2, "P2 activations are fp16 pairs");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int T = KS * KS, MT = TH * TW;
   constexpr int PH = (TH - 1) * S + KS, PW = (TW - 1) * S + KS, PPX = PH * PW;
@@ -123,7 +126,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((KS == 3 &&
     float xi, zi;
     if constexpr (XP2) xi = __uint_as_float(a.x_p2_rows[511]);  // (P2_INV_SLOT of row 0: one scale for the whole tensor in training)
     else wb_scale(conv_amax_read(a.x_amax), x_mul, xi);
-    wb_scale(conv_amax_read(a.dz_amax), z_mul, zi);
+    if constexpr (ZP2) zi = __uint_as_float(a.dz_p2_rows[511]);
+    else wb_scale(conv_amax_read(a.dz_amax), z_mul, zi);
     unscale = xi * zi;
   }
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -167,6 +171,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((KS == 3 &&
   f32x4 xr[NEX], zr[NEZ];
   // XP2: item j = tid % XQ of a pixel -> plane j / (CI / 8), 8-channel block j % (CI / 8)  (XQ = CI / 4 = 2 planes x CI / 8 blocks)
   const int xp_plane = (tid % XQ) / (CI / 8), xp_c8 = (tid % XQ) % (CI / 8);
+  const int zp_plane = (tid % ZQ) / (CO / 8), zp_c8 = (tid % ZQ) % (CO / 8);
   const int C8x = a.Cin >> 3;
   const int64_t xp_hw = (int64_t)a.Hin * a.Win;
   auto load_tile = [&](int t) {
@@ -191,9 +196,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((KS == 3 &&
     for (int i = 0; i < NEZ; i++) {
       const int pz = (tid + 256 * i) / ZQ;
       const int y = oy0 + pz / TW, x = ox0 + pz % TW;
+      if constexpr (ZP2) {
+        const bool ok = tid + 256 * i < MT * ZQ && co0 + zp_c8 * 8 < a.Cout && y < a.H && x < a.W;
+        const wb_u32x4 g = ok ? *reinterpret_cast<const wb_u32x4*>(a.dz_p2 + ((((int64_t)n * 2 + zp_plane) * (a.Cout >> 3) + (co0 >> 3) + zp_c8) * ((int64_t)a.H * a.W) + (int64_t)y * a.W + x) * 8)
+                              : (wb_u32x4){0u, 0u, 0u, 0u};
+        zr[i] = __builtin_bit_cast(f32x4, g);
+      } else {
       zr[i] = (tid + 256 * i < MT * ZQ && cz_ok && y < a.H && x < a.W)
                   ? *reinterpret_cast<const f32x4*>(a.dz + (((int64_t)n * a.H + y) * a.W + x) * a.Cout + co0 + zq4)
                   : (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
     }
   };
 
@@ -214,7 +226,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((KS == 3 &&
     for (int i = 0; i < NEZ; i++) {
       const int e = tid + 256 * i;
       if (e < MT * ZQ) {
-        if constexpr (PL == 3) wb_split_store(zr[i], zl + (e / ZQ) * ZROW + (e % ZQ) * 8, ZPLANE);
+        if constexpr (ZP2) *reinterpret_cast<wb_u32x4*>(zl + zp_plane * ZPLANE + (e / ZQ) * ZROW + zp_c8 * 16) = __builtin_bit_cast(wb_u32x4, zr[i]);
+        else if constexpr (PL == 3) wb_split_store(zr[i], zl + (e / ZQ) * ZROW + (e % ZQ) * 8, ZPLANE);
         else wb_split_store2(zr[i], z_mul, zl + (e / ZQ) * ZROW + (e % ZQ) * 8, ZPLANE);
       }
     }
@@ -281,7 +294,11 @@ template <int KS, int S, int TH, int TW, int NT, int MI>
 static void wb_launch(const WgradBf3Args& a, dim3 grid, hipStream_t s) {
   constexpr int PPX = ((TH - 1) * S + KS) * ((TW - 1) * S + KS);
   constexpr size_t plane = (size_t)PPX * (64 * MI + 32) + (size_t)TH * TW * (64 * NT + 32);
-  if (a.x_p2 && a.dz_amax)
+  if (a.x_p2 && a.dz_p2)
+    hipLaunchKernelGGL((conv_wgrad_bf3_kernel<2, KS, S, TH, TW, NT, MI, true, true>), grid, dim3(256), 2 * plane, s, a);
+  else if (a.dz_p2 && a.x_amax)
+    hipLaunchKernelGGL((conv_wgrad_bf3_kernel<2, KS, S, TH, TW, NT, MI, false, true>), grid, dim3(256), 2 * plane, s, a);
+  else if (a.x_p2 && a.dz_amax)
     hipLaunchKernelGGL((conv_wgrad_bf3_kernel<2, KS, S, TH, TW, NT, MI, true>), grid, dim3(256), 2 * plane, s, a);
   else if (a.x_amax && a.dz_amax)
     hipLaunchKernelGGL((conv_wgrad_bf3_kernel<2, KS, S, TH, TW, NT, MI>), grid, dim3(256), 2 * plane, s, a);
@@ -296,7 +313,7 @@ static void wb_launch(const WgradBf3Args& a, dim3 grid, hipStream_t s) {
 // x_amax / dz_amax: both non-null = the fp16x2 split with those magnitude rows, else bf16x3.
 int mval_launch_wgrad_bf3_p2(const float* x, const void* x_p2, const unsigned* x_p2_rows, const float* dz, float* slabs, int N, int Hin,
                              int Win, int Cin, int Hout, int Wout, int Cout, int k, int stride, int max_slabs, const unsigned* x_amax,
-                             const unsigned* dz_amax, hipStream_t s);
+                             const unsigned* dz_amax, hipStream_t s, const void* dz_p2 = nullptr, const unsigned* dz_p2_rows = nullptr);
 int mval_wgrad_bf3_covers(int Cin, int Cout, int k, int stride) {
   const char* e = getenv("MVAL_CONV");
   if ((e && e[0] == 'f') || (Cin & 3) || (Cout & 3) || Cin < 16 || Cout < 16) return 0;
@@ -312,7 +329,7 @@ int mval_launch_wgrad_bf3(const float* x, const float* dz, float* slabs, int N, 
 // x_p2 != nullptr: x as P2 planes (+ rows) instead of fp32 NHWC (needs dz_amax: the fp16 split; Cin % 8 == 0)
 int mval_launch_wgrad_bf3_p2(const float* x, const void* x_p2, const unsigned* x_p2_rows, const float* dz, float* slabs, int N, int Hin,
                              int Win, int Cin, int Hout, int Wout, int Cout, int k, int stride, int max_slabs, const unsigned* x_amax,
-                             const unsigned* dz_amax, hipStream_t s) {
+                             const unsigned* dz_amax, hipStream_t s, const void* dz_p2, const unsigned* dz_p2_rows) {
   static int enabled = -1;
   if (enabled < 0) {
     const char* e = getenv("MVAL_CONV");
@@ -326,7 +343,10 @@ int mval_launch_wgrad_bf3_p2(const float* x, const void* x_p2, const unsigned* x
   a.x = x; a.dz = dz; a.slabs = slabs;
   a.N = N; a.Hin = Hin; a.Win = Win; a.H = Hout; a.W = Wout; a.Cin = Cin; a.Cout = Cout;
   a.x_amax = x_amax; a.dz_amax = dz_amax;
-  a.x_p2 = (x_p2 && dz_amax && (Cin & 7) == 0) ? reinterpret_cast<const _Float16*>(x_p2) : nullptr;
+  a.dz_p2 = (dz_p2 && dz_p2_rows && (Cout & 7) == 0 && (x_p2 || x_amax)) ? reinterpret_cast<const _Float16*>(dz_p2) : nullptr;
+  a.dz_p2_rows = dz_p2_rows;
+  if (dz_p2 && !a.dz_p2) return 0;
+  a.x_p2 = (x_p2 && (dz_amax || a.dz_p2) && (Cin & 7) == 0) ? reinterpret_cast<const _Float16*>(x_p2) : nullptr;
   a.x_p2_rows = x_p2_rows;
   if (x_p2 && !a.x_p2) return 0;
   // 8-wide tiles also for widths like 72 / 36 / 18 / 24 where they waste fewer (zero-padded) columns than 16-wide ones

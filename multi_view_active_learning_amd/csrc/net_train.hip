@@ -27,6 +27,9 @@ extern "C" int mval_bn_bwd_fused_mask(const float*, const float*, const uint8_t*
                                       uint32_t*, void*);
 extern "C" int mval_bn_apply_fwd_p2(const float*, const float*, const float*, const float*, const float*, const float*, const float*, float*,
                                     void*, uint32_t*, int, int, int, int, int, int, uint32_t*, uint8_t*, const uint32_t*, const uint32_t*, void*);
+extern "C" int mval_bn_bwd_fused_p2(const float*, const float*, const uint8_t*, const float*, const float*, const float*, const float*,
+                                    const float*, float*, float*, float*, float*, float*, double*, float*, int, int, int, int, int, int,
+                                    uint32_t*, void*, uint32_t*, float*, uint32_t*, void*);
 extern "C" int mval_bn_finalize_stats(const double*, int, int64_t, int, float, float, float*, float*, float*, float*, void*);
 extern "C" int mval_bn_bwd_fused(const float*, const float*, const float*, const float*, const float*, const float*, const float*,
                                  float*, float*, float*, float*, float*, double*, float*, int, int, int, int, int, int, uint32_t*,
@@ -41,6 +44,7 @@ int mval_conv_wgrad_split_streams(const float* x, const float* dz, float* dw, fl
                                   const uint32_t* dz_amax_row, hipStream_t s, hipStream_t reduce_stream, hipEvent_t ready,
                                   hipEvent_t done);
 void mval_conv_wgrad_set_p2_x(const void* planes, const unsigned* rows);  // conv_wgrad.hip: x as P2 planes for the next weight gradient
+void mval_conv_wgrad_set_p2_dz(const void* planes, const unsigned* rows);  // ... and dz
 // Side stream of the weight-gradient slab reductions (one per device, created once, never destroyed -- as the branch lanes of
 // net.hip): a reduction only feeds the optimizer, so it runs beside the op's data gradient and the next op's BatchNorm
 // backward; the main stream waits for it before the shared slab workspace is written again and at the end of the call.
@@ -335,14 +339,19 @@ extern "C" int mval_train_backward(const mval_train_op* ops, int n_ops, int n_im
     MVAL_REQUIRE(!(op.relu && !outp), "mval_train_backward: op %d: ReLU on an external output", i);
     uint32_t* gz_row = (t.has_bn && t.gz_amax_off > 0) ? reinterpret_cast<uint32_t*>(arena + t.gz_amax_off) : nullptr;
     int rc;
+    // (p2_flags bit 2) the data gradient on the P2 kernels: the BatchNorm backward also leaves dz as P2 planes
+    const bool dz_p2 = (t.p2_flags & 4) && t.gz_p2_off > 0 && t.gin_off >= 0 && bwd_fused && t.has_bn && op.up == 0;
     {
     TtScope tt(TT_BN_BWD, s);
     if (bwd_fused && t.has_bn && op.up == 0 && (op.cout & 3) == 0)
-      rc = mval_bn_bwd_fused_mask(garena + t.gout_off, outp, t.mask_off > 0 ? reinterpret_cast<const uint8_t*>(arena + t.mask_off) : nullptr,
+      rc = mval_bn_bwd_fused_p2(garena + t.gout_off, outp, t.mask_off > 0 ? reinterpret_cast<const uint8_t*>(arena + t.mask_off) : nullptr,
                              arena + t.z_off, t.mean, t.invstd, t.gamma, t.beta,
-                             t.gres1_off >= 0 ? garena + t.gres1_off : nullptr, t.gres2_off >= 0 ? garena + t.gres2_off : nullptr, gz,
+                             t.gres1_off >= 0 ? garena + t.gres1_off : nullptr, t.gres2_off >= 0 ? garena + t.gres2_off : nullptr,
+                             (dz_p2 && (t.p2_flags & 8)) ? nullptr : gz,  // (bit 3: the weight gradient reads the planes too: no fp32 dz)
                              t.dgamma, t.dbeta, ws, sums, n_images, op.hout, op.wout, op.cout, op.relu, t.first_touch >> 1, gz_row,
-                             stream);
+                             dz_p2 ? arena + t.gz_p2_off : nullptr, dz_p2 ? reinterpret_cast<uint32_t*>(arena + t.gz_p2_rows_off) : nullptr,
+                             dz_p2 ? arena + t.gz_p2_rows_off + (int64_t)n_images * P2_ROW : nullptr,
+                             dz_p2 ? reinterpret_cast<uint32_t*>(arena + t.gz_p2_rows_off + (int64_t)n_images * P2_ROW + 512) : nullptr, stream);
     else
     rc = mval_bn_bwd_amax(garena + t.gout_off, outp, t.has_bn ? arena + t.z_off : nullptr, t.mean, t.invstd, t.gamma,
                               t.gres1_off >= 0 ? garena + t.gres1_off : nullptr,
@@ -395,6 +404,8 @@ extern "C" int mval_train_backward(const mval_train_op* ops, int n_ops, int n_im
       (void)hipStreamWaitEvent(s, side->done, 0);
       side_pending = false;
     }
+    if (dz_p2 && (t.p2_flags & 8))
+      mval_conv_wgrad_set_p2_dz(arena + t.gz_p2_off, reinterpret_cast<const unsigned*>(arena + t.gz_p2_rows_off));
     if (t.fwd_p2 && (t.p2_flags & 1))  // (wgrad_p2: this op's input exists as P2 planes and its weight gradient reads those)
       mval_conv_wgrad_set_p2_x(arena + t.in_p2_off, reinterpret_cast<const unsigned*>(arena + t.in_p2_rows_off));
     rc = mval_conv_wgrad_split_streams(x, gz, t.dweight, wsf, n_images, op.hin, op.win, op.cin, op.hout, op.wout, op.cout, op.k,
@@ -406,7 +417,25 @@ extern "C" int mval_train_backward(const mval_train_op* ops, int n_ops, int n_im
     if (t.gin_off >= 0) {
       MVAL_REQUIRE(t.dgrad_algo != MVAL_ALGO_MFMA_H2 || gz_row, "mval_train_backward: op %d: fp16-split data gradient without dz's magnitude row", i);
       TtScope tt(TT_DGRAD, s);
-      if (t.dgrad_form == 1)  // (dgrad_form: the four-parity form of a stride-2 3x3 data gradient)
+      if (dz_p2) {
+        // dx (+)= conv(dz, flip(W)^T) on conv_p2.hip: dz planes in, fp32 NHWC gradient slot out (accumulated in place unless first writer)
+        P2Args p = {};
+        p.in = reinterpret_cast<const _Float16*>(arena + t.gz_p2_off);
+        p.in_row = reinterpret_cast<const unsigned*>(arena + t.gz_p2_rows_off);
+        p.w = params + t.wd_off;
+        p.w_unscale = p.w + mval_packed_weight_floats(MVAL_PACK_MFMA16_H2, op.cin, op.cout, op.k) - 4;
+        p.scale = params + ones_off;
+        p.shift = params + zeros_off;
+        p.out_nhwc = garena + t.gin_off;
+        p.acc_nhwc = !(t.first_touch & 1);
+        p.N = n_images; p.Hin = op.hout; p.Win = op.wout; p.Cin = op.cout; p.Hout = op.hin; p.Wout = op.win; p.Cout = op.cin;
+        p.k = op.k; p.stride = 1;
+        if (mval_launch_conv_p2(p, s)) {
+          mval_set_error("mval_train_backward: op %d: no P2 kernel for the data gradient (k%d cin%d cout%d)", i, op.k, op.cin, op.cout);
+          return -1;
+        }
+        rc = 0;
+      } else if (t.dgrad_form == 1)  // (dgrad_form: the four-parity form of a stride-2 3x3 data gradient)
         rc = mval_conv_dgrad_parity(gz, params + t.wd_off, params + ones_off, params + zeros_off, garena + t.gin_off,
                                     !(t.first_touch & 1), n_images, op.hin, op.win, op.cin, op.hout, op.wout, op.cout, t.dgrad_algo,
                                     gz_row, stream);

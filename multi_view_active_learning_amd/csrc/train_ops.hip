@@ -14,6 +14,9 @@ extern "C" int mval_bn_apply_fwd_mask(const float*, const float*, const float*, 
 extern "C" int mval_bn_bwd_fused_mask(const float*, const float*, const uint8_t*, const float*, const float*, const float*, const float*,
                                       const float*, float*, float*, float*, float*, float*, double*, float*, int, int, int, int, int, int,
                                       uint32_t*, void*);
+extern "C" int mval_bn_bwd_fused_p2(const float*, const float*, const uint8_t*, const float*, const float*, const float*, const float*,
+                                    const float*, float*, float*, float*, float*, float*, double*, float*, int, int, int, int, int, int,
+                                    uint32_t*, void*, uint32_t*, float*, uint32_t*, void*);
 #define TR_BLOCKS 512
 // The two elementwise BatchNorm streams run 1024-thread workgroups, at most two per CU: every workgroup leaves ONE
 // partial maximum, and every workgroup of the consuming conv reads them all -- 2048 partials (256-thread workgroups)
@@ -261,6 +264,32 @@ extern "C" int mval_bn_apply_fwd(const float* z, const float* mean, const float*
   return mval_bn_apply_fwd_amax(z, mean, invstd, gamma, beta, res1, res2, out, N, H, W, C, up, relu, nullptr, stream);
 }
 
+// ---- NHWC float4 -> P2 granules without LDS (round 4) -------------------------------------------------------------------------
+// A wave covers PXW pixels x CB channels (CB = 32: 8 pixels x 8 float4; 16: 16 x 4; 8: 32 x 2): lane = (pixel lane / CQ, channel quad
+// lane % CQ).  The NHWC side reads / writes CB * 4 contiguous bytes per pixel (full 128-byte lines at CB = 32).  A P2 granule is 8
+// channels = the float4s of an EVEN lane and its odd neighbour: the pair swaps halves (one DPP quad permute per dword) so that the even
+// lane holds the whole h granule and the odd lane the whole l granule -- each lane stores ONE 16-byte granule, PXW consecutive pixels per
+// (plane, 8-channel block) and store instruction.
+struct P2WaveMap {
+  int CQ, PXW, NCB;  // float4 per pixel and channel block, pixels per wave, channel blocks
+};
+__device__ __forceinline__ P2WaveMap p2_wave_map(int C) {
+  const int CB = (C & 31) == 0 ? 32 : (C & 15) == 0 ? 16 : 8;
+  P2WaveMap m;
+  m.CQ = CB >> 2;
+  m.PXW = 64 / m.CQ;
+  m.NCB = C / CB;
+  return m;
+}
+// this lane's granule of the pair (even lane: [own h | neighbour's h] -> plane h; odd lane: [neighbour's l | own l] -> plane l)
+__device__ __forceinline__ p2_u32x4 p2_pair_granule(const p2_f16x4 h, const p2_f16x4 l, bool odd) {
+  const p2_u32x2 hu = __builtin_bit_cast(p2_u32x2, h), lu = __builtin_bit_cast(p2_u32x2, l);
+  const unsigned s0 = odd ? hu.x : lu.x, s1 = odd ? hu.y : lu.y;  // what the neighbour needs of this lane
+  const unsigned r0 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)s0, 0xB1, 0xf, 0xf, false);  // quad_perm [1,0,3,2]
+  const unsigned r1 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)s1, 0xB1, 0xf, 0xf, false);
+  return odd ? (p2_u32x4){r0, r1, lu.x, lu.y} : (p2_u32x4){hu.x, hu.y, r0, r1};
+}
+
 // ---- forward apply that ALSO writes the activation as P2 planes (round 4: the training forward's convs on conv_p2.hip) ----------
 // out = act(((bn(z) up) + res1) + res2) as fp32 NHWC (residual consumers, weight gradients) AND as the fp16 plane pairs
 // [n][plane][C/8][Ho][Wo][8] the P2 convs stage by copy.  The P2 scale must exist before the first store: it comes from a rigorous
@@ -276,12 +305,7 @@ __global__ __launch_bounds__(TR_APPLY_THREADS) void bn_apply_fwd_p2_kernel(
     _Float16* __restrict__ planes, unsigned* __restrict__ p2_rows, int N, int H, int W, int C, int up, int relu,
     unsigned* __restrict__ amax_row, unsigned char* __restrict__ relu_mask, const unsigned* __restrict__ res1_row,
     const unsigned* __restrict__ res2_row, float sqrt_m1) {
-  // A workgroup handles blocks of 4096 float4 = BP consecutive output pixels x C channels: the NHWC side (z, residuals, fp32 out, mask
-  // bytes) is read and written in float4 order (fully coalesced, as bn_apply_fwd_kernel), the (h, l) halves go through LDS as
-  // [plane][8-channel block][pixel][16 B] and leave as 16-byte granules, BP contiguous pixels per block and plane (>= 1 KiB runs).
-  extern __shared__ __attribute__((aligned(16))) char p2sh[];  // 2 planes x 4096 x 8 bytes = 64 KB
-  const int c4n = C >> 2, C8 = C >> 3;
-  const int BP = 4096 / c4n;  // pixels per block (48-channel multiples: BP * c4n < 4096, the tail items idle)
+  const int C8 = C >> 3;
   const int Ho = H << up, Wo = W << up;
   const int HWo = Ho * Wo;
   const int64_t npx = (int64_t)N * HWo;
@@ -295,59 +319,48 @@ __global__ __launch_bounds__(TR_APPLY_THREADS) void bn_apply_fwd_p2_kernel(
   p2_scale_of(bnd, out_mul, out_inv);
   if (blockIdx.x == 0)
     for (int n = threadIdx.x; n < N; n += TR_APPLY_THREADS) p2_rows[(int64_t)n * P2_ROW + P2_INV_SLOT] = __float_as_uint(out_inv);
-  const int64_t nblocks = (npx + BP - 1) / BP;
+  const P2WaveMap wm = p2_wave_map(C);
+  const int lane = threadIdx.x & 63;
+  const int p_lo = lane / wm.CQ, q_lo = lane - p_lo * wm.CQ;
+  const bool odd = q_lo & 1;
+  const int64_t nchunks = (npx + wm.PXW - 1) / wm.PXW;           // pixel chunks of a wave
+  const int64_t nwork = nchunks * wm.NCB;                          // wave work items: (pixel chunk, channel block)
   const int64_t plane_halves = (int64_t)C8 * HWo * 8;
-  const int lplane = 4096 * 8;  // bytes of one plane's LDS image
+  const int64_t wave0 = ((int64_t)blockIdx.x * TR_APPLY_THREADS + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * TR_APPLY_THREADS) >> 6;
   float amax = 0.f;
-  for (int64_t blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
-    const int64_t p0 = blk * BP;
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-      const int e = threadIdx.x + TR_APPLY_THREADS * i;  // float4 of the block: pixel e / c4n, channel quad e % c4n
-      const int pl = e / c4n, q = e - pl * c4n;
-      const int64_t pix = p0 + pl;
-      if (pl < BP && pix < npx) {
-        const int n = (int)(pix / HWo), pin = (int)(pix - (int64_t)n * HWo);
-        const int Y = pin / Wo, X = pin - Y * Wo;
-        const int64_t zi = (((int64_t)n * H + (Y >> up)) * W + (X >> up)) * C + q * 4;
-        const int64_t o = pix * C + q * 4;
-        const f32x4 zv = *reinterpret_cast<const f32x4*>(z + zi);
-        const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + q * 4);
-        const f32x4 is = *reinterpret_cast<const f32x4*>(invstd + q * 4);
-        const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + q * 4);
-        const f32x4 b = *reinterpret_cast<const f32x4*>(beta + q * 4);
-        f32x4 rr = bn_affine(zv, mu, is, g, b);
-        if (res1) rr += *reinterpret_cast<const f32x4*>(res1 + o);
-        if (res2) rr += *reinterpret_cast<const f32x4*>(res2 + o);
-        if (relu) {
-          rr.x = mval_relu(rr.x); rr.y = mval_relu(rr.y); rr.z = mval_relu(rr.z); rr.w = mval_relu(rr.w);
-        }
-        if (out) *reinterpret_cast<f32x4*>(out + o) = rr;
-        if (relu_mask) relu_mask[o >> 2] = (unsigned char)((rr.x > 0.f) | ((rr.y > 0.f) << 1) | ((rr.z > 0.f) << 2) | ((rr.w > 0.f) << 3));
-        amax = fmaxf(fmaxf(amax, fmaxf(fabsf(rr.x), fabsf(rr.y))), fmaxf(fabsf(rr.z), fabsf(rr.w)));
-        p2_f16x4 h, l;
-        p2_split(rr * out_mul, h, l);
-        // LDS image [8-channel block q / 2][pixel pl][half (q & 1)][8 bytes]
-        char* d = p2sh + (((q >> 1) * BP + pl) * 2 + (q & 1)) * 8;
-        *reinterpret_cast<p2_f16x4*>(d) = h;
-        *reinterpret_cast<p2_f16x4*>(d + lplane) = l;
+  for (int64_t wi = wave0; wi < nwork; wi += nwaves) {
+    const int64_t pchunk = wi / wm.NCB;
+    const int cb = (int)(wi - pchunk * wm.NCB);
+    const int64_t pix = pchunk * wm.PXW + p_lo;
+    const int q = cb * wm.CQ + q_lo;
+    const bool ok = pix < npx;
+    f32x4 rr = (f32x4){0.f, 0.f, 0.f, 0.f};
+    int n = 0, pin = 0;
+    if (ok) {
+      n = (int)(pix / HWo);
+      pin = (int)(pix - (int64_t)n * HWo);
+      const int Y = pin / Wo, X = pin - Y * Wo;
+      const int64_t zi = (((int64_t)n * H + (Y >> up)) * W + (X >> up)) * C + q * 4;
+      const int64_t o = pix * C + q * 4;
+      const f32x4 zv = *reinterpret_cast<const f32x4*>(z + zi);
+      const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + q * 4);
+      const f32x4 is = *reinterpret_cast<const f32x4*>(invstd + q * 4);
+      const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + q * 4);
+      const f32x4 b = *reinterpret_cast<const f32x4*>(beta + q * 4);
+      rr = bn_affine(zv, mu, is, g, b);
+      if (res1) rr += *reinterpret_cast<const f32x4*>(res1 + o);
+      if (res2) rr += *reinterpret_cast<const f32x4*>(res2 + o);
+      if (relu) {
+        rr.x = mval_relu(rr.x); rr.y = mval_relu(rr.y); rr.z = mval_relu(rr.z); rr.w = mval_relu(rr.w);
       }
+      if (out) *reinterpret_cast<f32x4*>(out + o) = rr;
+      if (relu_mask) relu_mask[o >> 2] = (unsigned char)((rr.x > 0.f) | ((rr.y > 0.f) << 1) | ((rr.z > 0.f) << 2) | ((rr.w > 0.f) << 3));
+      amax = fmaxf(fmaxf(amax, fmaxf(fabsf(rr.x), fabsf(rr.y))), fmaxf(fabsf(rr.z), fabsf(rr.w)));
     }
-    __syncthreads();
-    // granules out: item = (plane, 8-channel block, pixel), pixel fastest
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-      const int e = threadIdx.x + TR_APPLY_THREADS * i;  // 0 .. 4095 = 2 planes x C8 x BP
-      const int plane = e / (C8 * BP), r = e - plane * (C8 * BP);
-      const int c8 = r / BP, pl = r - c8 * BP;
-      const int64_t pix = p0 + pl;
-      if (plane < 2 && pix < npx) {
-        const int n = (int)(pix / HWo), pin = (int)(pix - (int64_t)n * HWo);
-        const p2_u32x4 gran = *reinterpret_cast<const p2_u32x4*>(p2sh + plane * lplane + (c8 * BP + pl) * 16);
-        *reinterpret_cast<p2_u32x4*>(planes + (((int64_t)n * 2 * C8 + c8) * HWo + pin) * 8 + plane * plane_halves) = gran;
-      }
-    }
-    __syncthreads();
+    p2_f16x4 h, l;
+    p2_split(rr * out_mul, h, l);
+    const p2_u32x4 gran = p2_pair_granule(h, l, odd);  // (every lane of the wave takes part in the exchange)
+    if (ok) *reinterpret_cast<p2_u32x4*>(planes + (((int64_t)n * 2 * C8 + (q >> 1)) * HWo + pin) * 8 + (odd ? plane_halves : 0)) = gran;
   }
   if (amax_row) tr_amax_store(amax_row, amax);
 }
@@ -360,17 +373,11 @@ extern "C" int mval_bn_apply_fwd_p2(const float* z, const float* mean, const flo
   MVAL_REQUIRE((!res1 || res1_row) && (!res2 || res2_row), "mval_bn_apply_fwd_p2: a residual needs its magnitude row (the P2 scale is a bound)");
   MVAL_REQUIRE((int64_t)N * (H << up) * (W << up) * C < ((int64_t)1 << 31), "mval_bn_apply_fwd_p2: tensor too large");
   MVAL_REQUIRE(C <= 4096, "mval_bn_apply_fwd_p2: more than 4096 channels");
-  const int64_t npx = (int64_t)N * (H << up) * (W << up);
-  const int BP = 4096 / (C >> 2);
-  int nb = (int)((npx + BP - 1) / BP);
+  const int64_t total4 = (int64_t)N * (H << up) * (W << up) * (C >> 2);
+  int nb = (int)((total4 + TR_APPLY_THREADS - 1) / TR_APPLY_THREADS);
   if (nb > TR_APPLY_BLOCKS) nb = TR_APPLY_BLOCKS;
   const double M = (double)N * H * W;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bn_apply_fwd_p2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-    attr_set = true;
-  }
-  hipLaunchKernelGGL(bn_apply_fwd_p2_kernel, dim3(nb), dim3(TR_APPLY_THREADS), 64 * 1024, mval_stream(stream), z, mean, invstd, gamma, beta, res1,
+  hipLaunchKernelGGL(bn_apply_fwd_p2_kernel, dim3(nb), dim3(TR_APPLY_THREADS), 0, mval_stream(stream), z, mean, invstd, gamma, beta, res1,
                      res2, out, reinterpret_cast<_Float16*>(p2_planes), p2_rows, N, H, W, C, up, relu, amax_row, relu_mask, res1_row, res2_row,
                      (float)sqrt(M > 1 ? M - 1.0 : 1.0));
   MVAL_CHECK_LAUNCH("mval_bn_apply_fwd_p2");
@@ -504,6 +511,34 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
 }
 
 // dbeta / dgamma (float, also kept in `sums` for stage 2)
+// The same, and this channel's share of an upper bound of |dz| = |gamma invstd (g - dbeta / M - xhat dgamma / M)|:
+//   |gamma invstd| (max|g| + |dbeta| / M + sqrt(M - 1) |dgamma| / M)      (|xhat| <= sqrt(M - 1): Samuelson)
+// folded into *bound_slot with atomicMax (non-negative float bits order like integers) -- the P2 scale of dz.
+__global__ __launch_bounds__(64) void bn_bwd_finalize_bound_kernel(const double* __restrict__ part, int nblocks, int C,
+                                                                   float* __restrict__ dbeta, float* __restrict__ dgamma,
+                                                                   float* __restrict__ sums, const float* __restrict__ gmax_part,
+                                                                   const float* __restrict__ gamma, const float* __restrict__ invstd,
+                                                                   float inv_m, float sqrt_m1, unsigned* __restrict__ bound_slot) {
+  const int c = blockIdx.x;
+  double a = 0, b = 0;
+  float gm = 0.f;
+  for (int k = threadIdx.x; k < nblocks; k += 64) {
+    a += part[((int64_t)k * C + c) * 2];
+    b += part[((int64_t)k * C + c) * 2 + 1];
+    gm = fmaxf(gm, gmax_part[k]);
+  }
+  a = wave_sum(a);
+  b = wave_sum(b);
+  gm = wave_max(gm);
+  if (threadIdx.x != 0) return;
+  dbeta[c] = (float)a;
+  dgamma[c] = (float)b;
+  sums[c] = (float)a;
+  sums[C + c] = (float)b;
+  const float bd = fabsf(gamma[c] * invstd[c]) * (gm + fabsf((float)a) * inv_m + sqrt_m1 * fabsf((float)b) * inv_m) * (1.f + 1e-5f);
+  atomicMax(bound_slot, __float_as_uint(bd));
+}
+
 __global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(const double* __restrict__ part, int nblocks, int C,
                                                              float* __restrict__ dbeta, float* __restrict__ dgamma,
                                                              float* __restrict__ sums) {
@@ -661,13 +696,16 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce2_kernel(const float* __rest
                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
                                                              float* __restrict__ gres1, float* __restrict__ gres2,
                                                              double* __restrict__ part, int M, int C, int mask_mode,
-                                                             int overwrite, const unsigned char* __restrict__ relu_mask) {
+                                                             int overwrite, const unsigned char* __restrict__ relu_mask,
+                                                             float* __restrict__ gmax_part, unsigned* __restrict__ bound_slot) {
   extern __shared__ double sh[];
   const int c4n = C >> 2;
   const int lanes = min(c4n, 256);
   const int rows = 256 / lanes;
   const int col = threadIdx.x % lanes, row = threadIdx.x / lanes;
   const f32x4 zero = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float gmax = 0.f;  // (gmax_part) max |masked gradient| of this workgroup: the data gradient's P2 scale is a bound built from it
+  if (bound_slot && blockIdx.x == 0 && threadIdx.x == 0) *bound_slot = 0u;  // (the finalize kernel folds the channels' bounds into it)
   for (int cb = 0; cb < c4n; cb += lanes) {
     const int q = cb + col;
     double sb[4] = {0, 0, 0, 0}, sg[4] = {0, 0, 0, 0};
@@ -700,6 +738,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce2_kernel(const float* __rest
           if (p >= M) break;
           const int64_t o = (int64_t)p * C + q * 4;
           const f32x4 gv = bwd_mask(g[u], mask_mode, ov[u], zv[u], mu, is, gm, bt);
+          gmax = fmaxf(fmaxf(gmax, fmaxf(fabsf(gv.x), fabsf(gv.y))), fmaxf(fabsf(gv.z), fabsf(gv.w)));
           if (gres1) *reinterpret_cast<f32x4*>(gres1 + o) = a1[u] + gv;
           if (gres2) *reinterpret_cast<f32x4*>(gres2 + o) = a2[u] + gv;
           const f32x4 xh = (zv[u] - mu) * is;
@@ -731,6 +770,14 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce2_kernel(const float* __rest
         part[((int64_t)blockIdx.x * C + q * 4 + k) * 2 + 1] = b;
       }
     }
+  }
+  if (gmax_part) {
+    __shared__ float gred[4];
+    gmax = wave_max(gmax);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) gred[threadIdx.x >> 6] = gmax;
+    __syncthreads();
+    if (threadIdx.x == 0) gmax_part[blockIdx.x] = fmaxf(fmaxf(gred[0], gred[1]), fmaxf(gred[2], gred[3]));
   }
 }
 
@@ -769,6 +816,65 @@ __global__ __launch_bounds__(TR_APPLY_THREADS) void bn_bwd_apply2_kernel(const f
   if (amax_row) tr_amax_store(amax_row, amax);
 }
 
+// dz as above, written as fp32 NHWC (gz, optional) AND as P2 planes for the data-gradient conv on the P2 kernels: the float4 side in
+// NHWC order, the granules through LDS (as bn_apply_fwd_p2_kernel); the scale from the bound the finalize step left in *bound_slot.
+__global__ __launch_bounds__(TR_APPLY_THREADS) void bn_bwd_apply2_p2_kernel(
+    const float* __restrict__ gsrc, const float* __restrict__ out, const float* __restrict__ z, const float* __restrict__ mean,
+    const float* __restrict__ invstd, const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ sums,
+    float* __restrict__ gz, _Float16* __restrict__ planes, unsigned* __restrict__ p2_rows, const unsigned* __restrict__ bound_slot, int N,
+    int HW, int C, int mask_mode, unsigned* __restrict__ amax_row, const unsigned char* __restrict__ relu_mask) {
+  const int C8 = C >> 3;
+  const int64_t npx = (int64_t)N * HW;
+  const float invM = 1.0f / (float)npx;
+  float out_mul, out_inv;
+  p2_scale_of(__uint_as_float(*bound_slot), out_mul, out_inv);
+  if (blockIdx.x == 0)
+    for (int n = threadIdx.x; n < N; n += TR_APPLY_THREADS) p2_rows[(int64_t)n * P2_ROW + P2_INV_SLOT] = __float_as_uint(out_inv);
+  const P2WaveMap wm = p2_wave_map(C);
+  const int lane = threadIdx.x & 63;
+  const int p_lo = lane / wm.CQ, q_lo = lane - p_lo * wm.CQ;
+  const bool odd = q_lo & 1;
+  const int64_t nchunks = (npx + wm.PXW - 1) / wm.PXW, nwork = nchunks * wm.NCB;
+  const int64_t plane_halves = (int64_t)C8 * HW * 8;
+  const int64_t wave0 = ((int64_t)blockIdx.x * TR_APPLY_THREADS + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * TR_APPLY_THREADS) >> 6;
+  const f32x4 zero = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float amax = 0.f;
+  for (int64_t wi = wave0; wi < nwork; wi += nwaves) {
+    const int64_t pchunk = wi / wm.NCB;
+    const int cb = (int)(wi - pchunk * wm.NCB);
+    const int64_t pix = pchunk * wm.PXW + p_lo;
+    const int q = cb * wm.CQ + q_lo;
+    const bool ok = pix < npx;
+    f32x4 r = zero;
+    int n = 0, pin = 0;
+    if (ok) {
+      n = (int)(pix / HW);
+      pin = (int)(pix - (int64_t)n * HW);
+      const int64_t o = pix * C + q * 4;
+      const f32x4 gv0 = *reinterpret_cast<const f32x4*>(gsrc + o);
+      const f32x4 zv = *reinterpret_cast<const f32x4*>(z + o);
+      f32x4 ov = mask_mode == 1 ? *reinterpret_cast<const f32x4*>(out + o) : zero;
+      if (mask_mode == 3) ov.x = __uint_as_float((unsigned)relu_mask[o >> 2]);
+      const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + q * 4);
+      const f32x4 is = *reinterpret_cast<const f32x4*>(invstd + q * 4);
+      const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + q * 4);
+      const f32x4 bt = mask_mode == 2 ? *reinterpret_cast<const f32x4*>(beta + q * 4) : zero;
+      const f32x4 db = *reinterpret_cast<const f32x4*>(sums + q * 4);
+      const f32x4 dg = *reinterpret_cast<const f32x4*>(sums + C + q * 4);
+      const f32x4 gv = bwd_mask(gv0, mask_mode, ov, zv, mu, is, g, bt);
+      const f32x4 xh = (zv - mu) * is;
+      r = (g * is) * (gv - db * invM - xh * (dg * invM));
+      if (gz) *reinterpret_cast<f32x4*>(gz + o) = r;
+      amax = fmaxf(fmaxf(amax, fmaxf(fabsf(r.x), fabsf(r.y))), fmaxf(fabsf(r.z), fabsf(r.w)));
+    }
+    p2_f16x4 h, l;
+    p2_split(r * out_mul, h, l);
+    const p2_u32x4 gran = p2_pair_granule(h, l, odd);
+    if (ok) *reinterpret_cast<p2_u32x4*>(planes + (((int64_t)n * 2 * C8 + (q >> 1)) * HW + pin) * 8 + (odd ? plane_halves : 0)) = gran;
+  }
+  if (amax_row) tr_amax_store(amax_row, amax);
+}
+
 // Backward of out = act(bn(z) + res1 + res2) at the conv resolution (no upsample): same results as mval_bn_bwd_amax
 // (dz in gz, dgamma, dbeta, residual gradients scattered), one tensor write and one to two tensor reads fewer.
 extern "C" int mval_bn_bwd_fused(const float* gout, const float* out, const float* z, const float* mean, const float* invstd,
@@ -783,7 +889,22 @@ extern "C" int mval_bn_bwd_fused_mask(const float* gout, const float* out, const
                                       const float* invstd, const float* gamma, const float* beta, float* gres1, float* gres2, float* gz,
                                       float* dgamma, float* dbeta, double* ws, float* sums, int N, int H, int W, int C, int relu,
                                       int overwrite, uint32_t* gz_amax_row, void* stream) {
-  MVAL_REQUIRE(gout && z && mean && invstd && gamma && beta && gz && ws && sums && N > 0 && H > 0 && W > 0 && C > 0 && (C & 3) == 0,
+  return mval_bn_bwd_fused_p2(gout, out, relu_mask, z, mean, invstd, gamma, beta, gres1, gres2, gz, dgamma, dbeta, ws, sums, N, H, W, C, relu,
+                              overwrite, gz_amax_row, nullptr, nullptr, nullptr, nullptr, stream);
+}
+// The same, and (dz_planes != NULL) dz ALSO as P2 planes [n][plane][C/8][H][W][8] with rows dz_rows[n][MVAL_P2_ROW] -- the input of the
+// data-gradient conv on the P2 kernels (round 4).  Its scale comes from a bound of |dz| built in the finalize step from max |masked
+// gradient| (kept by the reduction, gmax_ws >= 512 floats), dbeta, dgamma and Samuelson's |xhat| <= sqrt(M - 1); bound_slot: one dword of
+// scratch.  gz may be NULL then (no fp32 copy of dz).
+extern "C" int mval_bn_bwd_fused_p2(const float* gout, const float* out, const uint8_t* relu_mask, const float* z, const float* mean,
+                                    const float* invstd, const float* gamma, const float* beta, float* gres1, float* gres2, float* gz,
+                                    float* dgamma, float* dbeta, double* ws, float* sums, int N, int H, int W, int C, int relu,
+                                    int overwrite, uint32_t* gz_amax_row, void* dz_planes, uint32_t* dz_rows, float* gmax_ws,
+                                    uint32_t* bound_slot, void* stream) {
+  const bool p2 = dz_planes != nullptr;
+  MVAL_REQUIRE(!p2 || (dz_rows && gmax_ws && bound_slot && (C & 7) == 0 && dgamma && dbeta), "mval_bn_bwd_fused_p2: the P2 form needs rows, scratch and C % 8 == 0");
+  MVAL_REQUIRE(p2 || gz, "mval_bn_bwd_fused: no output for dz");
+  MVAL_REQUIRE(gout && z && mean && invstd && gamma && beta && ws && sums && N > 0 && H > 0 && W > 0 && C > 0 && (C & 3) == 0,
                "mval_bn_bwd_fused: bad arguments (C must be a multiple of 4)");
   MVAL_REQUIRE((int64_t)N * H * W * C < ((int64_t)1 << 33) && (int64_t)N * H * W < ((int64_t)1 << 31), "mval_bn_bwd_fused: more than 2^31 float4 elements");
   MVAL_REQUIRE(!gres1 || gres1 != gres2, "mval_bn_bwd_fused: the two residual gradients must be distinct buffers");
@@ -798,9 +919,13 @@ extern "C" int mval_bn_bwd_fused_mask(const float* gout, const float* out, const
   hipStream_t s = mval_stream(stream);
   const int mask_mode = !relu ? 0 : (gres1 || gres2) ? (relu_mask ? 3 : 1) : 2;
   hipLaunchKernelGGL(bn_bwd_reduce2_kernel, dim3(nb), dim3(256), sh, s, gout, out, z, mean, invstd, gamma, beta, gres1, gres2, ws,
-                     (int)M, C, mask_mode, overwrite, relu_mask);
+                     (int)M, C, mask_mode, overwrite, relu_mask, p2 ? gmax_ws : nullptr, p2 ? bound_slot : nullptr);
   MVAL_CHECK_LAUNCH("mval_bn_bwd_fused/reduce");
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, s, ws, nb, C, dbeta, dgamma, sums);
+  if (p2)
+    hipLaunchKernelGGL(bn_bwd_finalize_bound_kernel, dim3(C), dim3(64), 0, s, ws, nb, C, dbeta, dgamma, sums, gmax_ws, gamma, invstd,
+                       1.0f / (float)M, (float)sqrt(M > 1 ? (double)M - 1.0 : 1.0), bound_slot);
+  else
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, s, ws, nb, C, dbeta, dgamma, sums);
   MVAL_CHECK_LAUNCH("mval_bn_bwd_fused/finalize");
   // the masked gradient again: from the residual slot this op was the first to write (it holds exactly that), else
   // from gout with the mask re-derived
@@ -811,6 +936,12 @@ extern "C" int mval_bn_bwd_fused_mask(const float* gout, const float* out, const
   const int64_t total = M * c4n;
   int nb2 = (int)((total + TR_APPLY_THREADS - 1) / TR_APPLY_THREADS);
   if (nb2 > TR_APPLY_BLOCKS) nb2 = TR_APPLY_BLOCKS;
+  if (p2) {
+    hipLaunchKernelGGL(bn_bwd_apply2_p2_kernel, dim3(nb2), dim3(TR_APPLY_THREADS), 0, s, gsrc, out, z, mean, invstd, gamma, beta, sums, gz,
+                       reinterpret_cast<_Float16*>(dz_planes), dz_rows, bound_slot, N, H * W, C, apply_mask, gz_amax_row, relu_mask);
+    MVAL_CHECK_LAUNCH("mval_bn_bwd_fused/apply p2");
+    return 0;
+  }
   hipLaunchKernelGGL(bn_bwd_apply2_kernel, dim3(nb2), dim3(TR_APPLY_THREADS), 0, s, gsrc, out, z, mean, invstd, gamma, beta, sums, gz, M,
                      C, apply_mask, gz_amax_row, relu_mask);
   MVAL_CHECK_LAUNCH("mval_bn_bwd_fused/apply");

@@ -50,6 +50,7 @@ class MvalTrainOp(C.Structure):
         ("fwd_p2", C.c_int32), ("p2_flags", C.c_int32),
         ("in_p2_off", C.c_int64), ("in_p2_rows_off", C.c_int64), ("out_p2_off", C.c_int64), ("out_p2_rows_off", C.c_int64),
         ("res1_amax_off", C.c_int64), ("res2_amax_off", C.c_int64),
+        ("gz_p2_off", C.c_int64), ("gz_p2_rows_off", C.c_int64),
     ]
 
 
@@ -268,6 +269,36 @@ class TrainPlan:
                 own_ok = not (po.relu and (po.res1 is not None or po.res2 is not None)) or (os.environ.get("MVAL_TRAIN_RELU_MASK", "1") != "0" and po.up == 0)
                 if p2w and own_ok and a_ not in res_used and a_ != g.output and cons and all(self.ops[i].fwd_p2 and (self.ops[i].p2_flags & 1) for i in cons):
                     self.ops[producer[a_]].p2_flags |= 2
+            # data gradients of stride-1 convs on the P2 kernels: the BatchNorm backward also writes dz as P2 planes into ONE scratch
+            # (planes of the largest dz, rows, reduction scratch); MVAL_TRAIN_P2_DGRAD=0: the h2 data gradients
+            if os.environ.get("MVAL_TRAIN_P2_DGRAD", "1") != "0":
+                want = []
+                for i, op in enumerate(g.ops):
+                    t = self.ops[i]
+                    if not (t.dgrad_algo == ALGO_MFMA_H2 and t.dgrad_form == 0 and op.bn and op.up == 0 and op.stride == 1 and op.cout % 8 == 0 and op.cin % 4 == 0
+                            and t.gin_off >= 0):
+                        continue
+                    hin, win, hout, wout = geo[i]
+                    d = MvalOp()
+                    d.kind, d.k, d.stride, d.pad, d.cin, d.cout = 0, op.k, 1, op.k // 2, op.cout, op.cin
+                    d.hin, d.win, d.hout, d.wout = hout, wout, hin, win
+                    if op.pad == op.k // 2 and lib.mval_op_algo_supported(C.byref(d), C.c_int(n), C.c_int(4)):
+                        want.append(i)
+                if want:
+                    planes = self._row_top
+                    self._row_top += _align(max(n * geo[i][2] * geo[i][3] * g.ops[i].cout for i in want))
+                    rows = self._row_top
+                    self._row_top += _align(n * P2_ROW + 512 + 64)
+                    self.p2_rows.append((rows, n * P2_ROW + 512 + 64))
+                    for i in want:
+                        self.ops[i].p2_flags |= 4
+                        self.ops[i].gz_p2_off, self.ops[i].gz_p2_rows_off = planes, rows
+                        op = g.ops[i]
+                        # the weight gradient reads dz from the planes too where the split kernel covers the conv: no fp32 copy of dz
+                        if (os.environ.get("MVAL_TRAIN_P2_WGRAD", "1") != "0" and op.cout % 8 == 0
+                                and lib.mval_conv_wgrad_split_covers(C.c_int(op.cin), C.c_int(op.cout), C.c_int(op.k), C.c_int(op.stride))
+                                and ((self.ops[i].p2_flags & 1) or self.ops[i].op.in_amax_off > 0)):
+                            self.ops[i].p2_flags |= 8
         for i, op in enumerate(g.ops):  # producers leave max |out| where a split conv will look for it
             self.ops[i].out_amax_off = amax_row.get(op.dst, 0)
         # ReLU behind residual adds (BasicBlock / Bottleneck outputs, fuse sums at the conv resolution): the forward apply keeps
