@@ -237,16 +237,17 @@ def train_rooflines(model, step, frames, v, mode):
                     seconds_in_kernel_per_step=round(tt, 6), bytes_per_step=b)
 
     fams = [
-        mf("conv forward (conv_split_kernel / conv_mfma_kernel, raw z, bias-free accumulate; since round 4 the epilogue also keeps the "
-           "per-workgroup (sum, sum of squares) partials of BatchNorm's batch statistics)", fl_fwd, t[0]),
+        mf("conv forward (round 4: conv_p2_kernel<..., EPI 3> over fp16-pair activations -- raw fp32 NHWC z + the batch-statistics sums of "
+           "its persistent workgroups; conv_split_kernel / conv_mfma_kernel for the shapes P2 does not cover)", fl_fwd, t[0]),
         hb("BatchNorm statistics (bn_stats_finalize_tiles: the conv epilogues' float64 partials -> mean / invstd / running stats; the "
            "stem conv, whose kernel keeps none, still runs bn_stats_partial over z; bytes = one read of z, as in round 3, for comparison)", zb, t[1]),
-        hb("BatchNorm apply (bn_apply_fwd: z -> normalise + residuals + ReLU (+ upsample) -> out, + the ReLU mask bytes of residual ops)", zb + ob, t[2]),
-        hb("BatchNorm backward (bn_bwd_reduce2 + finalize + bn_bwd_apply2: gout, z [, mask bytes] -> dz, dgamma, dbeta, residual gradients; "
+        hb("BatchNorm apply (bn_apply_fwd_p2: z -> normalise + residuals + ReLU (+ upsample) -> out as P2 planes and, for residual inputs, fp32; "
+           "+ the ReLU mask bytes of residual ops; bytes = round 3's count)", zb + ob, t[2]),
+        hb("BatchNorm backward (bn_bwd_reduce2 + finalize + bn_bwd_apply2[_p2]: gout, z [, mask bytes] -> dz (as P2 planes where the P2 data gradient reads it), dgamma, dbeta, residual gradients; "
            "bytes = round 3's count (2 x out-sized + 4 x z-sized tensors), for comparison: the round-4 kernels move 5 - 7 of those 6 - 8)",
            2.0 * ob + 4.0 * zb, t[3]),
-        mf("weight gradient (conv_wgrad_bf3_kernel split-K + float64 slab reduction)", fl_fwd, t[4]),
-        mf("data gradient (forward kernels on flipped weights)", fl_dgrad, t[5]),
+        mf("weight gradient (conv_wgrad_bf3_kernel split-K, both operands staged from the P2 planes, + float64 slab reduction)", fl_fwd, t[4]),
+        mf("data gradient (conv_p2_kernel<..., EPI 3> accumulating into the fp32 gradient slot; stride 2: four 2x2 parity convs on conv_split_kernel)", fl_dgrad, t[5]),
     ]
     fams.sort(key=lambda f: -f["seconds_in_kernel_per_step"])
     top = fams[0]
