@@ -255,6 +255,7 @@ class TrainPlan:
             # weight gradients read x from the planes where the split kernel covers the conv; an activation whose EVERY consumer reads the
             # planes (P2 forward conv + P2 weight gradient, no residual use, not the network output) is not written as fp32 at all
             p2w = os.environ.get("MVAL_TRAIN_P2_WGRAD", "1") != "0"
+            fused_bwd = os.environ.get("MVAL_TRAIN_BWD_FUSED", "1") != "0"  # (round 3's BatchNorm backward reads `out` and writes fp32 dz only)
             res_used = {r for op in g.ops for r in (op.res1, op.res2) if r is not None}
             consumers = {}
             for i, op in enumerate(g.ops):
@@ -267,11 +268,11 @@ class TrainPlan:
                 po = g.ops[producer[a_]]
                 # (its own backward must not need `out` either: a ReLU behind residual adds takes its mask from the mask bytes)
                 own_ok = not (po.relu and (po.res1 is not None or po.res2 is not None)) or (os.environ.get("MVAL_TRAIN_RELU_MASK", "1") != "0" and po.up == 0)
-                if p2w and own_ok and a_ not in res_used and a_ != g.output and cons and all(self.ops[i].fwd_p2 and (self.ops[i].p2_flags & 1) for i in cons):
+                if p2w and fused_bwd and own_ok and a_ not in res_used and a_ != g.output and cons and all(self.ops[i].fwd_p2 and (self.ops[i].p2_flags & 1) for i in cons):
                     self.ops[producer[a_]].p2_flags |= 2
             # data gradients of stride-1 convs on the P2 kernels: the BatchNorm backward also writes dz as P2 planes into ONE scratch
             # (planes of the largest dz, rows, reduction scratch); MVAL_TRAIN_P2_DGRAD=0: the h2 data gradients
-            if os.environ.get("MVAL_TRAIN_P2_DGRAD", "1") != "0":
+            if os.environ.get("MVAL_TRAIN_P2_DGRAD", "1") != "0" and fused_bwd:
                 want = []
                 for i, op in enumerate(g.ops):
                     t = self.ops[i]

@@ -509,3 +509,29 @@ def test_c3_full_size_properties(dev):
         assert _rel(g2[k].cpu().numpy(), g0[k].cpu().numpy()) < 5e-3, k  # (the problem is ill-conditioned; the halves are summed in another order)
     for k in list(r0)[:8]:
         np.testing.assert_allclose(r2[k].cpu().numpy(), r0[k].cpu().numpy(), rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("off", ["MVAL_TRAIN_P2", "MVAL_TRAIN_P2_WGRAD", "MVAL_TRAIN_P2_DGRAD", "MVAL_TRAIN_EPI_STATS", "MVAL_TRAIN_BWD_FUSED",
+                                 "MVAL_TRAIN_RELU_MASK", "MVAL_TRAIN_DGRAD_PARITY"])
+def test_round4_training_paths_against_their_switches(dev, off, monkeypatch):
+    """Round 4 rebuilt the training step in layers (statistics from the conv epilogue, the fused BatchNorm backward, mask bytes, parity data
+    gradients, then forward / weight-gradient / data-gradient convs on the P2 kernels with Samuelson-bound scales), each behind a switch.
+    One HRNet-W32 step with every layer on against the same step with ONE switched off: the loss agrees to 2e-6 relative, the median
+    parameter gradient to 5e-3 and the worst to 5e-2 relative L2 -- the problem's own noise level: torch-CPU fp32 is 1e-2 .. 3e-2 from a
+    float64 run on the worst tensors (test_all_gradients_vs_cpu_oracle holds the default to that floor, the goldens to the reference) --
+    and the P2 plan really takes the P2 paths."""
+    from multi_view_active_learning_amd import engine_train
+
+    c = cases.train_cases()["w32_train"]
+    m1, _, hm1, l1, _ = _train_once(c, dev)
+    plan = next(iter(m1._train_plans.values()))
+    n_p2 = sum(int(t.fwd_p2) for t in plan.ops)
+    assert n_p2 > 200 and sum(int(t.p2_flags & 4 != 0) for t in plan.ops) > 150 and sum(int(t.p2_flags & 2 != 0) for t in plan.ops) > 80
+    g1 = {k: p.grad.detach().clone() for k, p in m1.named_parameters()}
+    monkeypatch.setenv(off, "0")
+    m0, _, hm0, l0, _ = _train_once(c, dev)
+    if off == "MVAL_TRAIN_P2":
+        assert sum(int(t.fwd_p2) for t in next(iter(m0._train_plans.values())).ops) == 0
+    assert abs(l1.item() - l0.item()) <= 2e-6 * abs(l0.item())
+    errs = sorted(_rel(g1[k].cpu().numpy(), p.grad.cpu().numpy()) for k, p in m0.named_parameters())
+    assert errs[-1] < 5e-2 and errs[len(errs) // 2] < 5e-3, (errs[-1], errs[len(errs) // 2])
