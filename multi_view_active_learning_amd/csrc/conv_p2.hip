@@ -632,7 +632,7 @@ __global__ __launch_bounds__(64 * WN * WM) __attribute__((amdgpu_waves_per_eu(P2
           // decode from the epilogue (hrnet.py:344-350,500 -> utils/evaluation.py:13-30): the 16 pixel lanes of a cout
           // quarter fold their keys; the wave's key of (tile, cout) goes to its slot of the map's row
           if (a.argmax_keys) {
-            const int timg = (oy0 / TH) * a.tiles_x + ox0 / TW;
+            const int timg = (oy0 / TH) * a.tiles_x + ox0 / TWE;
 #pragma unroll
             for (int j = 0; j < 4; j++) {
               const unsigned long long kk = mval_key_row16_max(bi[j] == 0xffffffffu ? 0ull : mval_argmax_key(bv[j], bi[j]));
@@ -693,7 +693,7 @@ __global__ __launch_bounds__(64 * WN * WM) __attribute__((amdgpu_waves_per_eu(P2
         if (atomicAdd(&wgred[1], 1u) == (unsigned)(WN * WM - 1)) {
           const unsigned m = atomicExch(&wgred[0], 0u);
           wgred[1] = 0u;
-          const int timg = (oy0 / TH) * a.tiles_x + ox0 / TW;
+          const int timg = (oy0 / TH) * a.tiles_x + ox0 / TWE;
           p2_slot_put(a.out_row + (int64_t)n * P2_ROW, timg * (int)gridDim.y + (int)blockIdx.y, tiles_img * (int)gridDim.y, m);
         }
       }
@@ -727,7 +727,7 @@ static int launch_p2e(P2Args a, hipStream_t s) {
   a.th = TH; a.tw = TWE;
   a.tiles_x = (a.Wout + TWE - 1) / TWE;
   a.tiles_y = (a.Hout + TH - 1) / TH;
-  if (OW && a.Wout != OW) return 1;
+  if (OW && a.Wout % OW != 0) return 1;  // (whole odd tiles per row: 18 -> 1, 36 -> 2 tiles of 18 columns)
   const unsigned groups = (unsigned)((a.NS_total + WN * NT - 1) / (WN * NT));
   a.amax_tiles = a.tiles_x * a.tiles_y;
   a.tiles_total = a.amax_tiles * a.N;
@@ -813,7 +813,10 @@ int mval_launch_conv_p2(const P2Args& a0, hipStream_t s) {
     // maps no power-of-two tile fits (HRNet-W48 at 384 x 288: 24 x 18 and 12 x 9): full-width odd tiles, 3 x 18 / 7 x 9 pixels
     const char* oe = getenv("MVAL_P2_ODD");
     if (!(oe && oe[0] == '0') && a.NS_total > 2 && !a.up && !a.out_f32) {
-      if (a.Wout == 18) return launch_p2<3, 1, 1, 4, 1, 1, 4, 8, false, 18>(a, s);
+      // (36-wide maps -- HRNet-W48's 96-channel branch -- as two 18-wide odd tiles per row: 54 of 64 slots used against 36 of 48 columns
+      // of three 16-wide row-sharing tiles: 84 -> 78 us for 96 -> 96 on 48 x 36; MVAL_P2_ODD36=0: the 16-wide tiles)
+      const char* o36 = getenv("MVAL_P2_ODD36");
+      if (a.Wout == 18 || (a.Wout == 36 && !(o36 && o36[0] == '0'))) return launch_p2<3, 1, 1, 4, 1, 1, 4, 8, false, 18>(a, s);
       if (a.Wout == 9) return launch_p2<3, 1, 1, 4, 1, 1, 4, 8, false, 9>(a, s);
     }
     if (a.Wout >= 16 && a.Hout >= 4) {

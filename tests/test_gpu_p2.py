@@ -62,6 +62,8 @@ P2_CASES = [
     (2, 96, 192, 10, 18, 3, 1, False, True, True, 0, False),
     (3, 192, 96, 5, 9, 3, 1, True, False, False, 0, False),
     (1, 64, 64, 23, 9, 3, 1, True, True, False, 0, False),
+    (2, 96, 96, 48, 36, 3, 1, True, True, False, 0, False),  # two 18-wide odd tiles per row
+    (1, 64, 128, 7, 36, 3, 1, False, False, False, 0, False),
     (2, 192, 384, 24, 18, 3, 2, True, True, True, 0, False),
     (1, 192, 48, 24, 18, 1, 1, False, True, False, 2, False),
     (2, 64, 256, 96, 72, 1, 1, True, True, False, 0, False),
