@@ -104,8 +104,14 @@ __device__ __forceinline__ f32x4 p2_mfma(const u32x4 a, const u32x4 b, const f32
 // floor(16 MS WM / OW) rows high -- full-width rows, pixel slot p -> (p / OW, p % OW), the slots past the last whole row are
 // padding.  On such maps the power-of-two tiles compute 1.33x (24 x 18 in 8 x 8 tiles) to 2.4x (12 x 9) the pixels that exist
 // (HRNet-W48 forced onto P2: 384 -> 384 on 12 x 9 took 134 us against 65 us for the h2 kernel's odd tiles).
-template <int KS, int S, int G, int WN, int WM, int NT, int MS, int TW, bool RS, int EPI, int OW = 0>
+// K48 (row-sharing 3x3 kernels, Cin = 48: HRNet-W48's first branch): the second 32-channel chunk holds 16 channels.  Its stage runs TWO
+// column steps instead of three: one PAIRED step whose k-octets 0, 1 are channels 32..47 of column tap 0 and octets 2, 3 the same
+// channels of column tap 1 (the lanes of the upper octets read their patch fragment one pixel to the right and their weight fragment from
+// the next tap's block: per-lane address constants, the packed weights and the LDS image are unchanged), then column tap 2 as before --
+// 15 instead of 18 MFMA column steps per tile.
+template <int KS, int S, int G, int WN, int WM, int NT, int MS, int TW, bool RS, int EPI, int OW = 0, bool K48 = false>
 __global__ __launch_bounds__(64 * WN * WM) __attribute__((amdgpu_waves_per_eu(P2_WAVES(MS, NT, EPI), 8))) void conv_p2_kernel(P2Args a) {
+  static_assert(!K48 || (RS && G == 1), "K48: the row-sharing 3x3 kernels");
   constexpr int NTH = 64 * WN * WM, TAPS = KS * KS, SPN = 8 * G, SPN_LOG2 = G == 1 ? 3 : G == 2 ? 4 : 5;
   constexpr int pad = KS / 2;
   static_assert(G == 1 || G == 2 || G == 4, "chunks per stage");
@@ -237,6 +243,8 @@ __global__ __launch_bounds__(64 * WN * WM) __attribute__((amdgpu_waves_per_eu(P2
       xb[ms] = ((lane >> 4) * PPX + (S == 1 ? ty * PW + tx : 2 * ty * PWh + tx)) * 16;
     }
   }
+  // K48 paired step: octets 0, 1 -> blocks 0, 1 (channels 32..47) at column tap 0; octets 2, 3 -> the same blocks one pixel to the right
+  const int xb_pair = K48 ? ((((lane >> 4) & 1) * PPX + wm * MS * PW + (lane & 15) + (lane >> 5)) * 16) : 0;
   constexpr int plane_b = 4 * PPX * 16;  // plane l behind plane h inside a chunk
   constexpr int chunk_b = 8 * PPX * 16;
   // weight fragments through a buffer descriptor: block offset in SGPRs, per-lane 32-bit offset, plane as immediate
@@ -253,6 +261,12 @@ __global__ __launch_bounds__(64 * WN * WM) __attribute__((amdgpu_waves_per_eu(P2
   for (int nt = 0; nt < NT; nt++) wlane[nt] = (min(ns0 + nt, a.NS_total - 1) * 128 + wsrc) * 16;
   auto wfrag = [&](int blk, int nt, int p) -> u32x4 {
     return __builtin_amdgcn_raw_buffer_load_b128(wr, wlane[nt] + p * 1024, blk * blk_bytes, 0);
+  };
+  // K48 paired weight fragment of row tap ky: lanes of octets 0, 1 read block (ky, kx = 0, chunk 1) as usual, lanes of octets 2, 3 the
+  // fragment lane 32 below theirs (octets 0, 1: channels 32..47) of block (ky, kx = 1, chunk 1) = two blocks further
+  const int pair_adj = (K48 && lane >= 32) ? 2 * blk_bytes - 512 : 0;
+  auto wfrag_pair = [&](int ky, int nt, int p) -> u32x4 {
+    return __builtin_amdgcn_raw_buffer_load_b128(wr, wlane[nt] + p * 1024 + pair_adj, ((ky * 3) * 2 + 1) * blk_bytes, 0);
   };
   const float w_unscale = *a.w_unscale;
   // output / residual planes through buffer descriptors: per tile ONE per-lane 32-bit byte offset (+ a scalar offset per
@@ -290,6 +304,17 @@ __global__ __launch_bounds__(64 * WN * WM) __attribute__((amdgpu_waves_per_eu(P2
   // RS: a "column" = the three row taps of column tap kx; else a "step" = one (chunk of the stage, tap) block
   auto wload = [&](int par, int stg, int u) {
     if constexpr (RS) {
+      if constexpr (K48) {
+        if (stg == 1) {  // the remainder stage: column 0 = the paired step, column 1 = column tap 2
+#pragma unroll
+          for (int ky = 0; ky < 3; ky++)
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+              for (int p = 0; p < 2; p++) B[par][ky][nt][p] = u == 0 ? wfrag_pair(ky, nt, p) : wfrag((ky * 3 + 2) * 2 + 1, nt, p);
+          return;
+        }
+      }
 #pragma unroll
       for (int ky = 0; ky < 3; ky++)
 #pragma unroll
@@ -311,23 +336,31 @@ __global__ __launch_bounds__(64 * WN * WM) __attribute__((amdgpu_waves_per_eu(P2
   };
 
   // One stage's MFMAs from LDS buffer `buf`; `pre` != 0: request the first weight blocks of stage `nst_next` at the end.
-  auto mfma_stage = [&](int buf, int st, bool pre, int st_next) {
+  auto mfma_stage = [&](auto rem_tag, int buf, int st, bool pre, int st_next) {
+    constexpr bool REM = decltype(rem_tag)::value;  // (K48) the remainder stage: two column steps
     if constexpr (RS) {
       const char* xs = smem + buf * buf_bytes + xb[0];
-      constexpr int Q = 3 * (MS + 2);  // (column tap kx, patch row pr) steps
+      const char* xsp = smem + buf * buf_bytes + xb_pair;
+      constexpr int NC = REM ? 2 : 3;
+      constexpr int Q = NC * (MS + 2);  // (column step, patch row pr) steps
+      // fragment of (column step c, patch row pr): the remainder stage's step 0 is the paired one, its step 1 column tap 2
+      auto frag_at = [&](int c, int pr) -> const char* {
+        if constexpr (REM) return c == 0 ? xsp + (pr * PW) * 16 : xs + (pr * PW + 2) * 16;
+        else return xs + (pr * PW + c) * 16;
+      };
       u32x4 Xf[2][2];
-      Xf[0][0] = *reinterpret_cast<const u32x4*>(xs);
-      Xf[0][1] = *reinterpret_cast<const u32x4*>(xs + plane_b);
+      Xf[0][0] = *reinterpret_cast<const u32x4*>(frag_at(0, 0));
+      Xf[0][1] = *reinterpret_cast<const u32x4*>(frag_at(0, 0) + plane_b);
 #pragma unroll
       for (int q = 0; q < Q; q++) {
         const int kx = q / (MS + 2), pr = q % (MS + 2);
-        if (pr == 0) {  // request the next column's weights (kx = 2: the first column of the next stage, into parity 1)
-          if (kx < 2) wload((kx + 1) & 1, st, kx + 1);
-          else if (pre) wload(1, st_next, 0);
+        if (pr == 0) {  // request the next column's weights (last column: the first column of the next stage, into parity NC & 1)
+          if (kx + 1 < NC) wload((kx + 1) & 1, st, kx + 1);
+          else if (pre) wload(NC & 1, st_next, 0);
         }
         if (q + 1 < Q) {
           const int kx1 = (q + 1) / (MS + 2), pr1 = (q + 1) % (MS + 2);
-          const char* ap = xs + (pr1 * PW + kx1) * 16;
+          const char* ap = frag_at(kx1, pr1);
           Xf[(q + 1) & 1][0] = *reinterpret_cast<const u32x4*>(ap);
           Xf[(q + 1) & 1][1] = *reinterpret_cast<const u32x4*>(ap + plane_b);
         }
@@ -348,7 +381,7 @@ __global__ __launch_bounds__(64 * WN * WM) __attribute__((amdgpu_waves_per_eu(P2
         }
         __builtin_amdgcn_sched_barrier(SB);
       }
-      if (pre) {  // the next stage starts on parity 0
+      if (pre && (NC & 1)) {  // the next stage starts on parity 0
 #pragma unroll
         for (int ky = 0; ky < 3; ky++)
 #pragma unroll
@@ -417,7 +450,7 @@ __global__ __launch_bounds__(64 * WN * WM) __attribute__((amdgpu_waves_per_eu(P2
       for (int nt = 0; nt < NT; nt++) acc[ms][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     for (int st = 0; st + 1 < nst; st++) {  // all but the tile's last stage
       load_stage(st + 1);
-      if (wave_active) mfma_stage(buf, st, true, st + 1);
+      if (wave_active) mfma_stage(std::false_type{}, buf, st, true, st + 1);
       P2_ACC(0);
       store_stage(buf ^ 1);
       __syncthreads();
@@ -481,7 +514,7 @@ __global__ __launch_bounds__(64 * WN * WM) __attribute__((amdgpu_waves_per_eu(P2
           for (int ms = 0; ms < MS; ms++) R1[ms][nt] = __builtin_amdgcn_raw_buffer_load_b128(r1r, voff(nt, ms), soff(ms), 0);
       }
       __builtin_amdgcn_sched_barrier(SB);
-      mfma_stage(buf, nst - 1, have_next, 0);
+      mfma_stage(std::integral_constant<bool, K48>{}, buf, nst - 1, have_next, 0);
     }
     P2_ACC(3);
 
@@ -714,7 +747,7 @@ __global__ __launch_bounds__(64 * WN * WM) __attribute__((amdgpu_waves_per_eu(P2
 
 static thread_local int g_p2_dry = 0;
 
-template <int KS, int S, int G, int WN, int WM, int NT, int MS, int TW, bool RS, int EPI, int OW = 0>
+template <int KS, int S, int G, int WN, int WM, int NT, int MS, int TW, bool RS, int EPI, int OW = 0, bool K48 = false>
 static int launch_p2e(P2Args a, hipStream_t s) {
   constexpr int TWE = OW ? OW : TW;
   constexpr int TH = 16 * MS * WM / TWE;
@@ -741,7 +774,7 @@ static int launch_p2e(P2Args a, hipStream_t s) {
   // registers), a multiple of 8 per cout group so that every XCD walks its own contiguous tile range; fewer tiles than
   // that: one tile each.  (No workgroup waits for another one: an optimistic answer only costs a second round.)
   static std::atomic<int> occ{0};
-  int per_cu = p2_resident_wgs(&conv_p2_kernel<KS, S, G, WN, WM, NT, MS, TW, RS, EPI, OW>, occ, smem, NTH / 64);
+  int per_cu = p2_resident_wgs(&conv_p2_kernel<KS, S, G, WN, WM, NT, MS, TW, RS, EPI, OW, K48>, occ, smem, NTH / 64);
   const char* pe = getenv("MVAL_P2_WGS");  // measurement override: workgroups per CU
   if (pe && atoi(pe) > 0) per_cu = atoi(pe);
   int wgs = (mval_cu_count() * per_cu / (int)groups) & ~7;
@@ -762,7 +795,7 @@ static int launch_p2e(P2Args a, hipStream_t s) {
     if (a.bn_part && (int64_t)a.Cout * a.bn_slots * 2 > a.bn_part_cap) a.bn_part = nullptr;  // (no room: the caller runs the separate statistics pass)
     if (a.bn_part && a.bn_slots_host) *a.bn_slots_host = a.bn_slots;
   }
-  hipLaunchKernelGGL((conv_p2_kernel<KS, S, G, WN, WM, NT, MS, TW, RS, EPI, OW>), grid, dim3(NTH), smem, s, a);
+  hipLaunchKernelGGL((conv_p2_kernel<KS, S, G, WN, WM, NT, MS, TW, RS, EPI, OW, K48>), grid, dim3(NTH), smem, s, a);
   return 0;
 }
 
@@ -817,9 +850,14 @@ int mval_launch_conv_p2(const P2Args& a0, hipStream_t s) {
       // of three 16-wide row-sharing tiles: 84 -> 78 us for 96 -> 96 on 48 x 36; MVAL_P2_ODD36=0: the 16-wide tiles)
       const char* o36 = getenv("MVAL_P2_ODD36");
       if (a.Wout == 18 || (a.Wout == 36 && !(o36 && o36[0] == '0'))) return launch_p2<3, 1, 1, 4, 1, 1, 4, 8, false, 18>(a, s);
+      // (9-wide odd tiles on the 72-wide maps -- 63 of 64 slots -- measured slower than the 16-wide row-sharing tiles: 105 vs 103 us)
       if (a.Wout == 9) return launch_p2<3, 1, 1, 4, 1, 1, 4, 8, false, 9>(a, s);
     }
     if (a.Wout >= 16 && a.Hout >= 4) {
+      // 48 input channels (HRNet-W48's first branch): the paired remainder stage (K48 above); MVAL_P2_K48=0: three column steps
+      const char* k48 = getenv("MVAL_P2_K48");
+      if (a.Cin == 48 && a.NS_total > 2 && !a.up && !a.out_f32 && !a.out_nhwc && !(k48 && k48[0] == '0') && !oms && !ont)
+        return launch_p2e<3, 1, 1, 4, 1, 1, 4, 16, true, 0, 0, true>(a, s);
       if (a.NS_total <= 2) return launch_p2<3, 1, 1, 2, 2, 1, 4, 16, true>(a, s);  // 32 couts: 2 x 2 waves, 4 rows each
       // 64-pixel tiles: measured faster than 128-pixel ones on every HRNet shape (128 -> 128 on 16x16: 28.8 vs 30.6 us,
       // 64 -> 64 on 32x32: 32.7 vs 39.5) -- more, shorter workgroups overlap their vector phases better
