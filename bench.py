@@ -919,10 +919,18 @@ def main():
             comp["note"] = ("BASELINE configs[2] (C3 training step) and configs[3]'s per-GPU slice (C4: HRNet-W48, 8 views, 384x288, 8 frames + MPE "
                             "scoring) run by this command as child processes after the headline: same box, same driver clock")
             out["companions"] = comp
-        print(json.dumps(out))
     if world > 1 or args.rccl_world_1:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # The JSON line is the LAST thing on stdout: RCCL's version banner sits in the C library's stdio buffer (flushed at exit when stdout is a
+        # file or a pipe), so the process group goes first and the C buffers are flushed before the line is written.
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
