@@ -12,12 +12,13 @@
 #include "mval_common.h"
 
 #define SC_THREADS 256
-#define SC_MAX_PEAKS 2048
+#define SC_MAX_PEAKS 512
 
 struct ScoreSmem {
   float red[SC_THREADS];
   int n_cand;
   int overflow;
+  int adjacent;
   float vmin;
   float ssum;
 };
@@ -54,6 +55,20 @@ __device__ __forceinline__ bool sc_better(float v, int i, float bv, int bi) {
   return (v > bv) || (v == bv && i < bi);
 }
 
+// python's sum() over a list of float32: strictly left to right.  Eight values per pair of 16-byte LDS reads (the one-at-a-time loop
+// paid the LDS latency per element: ~160 candidates x 2 sums per map on noise maps)
+__device__ __forceinline__ float serial_sum_lds(const float* a, int n) {
+  float s = 0.f;
+  int i = 0;
+  for (; i + 8 <= n; i += 8) {
+    const float4 u = *reinterpret_cast<const float4*>(a + i), w = *reinterpret_cast<const float4*>(a + i + 4);
+    s += u.x; s += u.y; s += u.z; s += u.w;
+    s += w.x; s += w.y; s += w.z; s += w.w;
+  }
+  for (; i < n; i++) s += a[i];
+  return s;
+}
+
 // DECODE: the same staged copy also yields the hard arg-max key-point of the map (utils/evaluation.py:13-30, what
 // mval_argmax_decode computes from a second read of the heat-maps): one pass over each map per scoring pass.
 struct ScoreDecodeArgs {
@@ -83,6 +98,7 @@ __global__ __launch_bounds__(SC_THREADS) void score_maps_kernel(const float* __r
 
   float bv = -INFINITY;
   int bi = 0x7fffffff;
+  float vmin = INFINITY;  // min of the map the peaks are searched in (MPE: the heat-map, here; BSB: its row softmax, below)
   if ((npix & 3) == 0 && (wh & 3) == 0) {  // float4 loads (maps are 16-byte aligned then); a quad never straddles rows
     const float4* p4 = reinterpret_cast<const float4*>(p);
     for (int i = tid; i < (npix >> 2); i += SC_THREADS) {
@@ -91,6 +107,7 @@ __global__ __launch_bounds__(SC_THREADS) void score_maps_kernel(const float* __r
       const int y = base / wh, x = base - y * wh;
       float* t = tile + y * ld + x;
       t[0] = q.x; t[1] = q.y; t[2] = q.z; t[3] = q.w;
+      if (KIND == MVAL_SCORE_MPE) vmin = fminf(fminf(vmin, fminf(q.x, q.y)), fminf(q.z, q.w));
       if (DECODE) {
         // a thread meets its pixels in increasing index order, so "strictly greater, or the first NaN" is the whole
         // torch.argmax order here (the cross-lane reduction below uses the full comparison)
@@ -105,10 +122,11 @@ __global__ __launch_bounds__(SC_THREADS) void score_maps_kernel(const float* __r
       const int y = i / wh, x = i - y * wh;
       const float q = p[i];
       tile[y * ld + x] = q;
+      if (KIND == MVAL_SCORE_MPE) vmin = fminf(vmin, q);
       if (DECODE && (q > bv || (q != q && bv == bv))) { bv = q; bi = i; }
     }
   }
-  if (tid == 0) { sm->n_cand = 0; sm->overflow = 0; }
+  if (tid == 0) { sm->n_cand = 0; sm->overflow = 0; sm->adjacent = 0; }
   if (DECODE) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -157,7 +175,11 @@ __global__ __launch_bounds__(SC_THREADS) void score_maps_kernel(const float* __r
       for (int c = c0; c < c1; c++) s += expf(row[c] - m);
       for (int o = T >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
       if (KIND == MVAL_SCORE_BSB && live) {
-        for (int c = c0; c < c1; c++) row[c] = expf(row[c] - m) / s;
+        for (int c = c0; c < c1; c++) {
+          const float q = expf(row[c] - m) / s;
+          row[c] = q;
+          vmin = fminf(vmin, q);
+        }
       }
       if (live) best = fmaxf(best, 1.0f / s);
     }
@@ -170,14 +192,39 @@ __global__ __launch_bounds__(SC_THREADS) void score_maps_kernel(const float* __r
   }
 
   // ---- peak_local_max(min_distance=2) -------------------------------------------------
-  float vmin = INFINITY;
-  for (int i = tid; i < npix; i += SC_THREADS) {
-    int y = i / wh, x = i - y * wh;
-    vmin = fminf(vmin, tile[y * ld + x]);
-  }
   vmin = block_reduce_min(vmin, sm->red);
   const int ih = hh - 4, iw = wh - 4;  // interior after the 2-px border exclusion
-  if (ih > 0 && iw > 0) {
+  auto put = [&](float v, int idx) {
+    int slot = atomicAdd(&sm->n_cand, 1);
+    if (slot < cap) {
+      cval[slot] = v;
+      cidx[slot] = idx;
+    } else {
+      sm->overflow = 1;
+    }
+  };
+  if (ih > 0 && iw > 0 && iw <= SC_THREADS) {
+    // a pixel is a candidate iff no value of its 5x5 window exceeds it (and none is NaN): the window maximum as the maximum of five
+    // ROW maxima -- a thread walks one interior column of its band of rows with the last five row maxima in registers: 5 + 1 LDS reads
+    // per pixel instead of 25 (consecutive lanes = consecutive columns: conflict-free with the odd row stride).  The maximum
+    // propagates NaN, so "m <= v" is exactly "every neighbour <= v".
+    const int G = SC_THREADS / iw, g = tid / iw, x = tid - g * iw + 2;
+    const int rows = (ih + G - 1) / G, ya = 2 + g * rows, yb = min(2 + ih, ya + rows);
+    if (g < G && ya < yb) {
+      auto rowmax = [&](int y) {
+        const float* t = tile + y * ld + x;
+        return __builtin_elementwise_maximum(__builtin_elementwise_maximum(__builtin_elementwise_maximum(t[-2], t[-1]), __builtin_elementwise_maximum(t[0], t[1])), t[2]);
+      };
+      float r0 = rowmax(ya - 2), r1 = rowmax(ya - 1), r2 = rowmax(ya), r3 = rowmax(ya + 1);
+      for (int y = ya; y < yb; y++) {
+        const float r4 = rowmax(y + 2);
+        const float m = __builtin_elementwise_maximum(__builtin_elementwise_maximum(__builtin_elementwise_maximum(r0, r1), __builtin_elementwise_maximum(r2, r3)), r4);
+        const float v = tile[y * ld + x];
+        if (v > vmin && m <= v) put(v, y * wh + x);
+        r0 = r1; r1 = r2; r2 = r3; r3 = r4;
+      }
+    }
+  } else if (ih > 0 && iw > 0) {
     for (int i = tid; i < ih * iw; i += SC_THREADS) {
       int y = i / iw + 2, x = i % iw + 2;
       float v = tile[y * ld + x];
@@ -187,15 +234,7 @@ __global__ __launch_bounds__(SC_THREADS) void score_maps_kernel(const float* __r
       for (int dy = -2; dy <= 2; dy++)
 #pragma unroll
         for (int dx = -2; dx <= 2; dx++) is_max = is_max && (tile[(y + dy) * ld + x + dx] <= v);
-      if (is_max) {
-        int slot = atomicAdd(&sm->n_cand, 1);
-        if (slot < cap) {
-          cval[slot] = v;
-          cidx[slot] = y * wh + x;
-        } else {
-          sm->overflow = 1;
-        }
-      }
+      if (is_max) put(v, y * wh + x);
     }
   }
   __syncthreads();
@@ -204,6 +243,32 @@ __global__ __launch_bounds__(SC_THREADS) void score_maps_kernel(const float* __r
     return;
   }
   int n = sm->n_cand;
+  if (n <= SC_THREADS) {
+    // short lists (what network outputs give: a handful to ~200 candidates): RANK sort -- thread i counts the candidates that come
+    // before its own (broadcast reads of four at a time, no barrier inside) and stores it at that position; the same scan sees
+    // whether any two candidates share a value (the only case the spacing pass below has work to do)
+    const int n4 = (n + 3) & ~3;
+    if (tid >= n && tid < n4) { cval[tid] = -INFINITY; cidx[tid] = 0x7fffffff; }
+    __syncthreads();
+    const float v = tid < n ? cval[tid] : 0.f;
+    const int ix = tid < n ? cidx[tid] : 0;
+    int rank = 0, same = 0;  // candidates with a larger value; with the same value (the thread's own among them)
+    for (int j = 0; j < n4; j += 4) {
+      const float4 vv = *reinterpret_cast<const float4*>(cval + j);
+      rank += (int)(vv.x > v) + (int)(vv.y > v) + (int)(vv.z > v) + (int)(vv.w > v);
+      same += (int)(vv.x == v) + (int)(vv.y == v) + (int)(vv.z == v) + (int)(vv.w == v);
+    }
+    const bool tie = tid < n && same > 1;
+    if (tie)  // equal values: row-major order among them (rare: the scan is repeated with the indices)
+      for (int j = 0; j < n; j++) rank += (int)(cval[j] == v && cidx[j] < ix);
+    __syncthreads();
+    if (tid < n) {
+      cval[rank] = v;
+      cidx[rank] = ix;
+      if (tie) sm->overflow = 1;  // (0 here: an overflowed list has returned above)
+    }
+    __syncthreads();
+  } else {
   // bitonic sort of the candidate list (padded with -inf / INT_MAX)
   int npow = 1;
   while (npow < n) npow <<= 1;
@@ -224,34 +289,72 @@ __global__ __launch_bounds__(SC_THREADS) void score_maps_kernel(const float* __r
       __syncthreads();
     }
   }
-  // ensure_spacing: in sorted order a kept peak rejects later peaks at Chebyshev distance < 2.  Two 5x5 maxima can only be that
-  // close when their values are equal (plateaus), and among equal values the order is row-major: a candidate is rejected iff one
-  // of its four row-major-earlier neighbours (up-left, up, up-right, left) was kept.  The staged map is not needed any more (the
-  // values live in cval): its memory becomes the "kept" map, and the pass is O(candidates) whatever the plateaus -- a final layer
-  // whose inputs are all zero over the background writes its bias there, thousands of equal candidates per map.
-  // No two equal values among the sorted candidates (what network outputs look like away from such plateaus): nothing can be
-  // rejected, no serial pass at all.
   for (int i = tid; i + 1 < n; i += SC_THREADS)
     if (cval[i] == cval[i + 1]) sm->overflow = 1;  // (0 here: an overflowed list has returned above)
   __syncthreads();
-  const bool ties = sm->overflow != 0;
+  }
+  // ensure_spacing: in sorted order a kept peak rejects later peaks at Chebyshev distance < 2.  Two 5x5 maxima can only be that
+  // close when their values are equal (plateaus), and among equal values the order is row-major: a candidate is rejected iff one
+  // of its four row-major-earlier neighbours (up-left, up, up-right, left) was kept.
+  //   * No two equal values among the candidates (what network outputs look like away from plateaus): nothing can be rejected.
+  //   * Equal values far apart (two of ~150 noise maxima sharing a float: a few maps per thousand) reject nothing either: only
+  //     candidates with an ADJACENT pixel of their own value -- looked up in the staged map, in parallel -- take part ("flagged":
+  //     the sign bit of their index).
+  //   * Flagged candidates exist: the staged map is not needed any more (the values live in cval), its memory becomes the "kept"
+  //     map, and ONE WAVE walks the sorted list 64 candidates at a time -- the flagged ones of a group decide one after the other
+  //     (a ballot names them; everybody else is kept without a look), the group is compacted with a prefix count.  O(flagged)
+  //     serial steps whatever the plateaus -- a final layer whose inputs are all zero over the background writes its bias there,
+  //     thousands of equal candidates per map.  (Round 4: the serial pass over ALL candidates by one thread cost 37 us for a
+  //     single map of a noise batch.)
+  bool ties = sm->overflow != 0;
+  if (ties) {
+    for (int i = tid; i < n; i += SC_THREADS) {
+      const float v = cval[i];
+      const int idx = cidx[i];
+      const int yi = idx / wh, xi = idx - yi * wh;
+      const float* t = tile + yi * ld + xi;  // (candidates are interior pixels: the neighbours exist)
+      if (t[-ld - 1] == v || t[-ld] == v || t[-ld + 1] == v || t[-1] == v || t[1] == v || t[ld - 1] == v || t[ld] == v || t[ld + 1] == v) {
+        cidx[i] = idx | (int)0x80000000;
+        sm->adjacent = 1;
+      }
+    }
+    __syncthreads();
+    ties = sm->adjacent != 0;
+  }
   if (ties)
     for (int i = tid; i < hh * ld; i += SC_THREADS) tile[i] = 0.f;
   __syncthreads();
-  if (ties && tid == 0) {
+  if (ties && tid < 64) {
+    const int lane = tid;
     int kept = 0;
-    for (int i = 0; i < n; i++) {
-      const int idx = cidx[i];
+    for (int base = 0; base < n; base += 64) {
+      const int i = base + lane;
+      const bool in = i < n;
+      const int raw = in ? cidx[i] : 0;
+      const float v = in ? cval[i] : 0.f;
+      const int idx = raw & 0x7fffffff;
       const int yi = idx / wh, xi = idx - yi * wh;
-      float* t = tile + yi * ld + xi;  // (candidates are interior pixels: the neighbours exist)
-      if (t[-ld - 1] == 0.f && t[-ld] == 0.f && t[-ld + 1] == 0.f && t[-1] == 0.f) {
-        *t = 1.f;
-        cval[kept] = cval[i];
-        cidx[kept] = idx;
-        kept++;
+      volatile float* t = tile + yi * ld + xi;  // (volatile: another LANE's store decides what this lane reads)
+      bool rejected = false;
+      unsigned long long fm = __ballot(in && raw < 0);
+      while (fm) {
+        const int l = __builtin_ctzll(fm);
+        fm &= fm - 1;
+        if (lane == l) {
+          rejected = !(t[-ld - 1] == 0.f && t[-ld] == 0.f && t[-ld + 1] == 0.f && t[-1] == 0.f);
+          if (!rejected) *t = 1.f;
+        }
+        __builtin_amdgcn_wave_barrier();  // (the next candidate's reads follow this one's write in program order)
       }
+      const unsigned long long km = __ballot(in && !rejected);
+      const int pos = kept + __popcll(km & ((1ull << lane) - 1ull));
+      if (in && !rejected) {  // (pos <= i, and the group's values are in registers: in place)
+        cval[pos] = v;
+        cidx[pos] = idx;
+      }
+      kept += __popcll(km);
     }
-    sm->n_cand = kept;
+    if (lane == 0) sm->n_cand = kept;
   }
   __syncthreads();
   n = sm->n_cand;  // (unchanged without ties)
@@ -266,11 +369,7 @@ __global__ __launch_bounds__(SC_THREADS) void score_maps_kernel(const float* __r
   // ---- MPE entropy (strategy.py:1171-1175) --------------------------------------------
   for (int i = tid; i < n; i += SC_THREADS) cval[i] = expf(cval[i]);
   __syncthreads();
-  if (tid == 0) {
-    float s = 0.f;  // python sum(): left to right in float32
-    for (int i = 0; i < n; i++) s += cval[i];
-    sm->ssum = s;
-  }
+  if (tid == 0) sm->ssum = serial_sum_lds(cval, n);  // python sum(): left to right in float32
   __syncthreads();
   const float s = sm->ssum;
   for (int i = tid; i < n; i += SC_THREADS) {
@@ -280,9 +379,7 @@ __global__ __launch_bounds__(SC_THREADS) void score_maps_kernel(const float* __r
   }
   __syncthreads();
   if (tid == 0) {
-    float e = 0.f;
-    for (int i = 0; i < n; i++) e += cval[i];
-    stat[map] = e;  // no peaks -> python int 0
+    stat[map] = serial_sum_lds(cval, n);  // no peaks -> python int 0
     n_peaks[map] = n;
   }
 }
@@ -293,7 +390,7 @@ static int launch_score(int kind, const float* heatmaps, float* stat, int32_t* n
   const size_t tile_b = (size_t)((hh * (wh + 1) + 3) & ~3) * 4, fixed_b = sizeof(ScoreSmem) + 16;
   dim3 grid((unsigned)n_maps), block(SC_THREADS);
   // the candidate list never needs more than the interior (hh-4)(wh-4), rounded up to the sort's power of two
-  int full = 1;
+  int full = 4;  // (at least one 16-byte group: the rank sort reads the list four candidates at a time)
   while (full < (hh - 4) * (wh - 4)) full <<= 1;
   for (int pass = 0; pass < 2; pass++) {
     const int cap = pass == 0 ? (full < SC_MAX_PEAKS ? full : SC_MAX_PEAKS) : full;

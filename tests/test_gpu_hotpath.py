@@ -264,6 +264,51 @@ def test_mpe_bsb_vs_real_scikit_image_goldens(dev):
     assert checked_mpe >= 20 and checked_bsb >= 10, (checked_mpe, checked_bsb)
 
 
+def test_mpe_candidate_list_sizes_and_tie_paths(dev):
+    """csrc/scoring.hip sorts lists of at most 256 candidates by rank, longer ones with the bitonic network, and redoes maps with
+    more than 512 in the rescue pass; equal values far apart must not start the spacing pass, an equal ADJACENT pixel that is no
+    candidate must start it and reject nothing.  Constructed 96 x 72 maps (peaks on a lattice, distinct values unless stated)
+    against the CPU restatement: counts exact, entropies within the float32 tolerance of the other MPE tests."""
+    from multi_view_active_learning_amd import _lib
+
+    hh, wh = 96, 72
+    rng = np.random.default_rng(5)
+
+    def lattice(step):
+        m = np.full((hh, wh), -1.0, np.float32)
+        ys, xs = np.arange(2, hh - 2, step), np.arange(2, wh - 2, step)
+        vals = rng.permutation(len(ys) * len(xs)).astype(np.float32) / (len(ys) * len(xs)) + 0.25
+        m[np.ix_(ys, xs)] = vals.reshape(len(ys), len(xs))
+        return m, len(ys) * len(xs)
+
+    maps, want_n = [], []
+    for step in (3, 4, 6):  # 713 (rescue pass), 391 (bitonic, first pass), 192 (rank sort) peaks
+        m, n = lattice(step)
+        maps.append(m); want_n.append(n)
+    m, n = lattice(6)  # two pairs of equal values far apart: ties, nothing adjacent
+    m[8, 8] = m[50, 44]
+    m[14, 20] = m[62, 32]
+    maps.append(m); want_n.append(n)
+    m, n = lattice(6)  # as above, and one peak with an equal neighbour that a larger value three pixels away keeps from being a candidate
+    m[8, 8] = m[50, 44]
+    m[20, 21] = m[20, 20]
+    m[20, 23] = 4.0
+    maps.append(m); want_n.append(n + 1)
+    m, n = lattice(6)  # a two-pixel plateau: one of the two survives
+    m[8, 8] = m[50, 44]
+    m[20, 21] = m[20, 20]
+    maps.append(m); want_n.append(n)
+    assert want_n[0] > 512 and 256 < want_n[1] <= 512 and want_n[2] <= 256
+    maps = np.stack(maps)
+    mpe, cnt = _lib.score_maps(_lib.SCORE_MPE, torch.from_numpy(maps).to(dev), len(maps), hh, wh)
+    mpe, cnt = mpe.cpu().numpy(), cnt.cpu().numpy()
+    for i, m in enumerate(maps):
+        peaks = scoring.peak_local_max(m, min_distance=2)
+        assert len(peaks) == want_n[i], (i, len(peaks), want_n[i])
+        assert cnt[i] == want_n[i], (i, cnt[i], want_n[i])
+        np.testing.assert_allclose(mpe[i], scoring.compute_mpes(m[None, None], [True])[0], rtol=3e-6, atol=2e-7, err_msg=str(i))
+
+
 def test_peak_known_answers_on_device(dev):
     from multi_view_active_learning_amd import _lib
 
