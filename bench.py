@@ -433,7 +433,15 @@ def main():
         net = model
         if world > 1 or args.rccl_world_1:
             net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], broadcast_buffers=True)
-        opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+        # strategy.py:405-407 builds torch.optim.Adam([{"params": ..., "lr": LR}]): optim.Adam is that class with its step() as ONE launch
+        # (csrc/optim.hip).  MVAL_BENCH_ADAM=torch / fused: torch's default (foreach) / fused implementation of the same update.
+        from multi_view_active_learning_amd.optim import Adam as MvalAdam
+
+        adam_kind = os.environ.get("MVAL_BENCH_ADAM", "mval")
+        if adam_kind == "mval":
+            opt = MvalAdam([{"params": model.parameters(), "lr": 1e-3}])
+        else:
+            opt = torch.optim.Adam([{"params": model.parameters(), "lr": 1e-3}], **({"fused": True} if adam_kind == "fused" else {}))
         loss_fn = Pose2DMeanSquaredError()
         gt = torch.rand(frames * v, j, h // 4, w // 4, device=dev)
         pv = torch.ones(frames * v, j, 1, 1, dtype=torch.uint8, device=dev)
@@ -822,6 +830,9 @@ def main():
             "roofline": roof,
             "parity_unpinned": PARITY_UNPINNED,
         }
+        if train:
+            out["config"]["optimizer"] = {"mval": "multi_view_active_learning_amd.optim.Adam (torch.optim.Adam subclass, step = one mval_adam_step launch)",
+                                          "torch": "torch.optim.Adam (foreach)", "fused": "torch.optim.Adam(fused=True)"}[adam_kind]
         if feed is not None:
             out["input_inclusive"] = {
                 "note": "NOT the headline contract: every batch starts from uint8 crops in pinned host memory -- H->D copy one batch ahead on a "

@@ -511,6 +511,26 @@ int mval_train_backward(const mval_train_op* ops, int n_ops, int n_images, float
                         const float* params, int64_t ones_off, int64_t zeros_off, const float* input_nchw,
                         float* gz, float* wsf, double* ws, float* sums, void* stream);
 
+/* ---- optimizer step (replaces torch.optim.Adam.step, /root/reference/strategy.py:405-407 and :479) -------------------
+ * Adam over MANY tensors in one launch, arithmetic = torch/optim/adam.py _single_tensor_adam in float32:
+ *   g = grad (+ weight_decay * p);  m += (1 - beta1) (g - m);  v = v beta2 + (1 - beta2) g g;
+ *   p -= step_size * m / (sqrt(v) / bias_correction2_sqrt + eps)
+ * with step_size = lr / (1 - beta1^t) and bias_correction2_sqrt = sqrt(1 - beta2^t) evaluated by the caller in double (as
+ * python does) and passed as float32 (as torch casts python scalars).  jobs_dev: n_jobs descriptors IN DEVICE MEMORY (device
+ * pointers to `count` contiguous float32 each; 16-byte aligned pointers take the vector path); first_block_dev[j] = blocks of
+ * the jobs before j, a job has ceil(count / mval_adam_block_elems()) blocks; total_blocks = their sum.  In place. */
+typedef struct mval_adam_job {
+  float* param;
+  const float* grad;
+  float* exp_avg;
+  float* exp_avg_sq;
+  int64_t count;
+} mval_adam_job;
+int mval_adam_block_elems(void);
+int mval_adam_step(const mval_adam_job* jobs_dev, const int* first_block_dev, int n_jobs, int total_blocks, float one_minus_beta1,
+                   float beta2, float one_minus_beta2, float eps, float weight_decay, float step_size, float bias_correction2_sqrt,
+                   void* stream);
+
 /* Measurement only (bench.py, training workload): with a non-NULL HOST array of 6 floats every later
  * mval_train_forward / mval_train_backward call brackets its launches with hipEvents and ADDS the elapsed
  * milliseconds per kernel family -- [conv forward, BN statistics, BN apply, BN backward, weight gradient, data

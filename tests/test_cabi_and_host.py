@@ -438,3 +438,33 @@ def test_python_constants_match_the_header():
     for name, val in (("MVAL_OP_BNECK", engine.OP_BNECK), ("MVAL_OP_STEM_P2", engine.OP_STEM_P2), ("MVAL_OP_FUSE_UP", engine.OP_FUSE_UP),
                       ("MVAL_OP_BLOCK", engine.OP_BLOCK)):
         assert enum(name) == val, name
+
+
+def test_adam_mirror_is_torch_adam_off_the_device():
+    """multi_view_active_learning_amd.optim.Adam (strategy.py:405-407, :479): on CPU tensors -- and for every configuration the kernel
+    does not implement -- it IS torch.optim.Adam: same updates bit for bit, same state_dict layout, StepLR drives it."""
+    from multi_view_active_learning_amd.optim import Adam, _JOB
+
+    assert _JOB.itemsize == 40  # = sizeof(mval_adam_job)
+    torch.manual_seed(0)
+    ws = [torch.randn(5, 3), torch.randn(7), torch.randn(2, 2, 3, 3)]
+    a = [torch.nn.Parameter(w.clone()) for w in ws]
+    b = [torch.nn.Parameter(w.clone()) for w in ws]
+    oa = Adam([{"params": a, "lr": 1e-2}], weight_decay=0.01)
+    ob = torch.optim.Adam([{"params": b, "lr": 1e-2}], weight_decay=0.01)
+    sa = torch.optim.lr_scheduler.StepLR(oa, step_size=2)
+    sb = torch.optim.lr_scheduler.StepLR(ob, step_size=2)
+    for it in range(5):
+        for pa, pb in zip(a, b):
+            g = torch.randn_like(pa)
+            pa.grad, pb.grad = g.clone(), g.clone()
+        oa.step(); ob.step(); sa.step(); sb.step()
+    for pa, pb in zip(a, b):
+        assert torch.equal(pa, pb)
+    da, db = oa.state_dict(), ob.state_dict()
+    assert da["param_groups"][0]["lr"] == db["param_groups"][0]["lr"]
+    assert da["state"].keys() == db["state"].keys()
+    for k in da["state"]:
+        assert da["state"][k].keys() == db["state"][k].keys()
+        for n in da["state"][k]:
+            assert torch.equal(da["state"][k][n], db["state"][k][n])

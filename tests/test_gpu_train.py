@@ -535,3 +535,86 @@ def test_round4_training_paths_against_their_switches(dev, off, monkeypatch):
     assert abs(l1.item() - l0.item()) <= 2e-6 * abs(l0.item())
     errs = sorted(_rel(g1[k].cpu().numpy(), p.grad.cpu().numpy()) for k, p in m0.named_parameters())
     assert errs[-1] < 5e-2 and errs[len(errs) // 2] < 5e-3, (errs[-1], errs[len(errs) // 2])
+
+
+@pytest.mark.parametrize("wd", [0.0, 0.01], ids=["plain", "weight_decay"])
+def test_adam_one_launch_vs_torch_adam(dev, wd):
+    """optim.Adam (csrc/optim.hip: the update of every parameter in one launch; reference strategy.py:405-407, :479) against
+    torch.optim.Adam's single-tensor implementation on the CPU -- the reference's optimizer -- over 12 steps with a StepLR
+    (strategy.py:408-410): shapes from one element to tensors of several blocks with ragged tails, gradients as unaligned views of
+    one flat buffer (what the training plan hands to autograd), a parameter without a gradient.  Tolerance: 2e-6 of the tensor's
+    scale per step budgeted as 4e-6 over the run (float32 rounding of the same expression; fused multiply-adds differ between
+    builds), bit-equal moments expected nowhere but checked to the same bound; state_dict() loads into torch.optim.Adam."""
+    from multi_view_active_learning_amd.optim import Adam
+
+    torch.manual_seed(1)
+    shapes = [(1,), (3,), (17, 5), (64, 32, 3, 3), (4099,), (32,), (2, 8200)]
+    ws = [torch.randn(s) for s in shapes]
+    a = [torch.nn.Parameter(w.clone().to(dev)) for w in ws]
+    b = [torch.nn.Parameter(w.clone()) for w in ws]
+    idle_a, idle_b = torch.nn.Parameter(torch.ones(5, device=dev)), torch.nn.Parameter(torch.ones(5))
+    oa = Adam([{"params": a + [idle_a], "lr": 1e-2}], weight_decay=wd)
+    ob = torch.optim.Adam([{"params": b + [idle_b], "lr": 1e-2}], weight_decay=wd, foreach=False)
+    sa, sb = torch.optim.lr_scheduler.StepLR(oa, step_size=5), torch.optim.lr_scheduler.StepLR(ob, step_size=5)
+    total = sum(w.numel() for w in ws) + len(ws)
+    for it in range(12):
+        flat = torch.randn(total, generator=torch.Generator().manual_seed(100 + it)) * (10.0 if it == 3 else 1.0)
+        flat_d = flat.to(dev)
+        off = 1  # (odd offsets: most gradients are NOT 16-byte aligned)
+        oa.zero_grad(); ob.zero_grad()
+        for pa, pb in zip(a, b):
+            n = pa.numel()
+            pa.grad = flat_d[off : off + n].view_as(pa)
+            pb.grad = flat[off : off + n].view_as(pb).clone()
+            off += n + 1
+        oa.step(); ob.step(); sa.step(); sb.step()
+        for pa, pb in zip(a, b):
+            scale = float(pb.detach().abs().max()) + 1e-3
+            assert float((pa.detach().cpu() - pb.detach()).abs().max()) <= 4e-6 * scale, (it, tuple(pa.shape))
+    assert torch.equal(idle_a.detach().cpu(), idle_b.detach()) and idle_a not in oa.state
+    da, db = oa.state_dict(), ob.state_dict()
+    assert da["state"].keys() == db["state"].keys() and da["param_groups"][0]["lr"] == db["param_groups"][0]["lr"]
+    for k in db["state"]:
+        assert float(da["state"][k]["step"]) == float(db["state"][k]["step"]) == 12.0
+        for nm in ("exp_avg", "exp_avg_sq"):
+            x, y = da["state"][k][nm].cpu(), db["state"][k][nm]
+            assert x.shape == y.shape and float((x - y).abs().max()) <= 4e-6 * (float(y.abs().max()) + 1e-6), (k, nm)
+    # the state travels: torch's own Adam continues from it, and this class continues from torch's
+    oc = torch.optim.Adam([{"params": [torch.nn.Parameter(p.detach().clone()) for p in a] + [torch.nn.Parameter(idle_a.detach().clone())], "lr": 1e-2}], weight_decay=wd)
+    oc.load_state_dict(da)
+    oa.load_state_dict(oc.state_dict())
+    for pa in a:
+        pa.grad = torch.ones_like(pa)
+    before = [p.detach().clone() for p in a]
+    oa.step()
+    assert all(not torch.equal(x, p.detach()) for x, p in zip(before, a))
+    assert float(oa.state[a[0]]["step"]) == 13.0
+
+
+def test_adam_falls_back_to_torch_for_what_the_kernel_does_not_cover(dev):
+    from multi_view_active_learning_amd.optim import Adam
+
+    torch.manual_seed(2)
+    w = torch.randn(300, device=dev)
+    for kw in ({"amsgrad": True}, {"maximize": True}, {"foreach": False}):
+        pa, pb = torch.nn.Parameter(w.clone()), torch.nn.Parameter(w.clone())
+        oa, ob = Adam([pa], lr=1e-2, **kw), torch.optim.Adam([pb], lr=1e-2, **kw)
+        for it in range(3):
+            g = torch.randn(300, device=dev, generator=torch.Generator(device=dev).manual_seed(it))
+            pa.grad, pb.grad = g.clone(), g.clone()
+            oa.step(); ob.step()
+        assert torch.equal(pa, pb), kw
+    # parameters whose step counts differ (one of them skipped a step): torch's implementation keeps their bias corrections apart
+    p1, p2 = torch.nn.Parameter(w.clone()), torch.nn.Parameter(w.clone() * 2)
+    q1, q2 = torch.nn.Parameter(w.clone()), torch.nn.Parameter(w.clone() * 2)
+    oa, ob = Adam([p1, p2], lr=1e-2), torch.optim.Adam([q1, q2], lr=1e-2, foreach=False)
+    for it in range(4):
+        g = torch.randn(300, device=dev, generator=torch.Generator(device=dev).manual_seed(10 + it))
+        for pp in (p1, q1):
+            pp.grad = g.clone()
+        for pp in (p2, q2):
+            pp.grad = None if it == 0 else (g * 0.5).clone()
+        oa.step(); ob.step()
+    for x, y in ((p1, q1), (p2, q2)):
+        assert float((x - y).abs().max()) <= 4e-6 * float(y.abs().max())
+    assert float(oa.state[p1]["step"]) == 4.0 and float(oa.state[p2]["step"]) == 3.0
