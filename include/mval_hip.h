@@ -284,7 +284,7 @@ typedef struct mval_pack_job {
 } mval_pack_job;
 int mval_pack_bf3_jobs(const mval_pack_job* jobs_dev, const int* first_block_dev, int n_jobs, int total_blocks, void* stream);
 /* The same for a mix of both splits: a job with bit 8 of `mode` set (mode | 0x100) is packed MVAL_PACK_MFMA16_H2
- * (its max |w| is taken first, in the same call: two launches in all), the others MVAL_PACK_MFMA16_BF3; a job's block
+ * (its max |w| is taken first, in the same call: three launches in all), the others MVAL_PACK_MFMA16_BF3; a job's block
  * count is the same for both. */
 int mval_pack_split_jobs(const mval_pack_job* jobs_dev, const int* first_block_dev, int n_jobs, int total_blocks, void* stream);
 /* scale = gamma / sqrt(var + eps) ; shift = beta - mean * scale  (all [c] f32). */

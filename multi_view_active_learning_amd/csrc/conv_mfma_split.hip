@@ -715,20 +715,42 @@ __global__ void pack_bf3_batch_kernel(const PackBf3Job* __restrict__ jobs, const
   pack_split_element<3>(jb.w, jb.p, jb.mode, jb.cout, jb.cin, jb.k, (int64_t)(blockIdx.x - first_block[lo]) * blockDim.x + threadIdx.x, 1.f);
 }
 
-// Mixed batch: jobs with bit 8 of `mode` are fp16-split packings (trailer after the fragments; max |w| by
-// pack_amax_batch_kernel first, one workgroup per job).
-__global__ __launch_bounds__(256) void pack_amax_batch_kernel(const PackBf3Job* __restrict__ jobs) {
+// Mixed batch: jobs with bit 8 of `mode` are fp16-split packings (trailer after the fragments; max |w| by the two kernels below first).
+#define PACK_AMAX_PARTS 32
+// max |w| of every job in two launches: PACK_AMAX_PARTS workgroups per job leave their partial maxima in the first floats of the job's
+// OWN packed buffer (the packing kernel, next on the stream, overwrites them with fragments: no scratch memory), one wave per job
+// folds them into the trailer.  (One workgroup per job walked the 590 k weights of a 256 -> 256 layer alone: 430 us per step.)
+__global__ __launch_bounds__(256) void pack_amax_part_kernel(const PackBf3Job* __restrict__ jobs) {
   const PackBf3Job jb = jobs[blockIdx.x];
   if (!(jb.mode & 0x100)) return;
   __shared__ float red[4];
   const int64_t n = (int64_t)jb.cout * jb.cin * ((jb.mode & 0xff) == 4 ? 9 : jb.k * jb.k);  // (mode 4: a 3x3 source packed as k = 4)
+  const int64_t per = (((n + PACK_AMAX_PARTS - 1) / PACK_AMAX_PARTS) + 3) & ~(int64_t)3;
+  const int64_t lo = min(n, per * blockIdx.y), hi = min(n, lo + per);
   float m = 0.f;
-  for (int64_t i = threadIdx.x; i < n; i += 256) m = fmaxf(m, fabsf(jb.w[i]));
+  if ((reinterpret_cast<uintptr_t>(jb.w) & 15) == 0) {
+    const int64_t hi4 = lo + ((hi - lo) & ~(int64_t)3);
+    for (int64_t i = lo + 4 * threadIdx.x; i < hi4; i += 1024) {
+      const float4 q = *reinterpret_cast<const float4*>(jb.w + i);
+      m = fmaxf(fmaxf(m, fmaxf(fabsf(q.x), fabsf(q.y))), fmaxf(fabsf(q.z), fabsf(q.w)));
+    }
+    for (int64_t i = hi4 + threadIdx.x; i < hi; i += 256) m = fmaxf(m, fabsf(jb.w[i]));
+  } else {
+    for (int64_t i = lo + threadIdx.x; i < hi; i += 256) m = fmaxf(m, fabsf(jb.w[i]));
+  }
   m = wave_max(m);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
   __syncthreads();
+  if (threadIdx.x == 0) reinterpret_cast<float*>(jb.p)[blockIdx.y] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
+__global__ __launch_bounds__(64) void pack_amax_fold_kernel(const PackBf3Job* __restrict__ jobs) {
+  const PackBf3Job jb = jobs[blockIdx.x];
+  if (!(jb.mode & 0x100)) return;
+  static_assert(PACK_AMAX_PARTS <= 64, "one wave folds a job's partial maxima");
+  float m = threadIdx.x < PACK_AMAX_PARTS ? reinterpret_cast<const float*>(jb.p)[threadIdx.x] : 0.f;
+  m = wave_max(m);
   if (threadIdx.x == 0) {
-    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
     const int G = (jb.cin + 31) / 32, NS = (jb.cout + 15) / 16;
     float* trailer = reinterpret_cast<float*>(jb.p) + (int64_t)jb.k * jb.k * G * NS * 512;
     float mul, inv;
@@ -760,7 +782,8 @@ __global__ void pack_split_batch_kernel(const PackBf3Job* __restrict__ jobs, con
 }
 
 int mval_pack_split_batch(const void* jobs_dev, const int* first_block_dev, int n_jobs, int total_blocks, hipStream_t s) {
-  hipLaunchKernelGGL(pack_amax_batch_kernel, dim3((unsigned)n_jobs), dim3(256), 0, s, reinterpret_cast<const PackBf3Job*>(jobs_dev));
+  hipLaunchKernelGGL(pack_amax_part_kernel, dim3((unsigned)n_jobs, PACK_AMAX_PARTS), dim3(256), 0, s, reinterpret_cast<const PackBf3Job*>(jobs_dev));
+  hipLaunchKernelGGL(pack_amax_fold_kernel, dim3((unsigned)n_jobs), dim3(64), 0, s, reinterpret_cast<const PackBf3Job*>(jobs_dev));
   hipLaunchKernelGGL(pack_split_batch_kernel, dim3((unsigned)total_blocks), dim3(256), 0, s,
                      reinterpret_cast<const PackBf3Job*>(jobs_dev), first_block_dev, n_jobs);
   return 0;
