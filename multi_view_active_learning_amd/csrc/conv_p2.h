@@ -187,6 +187,8 @@ struct P2Args {
 };
 
 int mval_launch_conv_p2(const P2Args& a, hipStream_t s);  // conv_p2.hip; 1 = unsupported (dry != 0: no launch)
+// 2 or 3 stride-2 3x3 convs over ONE input in one launch (conv_p2.hip: conv_p2_multi_kernel); 1 = not covered
+int mval_launch_conv_p2_multi(const P2Args* segs, int nseg, hipStream_t s);
 int mval_launch_nhwc_to_p2(const float* x, const unsigned* rows_in, _Float16* planes, unsigned* rows, int n_images, int HW, int C,
                             hipStream_t s);
 int mval_conv_p2_supported(int k, int stride, int cin, int cout, int hin, int win, int up, int out_nchw, int n);

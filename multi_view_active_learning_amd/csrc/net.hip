@@ -494,34 +494,54 @@ static int op_launch(const mval_op* op, int n_images, float* workspace, const fl
     return 0;
   }
   if (op->algo == MVAL_ALGO_MFMA_P2) {
-    MVAL_REQUIRE(op->kind == MVAL_OP_CONV && a.w && a.scale && a.shift && op->in_amax_off > 0 && op->in_off >= 0 &&
-                     (op->out_nchw || (op->out_amax_off > 0 && op->bound_off >= 0)) &&
-                     (op->res1_off < 0 || op->res1_amax_off > 0) && (op->res2_off < 0 || op->res2_amax_off > 0),
-                 "mval_op_launch: malformed MVAL_ALGO_MFMA_P2 op");
-    P2Args p = {};
-    p.in = reinterpret_cast<const _Float16*>(a.in);
-    p.w = a.w;
-    p.w_unscale = a.w + mval_packed_weight_floats(MVAL_PACK_MFMA16_H2, op->cout, op->cin, op->k) - 4;
-    p.scale = a.scale; p.shift = a.shift;
-    p.bound = op->bound_off >= 0 ? params + op->bound_off : nullptr;
-    p.res1 = reinterpret_cast<const _Float16*>(a.res1);
-    p.res2 = reinterpret_cast<const _Float16*>(a.res2);
-    p.in_row = reinterpret_cast<const unsigned*>(workspace + op->in_amax_off);
-    p.res1_row = a.res1 ? reinterpret_cast<const unsigned*>(workspace + op->res1_amax_off) : nullptr;
-    p.res2_row = a.res2 ? reinterpret_cast<const unsigned*>(workspace + op->res2_amax_off) : nullptr;
-    if (op->out_nchw) {
-      p.out_f32 = a.out;
-      p.argmax_keys = argmax_keys;
-    } else {
-      p.out = reinterpret_cast<_Float16*>(a.out);
-      p.out_row = reinterpret_cast<unsigned*>(workspace + op->out_amax_off);
+    if (op->multi_n < 0) return 0;  // launched by the head of its group (below)
+    // the arguments of one P2 conv (this op, or a follower of its group)
+    auto p2_args = [&](const mval_op* o, P2Args& p) -> int {
+      const float* w = o->w_off >= 0 ? params + o->w_off : nullptr;
+      MVAL_REQUIRE(o->kind == MVAL_OP_CONV && w && o->scale_off >= 0 && o->shift_off >= 0 && o->in_amax_off > 0 && o->in_off >= 0 &&
+                       (o->out_nchw || (o->out_amax_off > 0 && o->bound_off >= 0)) &&
+                       (o->res1_off < 0 || o->res1_amax_off > 0) && (o->res2_off < 0 || o->res2_amax_off > 0),
+                   "mval_op_launch: malformed MVAL_ALGO_MFMA_P2 op");
+      p = {};
+      p.in = reinterpret_cast<const _Float16*>(workspace + o->in_off);
+      p.w = w;
+      p.w_unscale = w + mval_packed_weight_floats(MVAL_PACK_MFMA16_H2, o->cout, o->cin, o->k) - 4;
+      p.scale = params + o->scale_off; p.shift = params + o->shift_off;
+      p.bound = o->bound_off >= 0 ? params + o->bound_off : nullptr;
+      p.res1 = o->res1_off >= 0 ? reinterpret_cast<const _Float16*>(workspace + o->res1_off) : nullptr;
+      p.res2 = o->res2_off >= 0 ? reinterpret_cast<const _Float16*>(workspace + o->res2_off) : nullptr;
+      p.in_row = reinterpret_cast<const unsigned*>(workspace + o->in_amax_off);
+      p.res1_row = p.res1 ? reinterpret_cast<const unsigned*>(workspace + o->res1_amax_off) : nullptr;
+      p.res2_row = p.res2 ? reinterpret_cast<const unsigned*>(workspace + o->res2_amax_off) : nullptr;
+      if (o->out_nchw) {
+        p.out_f32 = net_output;
+        p.argmax_keys = argmax_keys;
+      } else {
+        p.out = reinterpret_cast<_Float16*>(workspace + o->out_off);
+        p.out_row = reinterpret_cast<unsigned*>(workspace + o->out_amax_off);
+      }
+      p.N = n_images; p.Hin = o->hin; p.Win = o->win; p.Cin = o->cin;
+      p.Hout = o->hout; p.Wout = o->wout; p.Cout = o->cout;
+      p.k = o->k; p.stride = o->stride; p.up = o->up; p.relu = o->relu;
+      return 0;
+    };
+    const int group = op->multi_n >= 2 ? op->multi_n : 1;
+    MVAL_REQUIRE(group <= 3, "mval_op_launch: multi_n %d (at most 3 convs per launch)", group);
+    P2Args ps[3];
+    for (int g = 0; g < group; g++) {
+      MVAL_REQUIRE(g == 0 || (op[g].algo == MVAL_ALGO_MFMA_P2 && op[g].multi_n == -1), "mval_op_launch: op %d of a multi-conv group is not marked as a follower", g);
+      int rc = p2_args(op + g, ps[g]);
+      if (rc) return rc;
     }
-    p.N = n_images; p.Hin = op->hin; p.Win = op->win; p.Cin = op->cin;
-    p.Hout = op->hout; p.Wout = op->wout; p.Cout = op->cout;
-    p.k = op->k; p.stride = op->stride; p.up = op->up; p.relu = op->relu;
-    int rc = mval_launch_conv_p2(p, s);
-    MVAL_REQUIRE(rc == 0, "mval_op_launch: no P2 kernel for conv k%d s%d cin%d cout%d %dx%d", op->k, op->stride, op->cin,
-                 op->cout, op->hin, op->win);
+    if (group > 1 && mval_launch_conv_p2_multi(ps, group, s) == 0) {
+      MVAL_CHECK_LAUNCH("mval_op_launch/p2 multi");
+      return 0;
+    }
+    for (int g = 0; g < group; g++) {  // one by one (a single conv, or a group the multi kernel does not cover)
+      int rc = mval_launch_conv_p2(ps[g], s);
+      MVAL_REQUIRE(rc == 0, "mval_op_launch: no P2 kernel for conv k%d s%d cin%d cout%d %dx%d", op[g].k, op[g].stride, op[g].cin,
+                   op[g].cout, op[g].hin, op[g].win);
+    }
     MVAL_CHECK_LAUNCH("mval_op_launch/p2");
     return 0;
   }
@@ -624,6 +644,7 @@ MvalLanes* mval_device_lanes() {
   std::lock_guard<std::mutex> lock(g_lanes_mutex);
   if (L->ready) return L;
   if (hipEventCreateWithFlags(&L->fork_ev, hipEventDisableTiming) != hipSuccess) return nullptr;
+  if (hipEventCreateWithFlags(&L->group_ev, hipEventDisableTiming) != hipSuccess) return nullptr;
   for (int l = 1; l < MVAL_MAX_LANES; l++) {
     if (hipStreamCreateWithFlags(&L->side[l], hipStreamNonBlocking) != hipSuccess) return nullptr;
     if (hipEventCreateWithFlags(&L->join_ev[l], hipEventDisableTiming) != hipSuccess) return nullptr;
@@ -680,8 +701,13 @@ static int net_forward(void* net, int n_images, float* workspace, const float* p
   for (size_t i = 0; i < n->ops.size(); i++) {
     const mval_op& op = n->ops[i];
     hipStream_t s = walk.stream_for(op.phase, op.lane < n->n_lanes ? op.lane : 0);
+    if (op.multi_n < 0) {  // launched with the head of its group, on the head's lane: this op's lane goes on once that launch is done
+      walk.wait_for_group(s);
+      continue;
+    }
     int rc = op_launch(&n->ops[i], n_images, workspace, params, input_nchw, output_nchw, op.out_off < 0 ? argmax_keys : nullptr, s);
     if (rc) return rc;
+    if (op.multi_n >= 2) walk.group_launched(s);
   }
   walk.finish();
   return 0;

@@ -72,7 +72,7 @@ def test_plan_geometry_and_arena(lib, name):
     p = engine.InferencePlan(m, 4, c["h"], c["w"], torch.device("cpu"))
     assert p.out_hw == (c["h"] // 4, c["w"] // 4) and p.out_channels == c["j"]
     # no op may read and write overlapping arena ranges
-    g = m._graph
+    g = p.graph  # (the plan's own op order: a P2 plan regroups the fuse layers' first-level stride-2 convs)
     for i, op in enumerate(g.ops):
         o = p.graph_ops[i]
         if o.out_off < 0:

@@ -392,6 +392,38 @@ def test_p2_plan_structure(dev, monkeypatch):
     assert not engine._plan_for(mr, xr).p2
 
 
+@pytest.mark.parametrize("name", ["w32", "w48"])
+def test_p2_first_level_stride2_convs_in_one_launch(dev, monkeypatch, name):
+    """hrnet.py:398-423: the stride-2 convs that start a fuse layer's down-sampling chains from branch 0 (32 -> 64 and one or two
+    32 -> 32; HRNet-W48: 48 -> 96, 48 -> 48) are ONE launch of conv_p2_multi_kernel in the P2 plan -- 6 groups (4 of two, 2 of
+    three convs), their followers' own launches no-ops, the followers' lanes waiting for the group -- and the heat-maps are
+    bit-identical to the plan that launches them one by one (the default): every wave runs the single-conv body on its conv's arguments."""
+    from multi_view_active_learning_amd import engine
+
+    monkeypatch.setenv("MVAL_CONV", "p2")
+    monkeypatch.setenv("MVAL_P2_S2_MULTI", "1")  # (opt-in: beside each other on their lanes the separate launches make the faster STEP)
+    c = cases.model_cases()[name]
+    m, _ = _load(c, dev)
+    x = torch.from_numpy(cases.model_input(c)).to(dev)
+    with torch.no_grad():
+        got = m(x).clone()
+    plan = engine._plan_for(m, x)
+    assert plan.p2
+    heads = [i for i, o in enumerate(plan.ops) if o.multi_n >= 2]
+    assert sorted(plan.ops[i].multi_n for i in heads) == [2, 2, 2, 2, 3, 3]
+    for i in heads:
+        grp = [plan.ops[i + k] for k in range(plan.ops[i].multi_n)]
+        assert all(o.multi_n == -1 for o in grp[1:]) and len({o.in_off for o in grp}) == 1
+        assert all(o.kind == engine.OP_CONV and o.k == 3 and o.stride == 2 for o in grp)
+        assert len({o.phase for o in grp}) == 1 and len({o.lane for o in grp}) == len(grp)  # one launch on the head's lane, the others wait
+    m._plans.clear()
+    monkeypatch.setenv("MVAL_P2_S2_MULTI", "0")
+    with torch.no_grad():
+        want = m(x).clone()
+    assert not any(o.multi_n for o in engine._plan_for(m, x).ops)
+    assert torch.equal(got, want)
+
+
 def test_p2_argmax_census_vs_exact_fp32(dev, monkeypatch):
     """BASELINE config C2 decode parity over 256 frames x 4 views: the P2 plan against the exact-fp32 MFMA plan
     (MVAL_CONV=fp32).  Counts the (view, joint) maps whose arg-max differs and the top-2 margins involved: no map whose
