@@ -159,4 +159,8 @@ class Adam(torch.optim.Adam):
                                    C.c_float(1 - beta1), C.c_float(beta2), C.c_float(1 - beta2), C.c_float(group["eps"]),
                                    C.c_float(group["weight_decay"]), C.c_float(step_size), C.c_float(bias_correction2**0.5), _lib._stream()),
                 "mval_adam_step")
+            # the kernel wrote the parameters and moments through raw pointers: tell autograd (saved-tensor checks) and everything keyed on
+            # a parameter's version -- the inference / training plans re-pack their weights when it changes -- that they were modified
+            torch.autograd.graph.increment_version(ps)
+            torch.autograd.graph.increment_version([t for st in (self.state[p] for p in ps) for t in (st["exp_avg"], st["exp_avg_sq"])])
         return loss

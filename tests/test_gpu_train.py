@@ -618,3 +618,41 @@ def test_adam_falls_back_to_torch_for_what_the_kernel_does_not_cover(dev):
     for x, y in ((p1, q1), (p2, q2)):
         assert float((x - y).abs().max()) <= 4e-6 * float(y.abs().max())
     assert float(oa.state[p1]["step"]) == 4.0 and float(oa.state[p2]["step"]) == 3.0
+
+
+def test_adam_one_launch_trains_the_network_like_torch_adam(dev):
+    """The kernel writes the parameters through raw pointers; the training plan re-packs its conv weights when a parameter's version
+    changes -- optim.Adam must bump it (a first version did not: the forward kept running on the weights of step 0).  Three steps of the
+    reference's inner loop (strategy.py:460-487) on the small HRNet with optim.Adam and with torch.optim.Adam from the same start:
+    the losses and the final weights agree to the tolerance of the optimizer test, and the loss moves."""
+    from multi_view_active_learning_amd.optim import Adam
+    from multi_view_active_learning_amd.pose_estimators import Pose2DMeanSquaredError
+
+    c = cases.model_cases()["w32_small"]
+    sd = {k: torch.from_numpy(v) for k, v in cases.model_state_dict(c).items()}
+    x = torch.from_numpy(cases.model_input(c)).to(dev)
+    n = x.shape[0]
+    gt = torch.rand(n, c["j"], c["h"] // 4, c["w"] // 4, generator=torch.Generator().manual_seed(4)).to(dev)
+    pv = torch.ones(n, c["j"], 1, 1, dtype=torch.uint8, device=dev)
+    loss_fn = Pose2DMeanSquaredError()
+    runs = {}
+    for name, make in (("mval", lambda ps: Adam([{"params": ps, "lr": 1e-3}])), ("torch", lambda ps: torch.optim.Adam([{"params": ps, "lr": 1e-3}]))):
+        m = cases.product_model(c)
+        m.load_state_dict(sd, strict=True)
+        m = m.to(dev).train()
+        opt = make(m.parameters())
+        v0 = next(m.parameters())._version
+        losses = []
+        for _ in range(3):
+            opt.zero_grad()
+            loss = loss_fn.pose_2d_mse(m(x), gt, pv)
+            loss.backward()
+            opt.step()
+            losses.append(float(loss.detach()))
+        assert next(m.parameters())._version > v0
+        runs[name] = (losses, {k: p.detach().cpu().clone() for k, p in m.named_parameters()})
+    (la, pa), (lb, pb) = runs["mval"], runs["torch"]
+    assert la[0] == lb[0] and la[2] != la[0], (la, lb)
+    np.testing.assert_allclose(la, lb, rtol=2e-4)
+    for k in ("conv1.weight", "final_layer.weight", "stage3.0.branches.1.0.conv1.weight"):
+        assert _rel(pa[k].numpy(), pb[k].numpy()) < 1e-3, k
