@@ -514,7 +514,7 @@ static int op_launch(const mval_op* op, int n_images, float* workspace, const fl
       p.res1_row = p.res1 ? reinterpret_cast<const unsigned*>(workspace + o->res1_amax_off) : nullptr;
       p.res2_row = p.res2 ? reinterpret_cast<const unsigned*>(workspace + o->res2_amax_off) : nullptr;
       if (o->out_nchw) {
-        p.out_f32 = net_output;
+        p.out_f32 = o->out_off >= 0 ? workspace + o->out_off : net_output;
         p.argmax_keys = argmax_keys;
       } else {
         p.out = reinterpret_cast<_Float16*>(workspace + o->out_off);
