@@ -382,6 +382,13 @@ int mval_bn_apply_fwd_p2(const float* z, const float* mean, const float* invstd,
                          const float* res1, const float* res2, float* out, void* p2_planes, uint32_t* p2_rows, int N, int H, int W,
                          int C, int up, int relu, uint32_t* amax_row, uint8_t* relu_mask, const uint32_t* res1_row,
                          const uint32_t* res2_row, void* stream);
+/* The same with residuals that exist as P2 planes only (same shape as the output; res*_p2_rows: their rows, 2^-s in the scale slot):
+ * res1 / res1_p2 are alternatives (both NULL: no residual); the magnitude rows res*_row stay required for the output's scale. */
+int mval_bn_apply_fwd_p2_res(const float* z, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                             const float* res1, const float* res2, float* out, void* p2_planes, uint32_t* p2_rows, int N, int H, int W,
+                             int C, int up, int relu, uint32_t* amax_row, uint8_t* relu_mask, const uint32_t* res1_row,
+                             const uint32_t* res2_row, const void* res1_p2, const uint32_t* res1_p2_rows, const void* res2_p2,
+                             const uint32_t* res2_p2_rows, void* stream);
 /* Backward of the above: masks gout by (out > 0) when relu, adds it into gres1/gres2 (stores it
  * instead where `overwrite` bit 0 / bit 1 is set: the first writer of a gradient slot), window-sums
  * it to the conv resolution, then (has_bn) dgamma/dbeta and dz = gamma*invstd*(g - dbeta/M -
@@ -500,6 +507,9 @@ typedef struct mval_train_op {
    * scratch at gz_p2_off (float offset into `arena`: planes of the largest dz, then n_images * MVAL_P2_ROW row dwords (zeroed once by the
    * caller), then 512 floats + 64 dwords of reduction scratch), and mval_conv_p2 reads them with the data-gradient packing at wd_off. */
   int64_t gz_p2_off, gz_p2_rows_off;
+  /* p2_flags bit 4 / bit 5: the forward apply reads res1 / res2 from that activation's P2 planes at res1_p2_off / res2_p2_off (rows at
+   * res*_p2_rows_off) -- the residual's producer then writes no fp32 copy when its other readers take the planes too. */
+  int64_t res1_p2_off, res1_p2_rows_off, res2_p2_off, res2_p2_rows_off;
 } mval_train_op;
 
 /* ones_off / zeros_off: params offsets of >= max(cout) floats of 1.0 / 0.0.

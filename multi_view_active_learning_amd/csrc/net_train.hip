@@ -27,6 +27,9 @@ extern "C" int mval_bn_bwd_fused_mask(const float*, const float*, const uint8_t*
                                       uint32_t*, void*);
 extern "C" int mval_bn_apply_fwd_p2(const float*, const float*, const float*, const float*, const float*, const float*, const float*, float*,
                                     void*, uint32_t*, int, int, int, int, int, int, uint32_t*, uint8_t*, const uint32_t*, const uint32_t*, void*);
+extern "C" int mval_bn_apply_fwd_p2_res(const float*, const float*, const float*, const float*, const float*, const float*, const float*, float*,
+                                        void*, uint32_t*, int, int, int, int, int, int, uint32_t*, uint8_t*, const uint32_t*, const uint32_t*,
+                                        const void*, const uint32_t*, const void*, const uint32_t*, void*);
 extern "C" int mval_bn_bwd_fused_p2(const float*, const float*, const uint8_t*, const float*, const float*, const float*, const float*,
                                     const float*, float*, float*, float*, float*, float*, double*, float*, int, int, int, int, int, int,
                                     uint32_t*, void*, uint32_t*, float*, uint32_t*, void*);
@@ -280,14 +283,19 @@ extern "C" int mval_train_forward(const mval_train_op* ops, int n_ops, int n_ima
       }
       if (rc) return rc;
       TtScope tt(TT_BN_APPLY, s);
-      if (t.out_p2_off > 0)
-        rc = mval_bn_apply_fwd_p2(a.out, t.mean, t.invstd, t.gamma, t.beta, op.res1_off >= 0 ? arena + op.res1_off : nullptr,
-                                  op.res2_off >= 0 ? arena + op.res2_off : nullptr, (t.p2_flags & 2) ? nullptr : out, arena + t.out_p2_off,
+      if (t.out_p2_off > 0) {
+        // (p2_flags bit 4 / 5) a residual that exists as planes only is read from those
+        const bool r1p = (t.p2_flags & 16) && op.res1_off >= 0 && t.res1_p2_off > 0, r2p = (t.p2_flags & 32) && op.res2_off >= 0 && t.res2_p2_off > 0;
+        rc = mval_bn_apply_fwd_p2_res(a.out, t.mean, t.invstd, t.gamma, t.beta, (op.res1_off >= 0 && !r1p) ? arena + op.res1_off : nullptr,
+                                  (op.res2_off >= 0 && !r2p) ? arena + op.res2_off : nullptr, (t.p2_flags & 2) ? nullptr : out, arena + t.out_p2_off,
                                   reinterpret_cast<uint32_t*>(arena + t.out_p2_rows_off), n_images, op.hout, op.wout, op.cout, op.up, op.relu,
                                   t.out_amax_off > 0 ? reinterpret_cast<uint32_t*>(arena + t.out_amax_off) : nullptr,
                                   t.mask_off > 0 ? reinterpret_cast<uint8_t*>(arena + t.mask_off) : nullptr,
                                   t.res1_amax_off > 0 ? reinterpret_cast<const uint32_t*>(arena + t.res1_amax_off) : nullptr,
-                                  t.res2_amax_off > 0 ? reinterpret_cast<const uint32_t*>(arena + t.res2_amax_off) : nullptr, stream);
+                                  t.res2_amax_off > 0 ? reinterpret_cast<const uint32_t*>(arena + t.res2_amax_off) : nullptr,
+                                  r1p ? arena + t.res1_p2_off : nullptr, r1p ? reinterpret_cast<const uint32_t*>(arena + t.res1_p2_rows_off) : nullptr,
+                                  r2p ? arena + t.res2_p2_off : nullptr, r2p ? reinterpret_cast<const uint32_t*>(arena + t.res2_p2_rows_off) : nullptr, stream);
+      }
       else
       rc = mval_bn_apply_fwd_mask(a.out, t.mean, t.invstd, t.gamma, t.beta, op.res1_off >= 0 ? arena + op.res1_off : nullptr,
                                   op.res2_off >= 0 ? arena + op.res2_off : nullptr, out, n_images, op.hout, op.wout, op.cout,

@@ -299,12 +299,25 @@ __device__ __forceinline__ p2_u32x4 p2_pair_granule(const p2_f16x4 h, const p2_f
 // range where the pair keeps all 22 bits (conv_p2.h).  One scale for the tensor (BatchNorm couples the batch anyway): every image's row
 // gets the same 2^-s.  Thread = 8 channels of one pixel, sixteen consecutive pixels per 8-channel block and half-wave quarter: 128-byte
 // NHWC reads, 256-byte P2 stores.
+// the other direction: the granule this lane loaded of a RESIDUAL's planes (even lane: plane h of the pair's 8 channels, odd lane: plane l)
+// -> the (h, l) halves of this lane's own four channels
+__device__ __forceinline__ f32x4 p2_pair_ungranule(const p2_u32x4 g, bool odd) {
+  const unsigned s0 = odd ? g.x : g.z, s1 = odd ? g.y : g.w;  // what the neighbour needs of this lane's granule
+  const unsigned r0 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)s0, 0xB1, 0xf, 0xf, false);  // quad_perm [1,0,3,2]
+  const unsigned r1 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)s1, 0xB1, 0xf, 0xf, false);
+  const p2_u32x2 h = odd ? (p2_u32x2){r0, r1} : (p2_u32x2){g.x, g.y}, l = odd ? (p2_u32x2){g.z, g.w} : (p2_u32x2){r0, r1};
+  return p2_join(__builtin_bit_cast(p2_f16x4, h), __builtin_bit_cast(p2_f16x4, l));
+}
+
+// res1_p2 / res2_p2 (round 4, late): a residual read from ITS P2 planes (same shape as the output; rows: its 2^-s in the scale slot)
+// instead of an fp32 NHWC copy -- block outputs whose every reader takes the planes are then never written as fp32.
 __global__ __launch_bounds__(TR_APPLY_THREADS) void bn_apply_fwd_p2_kernel(
     const float* __restrict__ z, const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
     const float* __restrict__ beta, const float* __restrict__ res1, const float* __restrict__ res2, float* __restrict__ out,
     _Float16* __restrict__ planes, unsigned* __restrict__ p2_rows, int N, int H, int W, int C, int up, int relu,
     unsigned* __restrict__ amax_row, unsigned char* __restrict__ relu_mask, const unsigned* __restrict__ res1_row,
-    const unsigned* __restrict__ res2_row, float sqrt_m1) {
+    const unsigned* __restrict__ res2_row, float sqrt_m1, const _Float16* __restrict__ res1_p2, const unsigned* __restrict__ res1_p2_rows,
+    const _Float16* __restrict__ res2_p2, const unsigned* __restrict__ res2_p2_rows) {
   const int C8 = C >> 3;
   const int Ho = H << up, Wo = W << up;
   const int HWo = Ho * Wo;
@@ -328,6 +341,7 @@ __global__ __launch_bounds__(TR_APPLY_THREADS) void bn_apply_fwd_p2_kernel(
   const int64_t plane_halves = (int64_t)C8 * HWo * 8;
   const int64_t wave0 = ((int64_t)blockIdx.x * TR_APPLY_THREADS + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * TR_APPLY_THREADS) >> 6;
   float amax = 0.f;
+  const float r1_inv = res1_p2 ? __uint_as_float(res1_p2_rows[P2_INV_SLOT]) : 0.f, r2_inv = res2_p2 ? __uint_as_float(res2_p2_rows[P2_INV_SLOT]) : 0.f;
   for (int64_t wi = wave0; wi < nwork; wi += nwaves) {
     const int64_t pchunk = wi / wm.NCB;
     const int cb = (int)(wi - pchunk * wm.NCB);
@@ -339,6 +353,14 @@ __global__ __launch_bounds__(TR_APPLY_THREADS) void bn_apply_fwd_p2_kernel(
     if (ok) {
       n = (int)(pix / HWo);
       pin = (int)(pix - (int64_t)n * HWo);
+    }
+    // residuals kept as planes: this lane's granule (the exchange with its neighbour takes every lane of the wave)
+    const int64_t gaddr = (((int64_t)n * 2 * C8 + (q >> 1)) * HWo + pin) * 8 + (odd ? plane_halves : 0);
+    const p2_u32x4 zero4 = {0u, 0u, 0u, 0u};
+    f32x4 rp1 = (f32x4){0.f, 0.f, 0.f, 0.f}, rp2 = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (res1_p2) rp1 = p2_pair_ungranule(ok ? *reinterpret_cast<const p2_u32x4*>(res1_p2 + gaddr) : zero4, odd) * r1_inv;
+    if (res2_p2) rp2 = p2_pair_ungranule(ok ? *reinterpret_cast<const p2_u32x4*>(res2_p2 + gaddr) : zero4, odd) * r2_inv;
+    if (ok) {
       const int Y = pin / Wo, X = pin - Y * Wo;
       const int64_t zi = (((int64_t)n * H + (Y >> up)) * W + (X >> up)) * C + q * 4;
       const int64_t o = pix * C + q * 4;
@@ -349,7 +371,9 @@ __global__ __launch_bounds__(TR_APPLY_THREADS) void bn_apply_fwd_p2_kernel(
       const f32x4 b = *reinterpret_cast<const f32x4*>(beta + q * 4);
       rr = bn_affine(zv, mu, is, g, b);
       if (res1) rr += *reinterpret_cast<const f32x4*>(res1 + o);
+      else if (res1_p2) rr += rp1;
       if (res2) rr += *reinterpret_cast<const f32x4*>(res2 + o);
+      else if (res2_p2) rr += rp2;
       if (relu) {
         rr.x = mval_relu(rr.x); rr.y = mval_relu(rr.y); rr.z = mval_relu(rr.z); rr.w = mval_relu(rr.w);
       }
@@ -365,12 +389,15 @@ __global__ __launch_bounds__(TR_APPLY_THREADS) void bn_apply_fwd_p2_kernel(
   if (amax_row) tr_amax_store(amax_row, amax);
 }
 
-extern "C" int mval_bn_apply_fwd_p2(const float* z, const float* mean, const float* invstd, const float* gamma, const float* beta,
-                                    const float* res1, const float* res2, float* out, void* p2_planes, uint32_t* p2_rows, int N, int H,
-                                    int W, int C, int up, int relu, uint32_t* amax_row, uint8_t* relu_mask, const uint32_t* res1_row,
-                                    const uint32_t* res2_row, void* stream) {
+extern "C" int mval_bn_apply_fwd_p2_res(const float* z, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                                        const float* res1, const float* res2, float* out, void* p2_planes, uint32_t* p2_rows, int N, int H,
+                                        int W, int C, int up, int relu, uint32_t* amax_row, uint8_t* relu_mask, const uint32_t* res1_row,
+                                        const uint32_t* res2_row, const void* res1_p2, const uint32_t* res1_p2_rows, const void* res2_p2,
+                                        const uint32_t* res2_p2_rows, void* stream) {
   MVAL_REQUIRE(z && p2_planes && p2_rows && N > 0 && H > 0 && W > 0 && C > 0 && (C & 7) == 0 && up >= 0, "mval_bn_apply_fwd_p2: bad arguments (C % 8)");
-  MVAL_REQUIRE((!res1 || res1_row) && (!res2 || res2_row), "mval_bn_apply_fwd_p2: a residual needs its magnitude row (the P2 scale is a bound)");
+  MVAL_REQUIRE(((!res1 && !res1_p2) || res1_row) && ((!res2 && !res2_p2) || res2_row), "mval_bn_apply_fwd_p2: a residual needs its magnitude row (the P2 scale is a bound)");
+  MVAL_REQUIRE(!(res1 && res1_p2) && !(res2 && res2_p2) && (!res1_p2 || res1_p2_rows) && (!res2_p2 || res2_p2_rows),
+               "mval_bn_apply_fwd_p2: a residual comes either as fp32 NHWC or as planes with their rows");
   MVAL_REQUIRE((int64_t)N * (H << up) * (W << up) * C < ((int64_t)1 << 31), "mval_bn_apply_fwd_p2: tensor too large");
   MVAL_REQUIRE(C <= 4096, "mval_bn_apply_fwd_p2: more than 4096 channels");
   const int64_t total4 = (int64_t)N * (H << up) * (W << up) * (C >> 2);
@@ -379,9 +406,18 @@ extern "C" int mval_bn_apply_fwd_p2(const float* z, const float* mean, const flo
   const double M = (double)N * H * W;
   hipLaunchKernelGGL(bn_apply_fwd_p2_kernel, dim3(nb), dim3(TR_APPLY_THREADS), 0, mval_stream(stream), z, mean, invstd, gamma, beta, res1,
                      res2, out, reinterpret_cast<_Float16*>(p2_planes), p2_rows, N, H, W, C, up, relu, amax_row, relu_mask, res1_row, res2_row,
-                     (float)sqrt(M > 1 ? M - 1.0 : 1.0));
+                     (float)sqrt(M > 1 ? M - 1.0 : 1.0), reinterpret_cast<const _Float16*>(res1_p2), res1_p2_rows,
+                     reinterpret_cast<const _Float16*>(res2_p2), res2_p2_rows);
   MVAL_CHECK_LAUNCH("mval_bn_apply_fwd_p2");
   return 0;
+}
+
+extern "C" int mval_bn_apply_fwd_p2(const float* z, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                                    const float* res1, const float* res2, float* out, void* p2_planes, uint32_t* p2_rows, int N, int H,
+                                    int W, int C, int up, int relu, uint32_t* amax_row, uint8_t* relu_mask, const uint32_t* res1_row,
+                                    const uint32_t* res2_row, void* stream) {
+  return mval_bn_apply_fwd_p2_res(z, mean, invstd, gamma, beta, res1, res2, out, p2_planes, p2_rows, N, H, W, C, up, relu, amax_row, relu_mask,
+                                  res1_row, res2_row, nullptr, nullptr, nullptr, nullptr, stream);
 }
 
 // ---- backward, stage 1 ------------------------------------------------------------------

@@ -51,6 +51,7 @@ class MvalTrainOp(C.Structure):
         ("in_p2_off", C.c_int64), ("in_p2_rows_off", C.c_int64), ("out_p2_off", C.c_int64), ("out_p2_rows_off", C.c_int64),
         ("res1_amax_off", C.c_int64), ("res2_amax_off", C.c_int64),
         ("gz_p2_off", C.c_int64), ("gz_p2_rows_off", C.c_int64),
+        ("res1_p2_off", C.c_int64), ("res1_p2_rows_off", C.c_int64), ("res2_p2_off", C.c_int64), ("res2_p2_rows_off", C.c_int64),
     ]
 
 
@@ -263,13 +264,31 @@ class TrainPlan:
                 t = self.ops[i]
                 if p2w and t.fwd_p2 and t.gz_amax_off > 0 and lib.mval_conv_wgrad_p2_covers(C.c_int(op.cin), C.c_int(op.cout), C.c_int(op.k), C.c_int(op.stride)):
                     t.p2_flags |= 1
+            # a residual can be read from the planes as well (mval_bn_apply_fwd_p2_res) when the op that adds it runs the P2 apply: then
+            # a block output whose every reader takes the planes -- the next block's first conv, its weight gradient, the residual add at
+            # that block's end -- is P2-only too (MVAL_TRAIN_P2_RES=0: residuals stay fp32 NHWC)
+            p2res = os.environ.get("MVAL_TRAIN_P2_RES", "1") != "0"
+            res_users = {}
+            for i, op in enumerate(g.ops):
+                for r_, bit in ((op.res1, 16), (op.res2, 32)):
+                    if r_ is not None:
+                        res_users.setdefault(r_, []).append((i, bit))
             for a_ in p2_act:
                 cons = consumers.get(a_, [])
                 po = g.ops[producer[a_]]
                 # (its own backward must not need `out` either: a ReLU behind residual adds takes its mask from the mask bytes)
                 own_ok = not (po.relu and (po.res1 is not None or po.res2 is not None)) or (os.environ.get("MVAL_TRAIN_RELU_MASK", "1") != "0" and po.up == 0)
-                if p2w and fused_bwd and own_ok and a_ not in res_used and a_ != g.output and cons and all(self.ops[i].fwd_p2 and (self.ops[i].p2_flags & 1) for i in cons):
+                users = res_users.get(a_, [])
+                users_ok = all(self.ops[i].out_p2_off > 0 and g.ops[i].bn for i, _ in users) and (p2res or not users)
+                if p2w and fused_bwd and own_ok and users_ok and a_ != g.output and cons and all(self.ops[i].fwd_p2 and (self.ops[i].p2_flags & 1) for i in cons):
                     self.ops[producer[a_]].p2_flags |= 2
+                    for i, bit in users:
+                        t = self.ops[i]
+                        t.p2_flags |= bit
+                        if bit == 16:
+                            t.res1_p2_off, t.res1_p2_rows_off = p2_act[a_]
+                        else:
+                            t.res2_p2_off, t.res2_p2_rows_off = p2_act[a_]
             # data gradients of stride-1 convs on the P2 kernels: the BatchNorm backward also writes dz as P2 planes into ONE scratch
             # (planes of the largest dz, rows, reduction scratch); MVAL_TRAIN_P2_DGRAD=0: the h2 data gradients
             if os.environ.get("MVAL_TRAIN_P2_DGRAD", "1") != "0" and fused_bwd:

@@ -511,7 +511,7 @@ def test_c3_full_size_properties(dev):
         np.testing.assert_allclose(r2[k].cpu().numpy(), r0[k].cpu().numpy(), rtol=1e-5, atol=1e-7)
 
 
-@pytest.mark.parametrize("off", ["MVAL_TRAIN_P2", "MVAL_TRAIN_P2_WGRAD", "MVAL_TRAIN_P2_DGRAD", "MVAL_TRAIN_EPI_STATS", "MVAL_TRAIN_BWD_FUSED",
+@pytest.mark.parametrize("off", ["MVAL_TRAIN_P2", "MVAL_TRAIN_P2_WGRAD", "MVAL_TRAIN_P2_DGRAD", "MVAL_TRAIN_P2_RES", "MVAL_TRAIN_EPI_STATS", "MVAL_TRAIN_BWD_FUSED",
                                  "MVAL_TRAIN_RELU_MASK", "MVAL_TRAIN_DGRAD_PARITY"])
 def test_round4_training_paths_against_their_switches(dev, off, monkeypatch):
     """Round 4 rebuilt the training step in layers (statistics from the conv epilogue, the fused BatchNorm backward, mask bytes, parity data
