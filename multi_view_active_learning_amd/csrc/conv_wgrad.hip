@@ -179,6 +179,12 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restr
   double s = 0;
   if (i < n) {
     int p = part;
+    for (; p + 7 * parts < PS; p += 8 * parts) {  // eight slabs per round trip (the 32-channel layers: 768 slabs over 16 lanes per output)
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) v[u] = slabs[(int64_t)(p + u * parts) * n + i];
+      s += (((double)v[0] + (double)v[1]) + ((double)v[2] + (double)v[3])) + (((double)v[4] + (double)v[5]) + ((double)v[6] + (double)v[7]));
+    }
     for (; p + 3 * parts < PS; p += 4 * parts) {
       const float v0 = slabs[(int64_t)p * n + i], v1 = slabs[(int64_t)(p + parts) * n + i];
       const float v2 = slabs[(int64_t)(p + 2 * parts) * n + i], v3 = slabs[(int64_t)(p + 3 * parts) * n + i];
