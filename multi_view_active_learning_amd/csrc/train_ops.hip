@@ -311,7 +311,7 @@ __device__ __forceinline__ f32x4 p2_pair_ungranule(const p2_u32x4 g, bool odd) {
 
 // res1_p2 / res2_p2 (round 4, late): a residual read from ITS P2 planes (same shape as the output; rows: its 2^-s in the scale slot)
 // instead of an fp32 NHWC copy -- block outputs whose every reader takes the planes are then never written as fp32.
-__global__ __launch_bounds__(TR_APPLY_THREADS) void bn_apply_fwd_p2_kernel(
+__global__ __launch_bounds__(TR_APPLY_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void bn_apply_fwd_p2_kernel(
     const float* __restrict__ z, const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
     const float* __restrict__ beta, const float* __restrict__ res1, const float* __restrict__ res2, float* __restrict__ out,
     _Float16* __restrict__ planes, unsigned* __restrict__ p2_rows, int N, int H, int W, int C, int up, int relu,
@@ -902,11 +902,14 @@ __global__ __launch_bounds__(TR_APPLY_THREADS) void bn_bwd_apply2_kernel(const f
 
 // dz as above, written as fp32 NHWC (gz, optional) AND as P2 planes for the data-gradient conv on the P2 kernels: the float4 side in
 // NHWC order, the granules through LDS (as bn_apply_fwd_p2_kernel); the scale from the bound the finalize step left in *bound_slot.
-__global__ __launch_bounds__(TR_APPLY_THREADS) void bn_bwd_apply2_p2_kernel(
+// (MM = the mask mode as a template parameter and 8 waves per SIMD: with the mode at run time the kernel held 70 VGPRs -- 7 waves per
+// SIMD, i.e. ONE 1024-thread block per CU with 12 of 28 wave slots empty; bn_apply_fwd_p2_kernel likewise: 36.4 -> 31.9 us per launch)
+template <int MM>
+__global__ __launch_bounds__(TR_APPLY_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void bn_bwd_apply2_p2_kernel(
     const float* __restrict__ gsrc, const float* __restrict__ out, const float* __restrict__ z, const float* __restrict__ mean,
     const float* __restrict__ invstd, const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ sums,
     float* __restrict__ gz, _Float16* __restrict__ planes, unsigned* __restrict__ p2_rows, const unsigned* __restrict__ bound_slot, int N,
-    int HW, int C, int mask_mode, unsigned* __restrict__ amax_row, const unsigned char* __restrict__ relu_mask) {
+    int HW, int C, int, unsigned* __restrict__ amax_row, const unsigned char* __restrict__ relu_mask) {
   const int C8 = C >> 3;
   const int64_t npx = (int64_t)N * HW;
   const float invM = 1.0f / (float)npx;
@@ -937,15 +940,15 @@ __global__ __launch_bounds__(TR_APPLY_THREADS) void bn_bwd_apply2_p2_kernel(
       const int64_t o = pix * C + q * 4;
       const f32x4 gv0 = *reinterpret_cast<const f32x4*>(gsrc + o);
       const f32x4 zv = *reinterpret_cast<const f32x4*>(z + o);
-      f32x4 ov = mask_mode == 1 ? *reinterpret_cast<const f32x4*>(out + o) : zero;
-      if (mask_mode == 3) ov.x = __uint_as_float((unsigned)relu_mask[o >> 2]);
+      f32x4 ov = MM == 1 ? *reinterpret_cast<const f32x4*>(out + o) : zero;
+      if (MM == 3) ov.x = __uint_as_float((unsigned)relu_mask[o >> 2]);
       const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + q * 4);
       const f32x4 is = *reinterpret_cast<const f32x4*>(invstd + q * 4);
       const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + q * 4);
-      const f32x4 bt = mask_mode == 2 ? *reinterpret_cast<const f32x4*>(beta + q * 4) : zero;
+      const f32x4 bt = MM == 2 ? *reinterpret_cast<const f32x4*>(beta + q * 4) : zero;
       const f32x4 db = *reinterpret_cast<const f32x4*>(sums + q * 4);
       const f32x4 dg = *reinterpret_cast<const f32x4*>(sums + C + q * 4);
-      const f32x4 gv = bwd_mask(gv0, mask_mode, ov, zv, mu, is, g, bt);
+      const f32x4 gv = bwd_mask(gv0, MM, ov, zv, mu, is, g, bt);
       const f32x4 xh = (zv - mu) * is;
       r = (g * is) * (gv - db * invM - xh * (dg * invM));
       if (gz) *reinterpret_cast<f32x4*>(gz + o) = r;
@@ -1021,8 +1024,14 @@ extern "C" int mval_bn_bwd_fused_p2(const float* gout, const float* out, const u
   int nb2 = (int)((total + TR_APPLY_THREADS - 1) / TR_APPLY_THREADS);
   if (nb2 > TR_APPLY_BLOCKS) nb2 = TR_APPLY_BLOCKS;
   if (p2) {
-    hipLaunchKernelGGL(bn_bwd_apply2_p2_kernel, dim3(nb2), dim3(TR_APPLY_THREADS), 0, s, gsrc, out, z, mean, invstd, gamma, beta, sums, gz,
-                       reinterpret_cast<_Float16*>(dz_planes), dz_rows, bound_slot, N, H * W, C, apply_mask, gz_amax_row, relu_mask);
+#define BWD_P2_LAUNCH(MM_)                                                                                                              \
+  hipLaunchKernelGGL(bn_bwd_apply2_p2_kernel<MM_>, dim3(nb2), dim3(TR_APPLY_THREADS), 0, s, gsrc, out, z, mean, invstd, gamma, beta, sums, gz, \
+                     reinterpret_cast<_Float16*>(dz_planes), dz_rows, bound_slot, N, H * W, C, apply_mask, gz_amax_row, relu_mask)
+    if (apply_mask == 0) BWD_P2_LAUNCH(0);
+    else if (apply_mask == 1) BWD_P2_LAUNCH(1);
+    else if (apply_mask == 2) BWD_P2_LAUNCH(2);
+    else BWD_P2_LAUNCH(3);
+#undef BWD_P2_LAUNCH
     MVAL_CHECK_LAUNCH("mval_bn_bwd_fused/apply p2");
     return 0;
   }
