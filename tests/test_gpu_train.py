@@ -616,7 +616,7 @@ def test_adam_falls_back_to_torch_for_what_the_kernel_does_not_cover(dev):
             pp.grad = None if it == 0 else (g * 0.5).clone()
         oa.step(); ob.step()
     for x, y in ((p1, q1), (p2, q2)):
-        assert float((x - y).abs().max()) <= 4e-6 * float(y.abs().max())
+        assert float((x.detach() - y.detach()).abs().max()) <= 4e-6 * float(y.detach().abs().max())
     assert float(oa.state[p1]["step"]) == 4.0 and float(oa.state[p2]["step"]) == 3.0
 
 
@@ -656,3 +656,32 @@ def test_adam_one_launch_trains_the_network_like_torch_adam(dev):
     np.testing.assert_allclose(la, lb, rtol=2e-4)
     for k in ("conv1.weight", "final_layer.weight", "stage3.0.branches.1.0.conv1.weight"):
         assert _rel(pa[k].numpy(), pb[k].numpy()) < 1e-3, k
+
+
+def test_adam_one_launch_param_groups_and_closure(dev):
+    """Two parameter groups with their own learning rates / betas / eps (one launch each) and a closure, against torch.optim.Adam."""
+    from multi_view_active_learning_amd.optim import Adam
+
+    torch.manual_seed(3)
+    wa, wb = torch.randn(70, 9), torch.randn(513)
+    pa, pb = torch.nn.Parameter(wa.clone().to(dev)), torch.nn.Parameter(wb.clone().to(dev))
+    qa, qb = torch.nn.Parameter(wa.clone()), torch.nn.Parameter(wb.clone())
+    groups = lambda a, b: [{"params": [a], "lr": 1e-2}, {"params": [b], "lr": 3e-3, "betas": (0.8, 0.99), "eps": 1e-6}]
+    oa, ob = Adam(groups(pa, pb)), torch.optim.Adam(groups(qa, qb), foreach=False)
+    target_a, target_b = torch.randn(70, 9), torch.randn(513)
+
+    def closure_of(a, b, ta, tb, opt):
+        def closure():
+            opt.zero_grad()
+            loss = ((a - ta) ** 2).sum() + ((b - tb) ** 2).sum()
+            loss.backward()
+            return loss
+        return closure
+
+    for it in range(6):
+        la = oa.step(closure_of(pa, pb, target_a.to(dev), target_b.to(dev), oa))
+        lb = ob.step(closure_of(qa, qb, target_a, target_b, ob))
+        assert abs(float(la) - float(lb)) <= 1e-5 * abs(float(lb))
+    for x, y in ((pa, qa), (pb, qb)):
+        assert float((x.detach().cpu() - y.detach()).abs().max()) <= 4e-6 * float(y.detach().abs().max())
+    assert getattr(oa, "table_builds", 0) >= 2  # (one table per group)
