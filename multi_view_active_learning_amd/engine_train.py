@@ -257,7 +257,6 @@ class TrainPlan:
             # planes (P2 forward conv + P2 weight gradient, no residual use, not the network output) is not written as fp32 at all
             p2w = os.environ.get("MVAL_TRAIN_P2_WGRAD", "1") != "0"
             fused_bwd = os.environ.get("MVAL_TRAIN_BWD_FUSED", "1") != "0"  # (round 3's BatchNorm backward reads `out` and writes fp32 dz only)
-            res_used = {r for op in g.ops for r in (op.res1, op.res2) if r is not None}
             consumers = {}
             for i, op in enumerate(g.ops):
                 consumers.setdefault(op.src, []).append(i)
