@@ -685,3 +685,39 @@ def test_adam_one_launch_param_groups_and_closure(dev):
     for x, y in ((pa, qa), (pb, qb)):
         assert float((x.detach().cpu() - y.detach()).abs().max()) <= 4e-6 * float(y.detach().abs().max())
     assert getattr(oa, "table_builds", 0) >= 2  # (one table per group)
+
+
+def test_c3_full_size_training_trajectory(dev):
+    """Eight steps of the FULL-SIZE C3 loop (HRNet-W32, 128 images of 256 x 256: the plan with plane-only activations, residuals read
+    from planes, the one-launch Adam and the weight re-pack it triggers) next to the same loop with torch.optim.Adam: the losses agree
+    to 1 % (the runs drift apart like any two fp32 runs of this problem) and fall by more than half -- a forward that kept stale packed
+    weights, or an optimizer that lost a tensor, shows here."""
+    from multi_view_active_learning_amd import synth
+    from multi_view_active_learning_amd.optim import Adam
+    from multi_view_active_learning_amd.pose_estimators import Pose2DMeanSquaredError, PoseHighResolutionNet
+
+    x = torch.from_numpy(synth.images(77, 32, 4, 256, 256)).reshape(128, 3, 256, 256).to(dev)
+    gt = torch.rand(128, 19, 64, 64, generator=torch.Generator().manual_seed(3)).to(dev) * 0.1
+    pv = torch.ones(128, 19, 1, 1, dtype=torch.uint8, device=dev)
+    loss_fn = Pose2DMeanSquaredError()
+    traj = {}
+    for name in ("mval", "torch"):
+        m = PoseHighResolutionNet(19)
+        sd = {k: torch.from_numpy(v) for k, v in synth.synthetic_state_dict(m._graph.param_shapes(), 0).items()}
+        m.load_state_dict(sd, strict=True)
+        m = m.to(dev).train()
+        opt = Adam([{"params": m.parameters(), "lr": 1e-3}]) if name == "mval" else torch.optim.Adam([{"params": m.parameters(), "lr": 1e-3}])
+        ls = []
+        for _ in range(8):
+            opt.zero_grad()
+            loss = loss_fn.pose_2d_mse(m(x), gt, pv)
+            loss.backward()
+            opt.step()
+            ls.append(float(loss.detach()))
+        traj[name] = ls
+        del m, opt
+        torch.cuda.empty_cache()
+    a, b = traj["mval"], traj["torch"]
+    assert a[0] == b[0] and all(np.isfinite(a))
+    assert max(abs(p - q) / abs(q) for p, q in zip(a, b)) < 1e-2, (a, b)
+    assert a[-1] < 0.5 * a[0], a
