@@ -165,13 +165,18 @@ def cpu_baseline_train(wl, sd_np, seconds_target=20.0):
     v, h, w, j = wl["v"], wl["h"], wl["w"], wl["j"]
     frames_per_call = 2
     x = torch.from_numpy(synth.images(123, frames_per_call, v, h, w)).reshape(-1, 3, h, w)
-    gt = torch.rand(x.shape[0], j, h // 4, w // 4)
+    gt = torch.rand(x.shape[0], j, h // 4, w // 4, generator=torch.Generator().manual_seed(11))
     arch = models.HRNET_W48 if wl["arch"] == "hrnet_w48" else models.HRNET_W32
+    check = {}
 
     def step():
         sd = {k: torch.from_numpy(a).clone().requires_grad_(a.dtype == np.float32 and "running" not in k) for k, a in sd_np.items()}
-        loss = models.pose_2d_mse(models.hrnet_forward(sd, x, arch, training=True), gt)
+        hm = models.hrnet_forward(sd, x, arch, training=True)
+        loss = models.pose_2d_mse(hm, gt)
         loss.backward()
+        if not check:  # the parity sample of the line: this step's loss, heat-maps and two gradients, compared with the HIP path by main()
+            check.update(images=x, gt=gt, loss=float(loss.detach()), heatmaps=hm.detach().numpy().copy(),
+                         grads={k: sd[k].grad.numpy().copy() for k in ("final_layer.weight", "final_layer.bias", "conv1.weight")})
 
     ncpu = os.cpu_count() or 1
     tried = {}
@@ -189,11 +194,66 @@ def cpu_baseline_train(wl, sd_np, seconds_target=20.0):
         el = time.perf_counter() - t0
         if el > seconds_target or done >= 16:
             break
-    return dict(value=done * v / el, unit="frames*views/s", cores=best, kind="port", host_cpu=host_cpu_model(),
+    return dict(_check=check, value=done * v / el, unit="frames*views/s", cores=best, kind="port", host_cpu=host_cpu_model(),
                 host_logical_cpus=os.cpu_count(),
                 sample=f"{done} frames x {v} views of the same shapes, {el:.1f} s, stock torch fp32 train-mode forward + masked MSE + "
                        f"autograd backward (oracle/), {best} threads (best of {sorted(tried)}); no optimizer step",
                 threads_tried={str(k): round(frames_per_call * v / t, 2) for k, t in tried.items()})
+
+
+def train_bn_bytes(plan, n):
+    """Algorithmic bytes per step of the BatchNorm kernels of a training plan, op by op from the plan's own flags (engine_train.TrainPlan,
+    csrc/net_train.hip): every tensor pass a kernel makes counts 4 bytes per element (fp32 NHWC and the fp16 (h, l) planes alike), mask
+    bytes 1 byte per 4 elements.  Returns bytes and, per kernel, the pass counts in units of (tensor passes summed over the ops)."""
+    z_el = o_el = 0.0
+    apply_b = bwd_b = stats_b = 0.0
+    ap = dict(read_z=0, read_res=0, write_fp32=0, write_planes=0, write_mask=0)
+    bp = dict(reduce_read_gout=0, reduce_read_z=0, reduce_read_out_or_mask=0, reduce_rw_res_grads=0, apply_read_g=0, apply_read_z=0,
+              apply_read_out_or_mask=0, apply_write_fp32=0, apply_write_planes=0)
+    n_bn = 0
+    for o in plan.ops:
+        if not o.has_bn:
+            continue
+        n_bn += 1
+        op = o.op
+        ze = float(n) * op.hout * op.wout * op.cout
+        oe = float(n) * (op.hout << op.up) * (op.wout << op.up) * op.cout
+        z_el += ze
+        nres = int(op.res1_off >= 0) + int(op.res2_off >= 0)
+        o_el += oe * (1 + nres)
+        # forward apply
+        p2_only = bool(o.p2_flags & 2)
+        apply_b += 4 * ze + 4 * oe * nres + (0 if p2_only else 4 * oe) + (4 * oe if o.out_p2_off > 0 else 0) + (oe / 4 if o.mask_off > 0 else 0)
+        ap["read_z"] += 1; ap["read_res"] += nres; ap["write_fp32"] += int(not p2_only); ap["write_planes"] += int(o.out_p2_off > 0)
+        ap["write_mask"] += int(o.mask_off > 0)
+        # backward
+        fused = not (o.p2_flags & 64) and op.up == 0 and op.cout % 4 == 0
+        first = o.first_touch >> 1
+        acc_res = sum(1 for k_, off in ((1, o.gres1_off), (2, o.gres2_off)) if off >= 0 and not (first & k_))  # read-modify-write
+        st_res = sum(1 for k_, off in ((1, o.gres1_off), (2, o.gres2_off)) if off >= 0)
+        if fused:
+            mode_ = 0 if not op.relu else (3 if o.mask_off > 0 else 1) if nres else 2
+            mask_b = {0: 0.0, 1: 4 * oe, 2: 0.0, 3: oe / 4}[mode_]
+            from_slot = st_res > 0 and bool(first & 3)  # apply re-reads the residual slot this op stored the masked gradient in: no mask
+            dz_p2 = bool(o.p2_flags & 4) and o.gin_off >= 0
+            w32 = not (dz_p2 and (o.p2_flags & 8))
+            bwd_b += 4 * oe + 4 * ze + mask_b + 4 * oe * (acc_res + st_res) + 4 * oe + 4 * ze + (0 if from_slot else mask_b) + (4 * ze if w32 else 0) + (4 * ze if dz_p2 else 0)
+            bp["reduce_read_gout"] += 1; bp["reduce_read_z"] += 1; bp["reduce_read_out_or_mask"] += mask_b / (4 * oe)
+            bp["reduce_rw_res_grads"] += acc_res + st_res
+            bp["apply_read_g"] += 1; bp["apply_read_z"] += 1; bp["apply_read_out_or_mask"] += 0 if from_slot else mask_b / (4 * oe)
+            bp["apply_write_fp32"] += int(w32); bp["apply_write_planes"] += int(dz_p2)
+        else:  # round-3 pair: reduce (gout at the upsampled size [, out], z, residual gradients, masked / window-summed copy to gz), apply in place
+            bwd_b += 4 * oe * (1 + int(bool(op.relu))) + 4 * ze + 4 * oe * (acc_res + st_res) + 4 * ze + 3 * 4 * ze
+            bp["reduce_read_gout"] += oe / ze; bp["reduce_read_z"] += 1; bp["reduce_read_out_or_mask"] += int(bool(op.relu)) * oe / ze
+            bp["reduce_rw_res_grads"] += (acc_res + st_res) * oe / ze
+            bp["apply_read_g"] += 2; bp["apply_read_z"] += 1; bp["apply_write_fp32"] += 1  # (+ the reduce's write of gz counted under apply_read_g)
+    # ops whose conv epilogue keeps no statistics partials (3-channel stem: in_nchw) still read z once
+    for o in plan.ops:
+        if o.has_bn and (o.op.in_nchw or (o.p2_flags & 128)):
+            stats_b += 4.0 * n * o.op.hout * o.op.wout * o.op.cout
+    rnd = lambda d: {k_: round(float(v_), 1) for k_, v_ in d.items()}
+    return dict(apply=apply_b, bwd=bwd_b, stats=stats_b, apply_passes=rnd(ap), bwd_passes=rnd(bp), n_bn=n_bn,
+                apply_r3=4.0 * (z_el + o_el), bwd_r3=2.0 * 4.0 * o_el + 4.0 * 4.0 * z_el)
 
 
 def train_rooflines(model, step, frames, v, mode):
@@ -219,36 +279,64 @@ def train_rooflines(model, step, frames, v, mode):
     n = frames * v
     fl_fwd = sum(float(lib.mval_op_flops(C.byref(o.op), C.c_int(n))) for o in plan.ops)
     fl_dgrad = sum(float(lib.mval_op_flops(C.byref(o.op), C.c_int(n))) for o in plan.ops if o.gin_off >= 0)
-    # BatchNorm streams, float32 bytes per step: z = raw conv outputs, out = activations (at the upsampled size)
-    zb = sum(4.0 * n * o.op.hout * o.op.wout * o.op.cout for o in plan.ops if o.has_bn)
-    ob = sum(4.0 * n * (o.op.hout << o.op.up) * (o.op.wout << o.op.up) * o.op.cout * (1 + (o.op.res1_off >= 0) + (o.op.res2_off >= 0))
-             for o in plan.ops if o.has_bn)
     peak = PEAK_BF16_MFMA_TFLOPS / SPLIT_PRODUCTS.get(mode, 6) if mode != "fp32" else PEAK_FP32_MFMA_TFLOPS
     note = (f"dense 16-bit MFMA peak 2500 TFLOP/s / {SPLIT_PRODUCTS.get(mode, 6)} products (layers the fp16 split does not cover run "
             "the bf16x3 or exact-fp32 kernels: their time is in, the peak is the default split's)")
+    bn = train_bn_bytes(plan, n)
+    # HBM bytes per step by kernel from the committed rocprofv3 counter passes of THIS workload (tools/collect_profiles.sh: separate
+    # --pmc FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE x2 gfx950 correction; Infinity-Cache hits are counted by those counters)
+    pmc, pmc_src = {}, None
+    for r_ in ("r05", "r04"):
+        p_ = os.path.join(ROOT, "profiles", r_, f"bench_c3_{r_.replace('0', '')}_summary.json")
+        if os.path.exists(p_):
+            try:
+                with open(p_) as f:
+                    d = json.load(f)
+                steps_traced = max(1, int(d.get("launch_counts", {}).get("adam_step_kernel", 0)))
+                for row in d["hbm_traffic_by_instantiation"]:
+                    pmc[row["kernel"]] = row["launches"] * row["total_bytes"] / steps_traced
+                pmc_src = os.path.relpath(p_, ROOT)
+                break
+            except (OSError, KeyError, ValueError):
+                pmc = {}
 
-    def mf(name, f, tt):
+    def traffic_of(prefixes):
+        v_ = sum(b for k_, b in pmc.items() if k_.startswith(prefixes))
+        return round(v_) if v_ else None
+
+    def mf(name, f, tt, prefixes=()):
         return dict(bound="mfma", achieved=round(f / tt / 1e12, 2), peak=round(peak, 1), unit="TFLOP/s", frac=round(f / tt / 1e12 / peak, 4),
-                    traffic=None, kernel=name, peak_note=note, seconds_in_kernel_per_step=round(tt, 6), flops_per_step=f)
+                    traffic=traffic_of(prefixes) if prefixes else None, kernel=name, peak_note=note, seconds_in_kernel_per_step=round(tt, 6), flops_per_step=f)
 
-    def hb(name, b, tt):
+    def hb(name, b, tt, prefixes=(), **extra):
         return dict(bound="hbm", achieved=round(b / tt / 1e9, 1), peak=PEAK_HBM_GBPS, unit="GB/s", frac=round(b / tt / 1e9 / PEAK_HBM_GBPS, 4),
-                    traffic=None, kernel=name, peak_note="HBM3E ~8 TB/s (guide); ~6.3 TB/s achievable",
-                    seconds_in_kernel_per_step=round(tt, 6), bytes_per_step=b)
+                    traffic=traffic_of(prefixes) if prefixes else None, traffic_source=pmc_src, kernel=name,
+                    peak_note="HBM3E ~8 TB/s (guide); ~6.3 TB/s achievable", seconds_in_kernel_per_step=round(tt, 6), bytes_per_step=b, **extra)
 
     fams = [
-        mf("conv forward (round 4: conv_p2_kernel<..., EPI 3> over fp16-pair activations -- raw fp32 NHWC z + the batch-statistics sums of "
+        mf("conv forward (conv_p2_kernel<..., EPI 3> over fp16-pair activations -- raw fp32 NHWC z + the batch-statistics sums of "
            "its persistent workgroups; conv_split_kernel / conv_mfma_kernel for the shapes P2 does not cover)", fl_fwd, t[0]),
-        hb("BatchNorm statistics (bn_stats_finalize_tiles: the conv epilogues' float64 partials -> mean / invstd / running stats; the "
-           "stem conv, whose kernel keeps none, still runs bn_stats_partial over z; bytes = one read of z, as in round 3, for comparison)", zb, t[1]),
-        hb("BatchNorm apply (bn_apply_fwd_p2: z -> normalise + residuals + ReLU (+ upsample) -> out as P2 planes and, for residual inputs, fp32; "
-           "+ the ReLU mask bytes of residual ops; bytes = round 3's count)", zb + ob, t[2]),
-        hb("BatchNorm backward (bn_bwd_reduce2 + finalize + bn_bwd_apply2[_p2]: gout, z [, mask bytes] -> dz (as P2 planes where the P2 data gradient reads it), dgamma, dbeta, residual gradients; "
-           "bytes = round 3's count (2 x out-sized + 4 x z-sized tensors), for comparison: the round-4 kernels move 5 - 7 of those 6 - 8)",
-           2.0 * ob + 4.0 * zb, t[3]),
-        mf("weight gradient (conv_wgrad_bf3_kernel split-K, both operands staged from the P2 planes, + float64 slab reduction)", fl_fwd, t[4]),
-        mf("data gradient (conv_p2_kernel<..., EPI 3> accumulating into the fp32 gradient slot; stride 2: four 2x2 parity convs on conv_split_kernel)", fl_dgrad, t[5]),
+        dict(bound="latency", achieved=None, peak=None, unit=None, frac=None, traffic=None,
+             kernel="BatchNorm statistics (finalize of the conv epilogues' float64 partials -> mean / invstd / running stats: no pass over z; "
+                    "ops whose conv keeps no partials -- the stem -- run bn_stats_partial over z)",
+             peak_note="launch- / latency-bound: one small dependent launch per BatchNorm", launches_per_step=bn["n_bn"],
+             seconds_in_kernel_per_step=round(t[1], 6), bytes_per_step=bn["stats"]),
+        hb("BatchNorm apply (bn_apply_fwd[_p2]: z [+ residuals] -> normalise + residuals + ReLU (+ upsample) -> out as P2 planes and / or fp32 "
+           "[+ ReLU mask bytes])", bn["apply"], t[2], ("bn_apply_fwd",), passes=bn["apply_passes"],
+           bytes_round3_count=bn["apply_r3"], frac_round3_count=round(bn["apply_r3"] / t[2] / 1e9 / PEAK_HBM_GBPS, 4)),
+        hb("BatchNorm backward (bn_bwd_reduce2 + finalize + bn_bwd_apply2[_p2]; bn_bwd_reduce + bn_bwd_apply for up-sampled terms / the "
+           "final layer: gout, z [, mask] -> residual gradients, dgamma, dbeta, dz as P2 planes and / or fp32)", bn["bwd"], t[3], ("bn_bwd",),
+           passes=bn["bwd_passes"], bytes_round3_count=bn["bwd_r3"], frac_round3_count=round(bn["bwd_r3"] / t[3] / 1e9 / PEAK_HBM_GBPS, 4)),
+        mf("weight gradient (conv_wgrad_bf3_kernel split-K, both operands staged from the P2 planes, + float64 slab reduction)", fl_fwd, t[4],
+           ("conv_wgrad", "wgrad_reduce", "slab_reduce")),
+        mf("data gradient (conv_p2_kernel<..., EPI 3> accumulating into the fp32 gradient slot; stride 2: four 2x2 parity convs)", fl_dgrad, t[5]),
     ]
+    for f_ in fams:
+        if f_["bound"] == "hbm":
+            f_["bytes_note"] = ("bytes_per_step = what THIS round's kernels read and write, summed op by op from the plan (`passes`: the same in units "
+                                "of one fp32 tensor pass at the op's output size, per kernel); bytes_round3_count / frac_round3_count = the byte "
+                                "count round 3's kernels moved, for comparison across rounds only; traffic = rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE "
+                                "per step from traffic_source (counts Infinity-Cache hits)")
     fams.sort(key=lambda f: -f["seconds_in_kernel_per_step"])
     top = fams[0]
     top["other_kernels"] = fams[1:]
@@ -361,6 +449,11 @@ def main():
     ap.add_argument("--no-overlap", action="store_true",
                     help="run a batch's decode / scoring / triangulation on the network's stream instead of the side stream "
                          "(parallel.PostStream: by default it overlaps the next batch's network)")
+    ap.add_argument("--no-rooflines", action="store_true",
+                    help="profiling passes (tools/collect_profiles.sh): skip the per-kernel measurement runs after the timed region, so that a "
+                         "rocprofv3 trace of this command holds the workload's steps only")
+    ap.add_argument("--min-timed-seconds", type=float, default=2.0,
+                    help="the K-step region is repeated until it is at least this long (counter passes use 0: K steps exactly)")
     ap.add_argument("--no-companions", action="store_true",
                     help="default c2 run: skip the C3 / C4 companion lines (child processes after the headline)")
     args = ap.parse_args()
@@ -608,7 +701,7 @@ def main():
             r = step()
             sync()
             est = max(time.perf_counter() - t0, 1e-4) * args.steps
-            repeats = int(min(64, max(1, np.ceil(2.0 / est))))
+            repeats = int(min(64, max(1, np.ceil(args.min_timed_seconds / est))))
             if world > 1:  # every rank runs the same number of steps
                 t = torch.tensor([repeats], dtype=torch.int64, device=dev)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -673,12 +766,13 @@ def main():
 
     # ---- roofline of the dominant kernel family (outside the timed region) ------------------------
     roof = None
-    if rank == 0 and train:
+    rank_roof = -1 if args.no_rooflines else 0
+    if rank == rank_roof and train:
         with torch.enable_grad():
             roof = train_rooflines(model, step, frames, v, _conv_mode())
         # (SURVEY 8d convention for the whole step: 3 x the forward conv FLOPs over the step's wall time)
         roof["whole_step_tflops_3x_forward"] = round(3.0 * FLOP_PER_IMAGE["hrnet_w32_256"] * frames * v / (el / args.steps) / 1e12, 2)
-    if rank == 0 and not train:
+    if rank == rank_roof and not train:
         plan = _plan_for(model, images)
         with torch.no_grad():
             ms_acc, reps = None, 3
@@ -728,6 +822,10 @@ def main():
         stem2 = np.asarray([o.kind == 6 for o in plan.ops])
         fuseup = np.asarray([o.kind == 7 for o in plan.ops])
         fams = []
+        # the 256-channel Bottleneck of this plan (in + out, residual = input): algorithmic GB and GFLOP per launch, for its note below
+        bn_ops = [(o, f_) for o, f_ in zip(plan.ops, flops) if o.kind == 5 and o.cin == 256]
+        bneck_gb = (4.0 * plan.n * (bn_ops[0][0].hin * bn_ops[0][0].win * 256 * 2) / 1e9) if bn_ops else 0.0
+        bneck_gf = (bn_ops[0][1] / 1e9) if bn_ops else 0.0
         split_any = np.zeros(len(plan.ops), dtype=bool)
         for algo, pl, what in ((ALGO_MFMA_P2, "p2", "activations kept as fp16 (h, l) plane pairs in HBM, 3 x v_mfma_f32_16x16x32_f16 per 32-deep step"),
                                (ALGO_MFMA_H2, "h2", "fp32 values as scaled 2-way fp16 splits, 3 x v_mfma_f32_16x16x32_f16 per 32-deep step"),
@@ -748,7 +846,8 @@ def main():
                 family(m_ & k3 & ~s1 & ~stem2, ("conv_p2_kernel<3, 2, ...>" if pl == "p2" else f"conv_split_kernel<{2 if pl == 'h2' else 3}, 3, 2, ...>") + " (same, stride 2)", peak, note),
                 hbm_family(m_ & bneck, "conv_bneck_p2_kernel<CIN> (whole Bottlenecks of layer1 in one launch: 1x1 -> 3x3 -> 1x1 convs, BNs, residual, "
                                        "ReLUs; the 64-channel intermediates never leave the CU; HBM is the tighter of its two bounds: "
-                                       "1.07 GB / 8 TB/s = 134 us vs 80 GFLOP x 3 / 2500 TFLOP/s = 96 us per 128 images)"),
+                                       f"{bneck_gb:.2f} GB / 8 TB/s = {bneck_gb / 8e3 * 1e6:.0f} us vs {bneck_gf:.0f} GFLOP x 3 / 2500 TFLOP/s = "
+                                       f"{bneck_gf * 3 / 2500e3 * 1e6:.0f} us per launch of this step's {plan.n} images)"),
                 hbm_family(m_ & fuseup, "conv_fuse_up_p2_kernel<C> (the two or three up-sampling 1x1 terms of a fuse-layer output added to the partial sum in one "
                                         "launch: the sum is read once and written once)"),
                 hbm_family(m_ & ~k3 & ~bneck & ~fuseup, ("conv_p2_kernel<1, 1, ...>" if pl == "p2" else f"conv_split_kernel<{2 if pl == 'h2' else 3}, 1, 1, ...>") + " (fused 1x1 conv+BN+residual+ReLU(+upsample): "
@@ -831,6 +930,12 @@ def main():
             "parity_unpinned": PARITY_UNPINNED,
         }
         if train:
+            tp = next(iter(model._train_plans.values()), None)
+            out["p2_bound_slack"] = None if tp is None else tp.p2_slack
+            out["p2_bound_slack_note"] = ("training plan's probe (engine_train.TrainPlan: first step of the plan, then every 256): per kind (act = P2 activation planes, "
+                                          "dz = the BatchNorm backward's P2 planes) log2 of the largest a-priori bound / actual max |x| over the tensors and the largest "
+                                          "fraction of a tensor's non-zero values below 2^-3 scaled; past 2^15 (or 0.5 of an activation tensor) the model's next steps "
+                                          "run the h2 training kernels")
             out["config"]["optimizer"] = {"mval": "multi_view_active_learning_amd.optim.Adam (torch.optim.Adam subclass, step = one mval_adam_step launch)",
                                           "torch": "torch.optim.Adam (foreach)", "fused": "torch.optim.Adam(fused=True)"}[adam_kind]
         if feed is not None:
@@ -877,7 +982,28 @@ def main():
                              "bf16 split (six MFMA products), fp32 = exact-fp32 MFMA (v_mfma_f32_16x16x4_f32) everywhere")
             out["exact_modes"] = exact
         if not args.no_cpu_baseline and train and world == 1:
-            out["cpu_baseline"] = cpu_baseline_train(wl, sd_np, args.cpu_seconds)
+            cpu = cpu_baseline_train(wl, sd_np, args.cpu_seconds)
+            # the training step's parity sample: the HIP path (a fresh model from the same synthetic weights, train mode) on the oracle's
+            # sample -- loss, heat-maps and three gradients against the CPU oracle's autograd (outside every timed region)
+            chk = cpu.pop("_check")
+            m2, _ = build_model(wl["arch"], j, dev)
+            m2.train()
+            with torch.enable_grad():
+                hm2 = m2(chk["images"].to(dev))
+                l2 = loss_fn.pose_2d_mse(hm2, chk["gt"].to(dev), torch.ones(hm2.shape[0], j, 1, 1, dtype=torch.uint8, device=dev))
+                l2.backward()
+            named = dict(m2.named_parameters())
+            rel = lambda a, b: float(np.linalg.norm(a.astype(np.float64) - b) / (np.linalg.norm(b) + 1e-30))
+            cpu["parity_sample"] = {
+                "images": int(hm2.shape[0]), "loss_hip": float(l2.detach()), "loss_oracle": chk["loss"],
+                "loss_rel_err": abs(float(l2.detach()) - chk["loss"]) / abs(chk["loss"]),
+                "heatmap_max_abs_err": float(np.abs(hm2.detach().cpu().numpy() - chk["heatmaps"]).max()),
+                "grad_rel_l2_err": {k: rel(named[k].grad.cpu().numpy(), g_) for k, g_ in chk["grads"].items()},
+                "note": "one train-mode forward + masked MSE + backward of the same weights on the oracle's sample (batch statistics over these "
+                        "images); torch-CPU fp32 itself sits 1e-3 .. 3e-2 from a float64 run on the early layers' gradients (tests/test_gpu_train.py)",
+            }
+            del m2
+            out["cpu_baseline"] = cpu
         if not args.no_cpu_baseline and not train and world == 1:  # rank 0 at N = 1 only
             cpu = cpu_baseline(wl, sd_np, args.cpu_seconds)
             # BASELINE.json's "MPJPE vs ref": the HIP path on the oracle's first sample (outside every timed region)
@@ -901,9 +1027,13 @@ def main():
             import subprocess
 
             comp = {}
+            _CK = ("kernel", "bound", "achieved", "peak", "unit", "frac", "seconds_in_kernel_per_step", "traffic", "traffic_source", "bytes_per_step",
+                   "flops_per_step", "passes", "bytes_round3_count", "frac_round3_count", "launches_per_step", "avg_launch_us")
             for name, extra in (("c3", ["--steps", "20", "--warmup", "3", "--cpu-seconds", str(min(args.cpu_seconds, 12.0))]),
-                                ("c4", ["--steps", "100", "--warmup", "3", "--no-cpu-baseline"])):
-                cmd = [sys.executable, os.path.abspath(__file__), "--workload", name, "--no-companions", "--no-exact-modes"] + extra
+                                ("c4", ["--steps", "100", "--warmup", "3", "--no-cpu-baseline"]),
+                                # the headline's workload from uint8 crops in pinned host memory (H->D copy + device input pipeline in the step): never `value`
+                                ("c2_with_input", ["--steps", "100", "--warmup", "5", "--no-cpu-baseline", "--with-input", "--no-rooflines"])):
+                cmd = [sys.executable, os.path.abspath(__file__), "--workload", name.split("_")[0], "--no-companions", "--no-exact-modes"] + extra
                 if args.no_cpu_baseline and "--no-cpu-baseline" not in cmd:
                     cmd.append("--no-cpu-baseline")
                 t0 = time.perf_counter()
@@ -919,16 +1049,20 @@ def main():
                                       "steps": d["steps"], "timed_repeats": d["timed_repeats"],
                                       "timed_s": round(d["ms_per_step"] * d["steps"] * d["timed_repeats"] * 1e-3, 2),
                                       "config": d["config"], "dtype": d["dtype"],
-                                      "roofline": {k: roof_c.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "seconds_in_kernel_per_step")},
-                                      "families": [{k: f.get(k) for k in ("kernel", "bound", "achieved", "unit", "frac", "seconds_in_kernel_per_step")}
-                                                   for f in (roof_c.get("other_kernels") or [])[:6]]}
+                                      "roofline": {k: roof_c.get(k) for k in _CK if k in roof_c},
+                                      "families": [{k: f.get(k) for k in _CK if k in f} for f in (roof_c.get("other_kernels") or [])[:6]]}
+                        for k in ("input_inclusive", "p2_bound_slack"):
+                            if k in d:
+                                comp[name][k] = d[k]
                         if "cpu_baseline" in d:
                             comp[name]["cpu_baseline"] = {k: v_ for k, v_ in d["cpu_baseline"].items() if k != "threads_tried_note"}
                 except Exception as e:  # noqa: BLE001
                     comp[name] = {"error": f"{type(e).__name__}: {e}"}
                 comp[name]["wall_s"] = round(time.perf_counter() - t0, 1)
             comp["note"] = ("BASELINE configs[2] (C3 training step) and configs[3]'s per-GPU slice (C4: HRNet-W48, 8 views, 384x288, 8 frames + MPE "
-                            "scoring) run by this command as child processes after the headline: same box, same driver clock")
+                            "scoring) run by this command as child processes after the headline: same box, same driver clock; c2_with_input = the "
+                            "headline's workload with every batch starting from uint8 camera crops in pinned host memory (strategy.py:772-782, "
+                            "dataset/dataset.py:158-220: H->D copy one batch ahead + mval_prepare_views + network + decode + RANSAC-DLT) -- never `value`")
             out["companions"] = comp
     if world > 1 or args.rccl_world_1:
         dist.barrier()

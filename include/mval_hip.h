@@ -500,7 +500,10 @@ typedef struct mval_train_op {
    * res2_amax_off: the magnitude rows ([count, partials]) of its residuals, needed for the P2 scale (0: none / no residual). */
   int32_t fwd_p2;
   int32_t p2_flags; /* bit 0: this op's weight gradient reads its input from the P2 planes (mval_conv_wgrad_p2_covers); bit 1: this op's
-                     * apply writes ONLY the P2 planes (every consumer of its output reads those: no fp32 NHWC copy) */
+                     * apply writes ONLY the P2 planes (every consumer of its output reads those: no fp32 NHWC copy);
+                     * bit 6: this op's BatchNorm backward is round 3's pair (masked copy + in-place dz; reads `out`: not with bits 1 - 3);
+                     * bit 7: this op's batch statistics come from the separate pass over z, not from its conv's epilogue partials
+                     * (bits 6 / 7 are the caller's A/B switches: the library reads no environment variable for them) */
   int64_t in_p2_off, in_p2_rows_off, out_p2_off, out_p2_rows_off, res1_amax_off, res2_amax_off;
   /* p2_flags bit 3: with bit 2 -- the weight gradient reads dz from the planes as well, so the BatchNorm backward writes no fp32 dz.
    * p2_flags bit 2: the op's data gradient runs on the P2 kernels (stride 1): its BatchNorm backward ALSO writes dz as P2 planes into the
@@ -545,6 +548,17 @@ int mval_adam_block_elems(void);
 int mval_adam_step(const mval_adam_job* jobs_dev, const int* first_block_dev, int n_jobs, int total_blocks, float one_minus_beta1,
                    float beta2, float one_minus_beta2, float eps, float weight_decay, float step_size, float bias_correction2_sqrt,
                    void* stream);
+
+/* Bound-slack probe of the P2 training tensors (reference has no counterpart: a guard of this implementation's number format;
+ * /root/reference/strategy.py:460-487 is the step it watches).  mval_p2_plane_stats measures one P2 tensor ([n][plane][C/8][HW][8] fp16 planes,
+ * rows of MVAL_P2_ROW dwords per image) into out4 (device, zeroed by the caller): [0] float bits of 2^-s of image 0, [1] float bits of
+ * max |h + l| in scaled units (the a-priori bound sits in [2^13, 2^14) there), [2] number of non-zero values below 2^-3 scaled (fewer than
+ * 22 significand bits kept), [3] number of non-zero values.  mval_train_p2_probe(dev_out, n_ops): while dev_out != NULL every
+ * mval_train_forward / mval_train_backward call measures the P2 planes it writes -- op i's output planes into dev_out[i][0][4], its dz
+ * planes into dev_out[i][1][4] (i = position in the forward's op list; backward calls on a sub-range pass their base through
+ * mval_train_timing_base) -- NULL / 0 switches it off. */
+int mval_p2_plane_stats(const void* planes, const uint32_t* rows, int n_images, int channels, int hw, uint32_t* out4, void* stream);
+int mval_train_p2_probe(uint32_t* dev_out, int n_ops);
 
 /* Measurement only (bench.py, training workload): with a non-NULL HOST array of 6 floats every later
  * mval_train_forward / mval_train_backward call brackets its launches with hipEvents and ADDS the elapsed

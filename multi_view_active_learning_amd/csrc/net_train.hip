@@ -39,9 +39,11 @@ extern "C" int mval_bn_bwd_fused(const float*, const float*, const float*, const
                                  void*);
 #include <stdlib.h>
 #include <mutex>
-// A/B switches of round 4's BatchNorm restructuring (measurement and the tests' cross-checks; read per call):
-//   MVAL_TRAIN_EPI_STATS=0  batch statistics by the separate pass over z instead of the forward conv's epilogue partials
-//   MVAL_TRAIN_BWD_FUSED=0  round 3's backward pair (masked copy to gz, dz in place) instead of mval_bn_bwd_fused
+// The A/B switches of round 4's BatchNorm restructuring are decided ONCE, by the plan (engine_train.TrainPlan), and travel in
+// mval_train_op.p2_flags: bit 7 = batch statistics by the separate pass over z instead of the forward conv's epilogue partials
+// (MVAL_TRAIN_EPI_STATS=0), bit 6 = round 3's backward pair (masked copy to gz, dz in place) instead of mval_bn_bwd_fused
+// (MVAL_TRAIN_BWD_FUSED=0).  (Round 4 read the environment here on every call as well: a switch flipped between plan build and a later
+// step sent ops whose fp32 output was never written down the path that reads it -- ADVICE round 4.)
 int mval_conv_wgrad_split_streams(const float* x, const float* dz, float* dw, float* ws, int N, int Hin, int Win, int Cin, int Hout,
                                   int Wout, int Cout, int k, int stride, int pad, int x_nchw, const uint32_t* x_amax_row,
                                   const uint32_t* dz_amax_row, hipStream_t s, hipStream_t reduce_stream, hipEvent_t ready,
@@ -142,6 +144,19 @@ extern "C" int mval_train_timing_base(int first_op) {
   return 0;
 }
 
+// ---- bound-slack probe of the P2 training plan (engine_train.TrainPlan: first step of a plan, then every few hundred steps) ----
+// While armed, every P2 tensor a step writes -- an op's output planes after its BatchNorm apply, its dz planes after its BatchNorm
+// backward -- is measured by mval_p2_plane_stats into dev_out[op][0 | 1][4] (dwords, zeroed by the caller; op = position in the list
+// handed to mval_train_forward; backward calls on a sub-range pass their base with mval_train_timing_base).
+extern "C" int mval_p2_plane_stats(const void*, const uint32_t*, int, int, int, uint32_t*, void*);
+static uint32_t* g_probe = nullptr;
+static int g_probe_n = 0;
+extern "C" int mval_train_p2_probe(uint32_t* dev_out, int n_ops) {
+  g_probe = n_ops > 0 ? dev_out : nullptr;
+  g_probe_n = g_probe ? n_ops : 0;
+  return 0;
+}
+
 static void geometry(ConvArgs& a, const mval_op& op, int n_images) {
   a.N = n_images;
   a.Hin = op.hin; a.Win = op.win; a.Cin = op.cin;
@@ -200,11 +215,11 @@ extern "C" int mval_train_forward(const mval_train_op* ops, int n_ops, int n_ima
                                   double* ws, int64_t ws_doubles, float momentum, float eps, void* stream) {
   MVAL_REQUIRE(ops && n_ops > 0 && n_images > 0, "mval_train_forward: bad arguments");
   hipStream_t s = mval_stream(stream);
-  const bool epi_stats = env_on("MVAL_TRAIN_EPI_STATS");
   for (int i = 0; i < n_ops; i++) {
     g_tt_op = i;
     const mval_train_op& t = ops[i];
     const mval_op& op = t.op;
+    const bool epi_stats = !(t.p2_flags & 128);  // (bit 7: batch statistics by the separate pass over z -- the plan's decision, MVAL_TRAIN_EPI_STATS=0)
     ConvArgs a = {};
     geometry(a, op, n_images);
     a.in = op.in_off >= 0 ? arena + op.in_off : input_nchw;
@@ -295,6 +310,9 @@ extern "C" int mval_train_forward(const mval_train_op* ops, int n_ops, int n_ima
                                   t.res2_amax_off > 0 ? reinterpret_cast<const uint32_t*>(arena + t.res2_amax_off) : nullptr,
                                   r1p ? arena + t.res1_p2_off : nullptr, r1p ? reinterpret_cast<const uint32_t*>(arena + t.res1_p2_rows_off) : nullptr,
                                   r2p ? arena + t.res2_p2_off : nullptr, r2p ? reinterpret_cast<const uint32_t*>(arena + t.res2_p2_rows_off) : nullptr, stream);
+        if (!rc && g_probe && i < g_probe_n)
+          rc = mval_p2_plane_stats(arena + t.out_p2_off, reinterpret_cast<const uint32_t*>(arena + t.out_p2_rows_off), n_images, op.cout,
+                                   (op.hout << op.up) * (op.wout << op.up), g_probe + (int64_t)i * 8, stream);
       }
       else
       rc = mval_bn_apply_fwd_mask(a.out, t.mean, t.invstd, t.gamma, t.beta, op.res1_off >= 0 ? arena + op.res1_off : nullptr,
@@ -326,13 +344,14 @@ extern "C" int mval_train_backward(const mval_train_op* ops, int n_ops, int n_im
   MVAL_REQUIRE(ops && n_ops > 0 && n_images > 0 && garena && gz && wsf && ws && sums,
                "mval_train_backward: bad arguments");
   hipStream_t s = mval_stream(stream);
-  const bool bwd_fused = env_on("MVAL_TRAIN_BWD_FUSED");
   WgradSide* side = (env_is("MVAL_TRAIN_WGRAD_SIDE", '1') && !g_tt_out) ? wgrad_side() : nullptr;  // (measurement mode times the reduction in line)
   bool side_pending = false;
   for (int i = n_ops - 1; i >= 0; i--) {
     g_tt_op = g_tt_base + i;
     const mval_train_op& t = ops[i];
     const mval_op& op = t.op;
+    const bool bwd_fused = !(t.p2_flags & 64);  // (bit 6: round 3's backward pair -- the plan's decision, MVAL_TRAIN_BWD_FUSED=0; it reads `out`)
+    MVAL_REQUIRE(bwd_fused || !(t.p2_flags & (2 | 4 | 8)), "mval_train_backward: op %d: the round-3 BatchNorm backward with a P2-only output / P2 dz", i);
     MVAL_REQUIRE(t.gout_off >= 0, "mval_train_backward: op %d has no output gradient slot", i);
     if (op.kind == MVAL_OP_MAXPOOL) {
       if (t.gin_off >= 0) {
@@ -367,6 +386,11 @@ extern "C" int mval_train_backward(const mval_train_op* ops, int n_ops, int n_im
                               op.hout, op.wout, op.cout, op.up, op.relu, t.has_bn, t.first_touch >> 1, gz_row, stream);
     }
     if (rc) return rc;
+    if (dz_p2 && g_probe && g_tt_base + i < g_probe_n) {
+      rc = mval_p2_plane_stats(arena + t.gz_p2_off, reinterpret_cast<const uint32_t*>(arena + t.gz_p2_rows_off), n_images, op.cout,
+                               op.hout * op.wout, g_probe + (int64_t)(g_tt_base + i) * 8 + 4, stream);
+      if (rc) return rc;
+    }
     const float* x = op.in_off >= 0 ? arena + op.in_off : input_nchw;
     if (op.kind == MVAL_OP_DECONV) {
       // ConvTranspose2d(k, s, p): y = scatter of x through W[cin][cout][k][k].  With the roles swapped it

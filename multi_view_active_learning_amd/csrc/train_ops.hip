@@ -1041,6 +1041,50 @@ extern "C" int mval_bn_bwd_fused_p2(const float* gout, const float* out, const u
   return 0;
 }
 
+// ---- measurement of one P2 tensor (the training plan's bound-slack probe, engine_train.TrainPlan.p2_slack; not on the timed path) ----
+// out4 (zeroed by the caller): [0] float bits of 2^-s of image 0, [1] float bits of max |h + l| in SCALED units (the a-priori bound sits in
+// [2^13, 2^14) there), [2] count of non-zero values whose scaled magnitude is below 2^-3 (their l runs into fp16's subnormal spacing: fewer
+// than 22 significand bits survive, conv_p2.h), [3] count of non-zero values.
+__global__ __launch_bounds__(256) void p2_plane_stats_kernel(const _Float16* __restrict__ planes, const unsigned* __restrict__ rows, int N, int C8,
+                                                             int HW, unsigned* __restrict__ out4) {
+  const int64_t per_img = (int64_t)C8 * HW, total = (int64_t)N * per_img;
+  float mx = 0.f;
+  unsigned small = 0, nz = 0;
+  for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < total; g += (int64_t)gridDim.x * 256) {
+    const int64_t n = g / per_img, r = g - n * per_img;
+    const _Float16* hp = planes + (n * 2 * per_img + r) * 8;
+    const p2_f16x8 h = *reinterpret_cast<const p2_f16x8*>(hp), l = *reinterpret_cast<const p2_f16x8*>(hp + per_img * 8);
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const float v = fabsf((float)h[k] + (float)l[k]);
+      mx = fmaxf(mx, v);
+      nz += v > 0.f;
+      small += v > 0.f && v < 0.125f;
+    }
+  }
+  mx = wave_max(mx);
+  for (int o = 32; o > 0; o >>= 1) {
+    small += __shfl_xor(small, o);
+    nz += __shfl_xor(nz, o);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicMax(out4 + 1, __float_as_uint(mx));
+    atomicAdd(out4 + 2, small);
+    atomicAdd(out4 + 3, nz);
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) out4[0] = rows[P2_INV_SLOT];
+}
+extern "C" int mval_p2_plane_stats(const void* planes, const uint32_t* rows, int N, int C, int HW, uint32_t* out4, void* stream) {
+  MVAL_REQUIRE(planes && rows && out4 && N > 0 && C > 0 && (C & 7) == 0 && HW > 0, "mval_p2_plane_stats: bad arguments (C % 8)");
+  MVAL_REQUIRE((int64_t)N * C * HW < ((int64_t)1 << 32), "mval_p2_plane_stats: more than 2^32 elements (the counts are 32-bit)");
+  const int64_t total = (int64_t)N * (C >> 3) * HW;
+  const int nb = (int)std::min<int64_t>(1024, (total + 255) / 256);
+  hipLaunchKernelGGL(p2_plane_stats_kernel, dim3(nb), dim3(256), 0, mval_stream(stream), reinterpret_cast<const _Float16*>(planes), rows, N,
+                     C >> 3, HW, out4);
+  MVAL_CHECK_LAUNCH("mval_p2_plane_stats");
+  return 0;
+}
+
 // ---- max-pool backward (PoseResNet stem, pose_resnet.py:35: MaxPool2d(3, 2, 1)) ----------------
 // gin[n, iy, ix, c] (+)= sum of gout over the output windows whose arg-max is (iy, ix).  Gather form
 // (one thread per input float4, no atomics): each of the <= 4 windows covering the element is

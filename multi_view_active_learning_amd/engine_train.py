@@ -55,10 +55,31 @@ class MvalTrainOp(C.Structure):
     ]
 
 
+# Bound slack of the P2 training plan (ADVICE round 4 / the inference plan's engine.P2_MAX_SLACK_LOG2): the scale of a P2 tensor comes from an
+# a-priori bound -- Samuelson's |bn(z)| <= |gamma| sqrt(M - 1) + |beta| for activations, the same inequality around dgamma / dbeta for dz --
+# and values more than ~2^16 below it lose low-part bits.  The plan measures bound / actual maximum of every P2 tensor on its first step and
+# every SLACK_EVERY steps after (one extra read of the planes, a few ms); past the limit the model's later steps run the h2 training kernels
+# (exact per-tensor maxima) and a warning says so.  MVAL_TRAIN_SLACK_CHECK=0 switches the probe off, MVAL_TRAIN_P2=force ignores its verdict.
+TRAIN_P2_MAX_SLACK_LOG2 = 15.0
+# ... or when more than this fraction of a tensor's non-zero values sits below 2^-3 scaled (fewer than 22 significand bits kept): the
+# maximum alone does not see a tensor whose gammas spread widely -- ONE large channel sets the scale, the small ones lose the bits.  A
+# Gaussian tensor crosses 0.5 at a slack of ~2^14; the BASELINE plan measures < 0.02 (tests/test_gpu_train.py).
+TRAIN_P2_MAX_SMALL_FRAC = 0.5
+SLACK_EVERY = int(os.environ.get("MVAL_TRAIN_SLACK_EVERY", "256"))
+_SWITCHES = ("MVAL_TRAIN_P2", "MVAL_TRAIN_P2_WGRAD", "MVAL_TRAIN_P2_DGRAD", "MVAL_TRAIN_P2_RES", "MVAL_TRAIN_EPI_STATS", "MVAL_TRAIN_BWD_FUSED",
+             "MVAL_TRAIN_RELU_MASK", "MVAL_TRAIN_DGRAD_PARITY")
+
+
+def _switches():
+    """The A/B switches a training plan is built under (part of the plan-cache key: a plan never changes its paths after it is built)."""
+    return tuple(os.environ.get(k, "1") for k in _SWITCHES)
+
+
 class TrainPlan:
-    def __init__(self, model, n, h, w, device):
+    def __init__(self, model, n, h, w, device, p2=True):
         g = model._graph
         self.model, self.graph, self.n, self.device = model, g, n, device
+        self.steps, self.p2_slack, self._probe = 0, None, None
         lib = _lib.lib()
         dims = {g.input: (h, w)}
         geo = []
@@ -221,7 +242,7 @@ class TrainPlan:
         producer = {op.dst: k for k, op in enumerate(g.ops)}
         p2_act = {}
         self.p2_rows = []
-        if h2 and os.environ.get("MVAL_TRAIN_P2", "1") != "0":
+        if h2 and p2 and os.environ.get("MVAL_TRAIN_P2", "1") != "0":
             for i, op in enumerate(g.ops):
                 t = self.ops[i]
                 k = producer.get(op.src)
@@ -318,8 +339,13 @@ class TrainPlan:
                                 and lib.mval_conv_wgrad_split_covers(C.c_int(op.cin), C.c_int(op.cout), C.c_int(op.k), C.c_int(op.stride))
                                 and ((self.ops[i].p2_flags & 1) or self.ops[i].op.in_amax_off > 0)):
                             self.ops[i].p2_flags |= 8
+        # the two BatchNorm A/B switches are the PLAN's decision and travel in p2_flags (bit 6: round 3's backward pair, bit 7: statistics by
+        # the separate pass): net_train.hip does not read the environment
+        bits = (0 if os.environ.get("MVAL_TRAIN_BWD_FUSED", "1") != "0" else 64) | (0 if os.environ.get("MVAL_TRAIN_EPI_STATS", "1") != "0" else 128)
         for i, op in enumerate(g.ops):  # producers leave max |out| where a split conv will look for it
             self.ops[i].out_amax_off = amax_row.get(op.dst, 0)
+            self.ops[i].p2_flags |= bits
+        self.uses_p2 = any(t.out_p2_off > 0 or (t.p2_flags & 4) for t in self.ops)
         # ReLU behind residual adds (BasicBlock / Bottleneck outputs, fuse sums at the conv resolution): the forward apply keeps
         # (out > 0) as one byte per float4, the backward reads that instead of `out` (a sixteenth of the bytes)
         if os.environ.get("MVAL_TRAIN_RELU_MASK", "1") != "0":
@@ -509,8 +535,60 @@ class TrainPlan:
                 t.invstd = sbase + 4 * (self.stat_off[i] + _align(op.cout))
         self.param_sig = sig
 
+    # ---- bound-slack probe ----------------------------------------------------------------------
+    def _probe_due(self):
+        if not self.uses_p2 or os.environ.get("MVAL_TRAIN_SLACK_CHECK", "1") == "0":
+            return False
+        return self.steps == 0 or (SLACK_EVERY > 0 and self.steps % SLACK_EVERY == 0)
+
+    def _probe_arm(self):
+        self._probe = torch.zeros(len(self.ops) * 8, dtype=torch.int32, device=self.device)
+        _lib._check(_lib.lib().mval_train_p2_probe(C.c_void_p(self._probe.data_ptr()), C.c_int(len(self.ops))), "mval_train_p2_probe")
+
+    def _probe_read(self):
+        """Disarm and turn the measured rows into ``self.p2_slack``: per kind ("act" = output planes of the BatchNorm applies, "dz" = the
+        BatchNorm backward's planes) log2 of the largest bound / actual maximum over the plan's tensors, the op it belongs to, and the
+        largest fraction of a tensor's non-zero values that sit below 2^-3 scaled (fewer than 22 bits kept)."""
+        import numpy as np
+
+        _lib._check(_lib.lib().mval_train_p2_probe(C.c_void_p(0), C.c_int(0)), "mval_train_p2_probe")
+        raw = self._probe.cpu().numpy().reshape(len(self.ops), 2, 4)
+        self._probe = None
+        res = {"step": self.steps}
+        for kind, col in (("act", 0), ("dz", 1)):
+            r = raw[:, col]
+            mx, small, nz = r[:, 1].view(np.float32).astype(np.float64), r[:, 2].view(np.uint32).astype(np.float64), r[:, 3].view(np.uint32).astype(np.float64)
+            ok = (nz > 0) & np.isfinite(mx) & (mx > 0)
+            if not ok.any():
+                res[kind] = None
+                continue
+            slack = np.where(ok, np.log2(8192.0 / np.where(ok, mx, 1.0)), -np.inf)  # the bound sits in [2^13, 2^14) of the scaled range
+            frac = np.where(ok, small / np.maximum(nz, 1.0), 0.0)
+            k = int(np.argmax(slack))
+            res[kind] = {"tensors": int(ok.sum()), "max_log2": round(float(slack[k]), 2), "max_at": self.graph.ops[k].conv,
+                         "median_log2": round(float(np.median(slack[ok])), 2), "max_small_frac": round(float(frac.max()), 5),
+                         "max_small_frac_at": self.graph.ops[int(np.argmax(frac))].conv}
+        self.p2_slack = res
+        worst = max((res[k]["max_log2"] for k in ("act", "dz") if res[k]), default=0.0)
+        # (activations only: a dz tensor is mostly tiny values by construction -- the mean terms at masked positions -- whose ABSOLUTE error,
+        # <= 2^-25 scaled, is what enters the gradient sums; its fraction is reported, not judged)
+        small = res["act"]["max_small_frac"] if res["act"] else 0.0
+        if (worst > TRAIN_P2_MAX_SLACK_LOG2 or small > TRAIN_P2_MAX_SMALL_FRAC) and os.environ.get("MVAL_TRAIN_P2", "1") != "force":
+            import warnings
+
+            warnings.warn(f"P2 training plan: a-priori bound 2^{worst:.1f} above a tensor's maximum (limit 2^{TRAIN_P2_MAX_SLACK_LOG2:.0f}), {small:.2f} of a "
+                          f"tensor's non-zero values below 2^-3 scaled (limit {TRAIN_P2_MAX_SMALL_FRAC}): {res}; "
+                          "the next steps of this model run the h2 training kernels (scales from exact maxima).  MVAL_TRAIN_P2=force keeps P2, "
+                          "MVAL_TRAIN_SLACK_CHECK=0 skips the probe.", RuntimeWarning, stacklevel=2)
+            self.model.__dict__["_train_p2_off"] = True
+
     def forward(self, x):
         self._refresh()
+        if self._probe is not None:  # (an armed step whose backward never ran)
+            _lib._check(_lib.lib().mval_train_p2_probe(C.c_void_p(0), C.c_int(0)), "mval_train_p2_probe")
+            self._probe = None
+        if self._probe_due():
+            self._probe_arm()
         # the arena, z buffers and batch statistics of THIS forward are what backward reads: a second train-mode
         # forward of the same plan overwrites them, so backward checks that it pairs with the latest forward
         self.generation = getattr(self, "generation", 0) + 1
@@ -580,6 +658,10 @@ class TrainPlan:
             if op.bn:
                 out.append(grads[slots["g"] : slots["g"] + op.cout])
                 out.append(grads[slots["be"] : slots["be"] + op.cout])
+        if k == 0:  # the step's last segment
+            if self._probe is not None:
+                self._probe_read()
+            self.steps += 1
         return out
 
 
@@ -626,11 +708,12 @@ class _SegFn(torch.autograd.Function):
 def run_network_train(model, x):
     n, c, h, w = x.shape
     cache = model.__dict__.setdefault("_train_plans", {})
-    key = (n, h, w, x.device.index, _conv_mode())  # (the mode selects the plan's kernels and packings)
+    p2 = not model.__dict__.get("_train_p2_off", False)  # (the slack probe's verdict on this model's parameters, TrainPlan._probe_read)
+    key = (n, h, w, x.device.index, _conv_mode(), p2) + _switches()  # (the mode and the switches select the plan's kernels and packings)
     plan = cache.get(key)
     if plan is None:
         cache.clear()  # one training geometry at a time: the arenas are large
-        plan = cache[key] = TrainPlan(model, n, h, w, x.device)
+        plan = cache[key] = TrainPlan(model, n, h, w, x.device, p2=p2)
     carry = x
     for k in range(len(plan.segments)):
         carry = _SegFn.apply(carry, plan, k, *plan.seg_params[k])

@@ -84,9 +84,14 @@ class Adam(torch.optim.Adam):
     def _table(self, gi, ps):
         """(jobs, first_block, n_jobs, total_blocks, step count) of group gi: rebuilt when a pointer moved."""
         states = [self.state[p] for p in ps]
-        key = tuple(p.data_ptr() for p in ps) + tuple(p.grad.data_ptr() for p in ps) + tuple(s["exp_avg"].data_ptr() for s in states)
+        key = (tuple(p.data_ptr() for p in ps) + tuple(p.grad.data_ptr() for p in ps) + tuple(s["exp_avg"].data_ptr() for s in states)
+               + tuple(s["exp_avg_sq"].data_ptr() for s in states))
         c = self._mval_cache.get(gi)
-        if c is not None and c["key"] == key:
+        # (the cached step count is re-validated against the state every step: a caller that reset or edited state[p]["step"], or
+        # swapped a moment tensor, without load_state_dict gets a rebuilt table, not a stale pointer / bias correction -- ADVICE round 4;
+        # the steps are host scalars, so reading two of them costs no synchronisation)
+        if (c is not None and c["key"] == key and all(a is b for a, b in zip(c["steps"], (s["step"] for s in states)))
+                and float(states[0]["step"]) == c["t"] and float(states[-1]["step"]) == c["t"]):
             return c
         for s in states:
             if (s["exp_avg"].dtype != torch.float32 or not s["exp_avg"].is_contiguous() or not s["exp_avg_sq"].is_contiguous()
@@ -147,20 +152,21 @@ class Adam(torch.optim.Adam):
             tables.append(c)
         lib = _lib.lib()
         for (gi, group, ps), c in zip(work, tables):
-            torch._foreach_add_(c["steps"], 1)
-            c["t"] += 1
-            t = c["t"]
-            beta1, beta2 = group["betas"]
-            bias_correction1 = 1 - beta1**t
-            bias_correction2 = 1 - beta2**t
-            step_size = group["lr"] / bias_correction1
-            _lib._check(
-                lib.mval_adam_step(C.c_void_p(c["jobs"].data_ptr()), C.c_void_p(c["first"].data_ptr()), C.c_int(c["n"]), C.c_int(c["blocks"]),
-                                   C.c_float(1 - beta1), C.c_float(beta2), C.c_float(1 - beta2), C.c_float(group["eps"]),
-                                   C.c_float(group["weight_decay"]), C.c_float(step_size), C.c_float(bias_correction2**0.5), _lib._stream()),
-                "mval_adam_step")
-            # the kernel wrote the parameters and moments through raw pointers: tell autograd (saved-tensor checks) and everything keyed on
-            # a parameter's version -- the inference / training plans re-pack their weights when it changes -- that they were modified
-            torch.autograd.graph.increment_version(ps)
-            torch.autograd.graph.increment_version([t for st in (self.state[p] for p in ps) for t in (st["exp_avg"], st["exp_avg_sq"])])
+            with torch.cuda.device(ps[0].device):  # (the launch goes to the CURRENT device's stream: make that the parameters' device)
+                torch._foreach_add_(c["steps"], 1)
+                c["t"] += 1
+                t = c["t"]
+                beta1, beta2 = group["betas"]
+                bias_correction1 = 1 - beta1**t
+                bias_correction2 = 1 - beta2**t
+                step_size = group["lr"] / bias_correction1
+                _lib._check(
+                    lib.mval_adam_step(C.c_void_p(c["jobs"].data_ptr()), C.c_void_p(c["first"].data_ptr()), C.c_int(c["n"]), C.c_int(c["blocks"]),
+                                       C.c_float(1 - beta1), C.c_float(beta2), C.c_float(1 - beta2), C.c_float(group["eps"]),
+                                       C.c_float(group["weight_decay"]), C.c_float(step_size), C.c_float(bias_correction2**0.5), _lib._stream()),
+                    "mval_adam_step")
+                # the kernel wrote the parameters and moments through raw pointers: tell autograd (saved-tensor checks) and everything keyed on
+                # a parameter's version -- the inference / training plans re-pack their weights when it changes -- that they were modified
+                torch.autograd.graph.increment_version(ps)
+                torch.autograd.graph.increment_version([t for st in (self.state[p] for p in ps) for t in (st["exp_avg"], st["exp_avg_sq"])])
         return loss

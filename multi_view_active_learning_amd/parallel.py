@@ -24,8 +24,9 @@ _POST_STREAMS = {}
 
 
 class PostStream:
-    """``with post.batch(heatmaps): table = score(...)`` per batch, ``post.join()`` before the results are read on the
-    caller's stream.  A no-op for host tensors and with MVAL_POST_OVERLAP=0."""
+    """``with post.batch(heatmaps, keys, dp): table = score(...)`` per batch -- pass EVERY device tensor the body reads (a dict
+    counts with its values) --, ``post.join()`` before the results are read on the caller's stream.  A no-op for host tensors
+    and with MVAL_POST_OVERLAP=0."""
 
     def __init__(self, enabled=None):
         import os
@@ -35,7 +36,13 @@ class PostStream:
 
     class _Ctx:
         def __init__(self, outer, inputs):
-            self.outer, self.inputs, self.cm = outer, inputs, None
+            # every device tensor the body reads that was produced on the caller's stream: dicts (a batch ``dp``) count with their values.
+            # Each is record_stream()ed, so rebinding it on the next loop iteration cannot hand its block back to the caller's stream
+            # while the side stream still reads it (a device-resident loader / collate)
+            flat = []
+            for t in inputs:
+                flat.extend(t.values() if isinstance(t, dict) else (t,))
+            self.outer, self.inputs, self.cm = outer, flat, None
 
         def __enter__(self):
             o = self.outer

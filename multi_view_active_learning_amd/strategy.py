@@ -96,6 +96,30 @@ def tables_to_sal_dict(per_rank, batch_sizes, sal_dict=None):
     return sal_dict
 
 
+_SMALL_KEYS = ("proj_matrices", "joint_valid", "3d_keypoints", "pose", "frame_id")
+
+
+def _stage_batch(dp):
+    """The batch's SMALL tensors (cameras, validity, ground truth, ids) as device tensors, uploaded on the caller's stream BEFORE the
+    network is launched, through pinned staging (torch's caching host allocator) with non_blocking copies.  Why: score_batch /
+    evaluate_mkpe run inside the side-stream context (parallel.PostStream), and a pageable host -> device copy issued there blocks the
+    host until the side stream -- which has just waited for this batch's network -- drains, so the NEXT batch's network could not be
+    enqueued meanwhile.  Returns a shallow copy of ``dp``; host-only runs (no HIP device) get ``dp`` back."""
+    if not torch.cuda.is_available() or not isinstance(dp, dict):
+        return dp
+    dev = torch.device("cuda", torch.cuda.current_device())
+    out = dict(dp)
+    for k in _SMALL_KEYS:
+        if k not in dp:
+            continue
+        t = torch.as_tensor(dp[k])
+        if not t.is_cuda:
+            t = t.contiguous()
+            t = (t if t.is_pinned() else t.pin_memory()).to(dev, non_blocking=True)
+        out[k] = t
+    return out
+
+
 class ActiveLearningStrategy:
     def __init__(self, al_cfg):
         self.al_cfg = al_cfg
@@ -234,8 +258,9 @@ class ActiveLearningStrategy:
         post = PostStream()  # a batch's decode / scoring / triangulation runs beside the next batch's network
         with torch.no_grad():
             for dp in data_loader:
+                dp = _stage_batch(dp)  # (small tensors to the device before the network launch: no host-blocking copy on the side stream)
                 heatmaps = self._compute_batch_heatmap(pose_estimator, dp)
-                with post.batch(heatmaps, _lib.argmax_keys_of(heatmaps) if torch.is_tensor(heatmaps) and heatmaps.is_cuda else None):
+                with post.batch(heatmaps, _lib.argmax_keys_of(heatmaps) if torch.is_tensor(heatmaps) and heatmaps.is_cuda else None, dp):
                     t = self.score_batch(heatmaps, dp)
                 tables.append(t)
                 sizes.append(t.shape[0])
@@ -338,11 +363,12 @@ class ActiveLearningStrategy:
         post = PostStream()  # (decode + triangulation of a batch beside the next batch's network)
         with torch.no_grad():
             for dp in data_loader:
+                dp = _stage_batch(dp)
                 hm = self._compute_batch_heatmap(pose_estimator, dp)
                 b = torch.as_tensor(dp["pose"]).reshape(-1).shape[0] if "pose" in dp else dp["images"].shape[0]
                 _, j, hh, wh = hm.shape
                 jv = torch.as_tensor(dp["joint_valid"]).reshape(b, j)
-                with post.batch(hm, _lib.argmax_keys_of(hm) if hm.is_cuda else None):
+                with post.batch(hm, _lib.argmax_keys_of(hm) if hm.is_cuda else None, dp, jv):
                     r = triangulation.triangulate_batch(hm.reshape(b, -1, j, hh, wh), dp["proj_matrices"],
                                                         self.al_cfg.POSE_ESTIMATOR.STRIDE, jv)
                     preds.append(r["keypoints_3d"].to(torch.float32))

@@ -517,6 +517,16 @@ def test_decode_from_epilogue_large_maps_fold_with_atomics(dev, mode, monkeypatc
     assert np.array_equal(got[0].cpu().numpy(), np.stack([(idx % hh) * 4, (idx // hh) * 4], axis=-1))
 
 
+def _report(name, obj):
+    """Counts the review wants reproducible: written under gpurun_out/ (merged back from the GPU box), copied into profiles/rNN/."""
+    import json
+
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(d, exist_ok=True)
+    with open(os.path.join(d, name), "w") as f:
+        json.dump(obj, f, indent=1)
+
+
 def test_w48_argmax_census_headline_plan_vs_exact_fp32(dev, monkeypatch):
     """BASELINE configs[3] / [4] decode parity: HRNet-W48 at 384 x 288, 64 frames x 8 views (9 728 heat-maps), the plan the
     pool passes run (MVAL_CONV default: since round 4 the P2 plan -- full-width odd tiles on its 24 x 18 / 12 x 9 maps, fused
@@ -555,4 +565,7 @@ def test_w48_argmax_census_headline_plan_vs_exact_fp32(dev, monkeypatch):
                 assert err <= tol, (mode, err, tol)
     print(f"\nW48 arg-max census, {headline} (default) and h2 plans vs exact-fp32: {maps} maps, {flips} flips ({flips_above} above margin 2*tol), "
           f"max |heat-map difference| {worst_err:.2e}")
+    _report("census_w48_p2_h2_vs_fp32.json", dict(maps=maps, flips=flips, flips_above_margin=flips_above, max_abs_heatmap_difference=worst_err,
+                                                  plans=[headline, "h2"], frames=frames, views=v))
     assert maps == 2 * 64 * 8 * 19 and flips_above == 0
+    assert flips == 0  # (pinned: DESIGN 7.0's "0 flips" is this count)

@@ -3,7 +3,10 @@
 of the conv kernels from the FETCH_SIZE / WRITE_SIZE passes (separate --pmc runs, as the
 MI355X guide prescribes; gfx950 correction: FETCH_SIZE x2 for wide coalesced reads; unit KB).
 
-usage: pmc_summary.py <kernel_stats.csv> <fetch counter_collection.csv> <write counter_collection.csv> [sq counter_collection.csv]
+usage: pmc_summary.py [--all] <kernel_stats.csv> <fetch counter_collection.csv> <write counter_collection.csv> [sq counter_collection.csv]
+
+--all: the per-instantiation tables cover EVERY kernel that holds at least 0.3 % of the traced time (the training step's BatchNorm /
+weight-gradient / optimizer kernels, the scoring kernels), not only the conv kernels.
 
 The optional fourth file is an SQ pass (GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY
 SQ_WAIT_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU / _LDS): per conv instantiation, matrix-core busy cycles
@@ -42,17 +45,27 @@ def agg(path, counter, key=fam):
     return d
 
 
-stats, fetch, write = sys.argv[1:4]
-sq = sys.argv[4] if len(sys.argv) > 4 else None
+argv = [a for a in sys.argv[1:] if a != "--all"]
+ALL = "--all" in sys.argv[1:]
+stats, fetch, write = argv[0:3]
+sq = argv[3] if len(argv) > 3 else None
 rows = list(csv.DictReader(open(stats)))
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
+big = {inst(r["Name"]) for r in rows if float(r["TotalDurationNs"]) >= 0.003 * tot}
+
+
+def wanted(n):
+    return "conv_" in n or (ALL and n in big)
+
+
 k = {}
 for r in rows:
     a = k.setdefault(fam(r["Name"]), [0, 0.0])
     a[0] += int(r["Calls"])
     a[1] += float(r["TotalDurationNs"])
 out = {"kernel_stats": [dict(kernel=n, calls=c, avg_us=round(t / c / 1e3, 2), total_ms=round(t / 1e6, 3),
-                             pct=round(100 * t / tot, 2)) for n, (c, t) in sorted(k.items(), key=lambda kv: -kv[1][1])[:10]]}
+                             pct=round(100 * t / tot, 2)) for n, (c, t) in sorted(k.items(), key=lambda kv: -kv[1][1])[:24 if ALL else 10]]}
+out["traced_kernel_ms_total"] = round(tot / 1e6, 3)
 f, w = agg(fetch, "FETCH_SIZE"), agg(write, "WRITE_SIZE")
 out["hbm_traffic_per_launch"] = []
 for n in ("conv_p2_kernel", "conv_block_p2_kernel", "conv_bneck_p2_kernel", "conv_stem_p2_kernel", "conv_fuse_up_p2_kernel", "conv_split_kernel", "conv_block_kernel", "conv_bf3_kernel", "conv_mfma_kernel", "conv_stem_kernel"):
@@ -66,9 +79,12 @@ for n in ("conv_p2_kernel", "conv_block_p2_kernel", "conv_bneck_p2_kernel", "con
                                                   GBps=round((rd + wr) / (tf / nf), 1)))
 # the same per template instantiation of the conv kernels (bench.py picks the 3x3 stride-1 ones)
 fi, wi = agg(fetch, "FETCH_SIZE", inst), agg(write, "WRITE_SIZE", inst)
+out["launch_counts"] = {n.split("<")[0]: 0 for n in fi}  # launches per kernel (template arguments folded) in the FETCH_SIZE pass
+for n in fi:
+    out["launch_counts"][n.split("<")[0]] += fi[n][0]
 out["hbm_traffic_by_instantiation"] = []
 for n in sorted(fi, key=lambda n: -fi[n][2]):
-    if "conv_" not in n or n not in wi:
+    if not wanted(n) or n not in wi:
         continue
     nf, fs, tf = fi[n]
     nw, ws, _ = wi[n]
@@ -82,7 +98,7 @@ if sq:
     cnt = collections.Counter()
     for r in csv.DictReader(open(sq)):
         k_ = inst(r["Kernel_Name"])
-        if "conv_" not in k_:
+        if not wanted(k_):
             continue
         per[k_][r["Counter_Name"]] += float(r["Counter_Value"])
         if r["Counter_Name"] == "GRBM_GUI_ACTIVE":
