@@ -449,6 +449,8 @@ def main():
     ap.add_argument("--no-overlap", action="store_true",
                     help="run a batch's decode / scoring / triangulation on the network's stream instead of the side stream "
                          "(parallel.PostStream: by default it overlaps the next batch's network)")
+    ap.add_argument("--adam", default="mval", choices=("mval", "torch", "fused"),
+                    help="c3: the optimizer -- optim.Adam (one launch, default), torch.optim.Adam (foreach) or torch.optim.Adam(fused=True)")
     ap.add_argument("--no-rooflines", action="store_true",
                     help="profiling passes (tools/collect_profiles.sh): skip the per-kernel measurement runs after the timed region, so that a "
                          "rocprofv3 trace of this command holds the workload's steps only")
@@ -527,10 +529,10 @@ def main():
         if world > 1 or args.rccl_world_1:
             net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], broadcast_buffers=True)
         # strategy.py:405-407 builds torch.optim.Adam([{"params": ..., "lr": LR}]): optim.Adam is that class with its step() as ONE launch
-        # (csrc/optim.hip).  MVAL_BENCH_ADAM=torch / fused: torch's default (foreach) / fused implementation of the same update.
+        # (csrc/optim.hip).  --adam torch / fused: torch's default (foreach) / fused implementation of the same update.
         from multi_view_active_learning_amd.optim import Adam as MvalAdam
 
-        adam_kind = os.environ.get("MVAL_BENCH_ADAM", "mval")
+        adam_kind = args.adam
         if adam_kind == "mval":
             opt = MvalAdam([{"params": model.parameters(), "lr": 1e-3}])
         else:
@@ -932,7 +934,7 @@ def main():
         if train:
             tp = next(iter(model._train_plans.values()), None)
             out["p2_bound_slack"] = None if tp is None else tp.p2_slack
-            out["p2_bound_slack_note"] = ("training plan's probe (engine_train.TrainPlan: first step of the plan, then every 256): per kind (act = P2 activation planes, "
+            out["p2_bound_slack_note"] = ("training plan's probe (engine_train.TrainPlan: first step of the plan, then every 1 024): per kind (act = P2 activation planes, "
                                           "dz = the BatchNorm backward's P2 planes) log2 of the largest a-priori bound / actual max |x| over the tensors and the largest "
                                           "fraction of a tensor's non-zero values below 2^-3 scaled; past 2^15 (or 0.5 of an activation tensor) the model's next steps "
                                           "run the h2 training kernels")

@@ -251,11 +251,7 @@ typedef struct mval_op {
    * t_in_amax_off[j], 1x1 weights packed MVAL_PACK_MFMA16_H2 at t_w_off[j], folded BN at t_scale_off[j] / t_shift_off[j], bound
    * [A, B] at t_bound_off[j]; relu: the activation of the sum. */
   int32_t n_terms, t_cin[3], t_up[3];
-  /* multi_n >= 2 (MVAL_ALGO_MFMA_P2 convs, k 3 stride 2, same input, no upsample): this op and the multi_n - 1 ops that FOLLOW it in
-   * the op array are launched together by this op's launch (csrc/conv_p2.hip conv_p2_multi_kernel: the first-level stride-2 convs
-   * of a fuse layer, hrnet.py:398-423, read their common input once); the followers carry multi_n = -1 and their own launch is a
-   * no-op.  0: an op on its own.  (mval_op_launch on a group head therefore reads multi_n consecutive mval_op.) */
-  int32_t multi_n;
+  int32_t reserved0; /* (round 4's multi-conv launch marker; must be 0) */
   int64_t t_in_off[3], t_in_amax_off[3], t_w_off[3], t_scale_off[3], t_shift_off[3], t_bound_off[3];
 } mval_op;
 

@@ -16,7 +16,8 @@ import weakref
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libmval_hip.so")
+# (MVAL_LIB_TAG=<tag>: a variant library built by `MVAL_BUILD_TAG=<tag> MVAL_EXTRA_CFLAGS=... python -m ...build` -- measurement A/B only)
+LIB_PATH = os.path.join(_HERE, "csrc", "libmval_hip" + ("_" + os.environ["MVAL_LIB_TAG"] if os.environ.get("MVAL_LIB_TAG") else "") + ".so")
 
 _lock = threading.Lock()
 _lib = None

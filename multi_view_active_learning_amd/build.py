@@ -14,8 +14,11 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-OBJ = os.path.join(CSRC, "_obj")
-LIB = os.path.join(CSRC, "libmval_hip.so")
+# MVAL_BUILD_TAG=<tag> (measurement): a VARIANT library csrc/libmval_hip_<tag>.so with its own object cache, built with MVAL_EXTRA_CFLAGS
+# beside the product library; _lib.py loads it when MVAL_LIB_TAG=<tag> is set (tools/ A/B runs: several variants travel to one GPU call)
+TAG = os.environ.get("MVAL_BUILD_TAG", "")
+OBJ = os.path.join(CSRC, "_obj" + ("_" + TAG if TAG else ""))
+LIB = os.path.join(CSRC, "libmval_hip" + ("_" + TAG if TAG else "") + ".so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
          "-I", os.path.join(os.path.dirname(HERE), "include")] + os.environ.get("MVAL_EXTRA_CFLAGS", "").split()

@@ -440,8 +440,10 @@ static int launch_block_p2(P2BlockArgs a, hipStream_t s) {
 #endif
   static std::atomic<int> occ{0};
   int per_cu = p2_resident_wgs(&conv_block_p2_kernel<C>, occ, smem, 4);
+#ifdef P2_TUNE  // (measurement builds only: workgroups per CU)
   const char* pe = getenv("MVAL_P2_WGS");
   if (pe && atoi(pe) > 0) per_cu = atoi(pe);
+#endif
   int wgs = mval_cu_count() * per_cu;
   if (wgs >= a.tiles_total) wgs = a.tiles_total;
   else {
@@ -449,7 +451,6 @@ static int launch_block_p2(P2BlockArgs a, hipStream_t s) {
     wgs = 8 * ((per + rounds - 1) / rounds);
   }
   a.wgs_x = wgs;
-  if (getenv("MVAL_P2_DEBUG")) fprintf(stderr, "block_p2<%d> N %d %dx%d tiles %d per_cu %d wgs %d smem %zu\n", C, a.N, a.H, a.W, a.tiles_total, per_cu, wgs, smem);
   if (tiles_img > P2_SLOTS) mval_launch_zero_rows(a.out_row, (int64_t)a.N * P2_ROW, s);
   hipLaunchKernelGGL((conv_block_p2_kernel<C>), dim3((unsigned)wgs), dim3(256), smem, s, a);
   return 0;

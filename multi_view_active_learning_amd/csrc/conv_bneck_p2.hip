@@ -163,7 +163,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
   const unsigned hw16 = (unsigned)(a.H * a.W) * 16u;
   const unsigned in_img = 2u * C8I * hw16, out_img = 2u * C8O * hw16, out_plane = C8O * hw16;
   const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(a.in), 0, (unsigned)a.N * in_img, 0x00020000);
+#ifdef BNECK_NO_RES  // measurement build only (tools/run: what the residual re-read costs): an empty range -- every residual load returns 0 without a memory access
+  const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(a.res), 0, 0u, 0x00020000);
+#else
   const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(a.res), 0, (unsigned)a.N * out_img, 0x00020000);
+#endif
   const __amdgpu_buffer_rsrc_t orr = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (unsigned)a.N * out_img, 0x00020000);
   // ONE descriptor over the parameter buffer: weights, BN vectors and bounds are byte offsets into it
   const __amdgpu_buffer_rsrc_t pr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.params), 0, 0x7fffffff, 0x00020000);
@@ -531,8 +535,10 @@ static int launch_bneck_p2(P2BneckArgs a, hipStream_t s) {
 #endif
   static std::atomic<int> occ{0};
   int per_cu = p2_resident_wgs(&conv_bneck_p2_kernel<CIN>, occ, smem, 4);
+#ifdef P2_TUNE  // (measurement builds only: workgroups per CU)
   const char* pe = getenv("MVAL_P2_WGS");
   if (pe && atoi(pe) > 0) per_cu = atoi(pe);
+#endif
   int wgs = mval_cu_count() * per_cu;
   if (wgs >= a.tiles_total) wgs = a.tiles_total;
   else {
@@ -540,7 +546,6 @@ static int launch_bneck_p2(P2BneckArgs a, hipStream_t s) {
     wgs = 8 * ((per + rounds - 1) / rounds);
   }
   a.wgs_x = wgs;
-  if (getenv("MVAL_P2_DEBUG")) fprintf(stderr, "bneck_p2<%d> N %d %dx%d tiles %d per_cu %d wgs %d smem %zu\n", CIN, a.N, a.H, a.W, a.tiles_total, per_cu, wgs, smem);
   if (tiles_img > P2_SLOTS) mval_launch_zero_rows(a.out_row, (int64_t)a.N * P2_ROW, s);
   hipLaunchKernelGGL((conv_bneck_p2_kernel<CIN>), dim3((unsigned)wgs), dim3(256), smem, s, a);
   return 0;

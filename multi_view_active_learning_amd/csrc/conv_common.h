@@ -384,7 +384,6 @@ int mval_pack_h2(int mode, const float* w, float* packed, int cout, int cin, int
 struct MvalLanes {
   hipStream_t side[MVAL_MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t fork_ev = nullptr;
-  hipEvent_t group_ev = nullptr;  // a multi-conv launch on one lane is done (its followers' lanes wait for it)
   hipEvent_t join_ev[MVAL_MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};
   bool ready = false;
 };
@@ -427,13 +426,6 @@ struct MvalLaneWalk {
       used[lane] = true;
     }
     return L->side[lane];
-  }
-  // a multi-conv group (mval_op.multi_n): its head was launched on stream s / a follower's lane may go on once that launch is done
-  void group_launched(hipStream_t s) {
-    if (L) (void)hipEventRecord(L->group_ev, s);
-  }
-  void wait_for_group(hipStream_t s) {
-    if (L) (void)hipStreamWaitEvent(s, L->group_ev, 0);
   }
   void finish() {
     if (L) join();

@@ -187,8 +187,6 @@ struct P2Args {
 };
 
 int mval_launch_conv_p2(const P2Args& a, hipStream_t s);  // conv_p2.hip; 1 = unsupported (dry != 0: no launch)
-// 2 or 3 stride-2 3x3 convs over ONE input in one launch (conv_p2.hip: conv_p2_multi_kernel); 1 = not covered
-int mval_launch_conv_p2_multi(const P2Args* segs, int nseg, hipStream_t s);
 int mval_launch_nhwc_to_p2(const float* x, const unsigned* rows_in, _Float16* planes, unsigned* rows, int n_images, int HW, int C,
                             hipStream_t s);
 int mval_conv_p2_supported(int k, int stride, int cin, int cout, int hin, int win, int up, int out_nchw, int n);
@@ -219,7 +217,3 @@ int mval_launch_conv_fuse_up_p2(int cout, int n_terms, int relu, const void* res
                                 const void* const* in, const unsigned* const* in_row, const int* cin, const int* up, const int64_t* w,
                                 const int64_t* w_unscale, const int64_t* scale, const int64_t* shift, const int64_t* bound, int N, int H, int W,
                                 hipStream_t s);
-// conv_p2w.hip: the 3x3 stride-1 conv on v_mfma_f32_32x32x16_f16 (maps at least 32 wide, cout a multiple of 32 and >= 64, at most one
-// residual); 1 = unsupported
-int mval_conv_p2w_supported(const P2Args& a);
-int mval_launch_conv_p2w(const P2Args& a, hipStream_t s);

@@ -109,13 +109,11 @@ __device__ __forceinline__ f32x4 p2_mfma(const u32x4 a, const u32x4 b, const f32
 // channels of column tap 1 (the lanes of the upper octets read their patch fragment one pixel to the right and their weight fragment from
 // the next tap's block: per-lane address constants, the packed weights and the LDS image are unchanged), then column tap 2 as before --
 // 15 instead of 18 MFMA column steps per tile.
-// The kernel body: `by` / `gy` = the workgroup's cout group and the number of cout groups of ITS conv (blockIdx.y / gridDim.y for a
-// single conv; conv_p2_multi_kernel below runs several convs over one input in one launch, a range of blockIdx.y each).
-// MULTI (conv_p2_multi_kernel): `a` is the conv of THIS WAVE (a workgroup's four cout waves may belong to different convs over the
-// same input), by = the wave's 16-cout sub-tile inside its conv, gy = that conv's number of sub-tiles (0: the wave has no couts).
-template <int KS, int S, int G, int WN, int WM, int NT, int MS, int TW, bool RS, int EPI, int OW = 0, bool K48 = false, bool MULTI = false>
+// The kernel body: `by` / `gy` = the workgroup's cout group and the number of cout groups (blockIdx.y / gridDim.y).  (Round 4 also ran the
+// two or three first-level stride-2 convs of a fuse layer as ONE launch through this body -- 112 us of launches less per forward back to
+// back, but slower as a step under the multi-stream forward, C2 10.17 vs 10.10 ms: removed in round 5)
+template <int KS, int S, int G, int WN, int WM, int NT, int MS, int TW, bool RS, int EPI, int OW = 0, bool K48 = false>
 __device__ __forceinline__ void conv_p2_body(const P2Args& a, const int by, const int gy) {
-  static_assert(!MULTI || (WM == 1 && NT == 1 && EPI == 0), "multi-conv launches: one cout sub-tile per wave, P2 planes out");
   static_assert(!K48 || (RS && G == 1), "K48: the row-sharing 3x3 kernels");
   constexpr int NTH = 64 * WN * WM, TAPS = KS * KS, SPN = 8 * G, SPN_LOG2 = G == 1 ? 3 : G == 2 ? 4 : 5;
   constexpr int pad = KS / 2;
@@ -138,8 +136,8 @@ __device__ __forceinline__ void conv_p2_body(const P2Args& a, const int by, cons
   constexpr int NE = (PH * SPN * PW + NTH - 1) / NTH;  // staged granules per thread
   static_assert(PH * SPN * PW < 4096 && PH < 32 && PW < 127, "staging plan packing");
   unsigned* wgred = reinterpret_cast<unsigned*>(smem + 2 * buf_bytes);  // [max |x| of the tile, waves that added]
-  const int ns0 = MULTI ? by : (by * WN + wn) * NT;
-  const bool wave_active = MULTI ? gy > 0 : ns0 < a.NS_total;
+  const int ns0 = (by * WN + wn) * NT;
+  const bool wave_active = ns0 < a.NS_total;
 
   // ---- tile walk: workgroup b of this cout group -> XCD group b % X, contiguous tile range per XCD group ----------
   const int X = a.wgs_x >= 8 ? 8 : 1;
@@ -540,7 +538,7 @@ __device__ __forceinline__ void conv_p2_body(const P2Args& a, const int by, cons
           r2_inv = __uint_as_float(row_r2.inv);
         }
         p2_scale_of(bound, out_mul, out_inv);
-        if (oy0 == 0 && ox0 == 0 && by == 0 && (MULTI ? lane == 0 : tid == 0))
+        if (oy0 == 0 && ox0 == 0 && by == 0 && tid == 0)
           a.out_row[(int64_t)n * P2_ROW + P2_INV_SLOT] = __float_as_uint(out_inv);
       }
       const float unscale = in_inv * w_unscale;
@@ -722,12 +720,6 @@ __device__ __forceinline__ void conv_p2_body(const P2Args& a, const int by, cons
     if constexpr (EPI < 2) {
       // the workgroup's max |x| without a barrier: LDS atomics, the wave that arrives last publishes and re-arms
       const unsigned amax_bits = p2_wave_umax(__float_as_uint(amax));
-      if constexpr (MULTI) {  // every wave publishes the maximum of its own (tile, sub-tile): the workgroup's waves are not one conv's
-        if (lane == 0 && wave_active) {
-          const int timg = (oy0 / TH) * a.tiles_x + ox0 / TWE;
-          p2_slot_put(a.out_row + (int64_t)n * P2_ROW, timg * gy + by, tiles_img * gy, amax_bits);
-        }
-      } else
       if (lane == 0) {
 #ifdef P2_FENCE
         __threadfence_block();
@@ -762,36 +754,6 @@ __global__ __launch_bounds__(64 * WN * WM) __attribute__((amdgpu_waves_per_eu(P2
   conv_p2_body<KS, S, G, WN, WM, NT, MS, TW, RS, EPI, OW, K48>(a, (int)blockIdx.y, (int)gridDim.y);
 }
 
-// Several convs over ONE input in one launch (round 4: the first-level stride-2 convs of a fuse layer, hrnet.py:398-423 -- branch 0's
-// 64 x 64 x 32 tensor feeds the 32 -> 64 term of branch 1 and the 32 -> 32 heads of the chains to branches 2 and 3): the launch's
-// cout axis is the concatenation of the convs' 16-cout sub-tiles, one per wave, so a workgroup's four waves may serve two convs
-// (32 -> 32 and 32 -> 32 share a workgroup: no idle waves) and the staged input tile serves all of them.  Every wave runs exactly the
-// single-conv arithmetic on its conv's arguments, so the results are bit-identical to separate launches; the input is staged once
-// per 64 couts of the UNION instead of once per conv, and two or three ~30 us launches become one.
-#define P2_MULTI_MAX 3
-struct P2Multi {
-  P2Args seg[P2_MULTI_MAX];
-  int v0[P2_MULTI_MAX + 1];  // conv s owns the 16-cout sub-tiles v0[s] .. v0[s + 1] of the launch; wave wn of cout group g has 4 g + wn
-};
-template <int KS, int S, int G, int WN, int WM, int NT, int MS, int TW, bool RS, int EPI>
-__global__ __launch_bounds__(64 * WN * WM) __attribute__((amdgpu_waves_per_eu(P2_WAVES(MS, NT, EPI), 8))) void conv_p2_multi_kernel(P2Multi m) {
-  const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);  // (wave-uniform: the conv's arguments stay in SGPRs)
-  const int v = (int)blockIdx.y * WN + wv;
-  const int sg = v >= m.v0[2] ? 2 : v >= m.v0[1] ? 1 : 0;
-  const bool valid = v < m.v0[P2_MULTI_MAX];
-  // the wave's conv = conv 0's arguments with the per-conv fields selected ONCE here (scalar selects between kernel arguments at fixed
-  // offsets).  Indexing m.seg[sg] left 57 scalar loads inside the body (12 in the single-conv kernel), each behind an
-  // s_waitcnt lgkmcnt that also drains the LDS fragment reads in flight: 75 us per group instead of 50.
-  P2Args a = m.seg[0];
-#define P2_SEL(f) a.f = sg == 0 ? m.seg[0].f : sg == 1 ? m.seg[1].f : m.seg[2].f
-  P2_SEL(w); P2_SEL(w_unscale); P2_SEL(scale); P2_SEL(shift); P2_SEL(bound);
-  P2_SEL(res1); P2_SEL(res2); P2_SEL(res1_row); P2_SEL(res2_row); P2_SEL(out_row); P2_SEL(out);
-  P2_SEL(Cout); P2_SEL(NS_total); P2_SEL(relu);
-#undef P2_SEL
-  const int v_lo = sg == 0 ? m.v0[0] : sg == 1 ? m.v0[1] : m.v0[2], v_hi = sg == 0 ? m.v0[1] : sg == 1 ? m.v0[2] : m.v0[3];
-  conv_p2_body<KS, S, G, WN, WM, NT, MS, TW, RS, EPI, 0, false, true>(a, valid ? v - v_lo : 0, valid ? v_hi - v_lo : 0);
-}
-
 static thread_local int g_p2_dry = 0;
 
 template <int KS, int S, int G, int WN, int WM, int NT, int MS, int TW, bool RS, int EPI, int OW = 0, bool K48 = false>
@@ -822,8 +784,10 @@ static int launch_p2e(P2Args a, hipStream_t s) {
   // that: one tile each.  (No workgroup waits for another one: an optimistic answer only costs a second round.)
   static std::atomic<int> occ{0};
   int per_cu = p2_resident_wgs(&conv_p2_kernel<KS, S, G, WN, WM, NT, MS, TW, RS, EPI, OW, K48>, occ, smem, NTH / 64);
-  const char* pe = getenv("MVAL_P2_WGS");  // measurement override: workgroups per CU
+#ifdef P2_TUNE
+  const char* pe = getenv("MVAL_P2_WGS");  // measurement builds only: workgroups per CU
   if (pe && atoi(pe) > 0) per_cu = atoi(pe);
+#endif
   int wgs = (mval_cu_count() * per_cu / (int)groups) & ~7;
   if (wgs < 8) wgs = 8;
   // (a count >= 8 must be a multiple of 8: the kernel walks 8 XCD groups in steps of wgs / 8 -- with 12 workgroups for 12 tiles the
@@ -869,69 +833,13 @@ static int launch_p2(const P2Args& a, hipStream_t s) {
   return launch_p2e<KS, S, G, WN, WM, NT, MS, TW, RS, 0>(a, s);
 }
 
-// Launcher of conv_p2_multi_kernel: 2 or 3 stride-2 3x3 convs (P2 planes in and out at the conv resolution) over the same input.
-// Returns 1 when the set is not covered (the caller launches the convs one by one).
-int mval_launch_conv_p2_multi(const P2Args* segs, int nseg, hipStream_t s) {
-  constexpr int KS = 3, S = 2, G = 1, WN = 4, WM = 1, NT = 1, MS = 2, TW = 8, EPI = 0;
-  constexpr int TH = 16 * MS * WM / TW;
-  constexpr int PH = (TH - 1) * S + KS, PW = (TW - 1) * S + KS, PWh = (PW + 1) / 2;
-  constexpr int slots = 2 * PH * PWh;
-  constexpr int PPX = (slots + 15) & ~15;
-  constexpr size_t smem = (size_t)2 * 8 * G * PPX * 16 + 16;
-  constexpr int NTH = 64 * WN * WM;
-  if (nseg < 2 || nseg > P2_MULTI_MAX || g_p2_dry) return 1;
-  P2Multi m = {};
-  int subtiles = 0;
-  for (int i = 0; i < nseg; i++) {
-    P2Args a = segs[i];
-    const P2Args& f = segs[0];
-    if (a.k != 3 || a.stride != 2 || a.up || a.out_f32 || a.out_nhwc || !a.out || !a.out_row || !a.bound) return 1;
-    if (a.in != f.in || a.in_row != f.in_row || a.N != f.N || a.Hin != f.Hin || a.Win != f.Win || a.Cin != f.Cin || a.Hout != f.Hout ||
-        a.Wout != f.Wout)
-      return 1;
-    if ((a.Cin & 7) || (a.Cout & 7) || a.Wout < 8 || a.Hout < 4) return 1;
-    if ((int64_t)a.N * a.Hin * a.Win * a.Cin >= (int64_t)1 << 29 || (int64_t)a.N * a.Hout * a.Wout * a.Cout >= (int64_t)1 << 29) return 1;
-    a.NS_total = (a.Cout + 15) / 16;
-    a.th = TH; a.tw = TW;
-    a.tiles_x = (a.Wout + TW - 1) / TW;
-    a.tiles_y = (a.Hout + TH - 1) / TH;
-    a.amax_tiles = a.tiles_x * a.tiles_y;
-    a.tiles_total = a.amax_tiles * a.N;
-    a.tiles_img_magic = a.amax_tiles > 1 ? (unsigned)(((uint64_t)1 << 32) / (unsigned)a.amax_tiles + 1) : 0u;
-    a.tiles_x_magic = a.tiles_x > 1 ? (unsigned)(((uint64_t)1 << 32) / (unsigned)a.tiles_x + 1) : 0u;
-    m.seg[i] = a;
-    m.v0[i] = subtiles;
-    subtiles += a.NS_total;
-  }
-  for (int i = nseg; i <= P2_MULTI_MAX; i++) m.v0[i] = subtiles;  // (unused convs own no sub-tile)
-  const int groups = (subtiles + WN - 1) / WN;
-  static std::atomic<int> occ{0};
-  int per_cu = p2_resident_wgs(&conv_p2_multi_kernel<KS, S, G, WN, WM, NT, MS, TW, false, EPI>, occ, smem, NTH / 64);
-  const char* pe = getenv("MVAL_P2_WGS");
-  if (pe && atoi(pe) > 0) per_cu = atoi(pe);
-  const int tiles_total = m.seg[0].tiles_total;
-  int wgs = (mval_cu_count() * per_cu / groups) & ~7;
-  if (wgs < 8) wgs = 8;
-  if (wgs >= tiles_total) wgs = tiles_total < 8 ? tiles_total : (tiles_total + 7) & ~7;
-  else {
-    const int per = (tiles_total + 7) / 8, rounds = (per + wgs / 8 - 1) / (wgs / 8);
-    wgs = 8 * ((per + rounds - 1) / rounds);
-  }
-  for (int i = 0; i < nseg; i++) {
-    m.seg[i].wgs_x = wgs;  // (the tile walk: every wave of a workgroup must see the same one)
-    if ((int64_t)m.seg[i].amax_tiles * m.seg[i].NS_total > P2_SLOTS) mval_launch_zero_rows(m.seg[i].out_row, (int64_t)m.seg[i].N * P2_ROW, s);
-  }
-  // waves past the last sub-tile (v0[P2_MULTI_MAX] = the total) select the LAST slot: a copy of conv 0 -- they stage and take every
-  // barrier with the tile walk of the others (a slot left zeroed had wgs_x = 0: a workgroup whose waves disagreed on the walk hung)
-  for (int i = nseg; i < P2_MULTI_MAX; i++) m.seg[i] = m.seg[0];
-  hipLaunchKernelGGL((conv_p2_multi_kernel<KS, S, G, WN, WM, NT, MS, TW, false, EPI>), dim3((unsigned)wgs, (unsigned)groups), dim3(NTH), smem, s, m);
-  return 0;
-}
-
-// MVAL_P2_TILE: measurement override of the tile choice (tools/p2_sweep.py): "ms,nt,g" (0 = default)
+// measurement builds (-DP2_TUNE: tools/p2_sweep.py) read the tile choice from MVAL_P2_TILE="ms,nt,g" (0 = default) and the workgroups
+// per CU from MVAL_P2_WGS; the product library reads no environment variable here
 static void p2_override(int& ms, int& nt, int& g) {
+#ifdef P2_TUNE
   const char* e = getenv("MVAL_P2_TILE");
   if (e) (void)sscanf(e, "%d,%d,%d", &ms, &nt, &g);
+#endif
 }
 
 int mval_launch_conv_p2(const P2Args& a0, hipStream_t s) {
@@ -945,24 +853,19 @@ int mval_launch_conv_p2(const P2Args& a0, hipStream_t s) {
   p2_override(oms, ont, og);
   const int64_t px = (int64_t)a.N * a.Hout * a.Wout;
   if (a.k == 3 && a.stride == 1) {
-    // MVAL_P2_WIDE=1: the v_mfma_f32_32x32x16_f16 form (conv_p2w.hip) where it applies.  Measured equal or slower (64 -> 64 on 32x32:
-    // 33.1 vs 31.5 us; on 64x64: 115 vs 112.5): kept as the on-device cross-check of the kernels' arithmetic, not used by default
-    const char* we = getenv("MVAL_P2_WIDE");
-    if (we && we[0] == '1' && !g_p2_dry && mval_conv_p2w_supported(a)) return mval_launch_conv_p2w(a, s);
+    // (round 3 also built the v_mfma_f32_32x32x16_f16 form of this conv -- half the MFMA issues, two thirds of the LDS fragment reads per
+    // FLOP: 33.1 vs 31.5 us on 64 -> 64 at 32x32, 115 vs 112.5 at 64x64: equal or slower; removed in round 5)
     // maps no power-of-two tile fits (HRNet-W48 at 384 x 288: 24 x 18 and 12 x 9): full-width odd tiles, 3 x 18 / 7 x 9 pixels
-    const char* oe = getenv("MVAL_P2_ODD");
-    if (!(oe && oe[0] == '0') && a.NS_total > 2 && !a.up && !a.out_f32) {
+    if (a.NS_total > 2 && !a.up && !a.out_f32) {
       // (36-wide maps -- HRNet-W48's 96-channel branch -- as two 18-wide odd tiles per row: 54 of 64 slots used against 36 of 48 columns
-      // of three 16-wide row-sharing tiles: 84 -> 78 us for 96 -> 96 on 48 x 36; MVAL_P2_ODD36=0: the 16-wide tiles)
-      const char* o36 = getenv("MVAL_P2_ODD36");
-      if (a.Wout == 18 || (a.Wout == 36 && !(o36 && o36[0] == '0'))) return launch_p2<3, 1, 1, 4, 1, 1, 4, 8, false, 18>(a, s);
+      // of three 16-wide row-sharing tiles: 84 -> 78 us for 96 -> 96 on 48 x 36)
+      if (a.Wout == 18 || a.Wout == 36) return launch_p2<3, 1, 1, 4, 1, 1, 4, 8, false, 18>(a, s);
       // (9-wide odd tiles on the 72-wide maps -- 63 of 64 slots -- measured slower than the 16-wide row-sharing tiles: 105 vs 103 us)
       if (a.Wout == 9) return launch_p2<3, 1, 1, 4, 1, 1, 4, 8, false, 9>(a, s);
     }
     if (a.Wout >= 16 && a.Hout >= 4) {
-      // 48 input channels (HRNet-W48's first branch): the paired remainder stage (K48 above); MVAL_P2_K48=0: three column steps
-      const char* k48 = getenv("MVAL_P2_K48");
-      if (a.Cin == 48 && a.NS_total > 2 && !a.up && !a.out_f32 && !a.out_nhwc && !(k48 && k48[0] == '0') && !oms && !ont)
+      // 48 input channels (HRNet-W48's first branch): the paired remainder stage (K48 above: 103 -> 96 us for 48 -> 48 on 96 x 72)
+      if (a.Cin == 48 && a.NS_total > 2 && !a.up && !a.out_f32 && !a.out_nhwc && !oms && !ont)
         return launch_p2e<3, 1, 1, 4, 1, 1, 4, 16, true, 0, 0, true>(a, s);
       if (a.NS_total <= 2) return launch_p2<3, 1, 1, 2, 2, 1, 4, 16, true>(a, s);  // 32 couts: 2 x 2 waves, 4 rows each
       // 64-pixel tiles: measured faster than 128-pixel ones on every HRNet shape (128 -> 128 on 16x16: 28.8 vs 30.6 us,

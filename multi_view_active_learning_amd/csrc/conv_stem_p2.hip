@@ -493,8 +493,10 @@ int mval_launch_conv_stem_p2(const float* in, void* out, const float* w1, const 
   constexpr size_t smem = 2 * 8 * 170 * 16 + 3 * 11 * 68 * 4 + 16 + 512;
   static std::atomic<int> occ{0};
   int per_cu = p2_resident_wgs(&conv_stem_p2_kernel, occ, smem, 4);
+#ifdef P2_TUNE  // (measurement builds only: workgroups per CU)
   const char* pe = getenv("MVAL_P2_WGS");
   if (pe && atoi(pe) > 0) per_cu = atoi(pe);
+#endif
   int wgs = mval_cu_count() * per_cu;
   if (wgs >= a.tiles_total) wgs = a.tiles_total;
   else {
@@ -505,7 +507,6 @@ int mval_launch_conv_stem_p2(const float* in, void* out, const float* w1, const 
   a.dbg = g_p2_dbg_shared;
 #endif
   a.wgs_x = wgs;
-  if (getenv("MVAL_P2_DEBUG")) fprintf(stderr, "stem_p2 N %d %dx%d -> %dx%d tiles %d per_cu %d wgs %d smem %zu\n", N, H, W, a.H2, a.W2, a.tiles_total, per_cu, wgs, smem);
   if (tiles_img > P2_SLOTS) mval_launch_zero_rows(out_row, (int64_t)N * P2_ROW, s);
   hipLaunchKernelGGL(conv_stem_p2_kernel, dim3((unsigned)wgs), dim3(256), smem, s, a);
   return 0;

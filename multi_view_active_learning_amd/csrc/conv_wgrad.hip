@@ -29,7 +29,7 @@ int mval_launch_wgrad_bf3_p2(const float* x, const void* x_p2, const unsigned* x
 int mval_wgrad_bf3_covers(int Cin, int Cout, int k, int stride);
 extern "C" int mval_conv_wgrad_split_covers(int cin, int cout, int k, int stride) { return mval_wgrad_bf3_covers(cin, cout, k, stride); }
 extern "C" int mval_conv_wgrad_p2_covers(int cin, int cout, int k, int stride) { return mval_wgrad_bf3_covers(cin, cout, k, stride) && (cin & 7) == 0; }
-// x as P2 planes for the next mval_conv_wgrad_split_streams call of this thread (net_train.hip sets it per operator; nullptr = fp32 x)
+// x as P2 planes for the next mval_conv_wgrad_on call of this thread (net_train.hip sets it per operator; nullptr = fp32 x)
 static thread_local const void* g_wgrad_x_p2 = nullptr;
 static thread_local const unsigned* g_wgrad_x_p2_rows = nullptr;
 void mval_conv_wgrad_set_p2_x(const void* planes, const unsigned* rows) {
@@ -357,10 +357,8 @@ static int wg_splits(int cin, int cout, int target) {
   return ps;
 }
 
-int mval_conv_wgrad_split_streams(const float* x, const float* dz, float* dw, float* ws, int N, int Hin, int Win, int Cin, int Hout,
-                                  int Wout, int Cout, int k, int stride, int pad, int x_nchw, const uint32_t* x_amax_row,
-                                  const uint32_t* dz_amax_row, hipStream_t s, hipStream_t reduce_stream, hipEvent_t ready,
-                                  hipEvent_t done);
+int mval_conv_wgrad_on(const float* x, const float* dz, float* dw, float* ws, int N, int Hin, int Win, int Cin, int Hout, int Wout, int Cout,
+                       int k, int stride, int pad, int x_nchw, const uint32_t* x_amax_row, const uint32_t* dz_amax_row, hipStream_t s);
 
 extern "C" size_t mval_conv_wgrad_workspace_floats(int cin, int cout, int k) {
   return (size_t)wg_splits(cin, cout, 1024) * k * k * cin * cout;  // PS slabs of [tap][cin][cout]
@@ -375,17 +373,13 @@ extern "C" int mval_conv_wgrad(const float* x, const float* dz, float* dw, float
 extern "C" int mval_conv_wgrad_scaled(const float* x, const float* dz, float* dw, float* ws, int N, int Hin, int Win, int Cin,
                                       int Hout, int Wout, int Cout, int k, int stride, int pad, int x_nchw,
                                       const uint32_t* x_amax_row, const uint32_t* dz_amax_row, void* stream) {
-  return mval_conv_wgrad_split_streams(x, dz, dw, ws, N, Hin, Win, Cin, Hout, Wout, Cout, k, stride, pad, x_nchw, x_amax_row, dz_amax_row,
-                                       mval_stream(stream), nullptr, nullptr, nullptr);
+  return mval_conv_wgrad_on(x, dz, dw, ws, N, Hin, Win, Cin, Hout, Wout, Cout, k, stride, pad, x_nchw, x_amax_row, dz_amax_row, mval_stream(stream));
 }
 
-// The same with the slab reduction on a second stream (net_train.hip: it only feeds the optimizer, so it can run beside the
-// op's data gradient and the next op's BatchNorm backward): reduce_stream waits for `ready` (recorded behind the split-K
-// kernel on s) and records `done` behind the reduction; the caller makes s wait for `done` before ws is written again.
-int mval_conv_wgrad_split_streams(const float* x, const float* dz, float* dw, float* ws, int N, int Hin, int Win, int Cin, int Hout,
-                                  int Wout, int Cout, int k, int stride, int pad, int x_nchw, const uint32_t* x_amax_row,
-                                  const uint32_t* dz_amax_row, hipStream_t s, hipStream_t reduce_stream, hipEvent_t ready,
-                                  hipEvent_t done) {
+// (net_train.hip's entry: the HIP stream as such.  Round 4 also ran the slab reduction on a side stream beside the op's data gradient:
+// two event hand-overs per operator cost more than the 7 us reduction they hid, C3 79.9 vs 77.7 ms -- removed in round 5.)
+int mval_conv_wgrad_on(const float* x, const float* dz, float* dw, float* ws, int N, int Hin, int Win, int Cin, int Hout, int Wout, int Cout,
+                       int k, int stride, int pad, int x_nchw, const uint32_t* x_amax_row, const uint32_t* dz_amax_row, hipStream_t s) {
   MVAL_REQUIRE(N > 0 && Cin > 0 && Cout > 0 && k > 0 && stride > 0, "mval_conv_wgrad: bad dims");
   const int T = k * k;
   const int64_t n_out = (int64_t)T * Cin * Cout;
@@ -477,15 +471,7 @@ int mval_conv_wgrad_split_streams(const float* x, const float* dz, float* dw, fl
   }
   int parts = PS / 8;  // >= 8 slabs per lane
   parts = parts < 1 ? 1 : parts > 16 ? 16 : parts;
-  hipStream_t rs = s;
-  if (reduce_stream && ready && done) {
-    (void)hipEventRecord(ready, s);
-    (void)hipStreamWaitEvent(reduce_stream, ready, 0);
-    rs = reduce_stream;
-  }
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n_out + 63) / 64)), dim3(64 * parts), 0, rs, ws, PS, T, Cin,
-                     Cout, dw);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n_out + 63) / 64)), dim3(64 * parts), 0, s, ws, PS, T, Cin, Cout, dw);
   MVAL_CHECK_LAUNCH("mval_conv_wgrad/reduce");
-  if (rs != s) (void)hipEventRecord(done, rs);
   return 0;
 }

@@ -494,8 +494,6 @@ static int op_launch(const mval_op* op, int n_images, float* workspace, const fl
     return 0;
   }
   if (op->algo == MVAL_ALGO_MFMA_P2) {
-    if (op->multi_n < 0) return 0;  // launched by the head of its group (below)
-    // the arguments of one P2 conv (this op, or a follower of its group)
     auto p2_args = [&](const mval_op* o, P2Args& p) -> int {
       const float* w = o->w_off >= 0 ? params + o->w_off : nullptr;
       MVAL_REQUIRE(o->kind == MVAL_OP_CONV && w && o->scale_off >= 0 && o->shift_off >= 0 && o->in_amax_off > 0 && o->in_off >= 0 &&
@@ -525,23 +523,11 @@ static int op_launch(const mval_op* op, int n_images, float* workspace, const fl
       p.k = o->k; p.stride = o->stride; p.up = o->up; p.relu = o->relu;
       return 0;
     };
-    const int group = op->multi_n >= 2 ? op->multi_n : 1;
-    MVAL_REQUIRE(group <= 3, "mval_op_launch: multi_n %d (at most 3 convs per launch)", group);
-    P2Args ps[3];
-    for (int g = 0; g < group; g++) {
-      MVAL_REQUIRE(g == 0 || (op[g].algo == MVAL_ALGO_MFMA_P2 && op[g].multi_n == -1), "mval_op_launch: op %d of a multi-conv group is not marked as a follower", g);
-      int rc = p2_args(op + g, ps[g]);
-      if (rc) return rc;
-    }
-    if (group > 1 && mval_launch_conv_p2_multi(ps, group, s) == 0) {
-      MVAL_CHECK_LAUNCH("mval_op_launch/p2 multi");
-      return 0;
-    }
-    for (int g = 0; g < group; g++) {  // one by one (a single conv, or a group the multi kernel does not cover)
-      int rc = mval_launch_conv_p2(ps[g], s);
-      MVAL_REQUIRE(rc == 0, "mval_op_launch: no P2 kernel for conv k%d s%d cin%d cout%d %dx%d", op[g].k, op[g].stride, op[g].cin,
-                   op[g].cout, op[g].hin, op[g].win);
-    }
+    P2Args p2;
+    int rc = p2_args(op, p2);
+    if (rc) return rc;
+    rc = mval_launch_conv_p2(p2, s);
+    MVAL_REQUIRE(rc == 0, "mval_op_launch: no P2 kernel for conv k%d s%d cin%d cout%d %dx%d", op->k, op->stride, op->cin, op->cout, op->hin, op->win);
     MVAL_CHECK_LAUNCH("mval_op_launch/p2");
     return 0;
   }
@@ -644,7 +630,6 @@ MvalLanes* mval_device_lanes() {
   std::lock_guard<std::mutex> lock(g_lanes_mutex);
   if (L->ready) return L;
   if (hipEventCreateWithFlags(&L->fork_ev, hipEventDisableTiming) != hipSuccess) return nullptr;
-  if (hipEventCreateWithFlags(&L->group_ev, hipEventDisableTiming) != hipSuccess) return nullptr;
   for (int l = 1; l < MVAL_MAX_LANES; l++) {
     if (hipStreamCreateWithFlags(&L->side[l], hipStreamNonBlocking) != hipSuccess) return nullptr;
     if (hipEventCreateWithFlags(&L->join_ev[l], hipEventDisableTiming) != hipSuccess) return nullptr;
@@ -701,13 +686,8 @@ static int net_forward(void* net, int n_images, float* workspace, const float* p
   for (size_t i = 0; i < n->ops.size(); i++) {
     const mval_op& op = n->ops[i];
     hipStream_t s = walk.stream_for(op.phase, op.lane < n->n_lanes ? op.lane : 0);
-    if (op.multi_n < 0) {  // launched with the head of its group, on the head's lane: this op's lane goes on once that launch is done
-      walk.wait_for_group(s);
-      continue;
-    }
     int rc = op_launch(&n->ops[i], n_images, workspace, params, input_nchw, output_nchw, op.out_off < 0 ? argmax_keys : nullptr, s);
     if (rc) return rc;
-    if (op.multi_n >= 2) walk.group_launched(s);
   }
   walk.finish();
   return 0;

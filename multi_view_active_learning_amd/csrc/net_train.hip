@@ -38,52 +38,15 @@ extern "C" int mval_bn_bwd_fused(const float*, const float*, const float*, const
                                  float*, float*, float*, float*, float*, double*, float*, int, int, int, int, int, int, uint32_t*,
                                  void*);
 #include <stdlib.h>
-#include <mutex>
 // The A/B switches of round 4's BatchNorm restructuring are decided ONCE, by the plan (engine_train.TrainPlan), and travel in
 // mval_train_op.p2_flags: bit 7 = batch statistics by the separate pass over z instead of the forward conv's epilogue partials
 // (MVAL_TRAIN_EPI_STATS=0), bit 6 = round 3's backward pair (masked copy to gz, dz in place) instead of mval_bn_bwd_fused
 // (MVAL_TRAIN_BWD_FUSED=0).  (Round 4 read the environment here on every call as well: a switch flipped between plan build and a later
 // step sent ops whose fp32 output was never written down the path that reads it -- ADVICE round 4.)
-int mval_conv_wgrad_split_streams(const float* x, const float* dz, float* dw, float* ws, int N, int Hin, int Win, int Cin, int Hout,
-                                  int Wout, int Cout, int k, int stride, int pad, int x_nchw, const uint32_t* x_amax_row,
-                                  const uint32_t* dz_amax_row, hipStream_t s, hipStream_t reduce_stream, hipEvent_t ready,
-                                  hipEvent_t done);
+int mval_conv_wgrad_on(const float* x, const float* dz, float* dw, float* ws, int N, int Hin, int Win, int Cin, int Hout, int Wout, int Cout,
+                       int k, int stride, int pad, int x_nchw, const uint32_t* x_amax_row, const uint32_t* dz_amax_row, hipStream_t s);
 void mval_conv_wgrad_set_p2_x(const void* planes, const unsigned* rows);  // conv_wgrad.hip: x as P2 planes for the next weight gradient
 void mval_conv_wgrad_set_p2_dz(const void* planes, const unsigned* rows);  // ... and dz
-// Side stream of the weight-gradient slab reductions (one per device, created once, never destroyed -- as the branch lanes of
-// net.hip): a reduction only feeds the optimizer, so it runs beside the op's data gradient and the next op's BatchNorm
-// backward; the main stream waits for it before the shared slab workspace is written again and at the end of the call.
-struct WgradSide {
-  hipStream_t stream = nullptr;
-  hipEvent_t ready = nullptr, done = nullptr;
-  bool ok = false;
-};
-static WgradSide* wgrad_side() {
-  static WgradSide sides[64];
-  static std::mutex mu;
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-  std::lock_guard<std::mutex> lock(mu);
-  WgradSide& w = sides[dev];
-  if (!w.ok) {
-    if (hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
-    if (hipEventCreateWithFlags(&w.ready, hipEventDisableTiming) != hipSuccess) return nullptr;
-    if (hipEventCreateWithFlags(&w.done, hipEventDisableTiming) != hipSuccess) return nullptr;
-    w.ok = true;
-  }
-  return &w;
-}
-//   MVAL_TRAIN_WGRAD_SIDE=1  the slab reductions on the side stream (measured: C3 79.9 ms against 77.7 in line -- two event
-//                            hand-overs per operator cost more than the 7 us reduction they hide; off by default)
-static bool env_is(const char* name, char c) {
-  const char* v = getenv(name);
-  return v && v[0] == c;
-}
-static bool env_on(const char* name) {
-  const char* v = getenv(name);
-  return !(v && v[0] == '0');
-}
-
 // ---- measurement mode (bench.py, the c3 line's per-kernel roofline): hipEvents around every launch group of a
 // training step, summed per kernel family.  Off unless mval_train_timing() armed it; the events are resolved (one
 // stream synchronisation) at the end of each forward / backward call.
@@ -344,8 +307,6 @@ extern "C" int mval_train_backward(const mval_train_op* ops, int n_ops, int n_im
   MVAL_REQUIRE(ops && n_ops > 0 && n_images > 0 && garena && gz && wsf && ws && sums,
                "mval_train_backward: bad arguments");
   hipStream_t s = mval_stream(stream);
-  WgradSide* side = (env_is("MVAL_TRAIN_WGRAD_SIDE", '1') && !g_tt_out) ? wgrad_side() : nullptr;  // (measurement mode times the reduction in line)
-  bool side_pending = false;
   for (int i = n_ops - 1; i >= 0; i--) {
     g_tt_op = g_tt_base + i;
     const mval_train_op& t = ops[i];
@@ -397,10 +358,6 @@ extern "C" int mval_train_backward(const mval_train_op* ops, int n_ops, int n_im
       // is the conv  x' = conv(y', W as [cout' = cin][cin' = cout], stride s, pad p), so
       //   dW = weight gradient of that conv with input dz (at the output resolution) and "dz" = x;
       //   dx = that conv applied to dz (plain stride-2 conv on the matrix cores).
-      if (side_pending) {  // (the in-line weight gradient below writes the slab workspace too)
-        (void)hipStreamWaitEvent(s, side->done, 0);
-        side_pending = false;
-      }
       rc = mval_conv_wgrad(gz, x, t.dweight, wsf, n_images, op.hout, op.wout, op.cout, op.hin, op.win, op.cin, op.k,
                            op.stride, op.pad, 0, stream);
       if (rc) return rc;
@@ -432,18 +389,12 @@ extern "C" int mval_train_backward(const mval_train_op* ops, int n_ops, int n_im
     const uint32_t* x_row = (gz_row && op.in_amax_off > 0) ? reinterpret_cast<const uint32_t*>(arena + op.in_amax_off) : nullptr;
     {
     TtScope tt(TT_WGRAD, s);
-    if (side_pending) {  // the previous op's slab reduction still reads wsf
-      (void)hipStreamWaitEvent(s, side->done, 0);
-      side_pending = false;
-    }
     if (dz_p2 && (t.p2_flags & 8))
       mval_conv_wgrad_set_p2_dz(arena + t.gz_p2_off, reinterpret_cast<const unsigned*>(arena + t.gz_p2_rows_off));
     if (t.fwd_p2 && (t.p2_flags & 1))  // (wgrad_p2: this op's input exists as P2 planes and its weight gradient reads those)
       mval_conv_wgrad_set_p2_x(arena + t.in_p2_off, reinterpret_cast<const unsigned*>(arena + t.in_p2_rows_off));
-    rc = mval_conv_wgrad_split_streams(x, gz, t.dweight, wsf, n_images, op.hin, op.win, op.cin, op.hout, op.wout, op.cout, op.k,
-                                       op.stride, op.pad, op.in_nchw, x_row, x_row ? gz_row : nullptr, s, side ? side->stream : nullptr,
-                                       side ? side->ready : nullptr, side ? side->done : nullptr);
-    side_pending = side != nullptr;
+    rc = mval_conv_wgrad_on(x, gz, t.dweight, wsf, n_images, op.hin, op.win, op.cin, op.hout, op.wout, op.cout, op.k, op.stride, op.pad,
+                            op.in_nchw, x_row, x_row ? gz_row : nullptr, s);
     }
     if (rc) return rc;
     if (t.gin_off >= 0) {
@@ -479,7 +430,6 @@ extern "C" int mval_train_backward(const mval_train_op* ops, int n_ops, int n_im
       if (rc) return rc;
     }
   }
-  if (side_pending) (void)hipStreamWaitEvent(s, side->done, 0);  // the caller reads the weight gradients on s
   tt_flush();
   return 0;
 }

@@ -50,7 +50,7 @@ class MvalOp(C.Structure):
         ("w2_off", C.c_int64), ("scale2_off", C.c_int64), ("shift2_off", C.c_int64),
         ("bound_off", C.c_int64), ("bound2_off", C.c_int64), ("res1_amax_off", C.c_int64), ("res2_amax_off", C.c_int64),
         ("w3_off", C.c_int64), ("scale3_off", C.c_int64), ("shift3_off", C.c_int64), ("bound3_off", C.c_int64),
-        ("n_terms", C.c_int32), ("t_cin", C.c_int32 * 3), ("t_up", C.c_int32 * 3), ("multi_n", C.c_int32),
+        ("n_terms", C.c_int32), ("t_cin", C.c_int32 * 3), ("t_up", C.c_int32 * 3), ("reserved0", C.c_int32),
         ("t_in_off", C.c_int64 * 3), ("t_in_amax_off", C.c_int64 * 3), ("t_w_off", C.c_int64 * 3), ("t_scale_off", C.c_int64 * 3),
         ("t_shift_off", C.c_int64 * 3), ("t_bound_off", C.c_int64 * 3),
     ]
@@ -100,64 +100,10 @@ def _pack_mode(op, pack):
     return {PACK_HWIO: 1, PACK_MFMA16: 2, PACK_MFMA16_BF3: 3, PACK_MFMA16_H2: 3}[pack]
 
 
-def _group_first_level_stride2(g):
-    """hrnet.py:398-423: the fuse layers' down-sampling chains from branch 0 all start with a 3x3 stride-2 conv of the SAME tensor
-    (32 -> 64 for branch 1, 32 -> 32 heads of the chains to branches 2 and 3).  Returns a copy of the graph in which those first-level
-    convs of a fuse phase stand next to each other in the op list (phases and lanes unchanged), marked ``multi`` = group size on the
-    first and -1 on the others: the P2 plan launches a group as ONE kernel on the first one's lane (conv_p2_multi_kernel), the
-    other lanes wait for that launch (net.hip).  A conv qualifies when it is the first op of its lane in the phase (so moving it
-    up the list keeps its lane's order) and everything it reads comes from an earlier phase."""
-    import copy
-
-    producer_phase = {g.input: -1}
-    for op in g.ops:
-        producer_phase[op.dst] = op.phase
-    by_phase = {}
-    for i, op in enumerate(g.ops):
-        by_phase.setdefault(op.phase, []).append(i)
-    groups = {}  # phase -> indices of the group (head first)
-    for ph, idx in by_phase.items():
-        seen_lanes, cand = set(), {}
-        for i in idx:
-            op = g.ops[i]
-            first_of_lane = op.lane not in seen_lanes
-            seen_lanes.add(op.lane)
-            if (first_of_lane and op.kind == "conv" and op.k == 3 and op.stride == 2 and op.pad == 1 and op.up == 0 and op.bn
-                    and op.dst != g.output and op.cout % 8 == 0
-                    and all(a is None or producer_phase.get(a, ph) < ph for a in (op.src, op.res1, op.res2))):
-                cand.setdefault(op.src, []).append(i)
-        best = max(cand.values(), key=len, default=[])
-        if len(best) >= 2:
-            groups[ph] = best[:3]
-    if not groups:
-        return g
-    g2 = copy.copy(g)
-    g2.ops = []
-    for ph in sorted(by_phase):
-        grp = groups.get(ph, [])
-        for i in by_phase[ph]:
-            if i in grp[1:]:
-                continue
-            op = copy.copy(g.ops[i])
-            g2.ops.append(op)
-            if grp and i == grp[0]:
-                op.multi = len(grp)
-                for j in grp[1:]:
-                    f = copy.copy(g.ops[j])
-                    f.multi = -1
-                    g2.ops.append(f)
-    return g2
-
-
 class InferencePlan:
     def __init__(self, model, n, h, w, device):
         self.model, self.n, self.h, self.w, self.device = model, n, h, w, device
         g = model._graph
-        # (measured, round 4: the group launch takes 48 / 53 us against 60 / 86 us for its two / three convs one after the other, but in
-        # the multi-stream forward those convs run BESIDE each other on their lanes and the step gets slower -- C2 10.17 vs 10.10 ms,
-        # C4 21.0 vs 20.76; single-stream 10.98 vs 11.04.  Opt-in.)
-        if _conv_mode() == "p2" and os.environ.get("MVAL_P2_S2_MULTI", "0") == "1":
-            g = _group_first_level_stride2(g)
         self.graph = g
         # ---- activation geometry, op by op ------------------------------------------------
         dims = {g.input: (h, w)}
@@ -344,8 +290,8 @@ class InferencePlan:
         fuse = os.environ.get("MVAL_FUSE_BLOCKS", "1") != "0"
         # measured (128 images): 32 channels on 64x64 maps 81 us fused vs 2 x 44 us; 64 channels on 32x32 maps 77 us
         # fused vs 2 x 33 us -- the two 64-channel convs are no longer HBM-bound one by one, so only the 32-channel
-        # blocks are fused by default (MVAL_P2_BLOCKS=32,64 fuses both)
-        fuse_c = {int(v) for v in os.environ.get("MVAL_P2_BLOCKS", "32").split(",") if v}
+        # blocks are fused (round 3 measured the fused 64-channel block at 77 us against 2 x 33 for its two P2 convs; 10.38 vs 10.37 ms as a step)
+        fuse_c = {32}
         fuse_bneck = fuse and os.environ.get("MVAL_P2_BNECK", "1") != "0"
         fuse_up = fuse and os.environ.get("MVAL_P2_FUSE_UP", "1") != "0"
         uses = {}
@@ -461,7 +407,6 @@ class InferencePlan:
                     launch.append(blk)
                     i += 2
                     continue
-            m.multi_n = getattr(op, "multi", 0)  # (first-level stride-2 convs of a fuse layer: ONE launch for the group)
             launch.append(m)
             i += 1
         arr = (MvalOp * len(launch))()
@@ -787,7 +732,7 @@ def _plan_for(model, x):
         raise ValueError("expected (N, 3, H, W) images")
     cache = model.__dict__.setdefault("_plans", {})
     key = (n, h, w, x.device.index, os.environ.get("MVAL_FORCE_DIRECT") == "1", _conv_mode(), os.environ.get("MVAL_FUSE_BLOCKS", "1"),
-           os.environ.get("MVAL_P2_BLOCKS", "32"), os.environ.get("MVAL_P2", "1"), os.environ.get("MVAL_P2_W48", "1"), os.environ.get("MVAL_P2_BNECK", "1"), os.environ.get("MVAL_P2_STEM", "1"), os.environ.get("MVAL_P2_FUSE_UP", "1"),
+           os.environ.get("MVAL_P2", "1"), os.environ.get("MVAL_P2_W48", "1"), os.environ.get("MVAL_P2_BNECK", "1"), os.environ.get("MVAL_P2_STEM", "1"), os.environ.get("MVAL_P2_FUSE_UP", "1"),
            os.environ.get("MVAL_EPILOGUE_DECODE", "1"))
     plan = cache.get(key)
     if plan is None:

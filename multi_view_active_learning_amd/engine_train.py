@@ -58,14 +58,14 @@ class MvalTrainOp(C.Structure):
 # Bound slack of the P2 training plan (ADVICE round 4 / the inference plan's engine.P2_MAX_SLACK_LOG2): the scale of a P2 tensor comes from an
 # a-priori bound -- Samuelson's |bn(z)| <= |gamma| sqrt(M - 1) + |beta| for activations, the same inequality around dgamma / dbeta for dz --
 # and values more than ~2^16 below it lose low-part bits.  The plan measures bound / actual maximum of every P2 tensor on its first step and
-# every SLACK_EVERY steps after (one extra read of the planes, a few ms); past the limit the model's later steps run the h2 training kernels
+# every SLACK_EVERY (1 024) steps after (one extra read of every P2 tensor: ~70 ms at the C3 size, < 0.1 % amortised); past the limit the model's later steps run the h2 training kernels
 # (exact per-tensor maxima) and a warning says so.  MVAL_TRAIN_SLACK_CHECK=0 switches the probe off, MVAL_TRAIN_P2=force ignores its verdict.
 TRAIN_P2_MAX_SLACK_LOG2 = 15.0
 # ... or when more than this fraction of a tensor's non-zero values sits below 2^-3 scaled (fewer than 22 significand bits kept): the
 # maximum alone does not see a tensor whose gammas spread widely -- ONE large channel sets the scale, the small ones lose the bits.  A
 # Gaussian tensor crosses 0.5 at a slack of ~2^14; the BASELINE plan measures < 0.02 (tests/test_gpu_train.py).
 TRAIN_P2_MAX_SMALL_FRAC = 0.5
-SLACK_EVERY = int(os.environ.get("MVAL_TRAIN_SLACK_EVERY", "256"))
+SLACK_EVERY = int(os.environ.get("MVAL_TRAIN_SLACK_EVERY", "1024"))
 _SWITCHES = ("MVAL_TRAIN_P2", "MVAL_TRAIN_P2_WGRAD", "MVAL_TRAIN_P2_DGRAD", "MVAL_TRAIN_P2_RES", "MVAL_TRAIN_EPI_STATS", "MVAL_TRAIN_BWD_FUSED",
              "MVAL_TRAIN_RELU_MASK", "MVAL_TRAIN_DGRAD_PARITY")
 

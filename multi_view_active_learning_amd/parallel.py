@@ -26,12 +26,10 @@ _POST_STREAMS = {}
 class PostStream:
     """``with post.batch(heatmaps, keys, dp): table = score(...)`` per batch -- pass EVERY device tensor the body reads (a dict
     counts with its values) --, ``post.join()`` before the results are read on the caller's stream.  A no-op for host tensors
-    and with MVAL_POST_OVERLAP=0."""
+    and for PostStream(enabled=False) (bench.py --no-overlap: the A/B of the overlap)."""
 
     def __init__(self, enabled=None):
-        import os
-
-        self.enabled = (os.environ.get("MVAL_POST_OVERLAP", "1") != "0") if enabled is None else bool(enabled)
+        self.enabled = True if enabled is None else bool(enabled)
         self.side = None
 
     class _Ctx:

@@ -113,36 +113,6 @@ def test_p2_conv_vs_float64(dev, case):
         assert rms <= 1.25 * rms32 + 1e-8, (rms, rms32)
 
 
-@pytest.mark.parametrize("case", [(2, 64, 64, 32, 32, True), (2, 64, 128, 64, 48, False), (3, 128, 64, 36, 40, True), (1, 256, 64, 8, 32, True)],
-                         ids=lambda c: "n%d_c%d-%d_%dx%d_r%d" % tuple(int(v) for v in c))
-def test_p2_wide_mfma_form_vs_float64(dev, case, monkeypatch):
-    """MVAL_P2_WIDE=1: the 3x3 stride-1 conv on v_mfma_f32_32x32x16_f16 (csrc/conv_p2w.hip; maps at least 32 wide) against float64
-    and against the default kernel on the same problem (same arithmetic, another accumulation layout: equal at fp32 rounding)."""
-    from multi_view_active_learning_amd import ops
-
-    n, cin, cout, h, w, has_res = case
-    rng = np.random.default_rng(17 + h + cin)
-    x = torch.from_numpy(np.maximum(rng.standard_normal((n, cin, h, w)), 0).astype(np.float32) * 1.5)
-    wt = torch.from_numpy((rng.standard_normal((cout, cin, 3, 3)) * np.sqrt(2.0 / (cin * 9))).astype(np.float32))
-    sc = torch.from_numpy(rng.uniform(0.5, 1.5, cout).astype(np.float32))
-    sh = torch.from_numpy(rng.standard_normal(cout).astype(np.float32) * 0.1)
-    res = torch.from_numpy(rng.standard_normal((n, cout, h, w)).astype(np.float32)) if has_res else None
-    d = torch.float64
-    want = _ref_conv(x.to(d), wt.to(d), sc.to(d), sh.to(d), 1, True, None if res is None else res.to(d), None, 0)
-    nhwc = lambda v: v.permute(0, 2, 3, 1).contiguous().to(dev)
-    kw = dict(relu=True, res1=None if res is None else nhwc(res))
-    base = ops.fused_conv_p2(nhwc(x), wt.to(dev), sc.to(dev), sh.to(dev), **kw).permute(0, 3, 1, 2).cpu()
-    monkeypatch.setenv("MVAL_P2_WIDE", "1")
-    got = ops.fused_conv_p2(nhwc(x), wt.to(dev), sc.to(dev), sh.to(dev), **kw)
-    kept = ops.fused_conv_p2.last.kept_amax().cpu()
-    got = got.permute(0, 3, 1, 2).cpu()
-    np.testing.assert_allclose(got.numpy(), want.float().numpy(), rtol=1e-4, atol=3e-5)
-    assert torch.allclose(kept, got.abs().amax(dim=(1, 2, 3)), rtol=2.0**-21, atol=0)
-    rms = lambda y: (y.double() - want).pow(2).mean().sqrt().item()
-    assert rms(got) <= 1.25 * rms(base) + 1e-8 and float((got - base).abs().max()) <= 2e-5 * float(want.abs().max())
-    assert not torch.equal(got, base) or cin * 9 <= 32  # (a different accumulation order: the wide form really ran)
-
-
 @pytest.mark.parametrize("shape", [(3, 32, 64, 64), (2, 64, 32, 32), (2, 32, 21, 37), (1, 64, 9, 16), (5, 32, 8, 16), (2, 64, 24, 40), (2, 32, 96, 72)],
                          ids=lambda s: "n%d_c%d_%dx%d" % s)
 def test_p2_basic_block_vs_float64(dev, shape):
@@ -390,38 +360,6 @@ def test_p2_plan_structure(dev, monkeypatch):
     with torch.no_grad():
         mr(xr)
     assert not engine._plan_for(mr, xr).p2
-
-
-@pytest.mark.parametrize("name", ["w32", "w48"])
-def test_p2_first_level_stride2_convs_in_one_launch(dev, monkeypatch, name):
-    """hrnet.py:398-423: the stride-2 convs that start a fuse layer's down-sampling chains from branch 0 (32 -> 64 and one or two
-    32 -> 32; HRNet-W48: 48 -> 96, 48 -> 48) are ONE launch of conv_p2_multi_kernel in the P2 plan -- 6 groups (4 of two, 2 of
-    three convs), their followers' own launches no-ops, the followers' lanes waiting for the group -- and the heat-maps are
-    bit-identical to the plan that launches them one by one (the default): every wave runs the single-conv body on its conv's arguments."""
-    from multi_view_active_learning_amd import engine
-
-    monkeypatch.setenv("MVAL_CONV", "p2")
-    monkeypatch.setenv("MVAL_P2_S2_MULTI", "1")  # (opt-in: beside each other on their lanes the separate launches make the faster STEP)
-    c = cases.model_cases()[name]
-    m, _ = _load(c, dev)
-    x = torch.from_numpy(cases.model_input(c)).to(dev)
-    with torch.no_grad():
-        got = m(x).clone()
-    plan = engine._plan_for(m, x)
-    assert plan.p2
-    heads = [i for i, o in enumerate(plan.ops) if o.multi_n >= 2]
-    assert sorted(plan.ops[i].multi_n for i in heads) == [2, 2, 2, 2, 3, 3]
-    for i in heads:
-        grp = [plan.ops[i + k] for k in range(plan.ops[i].multi_n)]
-        assert all(o.multi_n == -1 for o in grp[1:]) and len({o.in_off for o in grp}) == 1
-        assert all(o.kind == engine.OP_CONV and o.k == 3 and o.stride == 2 for o in grp)
-        assert len({o.phase for o in grp}) == 1 and len({o.lane for o in grp}) == len(grp)  # one launch on the head's lane, the others wait
-    m._plans.clear()
-    monkeypatch.setenv("MVAL_P2_S2_MULTI", "0")
-    with torch.no_grad():
-        want = m(x).clone()
-    assert not any(o.multi_n for o in engine._plan_for(m, x).ops)
-    assert torch.equal(got, want)
 
 
 def _report(name, obj):

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """P2 conv kernels (csrc/conv_p2.hip): correctness against float64 torch-CPU next to the fp16-split NHWC kernel, and
 launch times of the HRNet-W32 layer shapes next to that kernel's, in one process.
-usage: p2_sweep.py [check|time|all] [n_images=128] [reps=50]   (MVAL_P2_TILE=ms,nt,g overrides the tile choice)"""
+usage: p2_sweep.py [check|time|all] [n_images=128] [reps=50]   (MVAL_P2_TILE=ms,nt,g overrides the tile choice in a -DP2_TUNE measurement build: MVAL_BUILD_TAG=tune MVAL_EXTRA_CFLAGS=-DP2_TUNE python -m multi_view_active_learning_amd.build, then MVAL_LIB_TAG=tune)"""
 import ctypes as C
 import os
 import sys

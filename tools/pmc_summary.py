@@ -18,7 +18,25 @@ import json
 import sys
 
 
+def demangle(n):
+    """_Z22bn_apply_fwd_p2_kernelPKf... -> bn_apply_fwd_p2_kernel ; _Z23bn_bwd_apply2_p2_kernelILi3EEv... -> bn_bwd_apply2_p2_kernel<3> (rocprofv3 leaves
+    some kernel names mangled; the Itanium prefix is all that is needed here)"""
+    import re
+
+    m = re.match(r"_Z(\d+)", n)
+    if not m:
+        return n
+    ln = int(m.group(1))
+    base = n[m.end(): m.end() + ln]
+    rest = n[m.end() + ln:]
+    t = re.match(r"I((?:L[a-z]-?\d+E)+)E", rest)
+    if t:
+        base += "<" + ", ".join(re.findall(r"L[a-z](-?\d+)E", t.group(1))) + ">"
+    return base
+
+
 def fam(n):
+    n = demangle(n)
     return ("conv_block_p2_kernel" if "conv_block_p2" in n else "conv_bneck_p2_kernel" if "conv_bneck_p2" in n else
             "conv_stem_p2_kernel" if "conv_stem_p2" in n else "conv_fuse_up_p2_kernel" if "conv_fuse_up_p2" in n else
             "conv_p2_kernel" if "conv_p2" in n else
@@ -29,7 +47,7 @@ def fam(n):
 
 def inst(n):
     """kernel name with its template arguments, without the parameter list"""
-    n = n.split("(")[0]
+    n = demangle(n).split("(")[0]
     return n[5:] if n.startswith("void ") else n
 
 
