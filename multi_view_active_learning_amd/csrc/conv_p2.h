@@ -178,6 +178,15 @@ struct P2Args {
   int N, Hin, Win, Cin, Hout, Wout, Cout;  // Hout / Wout before the fused upsample
   int k, stride;
   int up, relu;
+  // (round 5) k == 2: one PARITY of a transposed conv / of a stride-2 conv's data gradient (four 2 x 2 stride-1 convs over the input grid,
+  // conv_mfma_split.hip's pack modes 3 / 4): the window of output pixel (y, x) covers input rows y - pad_y .. y - pad_y + 1 (pad_y = 1 - py;
+  // columns alike), Hout x Wout = the INPUT grid, and with os = 1 the result goes to pixel (2 y + oy, 2 x + ox) of a (2 Hout) x (2 Wout)
+  // tensor (P2 planes or the fp32 NHWC slot).  The four launches of a tensor share its rows: slot_base / slot_total give each its share
+  // of the partial-maximum slots, keep_rows != 0 stops the launcher from zeroing rows an earlier parity has already written.
+  int pad_y, pad_x, os, oy, ox, slot_base, slot_total, keep_rows;
+  // in_sub = 1 (k == 1): the conv reads every second pixel of its input (a stride-2 1 x 1 conv as a stride-1 one over the sub-sampled view:
+  // pose_resnet.py's downsample branches); Hin / Win stay the full input size, Hout / Wout = ceil(Hin / 2), ceil(Win / 2)
+  int in_sub;
   int th, tw, tiles_x, tiles_y;
   int NS_total;
   int amax_tiles;
@@ -190,6 +199,7 @@ int mval_launch_conv_p2(const P2Args& a, hipStream_t s);  // conv_p2.hip; 1 = un
 int mval_launch_nhwc_to_p2(const float* x, const unsigned* rows_in, _Float16* planes, unsigned* rows, int n_images, int HW, int C,
                             hipStream_t s);
 int mval_conv_p2_supported(int k, int stride, int cin, int cout, int hin, int win, int up, int out_nchw, int n);
+int mval_conv_p2_parity_supported(int cin, int cout, int h, int w, int n, int nhwc_out);  // one parity conv (k 2) over an h x w grid
 
 // conv_block_p2.hip: a whole BasicBlock over P2 activations in one launch; 1 = unsupported
 int mval_conv_block_p2_supported(int C, int N, int H, int W);

@@ -116,7 +116,8 @@ template <int KS, int S, int G, int WN, int WM, int NT, int MS, int TW, bool RS,
 __device__ __forceinline__ void conv_p2_body(const P2Args& a, const int by, const int gy) {
   static_assert(!K48 || (RS && G == 1), "K48: the row-sharing 3x3 kernels");
   constexpr int NTH = 64 * WN * WM, TAPS = KS * KS, SPN = 8 * G, SPN_LOG2 = G == 1 ? 3 : G == 2 ? 4 : 5;
-  constexpr int pad = KS / 2;
+  static_assert(KS == 1 || KS == 2 || KS == 3, "kernel size");
+  static_assert(KS != 2 || (S == 1 && !RS && (EPI == 0 || EPI == 3)), "parity convs: stride 1, no row sharing, planes or fp32 NHWC out");
   static_assert(G == 1 || G == 2 || G == 4, "chunks per stage");
   static_assert(!RS || (KS == 3 && S == 1 && G == 1), "row sharing is for 3x3 stride 1");
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -204,13 +205,15 @@ __device__ __forceinline__ void conv_p2_body(const P2Args& a, const int by, cons
     lp[i] = py < PH ? ((unsigned)((sp * PPX + slot) * 16) << 16) | (c8 << 12) | (py << 7) | px : 127u;
     cb[i] = (unsigned)(pl * C8 + c8) * hw16;
   }
+  const int pad_y = KS == 2 ? a.pad_y : KS / 2, pad_x = KS == 2 ? a.pad_x : KS / 2;  // (KS 2: a parity conv's window origin)
+  const int isub = KS == 1 ? a.in_sub : 0;                                             // (KS 1: every 2^isub-th input pixel)
   auto plan = [&](int n, int oy0, int ox0) {
-    const int iy0 = oy0 * S - pad, ix0 = ox0 * S - pad;
+    const int iy0 = oy0 * S - pad_y, ix0 = ox0 * S - pad_x;
     const unsigned nbase = (unsigned)n * 2u * (unsigned)C8 * hw16;
 #pragma unroll
     for (int i = 0; i < NE; i++) {
       const int px = lp[i] & 127, py = (lp[i] >> 7) & 31;
-      const int iy = iy0 + py, ix = ix0 + px;
+      const int iy = (iy0 + py) << isub, ix = (ix0 + px) << isub;
       const bool inb = px != 127 && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
       goff[i] = inb ? nbase + cb[i] + (unsigned)(iy * a.Win + ix) * 16u : 0xffffffffu;
     }
@@ -275,15 +278,16 @@ __device__ __forceinline__ void conv_p2_body(const P2Args& a, const int by, cons
   // output / residual planes through buffer descriptors: per tile ONE per-lane 32-bit byte offset (+ a scalar offset per
   // pixel sub-tile); lanes outside the image or past Cout get offset 2^31 and the range check drops them -- the
   // epilogue has no branches and no 64-bit address arithmetic (the tensors are below 2^31 bytes: the launcher checks)
-  const unsigned obytes = (a.out_f32 || EPI == 3) ? 0u : (unsigned)((int64_t)a.N * (a.Cout >> 3) * (a.Hout << a.up) * (a.Wout << a.up) * 32);
-  const __amdgpu_buffer_rsrc_t zr = __builtin_amdgcn_make_buffer_rsrc(a.out_nhwc, 0, EPI == 3 ? (unsigned)((int64_t)a.N * a.Hout * a.Wout * a.Cout * 4) : 0u, 0x00020000);
+  const int osh = (EPI == 0 || EPI == 3) ? a.os : 0;  // (parity launches: the conv grid lands on every second pixel of the output)
+  const unsigned obytes = (a.out_f32 || EPI == 3) ? 0u : (unsigned)(((int64_t)a.N * (a.Cout >> 3) * (a.Hout << a.up) * (a.Wout << a.up) * 32) << (2 * osh));
+  const __amdgpu_buffer_rsrc_t zr = __builtin_amdgcn_make_buffer_rsrc(a.out_nhwc, 0, EPI == 3 ? (unsigned)(((int64_t)a.N * a.Hout * a.Wout * a.Cout * 4) << (2 * osh)) : 0u, 0x00020000);
   const __amdgpu_buffer_rsrc_t orr = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, obytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t r1r = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(a.res1), 0, a.res1 ? obytes : 0u, 0x00020000);
   const __amdgpu_buffer_rsrc_t r2r = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(a.res2), 0, a.res2 ? obytes : 0u, 0x00020000);
   // lane -> (row, column) inside a 16-pixel sub-tile, and the sub-tile's own (row, column) inside the tile
   const int ly = OW ? 0 : TW == 8 ? (lane >> 3) & 1 : 0, lx = OW ? 0 : TW == 8 ? lane & 7 : lane & 15;
   const float bound_a = (a.out_f32 || EPI == 3) ? 0.f : a.bound[0], bound_b = (a.out_f32 || EPI == 3) ? 0.f : a.bound[1];
-  const int Ho = a.Hout << a.up, Wo = a.Wout << a.up, rep = 1 << a.up;
+  const int Ho = (a.Hout << a.up) << osh, Wo = (a.Wout << a.up) << osh, rep = 1 << a.up;
   const int C8o = a.Cout >> 3;
   const int64_t oplane = (int64_t)C8o * Ho * Wo * 8;  // halves per plane of one image
   // odd tiles: the lane's pixel of sub-tile ms -> its row inside the tile (-1: padding slot) and its byte offset from the
@@ -295,7 +299,7 @@ __device__ __forceinline__ void conv_p2_body(const P2Args& a, const int by, cons
       const int p = (wm * MS + ms) * 16 + (lane & 15);
       const int ty = p / TWE, tx = p - ty * TWE;
       opty[ms] = ty < TH ? ty : -1;
-      opix[ms] = EPI == 3 ? tx : (ty * Wo + tx) * 16;
+      opix[ms] = EPI == 3 ? tx : ((ty << osh) * Wo + (tx << osh)) * 16;
     }
   }
 
@@ -481,7 +485,8 @@ __device__ __forceinline__ void conv_p2_body(const P2Args& a, const int by, cons
 #pragma unroll
     for (int nt = 0; nt < NT; nt++) {
       const int c0 = (ns0 + nt) * 16 + cq;
-      vb[nt] = c0 < a.Cout ? (unsigned)n * 2u * plane_bytes + (lane >= 32 ? plane_bytes : 0u) + (unsigned)(((c0 >> 3) * Ho + yl) * Wo + xl) * 16u
+      vb[nt] = c0 < a.Cout ? (unsigned)n * 2u * plane_bytes + (lane >= 32 ? plane_bytes : 0u) +
+                                 (unsigned)(((c0 >> 3) * Ho + (yl << osh) + (osh ? a.oy : 0)) * Wo + (xl << osh) + (osh ? a.ox : 0)) * 16u
                            : 0x80000000u;
     }
     // pixel sub-tile ms of the wave: its first row / column inside the tile (uniform)
@@ -491,7 +496,7 @@ __device__ __forceinline__ void conv_p2_body(const P2Args& a, const int by, cons
       if constexpr (OW > 0) return (opty[ms] >= 0 && oy0 + opty[ms] < a.Hout && vb[nt] != 0x80000000u) ? vb[nt] + (unsigned)opix[ms] : 0x80000000u;
       else return (yl + sub_ty(ms) < a.Hout && xl + sub_tx(ms) < a.Wout) ? vb[nt] : 0x80000000u;
     };
-    auto soff = [&](int ms) -> int { return OW ? 0 : (sub_ty(ms) * Wo + sub_tx(ms)) * 16; };
+    auto soff = [&](int ms) -> int { return OW ? 0 : (((sub_ty(ms) << osh) * Wo + (sub_tx(ms) << osh)) * 16); };
     if (wave_active) {
       p2_row_request(a.in_row, n, row_in);
       if (a.res1) p2_row_request(a.res1_row, n, row_r1);
@@ -611,7 +616,7 @@ __device__ __forceinline__ void conv_p2_body(const P2Args& a, const int by, cons
             bool ok;
             if constexpr (OW > 0) {
               y = oy0 + opty[ms];
-              x = opix[ms];
+              x = ox0 + opix[ms];  // (round 5 fix: a map of several odd tiles per row -- 36 = 2 x 18, 24 = 2 x 12 -- lost the tile's column origin here)
               ok = opty[ms] >= 0 && y < a.Hout;
             } else {
               y = yl + sub_ty(ms);
@@ -619,7 +624,8 @@ __device__ __forceinline__ void conv_p2_body(const P2Args& a, const int by, cons
               ok = y < a.Hout && x < a.Wout;
             }
             ok = ok && c0 < a.Cout;
-            zo[ms][nt] = ok ? (unsigned)((((unsigned)n * a.Hout + y) * a.Wout + x) * a.Cout + c0) * 4u : 0x80000000u;
+            zo[ms][nt] = ok ? (unsigned)((((unsigned)n * (a.Hout << osh) + (y << osh) + (osh ? a.oy : 0)) * (a.Wout << osh) + (x << osh) + (osh ? a.ox : 0)) * a.Cout + c0) * 4u
+                            : 0x80000000u;
             if (a.acc_nhwc) ex[ms][nt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(zr, zo[ms][nt], 0, 0));
           }
         }
@@ -730,7 +736,7 @@ __device__ __forceinline__ void conv_p2_body(const P2Args& a, const int by, cons
           const unsigned m = atomicExch(&wgred[0], 0u);
           wgred[1] = 0u;
           const int timg = (oy0 / TH) * a.tiles_x + ox0 / TWE;
-          p2_slot_put(a.out_row + (int64_t)n * P2_ROW, timg * gy + by, tiles_img * gy, m);
+          p2_slot_put(a.out_row + (int64_t)n * P2_ROW, a.slot_base + timg * gy + by, a.slot_total ? a.slot_total : tiles_img * gy, m);
         }
       }
     }
@@ -772,6 +778,10 @@ static int launch_p2e(P2Args a, hipStream_t s) {
   if (OW && a.Wout % OW != 0) return 1;  // (whole odd tiles per row: 18 -> 1, 36 -> 2 tiles of 18 columns)
   const unsigned groups = (unsigned)((a.NS_total + WN * NT - 1) / (WN * NT));
   a.amax_tiles = a.tiles_x * a.tiles_y;
+  if (a.os && EPI < 2) {  // a parity launch: its quarter of the output rows' partial-maximum slots
+    a.slot_total = 4 * a.amax_tiles * (int)groups;
+    a.slot_base = (a.oy * 2 + a.ox) * a.amax_tiles * (int)groups;
+  }
   a.tiles_total = a.amax_tiles * a.N;
   a.tiles_img_magic = a.amax_tiles > 1 ? (unsigned)(((uint64_t)1 << 32) / (unsigned)a.amax_tiles + 1) : 0u;  // (0: divide by one)
   a.tiles_x_magic = a.tiles_x > 1 ? (unsigned)(((uint64_t)1 << 32) / (unsigned)a.tiles_x + 1) : 0u;
@@ -799,7 +809,7 @@ static int launch_p2e(P2Args a, hipStream_t s) {
   }
   a.wgs_x = wgs;
   dim3 grid((unsigned)wgs, groups);
-  if (EPI < 2 && (int64_t)a.amax_tiles * groups > P2_SLOTS)
+  if (EPI < 2 && (a.slot_total ? a.slot_total : (int64_t)a.amax_tiles * groups) > P2_SLOTS && !a.keep_rows)
     mval_launch_zero_rows(a.out_row, (int64_t)a.N * P2_ROW, s);  // (the kernel rewrites the scale slots)
   if constexpr (EPI == 3) {
     a.bn_slots = wgs * WM;
@@ -860,6 +870,10 @@ int mval_launch_conv_p2(const P2Args& a0, hipStream_t s) {
       // (36-wide maps -- HRNet-W48's 96-channel branch -- as two 18-wide odd tiles per row: 54 of 64 slots used against 36 of 48 columns
       // of three 16-wide row-sharing tiles: 84 -> 78 us for 96 -> 96 on 48 x 36)
       if (a.Wout == 18 || a.Wout == 36) return launch_p2<3, 1, 1, 4, 1, 1, 4, 8, false, 18>(a, s);
+      // (round 5: PoseResNet at 256 x 192 -- 16 x 12 / 32 x 24 maps in 8 x 12-pixel tiles (six sub-tiles per wave), 8 x 6 maps whole (three):
+      // every slot a pixel, where 8-wide tiles compute 16 columns for 12 and 5 x 12 tiles 20 rows for 16)
+      if ((a.Wout == 12 || a.Wout == 24) && a.Hout % 8 == 0) return launch_p2<3, 1, 1, 4, 1, 1, 6, 8, false, 12>(a, s);
+      if (a.Wout == 6 && a.Hout % 8 == 0) return launch_p2<3, 1, 1, 4, 1, 1, 3, 8, false, 6>(a, s);
       // (9-wide odd tiles on the 72-wide maps -- 63 of 64 slots -- measured slower than the 16-wide row-sharing tiles: 105 vs 103 us)
       if (a.Wout == 9) return launch_p2<3, 1, 1, 4, 1, 1, 4, 8, false, 9>(a, s);
     }
@@ -875,7 +889,9 @@ int mval_launch_conv_p2(const P2Args& a0, hipStream_t s) {
       if (ont == 2) return launch_p2<3, 1, 1, 4, 1, 2, 4, 16, true>(a, s);
       return launch_p2<3, 1, 1, 4, 1, 1, 4, 16, true>(a, s);
     }
-    if (a.Wout >= 8 && a.Hout >= 8) {
+    // (round 5: also maps narrower than a tile -- PoseResNet's 8 x 6 layer4 at 256 x 192 inputs: one 8 x 8 tile per image, a quarter of its
+    // columns outside the map; staging zero-fills them, the stores mask them)
+    if (a.Wout >= 4 && a.Hout >= 4) {
       if (a.NS_total <= 2) return launch_p2<3, 1, 1, 2, 2, 1, 2, 8>(a, s);
       if (ont == 2) return launch_p2<3, 1, 1, 4, 1, 2, 4, 8>(a, s);
       return launch_p2<3, 1, 1, 4, 1, 1, 4, 8>(a, s);
@@ -883,7 +899,7 @@ int mval_launch_conv_p2(const P2Args& a0, hipStream_t s) {
     return 1;
   }
   if (a.k == 3 && a.stride == 2) {
-    if (a.Wout < 8 || a.Hout < 4) return 1;
+    if (a.Wout < 4 || a.Hout < 4) return 1;
     const int ms = oms ? oms : 2;
     if (a.NS_total <= 2) return launch_p2<3, 2, 1, 2, 2, 1, 1, 8>(a, s);  // (8 x 8 tiles instead of 4 x 8: no change, 36.8 vs 36.2 us)
     // (16-wide tiles measured the same or slower: 2 x 16 px 34.0 / 24.8 / 22.2 us on 32 -> 64 / 64 -> 128 / 128 -> 256 against
@@ -891,8 +907,34 @@ int mval_launch_conv_p2(const P2Args& a0, hipStream_t s) {
     if (ms == 4) return launch_p2<3, 2, 1, 4, 1, 1, 4, 8>(a, s);
     return launch_p2<3, 2, 1, 4, 1, 1, 2, 8>(a, s);
   }
+  if (a.k == 2 && a.stride == 1) {
+    // one parity of a transposed conv / of a stride-2 data gradient (P2Args.pad_y ...): plain 64-pixel tiles, 8 or 16 wide
+    if (a.up || a.out_f32 || a.res1 || a.res2 || a.Hout != a.Hin || a.Wout != a.Win || (unsigned)a.pad_y > 1u || (unsigned)a.pad_x > 1u ||
+        (unsigned)a.os > 1u)
+      return 1;
+    if (a.Wout < 4 || a.Hout < 4) return 1;
+    if (a.Wout == 12 && a.Hout % 8 == 0 && a.NS_total > 2) return launch_p2<2, 1, 1, 4, 1, 1, 6, 8, false, 12>(a, s);
+    if (a.Wout == 6 && a.Hout % 8 == 0 && a.NS_total > 2) return launch_p2<2, 1, 1, 4, 1, 1, 3, 8, false, 6>(a, s);
+    if ((((int64_t)a.N * a.Hout * a.Wout * a.Cout) << (2 * a.os)) >= (int64_t)1 << 29) return 1;
+    if (a.Wout >= 16 && a.Wout % 16 == 0) {
+      if (a.NS_total <= 2) return launch_p2<2, 1, 1, 2, 2, 1, 2, 16>(a, s);
+      return launch_p2<2, 1, 1, 4, 1, 1, 4, 16>(a, s);
+    }
+    if (a.NS_total <= 2) return launch_p2<2, 1, 1, 2, 2, 1, 2, 8>(a, s);
+    return launch_p2<2, 1, 1, 4, 1, 1, 4, 8>(a, s);
+  }
+  if (a.k == 1 && a.stride == 2 && !a.in_sub) {  // (pose_resnet.py's downsample branches) a stride-1 1x1 conv over every second input pixel
+    a.in_sub = 1;
+    a.stride = 1;
+  }
   if (a.k == 1 && a.stride == 1) {
-    if (a.Wout < 8 || a.Hout * a.Wout < 64) return 1;
+    if (a.Wout < 4 || a.Hout * a.Wout < 32) return 1;
+    // (round 5) a 1 x 1 stride-1 conv has no halo and its planes are flat in the pixel index: maps whose width fills no power-of-two tile
+    // (PoseResNet's 48 / 24 / 12 / 6 columns, HRNet-W48's 72 / 36 / 18 / 9) run as ONE row of H * W pixels in 64-pixel tiles
+    if (!a.up && !a.in_sub && !oms && (a.Wout & 63) != 0 && a.Hout > 1 && a.Hout * a.Wout >= 64 && a.Hin == a.Hout && a.Win == a.Wout) {
+      a.Wout = a.Win = a.Hout * a.Wout;
+      a.Hout = a.Hin = 1;
+    }
     const int g = og ? og : 2;
     const int ms = oms ? oms : 4;
     const int nt = ont ? ont : ((a.NS_total % 8 == 0 && ((px + 63) / 64) * (a.NS_total / 8) >= 1024) ? 2 : 1);
@@ -911,6 +953,17 @@ int mval_launch_conv_p2(const P2Args& a0, hipStream_t s) {
 #undef P2_1X1
   }
   return 1;
+}
+
+int mval_conv_p2_parity_supported(int cin, int cout, int h, int w, int n, int nhwc_out) {
+  P2Args a = {};
+  a.k = 2; a.stride = 1; a.os = 1;
+  a.Cin = cin; a.Cout = cout; a.Hin = a.Hout = h; a.Win = a.Wout = w; a.N = n;
+  a.out_nhwc = nhwc_out ? reinterpret_cast<float*>(1) : nullptr;
+  g_p2_dry = 1;
+  const int rc = mval_launch_conv_p2(a, nullptr);
+  g_p2_dry = 0;
+  return rc == 0;
 }
 
 int mval_conv_p2_supported(int k, int stride, int cin, int cout, int hin, int win, int up, int out_nchw, int n) {

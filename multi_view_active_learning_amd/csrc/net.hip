@@ -354,9 +354,15 @@ extern "C" int mval_op_algo_supported(const mval_op* op, int n_images, int algo)
            !op->up && !op->in_nchw && !op->out_nchw && op->hin == op->hout && op->win == op->wout &&
            mval_conv_block_supported(op->cin, n_images, op->hin, op->win);
   if (algo == MVAL_ALGO_MFMA) return mval_op_mfma_supported(op, n_images);
-  if (algo == MVAL_ALGO_MFMA_P2)
+  if (algo == MVAL_ALGO_MFMA_P2) {
+    // (round 5) ConvTranspose2d(k4, s2, p1) = four 2 x 2 parity convs over the input grid, each scattered to its parity of the output planes
+    if (op && op->kind == MVAL_OP_DECONV)
+      return n_images > 0 && !op->in_nchw && !op->out_nchw && !op->up && op->k == 4 && op->stride == 2 && op->pad == 1 && (op->cin & 7) == 0 &&
+             (op->cout & 7) == 0 && op->hout == 2 * op->hin && op->wout == 2 * op->win && op->res1_off < 0 && op->res2_off < 0 &&
+             mval_conv_p2_parity_supported(op->cin, op->cout, op->hin, op->win, n_images, 0);
     return op && op->kind == MVAL_OP_CONV && n_images > 0 && !op->in_nchw && op->pad == op->k / 2 &&
            mval_conv_p2_supported(op->k, op->stride, op->cin, op->cout, op->hin, op->win, op->up, op->out_nchw, n_images);
+  }
   if ((algo != MVAL_ALGO_MFMA_BF3 && algo != MVAL_ALGO_MFMA_H2) || !op || n_images <= 0) return 0;
   if (op->kind != MVAL_OP_CONV && op->kind != MVAL_OP_DECONV) return 0;
   ConvArgs a = {};
@@ -496,14 +502,14 @@ static int op_launch(const mval_op* op, int n_images, float* workspace, const fl
   if (op->algo == MVAL_ALGO_MFMA_P2) {
     auto p2_args = [&](const mval_op* o, P2Args& p) -> int {
       const float* w = o->w_off >= 0 ? params + o->w_off : nullptr;
-      MVAL_REQUIRE(o->kind == MVAL_OP_CONV && w && o->scale_off >= 0 && o->shift_off >= 0 && o->in_amax_off > 0 && o->in_off >= 0 &&
+      MVAL_REQUIRE((o->kind == MVAL_OP_CONV || o->kind == MVAL_OP_DECONV) && w && o->scale_off >= 0 && o->shift_off >= 0 && o->in_amax_off > 0 && o->in_off >= 0 &&
                        (o->out_nchw || (o->out_amax_off > 0 && o->bound_off >= 0)) &&
                        (o->res1_off < 0 || o->res1_amax_off > 0) && (o->res2_off < 0 || o->res2_amax_off > 0),
                    "mval_op_launch: malformed MVAL_ALGO_MFMA_P2 op");
       p = {};
       p.in = reinterpret_cast<const _Float16*>(workspace + o->in_off);
       p.w = w;
-      p.w_unscale = w + mval_packed_weight_floats(MVAL_PACK_MFMA16_H2, o->cout, o->cin, o->k) - 4;
+      p.w_unscale = w + mval_packed_weight_floats(MVAL_PACK_MFMA16_H2, o->cout, o->cin, o->k) - 4;  // (a transposed conv: k = 4, all 16 taps)
       p.scale = params + o->scale_off; p.shift = params + o->shift_off;
       p.bound = o->bound_off >= 0 ? params + o->bound_off : nullptr;
       p.res1 = o->res1_off >= 0 ? reinterpret_cast<const _Float16*>(workspace + o->res1_off) : nullptr;
@@ -526,6 +532,25 @@ static int op_launch(const mval_op* op, int n_images, float* workspace, const fl
     P2Args p2;
     int rc = p2_args(op, p2);
     if (rc) return rc;
+    if (op->kind == MVAL_OP_DECONV) {
+      // pose_resnet.py:107-137: output pixel (2a + py, 2b + px) sees 2 x 2 taps of the 4 x 4 kernel (pack mode 3: parity pp's taps are the
+      // pp-th quarter of the packed buffer), input rows a - 1 + py .. a + py: four stride-1 convs over the input grid, each written to its
+      // parity of the output planes; the launches share the output's rows (one scale from the one bound, a quarter of the slots each)
+      const size_t quarter = (mval_packed_weight_floats(MVAL_PACK_MFMA16_H2, op->cout, op->cin, 4) & ~(size_t)7) / 4;
+      for (int pp = 0; pp < 4; pp++) {
+        P2Args q = p2;
+        q.k = 2; q.stride = 1;
+        q.Hout = op->hin; q.Wout = op->win;
+        q.pad_y = 1 - (pp >> 1); q.pad_x = 1 - (pp & 1);
+        q.os = 1; q.oy = pp >> 1; q.ox = pp & 1;
+        q.keep_rows = pp != 0;
+        q.w = p2.w + pp * quarter;
+        rc = mval_launch_conv_p2(q, s);
+        MVAL_REQUIRE(rc == 0, "mval_op_launch: no P2 kernel for a parity of the transposed conv cin%d cout%d %dx%d", op->cin, op->cout, op->hin, op->win);
+      }
+      MVAL_CHECK_LAUNCH("mval_op_launch/p2 deconv");
+      return 0;
+    }
     rc = mval_launch_conv_p2(p2, s);
     MVAL_REQUIRE(rc == 0, "mval_op_launch: no P2 kernel for conv k%d s%d cin%d cout%d %dx%d", op->k, op->stride, op->cin, op->cout, op->hin, op->win);
     MVAL_CHECK_LAUNCH("mval_op_launch/p2");

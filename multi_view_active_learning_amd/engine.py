@@ -201,7 +201,7 @@ class InferencePlan:
                         if lib.mval_op_algo_supported(C.byref(m), C.c_int(n), C.c_int(split)):
                             m.algo = split
                             break
-            if self.p2 and op.src != g.input:
+            if self.p2 and op.src != g.input and op.kind != "maxpool":
                 m.algo = ALGO_MFMA_P2
             m.in_off = -1 if op.src == g.input else offset[op.src]
             m.out_off = -1 if op.dst == g.output else offset[op.dst]
@@ -259,13 +259,25 @@ class InferencePlan:
         if os.environ.get("MVAL_P2", "1") == "0":
             return False
         stems = 0
+        stem_dst = None
         for op, (hin, win, hout, wout) in zip(g.ops, geo):
             if op.src == g.input:
                 stems += 1
+                stem_dst = op.dst
                 if op.kind != "conv" or op.cout % 8 or op.res1 is not None or op.res2 is not None or op.up:
                     return False
                 continue
-            if op.kind != "conv" or g.acts[op.src].layout == "nchw":
+            if op.kind == "maxpool":
+                # (round 5: PoseResNet, pose_resnet.py:35) a max-pool directly behind the stem runs on the stem's fp32 NHWC output, before
+                # the change to planes; anywhere else there is no P2 kernel for it
+                if op.src != stem_dst or op.cout % 8 or sum(1 for o in g.ops if stem_dst in (o.src, o.res1, o.res2)) != 1:
+                    return False
+                continue
+            if op.kind not in ("conv", "deconv") or g.acts[op.src].layout == "nchw":
+                return False
+            # a transposed conv is four parity launches of persistent workgroups: on a few images (BASELINE configs[0]: 8) the h2 plan's
+            # one launch with small tiles is ahead (1.55 vs 1.68 ms), from ~32 images on the P2 plan (C1 x 16: 7.2 vs 7.8 ms)
+            if op.kind == "deconv" and n < 32 and os.environ.get("MVAL_P2") != "force":
                 return False
             # HRNet-W48 (48- / 96-channel branches: half-empty second K chunk; 24 x 18 and 12 x 9 maps) ran SLOWER on P2 than on
             # the h2 kernels through round 3 (C4 24.8 vs 22.4 ms); with round 4's full-width odd tiles (conv_p2.hip OW) and the
@@ -273,7 +285,9 @@ class InferencePlan:
             if op.cin % 32 and os.environ.get("MVAL_P2_W48", "1") == "0" and os.environ.get("MVAL_P2") != "force":
                 return False
             m = MvalOp()
-            m.kind, m.algo = OP_CONV, ALGO_MFMA_P2
+            m.kind, m.algo = _KIND[op.kind], ALGO_MFMA_P2
+            m.res1_off = -1 if op.res1 is None else 0
+            m.res2_off = -1 if op.res2 is None else 0
             m.k, m.stride, m.pad, m.cin, m.cout = op.k, op.stride, op.pad, op.cin, op.cout
             m.hin, m.win, m.hout, m.wout = hin, win, hout, wout
             m.up, m.relu, m.out_nchw = op.up, int(op.relu), int(g.acts[op.dst].layout == "nchw")
@@ -332,11 +346,30 @@ class InferencePlan:
                 self._amax_top += n * AMAX_ROW
                 m.out_off, m.out_amax_off = stem_off, stem_rows
                 launch.append(m)
+                last, src_off, src_rows = op, stem_off, stem_rows
+                b = g.ops[i + 1] if i + 1 < len(g.ops) else None
+                if b is not None and b.kind == "maxpool" and b.src == op.dst:
+                    # pose_resnet.py:35: the max-pool reads the stem's fp32 NHWC output and writes fp32 NHWC (a quarter of the pixels);
+                    # the change to planes follows it (the stem's own rows are not needed then)
+                    mp = MvalOp()
+                    C.memmove(C.byref(mp), C.byref(self.graph_ops[i + 1]), C.sizeof(MvalOp))
+                    hp, wp = dims[b.dst]
+                    mp.in_off = stem_off
+                    mp.out_off = self._amax_top
+                    self._amax_top += _align(n * hp * wp * b.cout)
+                    mp.out_amax_off = self._amax_top
+                    self._amax_top += n * AMAX_ROW
+                    m.out_amax_off = 0
+                    launch[-1] = m
+                    launch.append(mp)
+                    last, src_off, src_rows = b, mp.out_off, mp.out_amax_off
+                    ho, wo = hp, wp
+                    i += 1
                 t = MvalOp()
                 t.kind, t.algo = OP_TO_P2, ALGO_MFMA_P2
-                t.hin, t.win, t.cin, t.hout, t.wout, t.cout = ho, wo, op.cout, ho, wo, op.cout
-                t.in_off, t.in_amax_off = stem_off, stem_rows
-                t.out_off, t.out_amax_off = offset[op.dst], row_of[op.dst]
+                t.hin, t.win, t.cin, t.hout, t.wout, t.cout = ho, wo, last.cout, ho, wo, last.cout
+                t.in_off, t.in_amax_off = src_off, src_rows
+                t.out_off, t.out_amax_off = offset[last.dst], row_of[last.dst]
                 t.res1_off = t.res2_off = t.w_off = t.scale_off = t.shift_off = -1
                 t.phase, t.lane = m.phase, m.lane
                 launch.append(t)
@@ -552,7 +585,14 @@ class InferencePlan:
             gm = self.graph_ops[i]
             if gm.algo == ALGO_MFMA_P2 or (self.p2 and op.src == self.graph.input):
                 # [A, B] of the output bound |bn(conv(x))| <= A max|x| + B (csrc/conv_p2.h): A = max_c |scale_c| sum |w_c|
-                a_ = (w.abs().double().sum(dim=(1, 2, 3)) * self.params[s_off : s_off + op.cout].abs().double()).max() * (1.0 + 1e-6)
+                if op.kind == "deconv":
+                    # ConvTranspose2d weights are (cin, cout, 4, 4) and an output pixel of parity (py, px) sees the taps ky in {3 - py, 1 - py},
+                    # kx alike (conv_mfma_split.hip pack mode 3): per cout the largest of the four parities' sums
+                    wa = w.abs().double()
+                    sw = torch.stack([wa[:, :, [3 - py, 1 - py]][:, :, :, [3 - px, 1 - px]].sum(dim=(0, 2, 3)) for py in (0, 1) for px in (0, 1)]).max(dim=0).values
+                else:
+                    sw = w.abs().double().sum(dim=(1, 2, 3))
+                a_ = (sw * self.params[s_off : s_off + op.cout].abs().double()).max() * (1.0 + 1e-6)
                 b_ = self.params[b_off : b_off + op.cout].abs().double().max()
                 self.params[gm.bound_off : gm.bound_off + 2] = torch.stack([a_, b_]).to(torch.float32)
         self.param_sig = sig
@@ -758,8 +798,7 @@ def _max_images_per_launch(model, h, w):
         biggest = max(biggest, hin * win * op.cin, (hout << op.up) * (wout << op.up) * op.cout)
     # P2 plans address their planes with byte offsets below 2^31: 2^29 elements.  Whether a plan ends up on the P2 kernels is
     # InferencePlan._p2_covers' decision (and MVAL_P2=force's): the conservative limit applies whenever the mode allows them
-    # (a graph with max-pool / transposed convs -- PoseResNet -- never runs on them)
-    limit = 2**29 if (_conv_mode() == "p2" and all(op.kind == "conv" for op in g.ops)) else 2**31
+    limit = 2**29 if _conv_mode() == "p2" else 2**31
     return max(1, (limit - 1) // biggest)
 
 

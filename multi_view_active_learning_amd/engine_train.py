@@ -310,15 +310,17 @@ class TrainPlan:
                         else:
                             t.res2_p2_off, t.res2_p2_rows_off = p2_act[a_]
             # data gradients of stride-1 convs on the P2 kernels: the BatchNorm backward also writes dz as P2 planes into ONE scratch
-            # (planes of the largest dz, rows, reduction scratch); MVAL_TRAIN_P2_DGRAD=0: the h2 data gradients
+            # (planes of the largest dz, rows, reduction scratch); MVAL_TRAIN_P2_DGRAD=0: the h2 data gradients.  (Round 5 also ran the
+            # four parity convs of the stride-2 data gradients on conv_p2_kernel<2, ...> from the dz planes: 65.47 vs 65.2 ms per C3 step --
+            # four persistent launches against the h2 kernel's one: not kept.)
             if os.environ.get("MVAL_TRAIN_P2_DGRAD", "1") != "0" and fused_bwd:
                 want = []
                 for i, op in enumerate(g.ops):
                     t = self.ops[i]
+                    hin, win, hout, wout = geo[i]
                     if not (t.dgrad_algo == ALGO_MFMA_H2 and t.dgrad_form == 0 and op.bn and op.up == 0 and op.stride == 1 and op.cout % 8 == 0 and op.cin % 4 == 0
                             and t.gin_off >= 0):
                         continue
-                    hin, win, hout, wout = geo[i]
                     d = MvalOp()
                     d.kind, d.k, d.stride, d.pad, d.cin, d.cout = 0, op.k, 1, op.k // 2, op.cout, op.cin
                     d.hin, d.win, d.hout, d.wout = hout, wout, hin, win

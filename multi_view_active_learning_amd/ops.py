@@ -199,10 +199,16 @@ def conv_dgrad_parity(dz, weight, in_hw, algo=ALGO_MFMA_BF3, accumulate_into=Non
     return dx
 
 
-def p2_bound(weight, scale, shift):
+def p2_bound(weight, scale, shift, transposed=False):
     """[A, B] of csrc/conv_p2.h: |bn(conv(x))| <= A * max|x| + B with A = max_c |scale_c| * sum |w_c|, B = max_c |shift_c|
-    (one float32 rounding of slack each: the kernel's scale leaves a factor 2)."""
-    a = (weight.detach().abs().double().sum(dim=(1, 2, 3)) * scale.detach().abs().double()).max() * (1.0 + 1e-6)
+    (one float32 rounding of slack each: the kernel's scale leaves a factor 2).  transposed (k4 s2 p1, weights (cin, cout, 4, 4)): an
+    output pixel of parity (py, px) sees the taps ky in {3 - py, 1 - py}, kx alike -- the largest parity sum per cout."""
+    wa = weight.detach().abs().double()
+    if transposed:
+        sw = torch.stack([wa[:, :, [3 - py, 1 - py]][:, :, :, [3 - px, 1 - px]].sum(dim=(0, 2, 3)) for py in (0, 1) for px in (0, 1)]).max(dim=0).values
+    else:
+        sw = wa.sum(dim=(1, 2, 3))
+    a = (sw * scale.detach().abs().double()).max() * (1.0 + 1e-6)
     b = shift.detach().abs().double().max()
     return torch.stack([a, b]).to(torch.float32)
 
@@ -233,13 +239,18 @@ class P2Conv:
     layer-wise tests and tools/p2_sweep.py.  x / res1 / res2 are fp32 NHWC (converted to P2 here); result() converts
     the output planes back (or returns the fp32 NCHW heat-maps when out_nchw)."""
 
-    def __init__(self, x, weight, scale, shift, stride=1, relu=False, res1=None, res2=None, up=0, out_nchw=False):
+    def __init__(self, x, weight, scale, shift, stride=1, relu=False, res1=None, res2=None, up=0, out_nchw=False, transposed=False):
         dev = x.device
         lib = _lib.lib()
-        cout, cin, k, _ = weight.shape
         n, hin, win, _ = x.shape
-        pad = k // 2
-        hout, wout = (hin + 2 * pad - k) // stride + 1, (win + 2 * pad - k) // stride + 1
+        if transposed:  # ConvTranspose2d(k4, s2, p1) weights (cin, cout, 4, 4): four parity launches (csrc/net.hip)
+            cin, cout, k, _ = weight.shape
+            stride, pad = 2, 1
+            hout, wout = 2 * hin, 2 * win
+        else:
+            cout, cin, k, _ = weight.shape
+            pad = k // 2
+            hout, wout = (hin + 2 * pad - k) // stride + 1, (win + 2 * pad - k) // stride + 1
         ho, wo = hout << up, wout << up
         self.shape = (n, ho, wo, cout)
         self.out_nchw = out_nchw
@@ -256,7 +267,7 @@ class P2Conv:
         for i, (pl, rows) in enumerate(parts):
             self.arena[offs[i] : offs[i] + pl.numel()] = pl
             self.arena[row_off + i * n * P2_ROW : row_off + (i + 1) * n * P2_ROW] = rows.view(torch.float32)
-        pw = pack_weights(weight, ALGO_MFMA_H2)
+        pw = pack_weights(weight, ALGO_MFMA_H2, transposed=transposed)
         s_off = _align(pw.numel())
         b_off = s_off + _align(cout)
         bd_off = b_off + _align(cout)
@@ -264,9 +275,9 @@ class P2Conv:
         self.params[: pw.numel()] = pw
         self.params[s_off : s_off + cout] = scale
         self.params[b_off : b_off + cout] = shift
-        self.params[bd_off : bd_off + 2] = p2_bound(weight, scale, shift).to(dev)
+        self.params[bd_off : bd_off + 2] = p2_bound(weight, scale, shift, transposed).to(dev)
         m = MvalOp()
-        m.kind, m.algo = OP_CONV, 4
+        m.kind, m.algo = (OP_DECONV if transposed else OP_CONV), 4
         m.k, m.stride, m.pad, m.cin, m.cout = k, stride, pad, cin, cout
         m.hin, m.win, m.hout, m.wout = hin, win, hout, wout
         m.up, m.relu, m.in_nchw, m.out_nchw = up, int(relu), 0, int(out_nchw)

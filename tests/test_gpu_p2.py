@@ -329,8 +329,8 @@ def _load(c, dev):
 
 
 def test_p2_plan_structure(dev, monkeypatch):
-    """HRNet plans run on P2 activations end to end (stem -> format change -> P2 ops -> fp32 heat-maps); PoseResNet
-    (max-pool, transposed convs) keeps the h2 kernels -- all or nothing per plan."""
+    """HRNet and (round 5) PoseResNet plans run on P2 activations end to end (stem -> format change -> P2 ops -> fp32 heat-maps) -- all
+    or nothing per plan; MVAL_P2=0 keeps the h2 kernels."""
     from multi_view_active_learning_amd import engine
 
     monkeypatch.setenv("MVAL_CONV", "p2")
@@ -354,12 +354,76 @@ def test_p2_plan_structure(dev, monkeypatch):
     # fuse layers: the up-sampling terms of an output are one launch where there are two or three of them
     fu = [o for o in plan.ops if o.kind == engine.OP_FUSE_UP]
     assert sorted((o.cout, o.n_terms) for o in fu) == sorted([(32, 2)] * 4 + [(32, 3)] * 3 + [(64, 2)] * 2)
+    # PoseResNet (round 5): stem -> max-pool (both fp32 NHWC) -> format change -> P2 ops: the first Bottleneck of layer1 fused, 1x1 stride-2
+    # downsample convs as stride-1 convs over the sub-sampled view, the three transposed convs as parity launches, fp32 heat-maps out
     r = cases.model_cases()["r50"]
     mr, _ = _load(r, dev)
     xr = torch.from_numpy(cases.model_input(r)).to(dev)
     with torch.no_grad():
         mr(xr)
+    assert not engine._plan_for(mr, xr).p2  # (a few images: the h2 plan, whose transposed convs are one launch each)
+    monkeypatch.setenv("MVAL_P2", "force")
+    with torch.no_grad():
+        mr(xr)
+    pr = engine._plan_for(mr, xr)
+    assert pr.p2
+    kr = [o.kind for o in pr.ops]
+    assert kr[0] == engine.OP_CONV and pr.ops[0].in_off == -1 and kr[1] == engine.OP_MAXPOOL and kr[2] == engine.OP_TO_P2
+    assert all(o.algo == engine.ALGO_MFMA_P2 for o in pr.ops[2:]) and kr.count(engine.OP_DECONV) == 3 and pr.ops[-1].out_nchw == 1
+    assert sum(1 for o in pr.ops if o.kind == engine.OP_CONV and o.k == 1 and o.stride == 2) == 3
+    monkeypatch.setenv("MVAL_P2", "0")
+    with torch.no_grad():
+        mr(xr)
     assert not engine._plan_for(mr, xr).p2
+
+
+@pytest.mark.parametrize("case", [(2, 256, 256, 16, 12, True), (1, 2048, 256, 8, 6, True), (3, 64, 48, 32, 24, False), (2, 32, 32, 8, 16, True), (2, 256, 256, 32, 24, True)],
+                         ids=lambda c: "n%d_c%d-%d_%dx%d_r%d" % tuple(int(v) for v in c))
+def test_p2_transposed_conv_vs_float64(dev, case):
+    """ConvTranspose2d(k4, s2, p1) + BN (+ ReLU) over P2 planes (pose_resnet.py:107-137; csrc/net.hip: four 2 x 2 parity convs over the input
+    grid on conv_p2_kernel<2, ...>, each scattered to its parity of the output planes) against float64 torch, not less accurate than the
+    h2 parity kernels on the same problem; the four launches leave ONE scale and the exact per-image maximum in the shared rows."""
+    from multi_view_active_learning_amd import ops
+
+    n, cin, cout, h, w, relu = case
+    rng = np.random.default_rng(31 + cin + h)
+    x = torch.from_numpy(np.maximum(rng.standard_normal((n, cin, h, w)), 0).astype(np.float32) * 1.5)
+    wt = torch.from_numpy((rng.standard_normal((cin, cout, 4, 4)) * np.sqrt(2.0 / (cin * 4))).astype(np.float32))
+    sc = torch.from_numpy(rng.uniform(0.5, 1.5, cout).astype(np.float32))
+    sh = torch.from_numpy(rng.standard_normal(cout).astype(np.float32) * 0.1)
+    d = torch.float64
+    want = F.conv_transpose2d(x.to(d), wt.to(d), stride=2, padding=1) * sc.to(d)[None, :, None, None] + sh.to(d)[None, :, None, None]
+    if relu:
+        want = torch.relu(want)
+    nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().to(dev)
+    got = ops.fused_conv_p2(nhwc(x), wt.to(dev), sc.to(dev), sh.to(dev), relu=bool(relu), transposed=True)
+    kept = ops.fused_conv_p2.last.kept_amax().cpu()
+    got = got.permute(0, 3, 1, 2).cpu()
+    assert got.shape == want.shape
+    np.testing.assert_allclose(got.numpy(), want.float().numpy(), rtol=1e-4, atol=3e-5)
+    assert torch.allclose(kept, got.abs().amax(dim=(1, 2, 3)), rtol=2.0**-21, atol=0)
+    if cin % 32 == 0:
+        y = ops.fused_conv(nhwc(x), wt.to(dev), sc.to(dev), sh.to(dev), stride=2, pad=1, relu=bool(relu), algo=ops.ALGO_MFMA, kind=ops.OP_DECONV).permute(0, 3, 1, 2).cpu()
+        rms = lambda v: (v.double() - want).pow(2).mean().sqrt().item()
+        assert rms(got) <= 1.25 * rms(y) + 1e-8, (rms(got), rms(y))
+
+
+@pytest.mark.parametrize("case", [(2, 256, 512, 64, 48), (3, 512, 1024, 32, 24), (2, 64, 128, 17, 24), (1, 1024, 2048, 16, 12)], ids=lambda c: "n%d_c%d-%d_%dx%d" % c)
+def test_p2_conv1x1_stride2_vs_float64(dev, case):
+    """A 1 x 1 stride-2 conv (pose_resnet.py's downsample branches) over P2 planes: the stride-1 kernel over every second input pixel."""
+    from multi_view_active_learning_amd import ops
+
+    n, cin, cout, h, w = case
+    rng = np.random.default_rng(5 + cin)
+    x = torch.from_numpy(rng.standard_normal((n, cin, h, w)).astype(np.float32))
+    wt = torch.from_numpy((rng.standard_normal((cout, cin, 1, 1)) * np.sqrt(2.0 / cin)).astype(np.float32))
+    sc = torch.from_numpy(rng.uniform(0.5, 1.5, cout).astype(np.float32))
+    sh = torch.from_numpy(rng.standard_normal(cout).astype(np.float32) * 0.1)
+    d = torch.float64
+    want = F.conv2d(x.to(d), wt.to(d), stride=2) * sc.to(d)[None, :, None, None] + sh.to(d)[None, :, None, None]
+    got = ops.fused_conv_p2(x.permute(0, 2, 3, 1).contiguous().to(dev), wt.to(dev), sc.to(dev), sh.to(dev), stride=2).permute(0, 3, 1, 2).cpu()
+    assert got.shape == want.shape
+    np.testing.assert_allclose(got.numpy(), want.float().numpy(), rtol=1e-4, atol=3e-5)
 
 
 def _report(name, obj):

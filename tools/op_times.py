@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-op times of an inference plan (hipEvents around every launch), grouped by operator shape.
-usage: op_times.py [n_images=128] [arch=hrnet_w32|hrnet_w48] (MVAL_CONV / MVAL_P2=force select the plan)"""
+usage: op_times.py [n_images=128] [arch=hrnet_w32|hrnet_w48|resnet50] (MVAL_CONV / MVAL_P2=force select the plan)"""
 import os
 import sys
 from collections import defaultdict
@@ -11,16 +11,16 @@ import torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden"))
 from multi_view_active_learning_amd import synth
 from multi_view_active_learning_amd.engine import _plan_for
-from multi_view_active_learning_amd.pose_estimators import PoseHighResolutionNet, hrnet_w48
+from multi_view_active_learning_amd.pose_estimators import PoseHighResolutionNet, PoseResNet, hrnet_w48
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 arch = sys.argv[2] if len(sys.argv) > 2 else "hrnet_w32"
 dev = torch.device("cuda:0")
-m = PoseHighResolutionNet(19) if arch == "hrnet_w32" else PoseHighResolutionNet(19, hrnet_cfg=hrnet_w48())
+m = PoseHighResolutionNet(19) if arch == "hrnet_w32" else PoseResNet(19) if arch == "resnet50" else PoseHighResolutionNet(19, hrnet_cfg=hrnet_w48())
 sd = {k: torch.from_numpy(v) for k, v in synth.synthetic_state_dict(m._graph.param_shapes(), 0).items()}
 m.load_state_dict(sd, strict=True)
 m = m.to(dev).eval()
-x = torch.randn(n, 3, 256, 256, device=dev) if arch == "hrnet_w32" else torch.randn(n, 3, 384, 288, device=dev)
+x = torch.randn(n, 3, 256, 256, device=dev) if arch == "hrnet_w32" else torch.randn(n, 3, 256, 192, device=dev) if arch == "resnet50" else torch.randn(n, 3, 384, 288, device=dev)
 with torch.no_grad():
     m(x)
     plan = _plan_for(m, x)
