@@ -23,7 +23,7 @@ Prints ONE JSON line on rank 0 with the driver's contract fields plus
                split in use (three fp16 MFMA products per fp32 product: 2500 / 3 = 833 TFLOP/s); the other kernels of
                the step under "other_kernels", each against its own bound (stride-2 convs: the same matrix-core peak;
                1x1 channel GEMMs and the stem: algorithmic bytes / time against HBM); HBM bytes per launch from the
-               committed rocprofv3 PMC passes (profiles/r04);
+               committed rocprofv3 PMC passes (profiles/r05);
   exact_modes  ms per step of the same workload with the bit-faithful conv kernels (MVAL_CONV=bf3: exact 3-way bf16
                split, six MFMA products; fp32: v_mfma_f32_16x16x4_f32) and with round 2's fp32-activation fp16 split
                (h2), 20 steps each, outside the headline's timed region;
@@ -866,8 +866,8 @@ def main():
         # HBM bytes per launch of the dominant kernel: PMC counters cannot be read from inside
         # the process, so this is the committed rocprofv3 measurement of THIS command (separate
         # --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE x2 gfx950 correction; tools/pmc_summary.py)
-        summary = next((p_ for p_ in (os.path.join("profiles", r_, f"bench_c2_{_conv_mode()}_summary.json") for r_ in ("r04", "r03"))
-                        if os.path.exists(os.path.join(ROOT, p_))), os.path.join("profiles", "r04", f"bench_c2_{_conv_mode()}_summary.json"))
+        summary = next((p_ for p_ in (os.path.join("profiles", r_, f"bench_c2_{_conv_mode()}_summary.json") for r_ in ("r05", "r04", "r03"))
+                        if os.path.exists(os.path.join(ROOT, p_))), os.path.join("profiles", "r05", f"bench_c2_{_conv_mode()}_summary.json"))
         try:
             with open(os.path.join(ROOT, summary)) as f:
                 pre = (roof["kernel"].split(" ...>")[0],) + (("conv_block_kernel",) if "conv_block_kernel" in roof["kernel"] else ()) + \
