@@ -869,6 +869,10 @@ int mval_launch_conv_p2(const P2Args& a0, hipStream_t s) {
     if (a.NS_total > 2 && !a.up && !a.out_f32) {
       // (36-wide maps -- HRNet-W48's 96-channel branch -- as two 18-wide odd tiles per row: 54 of 64 slots used against 36 of 48 columns
       // of three 16-wide row-sharing tiles: 84 -> 78 us for 96 -> 96 on 48 x 36)
+      // (round 5: exact tiles -- every slot a pixel, six / three sub-tiles per wave -- on HRNet-W48's 48 x 36 maps (8 x 12 pixels: 96 -> 96
+      // 79 -> 68.6 us) and 24 x 18 maps (8 x 6: 192 -> 192 73 -> 66 us) where the 3 x 18 tiles below fill 54 of 64 slots; C4 20.93 -> 19.85 ms)
+      if (a.Wout == 36 && a.Hout % 8 == 0) return launch_p2<3, 1, 1, 4, 1, 1, 6, 8, false, 12>(a, s);
+      if (a.Wout == 18 && a.Hout % 8 == 0) return launch_p2<3, 1, 1, 4, 1, 1, 3, 8, false, 6>(a, s);
       if (a.Wout == 18 || a.Wout == 36) return launch_p2<3, 1, 1, 4, 1, 1, 4, 8, false, 18>(a, s);
       // (round 5: PoseResNet at 256 x 192 -- 16 x 12 / 32 x 24 maps in 8 x 12-pixel tiles (six sub-tiles per wave), 8 x 6 maps whole (three):
       // every slot a pixel, where 8-wide tiles compute 16 columns for 12 and 5 x 12 tiles 20 rows for 16)
@@ -877,6 +881,9 @@ int mval_launch_conv_p2(const P2Args& a0, hipStream_t s) {
       // (9-wide odd tiles on the 72-wide maps -- 63 of 64 slots -- measured slower than the 16-wide row-sharing tiles: 105 vs 103 us)
       if (a.Wout == 9) return launch_p2<3, 1, 1, 4, 1, 1, 4, 8, false, 9>(a, s);
     }
+    // (round 5: 72-wide maps -- HRNet-W48's first branch -- in the same exact 8 x 12 tiles: 80 columns were computed for 72 by the 16-wide
+    // row-sharing tiles; 48 -> 48 99.5 / 95.7 -> 97.5 / 92.9 us even without the paired K remainder, 256 -> 48 353 -> 321 us)
+    if (a.Wout == 72 && a.Hout % 8 == 0 && a.NS_total > 2 && !a.up && !a.out_f32) return launch_p2<3, 1, 1, 4, 1, 1, 6, 8, false, 12>(a, s);
     if (a.Wout >= 16 && a.Hout >= 4) {
       // 48 input channels (HRNet-W48's first branch): the paired remainder stage (K48 above: 103 -> 96 us for 48 -> 48 on 96 x 72)
       if (a.Cin == 48 && a.NS_total > 2 && !a.up && !a.out_f32 && !a.out_nhwc && !oms && !ont)
