@@ -129,7 +129,7 @@ __device__ __forceinline__ void conv_p2_body(const P2Args& a, const int by, cons
   constexpr int TH = 16 * MS * WM / TWE, TW_LOG2 = TW == 8 ? 3 : TW == 16 ? 4 : TW == 32 ? 5 : 6;
   static_assert(OW || (TH * TW == 16 * MS * WM && (TW == 8 || TW == 16 || TW == 32 || TW == 64)), "tile shape");
   static_assert(!RS || TW == 16, "row sharing: 16-wide tiles");
-  static_assert(OW == 0 || (!RS && S == 1 && (EPI == 0 || EPI == 3) && TH >= 1), "odd tiles: stride 1, no fused upsample, no row sharing");
+  static_assert(OW == 0 || (!RS && (EPI == 0 || EPI == 3) && TH >= 1), "odd tiles: no fused upsample, no row sharing");
   constexpr int PH = (TH - 1) * S + KS, PW = (TWE - 1) * S + KS, PWh = (PW + 1) >> 1;
   constexpr int slots = S == 1 ? PH * PW : 2 * PH * PWh;
   constexpr int PPX = (slots + 15) & ~15;  // slots per 8-channel block (256-byte aligned blocks)
@@ -908,6 +908,10 @@ int mval_launch_conv_p2(const P2Args& a0, hipStream_t s) {
   if (a.k == 3 && a.stride == 2) {
     if (a.Wout < 4 || a.Hout < 4) return 1;
     const int ms = oms ? oms : 2;
+    // (round 5: exact 4 x 12 / 8 x 6-pixel tiles on output maps 36 / 12 resp. 18 / 6 columns wide -- HRNet-W48 at 384 x 288, PoseResNet at
+    // 256 x 192 --, where 8-wide tiles compute 40 columns for 36 and 24 for 18: 48 -> 96 89 -> 83 us, 96 -> 192 68.5 -> 58, C4 20.77 -> 20.40 ms)
+    if (a.NS_total > 2 && a.Wout % 12 == 0 && (a.Wout & 7) != 0 && a.Hout % 4 == 0) return launch_p2<3, 2, 1, 4, 1, 1, 3, 8, false, 12>(a, s);
+    if (a.NS_total > 2 && a.Wout % 6 == 0 && a.Wout % 12 != 0 && a.Hout % 8 == 0) return launch_p2<3, 2, 1, 4, 1, 1, 3, 8, false, 6>(a, s);
     if (a.NS_total <= 2) return launch_p2<3, 2, 1, 2, 2, 1, 1, 8>(a, s);  // (8 x 8 tiles instead of 4 x 8: no change, 36.8 vs 36.2 us)
     // (16-wide tiles measured the same or slower: 2 x 16 px 34.0 / 24.8 / 22.2 us on 32 -> 64 / 64 -> 128 / 128 -> 256 against
     // 34.1 / 24.8 / 22.1 for 4 x 8; 4 x 16 px 39.7 / 29.3 / 22.3)
