@@ -960,9 +960,17 @@ int mval_launch_conv_p2(const P2Args& a0, hipStream_t s) {
     if (nt == 2) return g == 4 ? launch_p2<1, 1, 4, 4, 1, 2, 4, TW_>(a, s) : launch_p2<1, 1, 2, 4, 1, 2, 4, TW_>(a, s); \
     return g == 4 ? launch_p2<1, 1, 4, 4, 1, 1, 4, TW_>(a, s) : g == 1 ? launch_p2<1, 1, 1, 4, 1, 1, 4, TW_>(a, s) : launch_p2<1, 1, 2, 4, 1, 1, 4, TW_>(a, s); \
   } while (0)
-    if (a.Wout >= 64) P2_1X1(64);
-    if (a.Wout >= 32) P2_1X1(32);
-    if (a.Wout >= 16) P2_1X1(16);
+    // tile width: the widest power of two among those that compute the fewest padded columns (36-wide maps: five 8-wide tiles = 40
+    // columns, not two 32-wide ones = 64; round 5)
+    int tw = 8, best = ((a.Wout + 7) / 8) * 8;
+    for (int c = 16; c <= 64; c *= 2)
+      if (a.Wout >= c && ((a.Wout + c - 1) / c) * c <= best) {
+        tw = c;
+        best = ((a.Wout + c - 1) / c) * c;
+      }
+    if (tw == 64) P2_1X1(64);
+    if (tw == 32) P2_1X1(32);
+    if (tw == 16) P2_1X1(16);
     P2_1X1(8);
 #undef P2_1X1
   }
