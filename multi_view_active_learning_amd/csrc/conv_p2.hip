@@ -879,6 +879,9 @@ int mval_launch_conv_p2(const P2Args& a0, hipStream_t s) {
       if ((a.Wout == 12 || a.Wout == 24) && a.Hout % 8 == 0) return launch_p2<3, 1, 1, 4, 1, 1, 6, 8, false, 12>(a, s);
       if (a.Wout == 6 && a.Hout % 8 == 0) return launch_p2<3, 1, 1, 4, 1, 1, 3, 8, false, 6>(a, s);
       // (9-wide odd tiles on the 72-wide maps -- 63 of 64 slots -- measured slower than the 16-wide row-sharing tiles: 105 vs 103 us)
+      // (round 5: a whole 12 x 9 map per tile -- seven sub-tiles per wave, 108 of 112 slots, ONE tile per image instead of two 7 x 9 ones
+      // of which the second is mostly padding: 384 -> 384 77.5 -> 61.3 us, C4 19.23 -> 18.89 ms)
+      if (a.Wout == 9 && a.Hout == 12) return launch_p2<3, 1, 1, 4, 1, 1, 7, 8, false, 9>(a, s);
       if (a.Wout == 9) return launch_p2<3, 1, 1, 4, 1, 1, 4, 8, false, 9>(a, s);
     }
     // (round 5: 72-wide maps -- HRNet-W48's first branch -- in the same exact 8 x 12 tiles: 80 columns were computed for 72 by the 16-wide
