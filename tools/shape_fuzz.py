@@ -9,7 +9,11 @@ from oracle import models
 dev = torch.device("cuda:0")
 for arch, n, h, w in [("hrnet_w32", 3, 384, 288), ("hrnet_w32", 2, 320, 256), ("hrnet_w32", 1, 256, 192), ("hrnet_w32", 4, 192, 256), ("hrnet_w32", 1, 512, 384),
                       ("hrnet_w32", 5, 160, 224), ("hrnet_w32", 1, 256, 256), ("hrnet_w32", 7, 96, 64), ("resnet50", 3, 224, 160),
-                      ("resnet50", 1, 256, 192), ("hrnet_w48", 2, 96, 128), ("hrnet_w48", 3, 160, 96), ("hrnet_w32", 33, 64, 64)]:
+                      ("resnet50", 1, 256, 192), ("hrnet_w48", 2, 96, 128), ("hrnet_w48", 3, 160, 96), ("hrnet_w32", 33, 64, 64),
+                      # round 5: the exact-tile / small-map / flattened-1x1 / parity paths at other sizes than the BASELINE ones
+                      ("hrnet_w48", 2, 384, 288), ("hrnet_w48", 2, 288, 384), ("hrnet_w48", 3, 192, 288), ("hrnet_w48", 1, 384, 192), ("hrnet_w32", 2, 384, 192),
+                      ("hrnet_w32", 2, 192, 96), ("hrnet_w32", 3, 128, 128), ("resnet50", 33, 256, 192), ("resnet50", 34, 192, 256), ("resnet50", 40, 128, 96),
+                      ("resnet50", 32, 384, 288), ("resnet50", 36, 160, 224)]:
     model, sd = bench.build_model(arch, 19, dev, seed=4)
     x = synth.images(11, n, 1, h, w).reshape(n, 3, h, w)
     with torch.no_grad():
