@@ -477,8 +477,10 @@ __device__ __forceinline__ void conv_p2_body(const P2Args& a, const int by, cons
     P2RowRegs row_in, row_r1, row_r2;
     f32x4 sc[NT], sh[NT];
     // residual granules: lanes < 32 request the h-plane granule of (pixel, 8-channel block), lanes >= 32 the l-plane one
-    u32x4 R1[EPI == 0 ? MS : 1][EPI == 0 ? NT : 1];
-    constexpr bool pre_res = EPI == 0;
+    // (3x3 kernels with more than seven accumulator tiles per wave -- NT = 3: nine + six weight fragments per parity -- have no room for as
+    // many residual granules held across the last stage: they are requested per cout sub-tile inside the epilogue instead)
+    constexpr bool pre_res = EPI == 0 && !(KS == 3 && MS * NT > 7);
+    u32x4 R1[pre_res ? MS : 1][pre_res ? NT : 1];
     const unsigned plane_bytes = (unsigned)(oplane * 2);
     const int yl = oy0 + ly, xl = ox0 + lx;
     unsigned vb[NT];  // byte offset of the lane's granule of sub-tile row 0 / column 0 (its plane: h for lanes < 32)
@@ -547,7 +549,7 @@ __device__ __forceinline__ void conv_p2_body(const P2Args& a, const int by, cons
           a.out_row[(int64_t)n * P2_ROW + P2_INV_SLOT] = __float_as_uint(out_inv);
       }
       const float unscale = in_inv * w_unscale;
-      u32x4 R2[EPI == 0 ? MS : 1][EPI == 0 ? NT : 1];  // a second residual (fuse layers) is requested here: its registers are the weight fragments'
+      u32x4 R2[pre_res ? MS : 1][pre_res ? NT : 1];  // a second residual (fuse layers) is requested here: its registers are the weight fragments'
       if (pre_res && a.res2) {
 #pragma unroll
         for (int nt = 0; nt < NT; nt++)
@@ -587,17 +589,32 @@ __device__ __forceinline__ void conv_p2_body(const P2Args& a, const int by, cons
       // they were a dozen scalar branches per granule
       auto plain = [&](auto has_r1, auto has_r2) {
 #pragma unroll
-        for (int nt = 0; nt < NT; nt++)
+        for (int nt = 0; nt < NT; nt++) {
+          u32x4 q1[pre_res ? 1 : MS], q2[pre_res ? 1 : MS];
+          if constexpr (!pre_res) {
+#pragma unroll
+            for (int ms = 0; ms < MS; ms++) {
+              if constexpr (decltype(has_r1)::value) q1[ms] = __builtin_amdgcn_raw_buffer_load_b128(r1r, voff(nt, ms), soff(ms), 0);
+              if constexpr (decltype(has_r2)::value) q2[ms] = __builtin_amdgcn_raw_buffer_load_b128(r2r, voff(nt, ms), soff(ms), 0);
+            }
+          }
 #pragma unroll
           for (int ms = 0; ms < MS; ms++) {
             f32x4 r = acc[ms][nt] * scu[nt] + sh[nt];
-            if constexpr (decltype(has_r1)::value) r += res_of(R1[ms][nt], r1_inv);
-            if constexpr (decltype(has_r2)::value) r += res_of(R2[ms][nt], r2_inv);
+            if constexpr (decltype(has_r1)::value) {
+              if constexpr (pre_res) r += res_of(R1[ms][nt], r1_inv);
+              else r += res_of(q1[ms], r1_inv);
+            }
+            if constexpr (decltype(has_r2)::value) {
+              if constexpr (pre_res) r += res_of(R2[ms][nt], r2_inv);
+              else r += res_of(q2[ms], r2_inv);
+            }
             put(r, voff(nt, ms), soff(ms));
 #ifndef P2_NO_EPI_SB
             __builtin_amdgcn_sched_barrier(SB);  // one granule at a time: interleaving them all costs ~60 registers
 #endif
           }
+        }
       };
       using T_ = std::true_type;
       using F_ = std::false_type;
@@ -826,21 +843,22 @@ static int launch_p2(const P2Args& a, hipStream_t s) {
     if (a.out_f32 || a.up) return 1;
     if (a.out_nhwc) return launch_p2e<KS, S, G, WN, WM, NT, MS, TW, RS, 3, OW>(a, s);
     return launch_p2e<KS, S, G, WN, WM, NT, MS, TW, RS, 0, OW>(a, s);
+  } else {  // (else: the power-of-two forms of an odd-tile configuration are never instantiated)
+    if (a.out_nhwc) {
+      if (a.up || a.res1 || a.res2 || a.out_f32) return 1;
+      if constexpr (MS <= 4 || KS == 3) return launch_p2e<KS, S, G, WN, WM, NT, MS, TW, RS, 3>(a, s);
+      return 1;
+    }
+    if (a.out_f32) {
+      if constexpr (KS == 1 && NT == 1 && MS <= 4) return launch_p2e<KS, S, G, WN, WM, NT, MS, TW, RS, 2>(a, s);
+      return 1;
+    }
+    if (a.up) {
+      if constexpr (KS == 1 && MS <= 4) return launch_p2e<KS, S, G, WN, WM, NT, MS, TW, RS, 1>(a, s);
+      return 1;
+    }
+    return launch_p2e<KS, S, G, WN, WM, NT, MS, TW, RS, 0>(a, s);
   }
-  if (a.out_nhwc) {
-    if (a.up || a.res1 || a.res2 || a.out_f32) return 1;
-    if constexpr (MS <= 4 || KS == 3) return launch_p2e<KS, S, G, WN, WM, NT, MS, TW, RS, 3>(a, s);
-    return 1;
-  }
-  if (a.out_f32) {
-    if constexpr (KS == 1 && NT == 1 && MS <= 4) return launch_p2e<KS, S, G, WN, WM, NT, MS, TW, RS, 2>(a, s);
-    return 1;
-  }
-  if (a.up) {
-    if constexpr (KS == 1 && MS <= 4) return launch_p2e<KS, S, G, WN, WM, NT, MS, TW, RS, 1>(a, s);
-    return 1;
-  }
-  return launch_p2e<KS, S, G, WN, WM, NT, MS, TW, RS, 0>(a, s);
 }
 
 // measurement builds (-DP2_TUNE: tools/p2_sweep.py) read the tile choice from MVAL_P2_TILE="ms,nt,g" (0 = default) and the workgroups
@@ -866,6 +884,27 @@ int mval_launch_conv_p2(const P2Args& a0, hipStream_t s) {
     // (round 3 also built the v_mfma_f32_32x32x16_f16 form of this conv -- half the MFMA issues, two thirds of the LDS fragment reads per
     // FLOP: 33.1 vs 31.5 us on 64 -> 64 at 32x32, 115 vs 112.5 at 64x64: equal or slower; removed in round 5)
     // maps no power-of-two tile fits (HRNet-W48 at 384 x 288: 24 x 18 and 12 x 9): full-width odd tiles, 3 x 18 / 7 x 9 pixels
+    // (round 5: THREE cout sub-tiles per wave on HRNet-W48's 96- and 192-channel branches: 96 couts = 6 sub-tiles are 2 cout waves x 3 -- with
+    // one sub-tile per wave the second group of four waves ran half empty --, 192 couts = 4 x 3 in ONE group instead of three that each staged
+    // the same patch; a third of the x fragment reads per MFMA.  96 -> 96 on 48 x 36 70.9 / 68.9 -> 65.9 / 64.8 us; 192 -> 192 on 24 x 18 is
+    // slower on its own (68.5 -> 71.7 us) and faster inside the multi-stream forward: C4 19.79 -> 19.04 (96 only) -> 18.64 ms (both),
+    // profiles/r05/w48_nt3.log.  The same on the 48-channel branch (one wave per 16 x 12 or 16 x 8 pixels x 48 couts: every wave pulls all
+    // weight fragments) measured slower: 96.6 -> 107 / 102 us.)
+    if (!a.up && !a.out_f32) {
+      if (a.NS_total == 6 && a.Wout == 36 && a.Hout % 8 == 0) return launch_p2<3, 1, 1, 2, 2, 3, 3, 8, false, 12>(a, s);
+      if (a.NS_total == 12 && a.Wout == 18 && a.Hout % 8 == 0) return launch_p2<3, 1, 1, 4, 1, 3, 3, 8, false, 6>(a, s);
+    }
+    // (round 5: TWO cout sub-tiles per wave where the cout sub-tiles come in multiples of eight -- HRNet-W32's 128- / 256-channel branches:
+    // half the cout groups, so half the patch staging and barriers per MFMA.  Slower or equal launch by launch (tools/p2_sweep.py, rounds
+    // 3-4) and faster inside the multi-stream forward: C2 10.12 -> 10.05 (128 ch) / 10.02 (256 ch) / 9.95 ms (both), three runs each on
+    // one box, profiles/r05/w32_nt2_step.log.  Inference only: in the training step the same forms measure slower (C3 65.4 / 65.9 -> 65.6 / 66.1 with the
+    // 256-channel branch, 66.1 / 66.3 with both: nt2_more.log).  Also measured flat there: two / four sub-tiles per wave on the stride-2
+    // convs (C2 10.03 -> 9.98-10.02), two on HRNet-W48's 384-channel branch (92 bytes of spills; C4 17.88 -> 17.78), three on its stride-2
+    // 96 -> 192 convs (17.92).)
+    if (!a.up && !a.out_f32 && !a.out_nhwc && a.NS_total % 8 == 0 && !oms && !ont) {
+      if (a.Wout % 16 == 0 && a.Hout >= 4) return launch_p2<3, 1, 1, 4, 1, 2, 4, 16, true>(a, s);
+      if (a.Wout == 8 && a.Hout >= 4) return launch_p2<3, 1, 1, 4, 1, 2, 4, 8>(a, s);
+    }
     if (a.NS_total > 2 && !a.up && !a.out_f32) {
       // (36-wide maps -- HRNet-W48's 96-channel branch -- as two 18-wide odd tiles per row: 54 of 64 slots used against 36 of 48 columns
       // of three 16-wide row-sharing tiles: 84 -> 78 us for 96 -> 96 on 48 x 36)

@@ -274,6 +274,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((KS == 3 &&
     }
   }
   // slab[ps][t][ci][co]; C layout: row (cin) = (lane >> 4) * 4 + r, col (cout) = lane & 15
+#ifdef WB_NO_SLAB_STORE  // (measurement: the loop without its 28-56 MB slab burst; results are garbage)
+  if (acc[0][0][0][0] != 12345.678f) return;
+#endif
 #pragma unroll
   for (int nt = 0; nt < NT; nt++) {
     const int co = co0 + co_g * (16 * NT) + nt * 16 + (lane & 15);
@@ -357,7 +360,10 @@ int mval_launch_wgrad_bf3_p2(const float* x, const void* x_p2, const unsigned* x
   a.ntiles = a.tiles_x * a.tiles_y * N;
   const int nt = (k1 || Cout > 32) ? 2 : 1, mi = k1 ? 2 : 1;
   const int cb = ((Cin + 32 * mi - 1) / (32 * mi)) * ((Cout + 32 * nt - 1) / (32 * nt));
-  int PS = 768 / cb;  // ~3 workgroups per CU resident (50-62 KB of LDS each)
+#ifndef WB_PS_TARGET
+#define WB_PS_TARGET 768  // (measurement knob: -DWB_PS_TARGET=512 / 384 / 256 -- profiles/r05/wgrad_slabs.log)
+#endif
+  int PS = WB_PS_TARGET / cb;  // ~3 workgroups per CU resident (50-62 KB of LDS each)
   if (PS < 1) PS = 1;
   if (PS > max_slabs) PS = max_slabs;
   if (PS > a.ntiles) PS = a.ntiles;
