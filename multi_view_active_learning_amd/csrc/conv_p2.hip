@@ -915,6 +915,11 @@ int mval_launch_conv_p2(const P2Args& a0, hipStream_t s) {
       if (a.Wout == 18 || a.Wout == 36) return launch_p2<3, 1, 1, 4, 1, 1, 4, 8, false, 18>(a, s);
       // (round 5: PoseResNet at 256 x 192 -- 16 x 12 / 32 x 24 maps in 8 x 12-pixel tiles (six sub-tiles per wave), 8 x 6 maps whole (three):
       // every slot a pixel, where 8-wide tiles compute 16 columns for 12 and 5 x 12 tiles 20 rows for 16)
+      // (two cout sub-tiles per wave as on HRNet-W32's deep branches: PoseResNet C1 x 16 6.44 -> 6.36 ms, profiles/r05/r50_nt2.log)
+      if (!a.out_nhwc && a.NS_total % 8 == 0) {
+        if ((a.Wout == 12 || a.Wout == 24) && a.Hout % 8 == 0) return launch_p2<3, 1, 1, 4, 1, 2, 6, 8, false, 12>(a, s);
+        if (a.Wout == 6 && a.Hout % 8 == 0) return launch_p2<3, 1, 1, 4, 1, 2, 3, 8, false, 6>(a, s);
+      }
       if ((a.Wout == 12 || a.Wout == 24) && a.Hout % 8 == 0) return launch_p2<3, 1, 1, 4, 1, 1, 6, 8, false, 12>(a, s);
       if (a.Wout == 6 && a.Hout % 8 == 0) return launch_p2<3, 1, 1, 4, 1, 1, 3, 8, false, 6>(a, s);
       // (9-wide odd tiles on the 72-wide maps -- 63 of 64 slots -- measured slower than the 16-wide row-sharing tiles: 105 vs 103 us)

@@ -68,6 +68,13 @@ P2_CASES = [
     (1, 192, 48, 24, 18, 1, 1, False, True, False, 2, False),
     (2, 64, 256, 96, 72, 1, 1, True, True, False, 0, False),
     (2, 48, 19, 96, 72, 1, 1, False, False, False, 0, True),
+    # round 5: two / three cout sub-tiles per wave (128 / 256 / 96 / 192 channels): residual granules requested inside the epilogue --
+    # both residuals, no ReLU, a batch that leaves the tile walk uneven
+    (3, 128, 128, 16, 16, 3, 1, False, True, True, 0, False),
+    (7, 256, 256, 8, 8, 3, 1, True, True, True, 0, False),
+    (1, 96, 96, 48, 36, 3, 1, False, True, True, 0, False),
+    (3, 192, 192, 24, 18, 3, 1, True, True, True, 0, False),
+    (2, 128, 128, 32, 48, 3, 1, True, False, False, 0, False),
 ]
 
 
