@@ -524,6 +524,22 @@ int mval_train_forward(const mval_train_op* ops, int n_ops, int n_images, float*
 int mval_train_backward(const mval_train_op* ops, int n_ops, int n_images, float* arena, float* garena,
                         const float* params, int64_t ones_off, int64_t zeros_off, const float* input_nchw,
                         float* gz, float* wsf, double* ws, float* sums, void* stream);
+/* Round 5: the same two passes with the independent lanes of a phase (mval_op.phase / .lane: HRNet branches, hrnet.py:199-287) on
+ * separate HIP streams, joined on `stream` at every phase change and before returning.  An op runs on side stream op.lane (1 ..
+ * n_lanes - 1 <= 3) in the forward if p2_flags carries MVAL_TRAIN_LANE_FWD, in the backward if it carries MVAL_TRAIN_LANE_BWD -- the
+ * caller sets the backward bit only for phases in which every gradient slot (gin / gres1 / gres2) has all its writers on ONE lane, so
+ * the first-touch / accumulate order of every slot is the serial one and the results are bit-identical to mval_train_forward /
+ * mval_train_backward.  Every scratch buffer holds n_lanes slices (lane l at base + l * its per-lane size); the per-op dz plane
+ * scratch (gz_p2_off ...) must be distinct per lane as well.  One pass per device at a time (the side streams are per device). */
+#define MVAL_TRAIN_LANE_FWD 256
+#define MVAL_TRAIN_LANE_BWD 512
+int mval_train_forward_lanes(const mval_train_op* ops, int n_ops, int n_images, float* arena, const float* params,
+                             int64_t ones_off, int64_t zeros_off, const float* input_nchw, float* output_nchw,
+                             double* ws, int64_t ws_doubles_per_lane, int n_lanes, float momentum, float eps, void* stream);
+int mval_train_backward_lanes(const mval_train_op* ops, int n_ops, int n_images, float* arena, float* garena,
+                              const float* params, int64_t ones_off, int64_t zeros_off, const float* input_nchw,
+                              float* gz, float* wsf, double* ws, float* sums, int n_lanes, int64_t gz_floats_per_lane,
+                              int64_t wsf_floats_per_lane, int64_t ws_doubles_per_lane, int64_t sums_floats_per_lane, void* stream);
 
 /* ---- optimizer step (replaces torch.optim.Adam.step, /root/reference/strategy.py:405-407 and :479) -------------------
  * Adam over MANY tensors in one launch, arithmetic = torch/optim/adam.py _single_tensor_adam in float32:

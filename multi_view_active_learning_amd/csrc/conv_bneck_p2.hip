@@ -536,7 +536,7 @@ static int launch_bneck_p2(P2BneckArgs a, hipStream_t s) {
   static std::atomic<int> occ{0};
   int per_cu = p2_resident_wgs(&conv_bneck_p2_kernel<CIN>, occ, smem, 4);
 #ifdef P2_TUNE  // (measurement builds only: workgroups per CU)
-  const char* pe = getenv("MVAL_P2_WGS");
+  const char* pe = getenv("MVAL_P2_WGS_BS");
   if (pe && atoi(pe) > 0) per_cu = atoi(pe);
 #endif
   int wgs = mval_cu_count() * per_cu;

@@ -430,6 +430,7 @@ struct MvalLaneWalk {
   void finish() {
     if (L) join();
   }
+  ~MvalLaneWalk() { finish(); }  // (an error return in the middle of a pass still joins the side streams)
 };
 
 // conv_block.hip: a whole BasicBlock (two 3x3 convs + BNs + residual + ReLUs) in one launch; returns 1 if unsupported

@@ -494,7 +494,7 @@ int mval_launch_conv_stem_p2(const float* in, void* out, const float* w1, const 
   static std::atomic<int> occ{0};
   int per_cu = p2_resident_wgs(&conv_stem_p2_kernel, occ, smem, 4);
 #ifdef P2_TUNE  // (measurement builds only: workgroups per CU)
-  const char* pe = getenv("MVAL_P2_WGS");
+  const char* pe = getenv("MVAL_P2_WGS_BS");
   if (pe && atoi(pe) > 0) per_cu = atoi(pe);
 #endif
   int wgs = mval_cu_count() * per_cu;

@@ -173,15 +173,33 @@ static int run_conv(const ConvArgs& a0, int algo, hipStream_t s, const char* wha
   return 0;
 }
 
-extern "C" int mval_train_forward(const mval_train_op* ops, int n_ops, int n_images, float* arena, const float* params,
-                                  int64_t ones_off, int64_t zeros_off, const float* input_nchw, float* output_nchw,
-                                  double* ws, int64_t ws_doubles, float momentum, float eps, void* stream) {
-  MVAL_REQUIRE(ops && n_ops > 0 && n_images > 0, "mval_train_forward: bad arguments");
-  hipStream_t s = mval_stream(stream);
+// Lanes (round 5): ops of one phase that sit on different lanes (graph.py: HRNet branches, fuse outputs) are independent; with
+// n_lanes > 1 an op whose p2_flags carries MVAL_TRAIN_LANE_FWD (forward) / MVAL_TRAIN_LANE_BWD (backward) runs on its lane's side
+// stream with its lane's slice of every scratch buffer, phases join on the caller's stream (MvalLaneWalk, as the inference executor).
+// The deep branches' kernels (8 x 8 / 16 x 16 maps: a few MB per tensor) and the ~880 one-workgroup-per-channel finalize launches
+// leave most of the chip idle on their own; next to another branch's kernels they fill its tails.  What each op computes, and the
+// order in which every gradient slot is written, does not change: the plan marks a phase for the backward only if each gradient
+// slot it writes has all its writers on one lane.
+static int lane_of(const mval_train_op& t, int bit, int n_lanes) {
+  return (n_lanes > 1 && (t.p2_flags & bit) && t.op.lane > 0 && t.op.lane < n_lanes) ? t.op.lane : 0;
+}
+
+static int train_forward(const mval_train_op* ops, int n_ops, int n_images, float* arena, const float* params,
+                         int64_t ones_off, int64_t zeros_off, const float* input_nchw, float* output_nchw,
+                         double* ws0, int64_t ws_doubles, int n_lanes, float momentum, float eps, void* stream0) {
+  MVAL_REQUIRE(ops && n_ops > 0 && n_images > 0 && n_lanes >= 1 && n_lanes <= MVAL_MAX_LANES, "mval_train_forward: bad arguments");
+  if (g_tt_out) n_lanes = 1;  // (measurement mode times every launch group on its own: one stream)
+  MvalLanes* L = n_lanes > 1 ? mval_device_lanes() : nullptr;
+  if (n_lanes > 1) MVAL_REQUIRE(L != nullptr, "mval_train_forward: could not create the side streams");
+  MvalLaneWalk walk(L, mval_stream(stream0));
   for (int i = 0; i < n_ops; i++) {
     g_tt_op = i;
     const mval_train_op& t = ops[i];
     const mval_op& op = t.op;
+    const int lane = lane_of(t, MVAL_TRAIN_LANE_FWD, n_lanes);
+    hipStream_t s = walk.stream_for(op.phase, lane);
+    void* stream = reinterpret_cast<void*>(s);
+    double* ws = ws0 + (int64_t)lane * ws_doubles;
     const bool epi_stats = !(t.p2_flags & 128);  // (bit 7: batch statistics by the separate pass over z -- the plan's decision, MVAL_TRAIN_EPI_STATS=0)
     ConvArgs a = {};
     geometry(a, op, n_images);
@@ -297,20 +315,45 @@ extern "C" int mval_train_forward(const mval_train_op* ops, int n_ops, int n_ima
       if (rc) return rc;
     }
   }
+  walk.finish();
   tt_flush();
   return 0;
 }
 
-extern "C" int mval_train_backward(const mval_train_op* ops, int n_ops, int n_images, float* arena, float* garena,
-                                   const float* params, int64_t ones_off, int64_t zeros_off, const float* input_nchw,
-                                   float* gz, float* wsf, double* ws, float* sums, void* stream) {
-  MVAL_REQUIRE(ops && n_ops > 0 && n_images > 0 && garena && gz && wsf && ws && sums,
+extern "C" int mval_train_forward(const mval_train_op* ops, int n_ops, int n_images, float* arena, const float* params,
+                                  int64_t ones_off, int64_t zeros_off, const float* input_nchw, float* output_nchw,
+                                  double* ws, int64_t ws_doubles, float momentum, float eps, void* stream) {
+  return train_forward(ops, n_ops, n_images, arena, params, ones_off, zeros_off, input_nchw, output_nchw, ws, ws_doubles, 1, momentum, eps, stream);
+}
+
+extern "C" int mval_train_forward_lanes(const mval_train_op* ops, int n_ops, int n_images, float* arena, const float* params,
+                                        int64_t ones_off, int64_t zeros_off, const float* input_nchw, float* output_nchw,
+                                        double* ws, int64_t ws_doubles_per_lane, int n_lanes, float momentum, float eps, void* stream) {
+  return train_forward(ops, n_ops, n_images, arena, params, ones_off, zeros_off, input_nchw, output_nchw, ws, ws_doubles_per_lane, n_lanes, momentum,
+                       eps, stream);
+}
+
+static int train_backward(const mval_train_op* ops, int n_ops, int n_images, float* arena, float* garena,
+                          const float* params, int64_t ones_off, int64_t zeros_off, const float* input_nchw,
+                          float* gz0, float* wsf0, double* ws0, float* sums0, int n_lanes, int64_t gz_stride, int64_t wsf_stride,
+                          int64_t ws_stride, int64_t sums_stride, void* stream0) {
+  MVAL_REQUIRE(ops && n_ops > 0 && n_images > 0 && garena && gz0 && wsf0 && ws0 && sums0 && n_lanes >= 1 && n_lanes <= MVAL_MAX_LANES,
                "mval_train_backward: bad arguments");
-  hipStream_t s = mval_stream(stream);
+  if (g_tt_out) n_lanes = 1;
+  MvalLanes* L = n_lanes > 1 ? mval_device_lanes() : nullptr;
+  if (n_lanes > 1) MVAL_REQUIRE(L != nullptr, "mval_train_backward: could not create the side streams");
+  MvalLaneWalk walk(L, mval_stream(stream0));
   for (int i = n_ops - 1; i >= 0; i--) {
     g_tt_op = g_tt_base + i;
     const mval_train_op& t = ops[i];
     const mval_op& op = t.op;
+    const int lane = lane_of(t, MVAL_TRAIN_LANE_BWD, n_lanes);
+    hipStream_t s = walk.stream_for(op.phase, lane);
+    void* stream = reinterpret_cast<void*>(s);
+    float* gz = gz0 + (int64_t)lane * gz_stride;
+    float* wsf = wsf0 + (int64_t)lane * wsf_stride;
+    double* ws = ws0 + (int64_t)lane * ws_stride;
+    float* sums = sums0 + (int64_t)lane * sums_stride;
     const bool bwd_fused = !(t.p2_flags & 64);  // (bit 6: round 3's backward pair -- the plan's decision, MVAL_TRAIN_BWD_FUSED=0; it reads `out`)
     MVAL_REQUIRE(bwd_fused || !(t.p2_flags & (2 | 4 | 8)), "mval_train_backward: op %d: the round-3 BatchNorm backward with a P2-only output / P2 dz", i);
     MVAL_REQUIRE(t.gout_off >= 0, "mval_train_backward: op %d has no output gradient slot", i);
@@ -430,8 +473,23 @@ extern "C" int mval_train_backward(const mval_train_op* ops, int n_ops, int n_im
       if (rc) return rc;
     }
   }
+  walk.finish();
   tt_flush();
   return 0;
+}
+
+extern "C" int mval_train_backward(const mval_train_op* ops, int n_ops, int n_images, float* arena, float* garena,
+                                   const float* params, int64_t ones_off, int64_t zeros_off, const float* input_nchw,
+                                   float* gz, float* wsf, double* ws, float* sums, void* stream) {
+  return train_backward(ops, n_ops, n_images, arena, garena, params, ones_off, zeros_off, input_nchw, gz, wsf, ws, sums, 1, 0, 0, 0, 0, stream);
+}
+
+extern "C" int mval_train_backward_lanes(const mval_train_op* ops, int n_ops, int n_images, float* arena, float* garena,
+                                         const float* params, int64_t ones_off, int64_t zeros_off, const float* input_nchw,
+                                         float* gz, float* wsf, double* ws, float* sums, int n_lanes, int64_t gz_floats_per_lane,
+                                         int64_t wsf_floats_per_lane, int64_t ws_doubles_per_lane, int64_t sums_floats_per_lane, void* stream) {
+  return train_backward(ops, n_ops, n_images, arena, garena, params, ones_off, zeros_off, input_nchw, gz, wsf, ws, sums, n_lanes, gz_floats_per_lane,
+                        wsf_floats_per_lane, ws_doubles_per_lane, sums_floats_per_lane, stream);
 }
 
 // dx (+)= conv(dz [zero-dilated by the stride], flip(W)^T), stride 1, pad k-1-p: the forward

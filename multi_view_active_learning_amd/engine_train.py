@@ -67,7 +67,9 @@ TRAIN_P2_MAX_SLACK_LOG2 = 15.0
 TRAIN_P2_MAX_SMALL_FRAC = 0.5
 SLACK_EVERY = int(os.environ.get("MVAL_TRAIN_SLACK_EVERY", "1024"))
 _SWITCHES = ("MVAL_TRAIN_P2", "MVAL_TRAIN_P2_WGRAD", "MVAL_TRAIN_P2_DGRAD", "MVAL_TRAIN_P2_RES", "MVAL_TRAIN_EPI_STATS", "MVAL_TRAIN_BWD_FUSED",
-             "MVAL_TRAIN_RELU_MASK", "MVAL_TRAIN_DGRAD_PARITY")
+             "MVAL_TRAIN_RELU_MASK", "MVAL_TRAIN_DGRAD_PARITY", "MVAL_TRAIN_LANES")
+MAX_LANES = 4            # (csrc/conv_common.h MVAL_MAX_LANES)
+TRAIN_LANE_FWD, TRAIN_LANE_BWD = 256, 512  # (include/mval_hip.h MVAL_TRAIN_LANE_FWD / _BWD)
 
 
 def _switches():
@@ -142,6 +144,7 @@ class TrainPlan:
             m.k, m.stride, m.pad, m.cin, m.cout = op.k, op.stride, op.pad, op.cin, op.cout
             m.hin, m.win, m.hout, m.wout = hin, win, hout, wout
             m.up, m.relu, m.in_nchw, m.out_nchw = op.up, int(op.relu), int(in_nchw), int(out_nchw)
+            m.phase, m.lane = op.phase, op.lane
             m.algo = ALGO_DIRECT
             bf3 = _conv_mode() in ("bf3", "h2", "p2")  # (p2 is an inference activation format: training runs its h2 arithmetic)
             h2 = _conv_mode() in ("h2", "p2")  # fp16x2 split (3 products) where it applies, else bf16x3 (6)
@@ -357,6 +360,7 @@ class TrainPlan:
                     self._row_top += _align((n * geo[i][2] * geo[i][3] * op.cout // 4 + 3) // 4)
         if g.input in amax_row:
             raise _lib.MvalError("the network input cannot feed an fp16-split conv")
+        self._assign_lanes(g, n, geo)
         self.arena_floats = _align(self._row_top)
         # first writer of every activation-gradient slot (backward order) stores, later ones accumulate;
         # slots nobody writes (activations without a consumer) are the only ones zero-filled
@@ -387,13 +391,17 @@ class TrainPlan:
         self.params = torch.zeros(self.param_floats, **f32)
         self.params[self.ones_off : self.ones_off + maxc] = 1.0
         self.stats = torch.zeros(max(stat_top, 64), **f32)
-        self.gz = torch.empty(max(gz_max, 64), **f32)
-        self.wsf = torch.empty(max(wsf_max, 64), **f32)
+        # (lanes: one slice of every scratch buffer per lane, mval_train_*_lanes)
+        self.gz_lane, self.wsf_lane = _align(max(gz_max, 64)), _align(max(wsf_max, 64))
+        self.gz = torch.empty(self.gz_lane * self.n_lanes, **f32)
+        self.wsf = torch.empty(self.wsf_lane * self.n_lanes, **f32)
         # float64 scratch of the BatchNorm reductions; sized so that the forward conv epilogues' per-workgroup statistics
         # partials fit (cout x workgroups x 2, workgroups <= pixels / 32 for every tile the large layers use)
         epi = max((op.cout * ((n * geo[i][2] * geo[i][3] + 31) // 32 + 64) * 2 for i, op in enumerate(g.ops) if op.bn), default=0)
-        self.ws = torch.empty(max(512 * maxc * 2, epi) + 64, dtype=torch.float64, device=device)
-        self.sums = torch.empty(2 * maxc + 64, **f32)
+        self.ws_lane = _align(max(512 * maxc * 2, epi) + 64)
+        self.ws = torch.empty(self.ws_lane * self.n_lanes, dtype=torch.float64, device=device)
+        self.sums_lane = _align(2 * maxc + 64)
+        self.sums = torch.empty(self.sums_lane * self.n_lanes, **f32)
         self.param_sig = None
         self._pack_ptrs, self._pack_jobs = None, None
         # parameter order of the autograd node: conv.weight [, conv.bias] [, bn.weight, bn.bias] per op
@@ -450,6 +458,54 @@ class TrainPlan:
         self.bn_counters = [holders[op.bn].num_batches_tracked for op in g.ops if op.bn]
 
     # ---- parameters ---------------------------------------------------------------------------
+    def _assign_lanes(self, g, n, geo):
+        """Lanes of the training passes (csrc/net_train.hip, mval_train_*_lanes): the ops of a phase that sit on different lanes -- HRNet's
+        branches, the chains of a fuse layer (graph.py; hrnet.py:199-287) -- are independent, so they run on separate streams.  Forward:
+        every op on a lane > 0 (each writes only its own tensors' slots, rows, masks, statistics).  Backward: only in phases where every
+        gradient slot has ALL its writers on one lane (the branch bodies; a fuse layer's chains all add into the branches' output
+        gradients and stay serial), so each slot sees its first-touch store and its accumulations in the serial order: same bits as
+        MVAL_TRAIN_LANES=0.  What the ops of a lane share -- dz's magnitude row, the dz plane scratch, and the buffers the C call slices
+        per lane -- exists once per lane."""
+        self.n_lanes = 1
+        if os.environ.get("MVAL_TRAIN_LANES", "1") == "0" or not g.ops:
+            return
+        nl = min(MAX_LANES, max(op.lane for op in g.ops) + 1)
+        if nl <= 1:
+            return
+        from .engine import P2_ROW
+        writers = {}  # (phase, activation) -> lanes of the ops whose backward writes that activation's gradient
+        for op in g.ops:
+            for a in (None if op.src == g.input else op.src, op.res1, op.res2):
+                if a is not None:
+                    writers.setdefault((op.phase, a), set()).add(op.lane if op.lane < nl else 0)
+        serial = {ph for (ph, _a), lanes in writers.items() if len(lanes) > 1}
+        row = {0: self.gz_amax_off}
+        scratch = {}
+        for i, op in enumerate(g.ops):
+            t = self.ops[i]
+            if not (0 < op.lane < nl):
+                continue
+            t.p2_flags |= TRAIN_LANE_FWD
+            if op.phase in serial:
+                continue
+            t.p2_flags |= TRAIN_LANE_BWD
+            if t.gz_amax_off > 0:
+                if op.lane not in row:
+                    row[op.lane] = self._row_top
+                    self._row_top += TRAIN_AMAX_ROW
+                t.gz_amax_off = row[op.lane]
+            if t.p2_flags & 4:
+                scratch.setdefault(op.lane, []).append(i)
+        for lane, idx in scratch.items():
+            planes = self._row_top
+            self._row_top += _align(max(n * geo[i][2] * geo[i][3] * g.ops[i].cout for i in idx))
+            rows = self._row_top
+            self._row_top += _align(n * P2_ROW + 512 + 64)
+            self.p2_rows.append((rows, n * P2_ROW + 512 + 64))
+            for i in idx:
+                self.ops[i].gz_p2_off, self.ops[i].gz_p2_rows_off = planes, rows
+        self.n_lanes = nl
+
     def _build_pack_table(self, holders, base):
         """Device-side job table of every split-bf16 weight packing of the plan (forward and data-gradient
         forms) for ``mval_pack_bf3_jobs``: rebuilt only when a parameter's storage moves."""
@@ -596,12 +652,12 @@ class TrainPlan:
         self.generation = getattr(self, "generation", 0) + 1
         out = torch.empty((self.n, self.out_channels) + tuple(self.out_hw), dtype=torch.float32, device=self.device)
         _lib._check(
-            _lib.lib().mval_train_forward(
+            _lib.lib().mval_train_forward_lanes(
                 self.ops, C.c_int(len(self.ops)), C.c_int(self.n), C.c_void_p(self.arena.data_ptr()),
                 C.c_void_p(self.params.data_ptr()), C.c_int64(self.ones_off), C.c_int64(self.zeros_off),
                 C.c_void_p(x.data_ptr()), C.c_void_p(out.data_ptr()), C.c_void_p(self.ws.data_ptr()),
-                C.c_int64(self.ws.numel()), C.c_float(BN_MOMENTUM), C.c_float(BN_EPS), _lib._stream()),
-            "mval_train_forward")
+                C.c_int64(self.ws_lane), C.c_int(self.n_lanes), C.c_float(BN_MOMENTUM), C.c_float(BN_EPS), _lib._stream()),
+            "mval_train_forward_lanes")
         if self.bn_counters:
             torch._foreach_add_(self.bn_counters, 1)
         return out
@@ -641,13 +697,14 @@ class TrainPlan:
         sub = (MvalTrainOp * (hi - lo)).from_address(C.addressof(self.ops) + lo * C.sizeof(MvalTrainOp))
         _lib.lib().mval_train_timing_base(C.c_int(lo))  # (measurement mode's per-operator breakdown)
         _lib._check(
-            _lib.lib().mval_train_backward(
+            _lib.lib().mval_train_backward_lanes(
                 sub, C.c_int(hi - lo), C.c_int(self.n), C.c_void_p(self.arena.data_ptr()),
                 C.c_void_p(self.garena.data_ptr()), C.c_void_p(self.params.data_ptr()), C.c_int64(self.ones_off),
                 C.c_int64(self.zeros_off), C.c_void_p(x.data_ptr()), C.c_void_p(self.gz.data_ptr()),
                 C.c_void_p(self.wsf.data_ptr()), C.c_void_p(self.ws.data_ptr()), C.c_void_p(self.sums.data_ptr()),
+                C.c_int(self.n_lanes), C.c_int64(self.gz_lane), C.c_int64(self.wsf_lane), C.c_int64(self.ws_lane), C.c_int64(self.sums_lane),
                 _lib._stream()),
-            "mval_train_backward")
+            "mval_train_backward_lanes")
         out = []
         holders = self.model._holders
         for slots, op in zip(self.grad_slots[lo:hi], g.ops[lo:hi]):

@@ -546,6 +546,36 @@ def test_round4_training_paths_against_their_switches(dev, off, monkeypatch):
     assert errs[-1] < 5e-2 and errs[len(errs) // 2] < 5e-3, (errs[-1], errs[len(errs) // 2])
 
 
+@pytest.mark.parametrize("case", [cases.train_cases()["w32_train"], dict(arch="hrnet_w48", seed=9, n=2, h=192, w=288, j=5)], ids=lambda c: c["arch"])
+def test_training_lanes_are_bit_identical_to_the_serial_passes(dev, case, monkeypatch):
+    """Round 5: the training passes run HRNet's branches (hrnet.py:199-287) on separate streams (mval_train_*_lanes: forward every op of
+    a lane, backward the phases whose gradient slots each have one writing lane).  No arithmetic and no accumulation order changes, so one
+    step -- heat-maps, loss, EVERY parameter gradient, the BatchNorm running statistics -- equals the single-stream step
+    (MVAL_TRAIN_LANES=0) bit for bit, twice in a row (the side streams leave nothing behind)."""
+    from multi_view_active_learning_amd import engine_train
+
+    c = case
+    runs = []
+    for rep in range(2):
+        m1, _, hm1, l1, _ = _train_once(c, dev)
+        plan = next(iter(m1._train_plans.values()))
+        assert plan.n_lanes == 4
+        assert sum(int(t.p2_flags & engine_train.TRAIN_LANE_BWD != 0) for t in plan.ops) > 100
+        assert sum(int(t.p2_flags & engine_train.TRAIN_LANE_FWD != 0) for t in plan.ops) > sum(int(t.p2_flags & engine_train.TRAIN_LANE_BWD != 0) for t in plan.ops)
+        runs.append((hm1.detach().clone(), l1.detach().clone(), {k: p.grad.detach().clone() for k, p in m1.named_parameters()},
+                     {k: b.detach().clone() for k, b in m1.named_buffers() if "running" in k}))
+    monkeypatch.setenv("MVAL_TRAIN_LANES", "0")
+    m0, _, hm0, l0, _ = _train_once(c, dev)
+    assert next(iter(m0._train_plans.values())).n_lanes == 1
+    g0 = {k: p.grad for k, p in m0.named_parameters()}
+    r0 = {k: b for k, b in m0.named_buffers() if "running" in k}
+    for hm1, l1, g1, r1 in runs:
+        assert torch.equal(hm1, hm0) and torch.equal(l1, l0)
+        bad = [k for k in g0 if not torch.equal(g0[k], g1[k])]
+        assert not bad, bad[:5]
+        assert all(torch.equal(r0[k], r1[k]) for k in r0)
+
+
 @pytest.mark.parametrize("wd", [0.0, 0.01], ids=["plain", "weight_decay"])
 def test_adam_one_launch_vs_torch_adam(dev, wd):
     """optim.Adam (csrc/optim.hip: the update of every parameter in one launch; reference strategy.py:405-407, :479) against
