@@ -938,6 +938,10 @@ def main():
                                           "dz = the BatchNorm backward's P2 planes) log2 of the largest a-priori bound / actual max |x| over the tensors and the largest "
                                           "fraction of a tensor's non-zero values below 2^-3 scaled; past 2^15 (or 0.5 of an activation tensor) the model's next steps "
                                           "run the h2 training kernels")
+            out["config"]["training_passes"] = (
+                "one stream" if tp is None or tp.n_lanes <= 1 else
+                f"{tp.n_lanes} lanes (HRNet's branches on separate streams: forward every op of a lane, backward the phases whose gradient slots each have "
+                "one writing lane; bit-identical to the one-stream step, MVAL_TRAIN_LANES=0; the per-kernel rooflines below are timed on one stream)")
             out["config"]["optimizer"] = {"mval": "multi_view_active_learning_amd.optim.Adam (torch.optim.Adam subclass, step = one mval_adam_step launch)",
                                           "torch": "torch.optim.Adam (foreach)", "fused": "torch.optim.Adam(fused=True)"}[adam_kind]
         if feed is not None:
