@@ -725,10 +725,21 @@ class InferencePlan:
 
 
 def _param_signature(model):
-    holders = model._holders
-    return tuple(t._version for h in holders.values() for t in list(h.parameters()) + list(h.buffers())) + tuple(
-        t.data_ptr() for h in holders.values() for t in h.parameters()
-    )
+    """(version counters of every parameter and buffer, data pointers of the parameters): what a plan's packed weights depend on.
+    Evaluated on EVERY forward, so the walk over the module tree is done once (nn.Module.parameters() / .buffers() are generators over
+    named_modules: 4 400 calls and ~2 ms of host time per HRNet forward -- a third of what a 64-image batch takes on the device) and
+    kept as (owning dict, key) slots; a slot is read through its module's own dict, so a parameter REPLACED by assignment
+    (`conv.weight = nn.Parameter(...)`, `.to(device)`) is seen like one modified in place."""
+    slots = model.__dict__.get("_sig_slots")
+    if slots is None:
+        ps, bs = [], []
+        for h in model._holders.values():
+            for m in h.modules():
+                ps += [(m._parameters, k) for k, v in m._parameters.items() if v is not None]
+                bs += [(m._buffers, k) for k, v in m._buffers.items() if v is not None]
+        slots = model.__dict__["_sig_slots"] = (ps, bs)
+    ps, bs = slots
+    return tuple(d[k]._version for d, k in ps) + tuple(d[k]._version for d, k in bs) + tuple(d[k].data_ptr() for d, k in ps)
 
 
 # bound / actual maximum above which a P2 plan hands over to h2.  The pair (h, l) keeps all 22 significand bits of a value whose

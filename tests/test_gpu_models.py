@@ -347,6 +347,26 @@ def test_state_dict_reload_repacks(dev):
         m(x.cpu())  # no CPU path
 
 
+def test_parameter_replaced_by_assignment_repacks(dev):
+    """The plan's per-forward parameter signature (engine._param_signature) reads every parameter through its module's own dict: a
+    Parameter OBJECT replaced by assignment -- what `module.weight = nn.Parameter(...)` or a pruning / re-initialisation helper does --
+    is picked up like an in-place edit, and so is a buffer (BatchNorm running statistics) edited in place."""
+    c = cases.model_cases()["w32_small"]
+    m, sd = _load(c, dev)
+    x = torch.from_numpy(cases.model_input(c)).to(dev)
+    sd2 = {k: v.clone() for k, v in sd.items()}
+    sd2["final_layer.weight"] = sd["final_layer.weight"] * -1.5
+    sd2["bn1.running_mean"] = sd["bn1.running_mean"] + 0.25
+    with torch.no_grad():
+        y1 = m(x).cpu()
+        m.final_layer.weight = torch.nn.Parameter(sd2["final_layer.weight"].to(dev))
+        m.bn1.running_mean.add_(0.25)
+        y2 = m(x).cpu()
+        want2 = models.hrnet_forward(sd2, x.cpu(), models.HRNET_W32)
+    assert (y1 - y2).abs().max() > 1e-3
+    assert (y2 - want2).abs().max() < 2e-4 * want2.abs().max()
+
+
 def test_reference_shape_tests(dev):
     """The reference's own model tests (tests/test_hrnet.py:14-22, test_pose_resnet.py:14-22):
     default-initialised model, (2,3,256,256) -> [2,19,64,64]."""
