@@ -533,6 +533,10 @@ int mval_train_backward(const mval_train_op* ops, int n_ops, int n_images, float
  * scratch (gz_p2_off ...) must be distinct per lane as well.  One pass per device at a time (the side streams are per device). */
 #define MVAL_TRAIN_LANE_FWD 256
 #define MVAL_TRAIN_LANE_BWD 512
+/* With MVAL_TRAIN_LANE_BWD on the ops of a phase whose lanes DO share gradient slots (a fuse layer's chains, a transition), EVERY op
+ * of that phase -- lane 0 included -- carries MVAL_TRAIN_LANE_ORD: each kernel that writes a gradient slot then waits for the slot's
+ * previous writer of the phase (list order) through an event, so the slot's store / accumulate order stays the one-stream order. */
+#define MVAL_TRAIN_LANE_ORD 1024
 int mval_train_forward_lanes(const mval_train_op* ops, int n_ops, int n_images, float* arena, const float* params,
                              int64_t ones_off, int64_t zeros_off, const float* input_nchw, float* output_nchw,
                              double* ws, int64_t ws_doubles_per_lane, int n_lanes, float momentum, float eps, void* stream);

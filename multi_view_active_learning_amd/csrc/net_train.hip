@@ -180,6 +180,53 @@ static int run_conv(const ConvArgs& a0, int algo, hipStream_t s, const char* wha
 // leave most of the chip idle on their own; next to another branch's kernels they fill its tails.  What each op computes, and the
 // order in which every gradient slot is written, does not change: the plan marks a phase for the backward only if each gradient
 // slot it writes has all its writers on one lane.
+// MVAL_TRAIN_LANE_ORD (backward): the op belongs to a phase whose lanes DO share gradient slots (the chains of a fuse layer all add into
+// the branches' output gradients; a transition's convs into the last branch's).  Its lanes still run on their streams, but every kernel
+// that writes a gradient slot first waits for the slot's previous writer of this phase (in list order, the order of the one-stream pass)
+// and leaves an event behind for the next one: each slot sees its first-touch store and its accumulations in the same order as before,
+// whichever stream they come from.  Nothing in a phase READS a slot another lane of the phase writes (an op reads its own output's
+// gradient, written by its consumers: later phases, or its own lane's chain).
+struct SlotOrder {
+  struct Entry { int64_t off; hipEvent_t ev; hipStream_t s; };
+  std::vector<Entry> last;
+  int phase = -0x7fffffff;
+  static std::vector<hipEvent_t>& pool() {
+    static std::vector<hipEvent_t> p[16];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    return p[dev & 15];
+  }
+  void enter(int ph) {
+    if (ph != phase) {  // (phases join on the caller's stream: everything before is ordered)
+      last.clear();
+      phase = ph;
+    }
+  }
+  void before(int64_t off, hipStream_t s) {
+    if (off < 0) return;
+    for (auto& e : last)
+      if (e.off == off && e.s != s) (void)hipStreamWaitEvent(s, e.ev, 0);
+  }
+  void after(int64_t off, hipStream_t s) {
+    if (off < 0) return;
+    for (auto& e : last)
+      if (e.off == off) {
+        (void)hipEventRecord(e.ev, s);
+        e.s = s;
+        return;
+      }
+    auto& p = pool();
+    if (last.size() >= p.size()) {
+      hipEvent_t ev = nullptr;
+      (void)hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+      p.push_back(ev);
+    }
+    hipEvent_t ev = p[last.size()];
+    (void)hipEventRecord(ev, s);
+    last.push_back({off, ev, s});
+  }
+};
+
 static int lane_of(const mval_train_op& t, int bit, int n_lanes) {
   return (n_lanes > 1 && (t.p2_flags & bit) && t.op.lane > 0 && t.op.lane < n_lanes) ? t.op.lane : 0;
 }
@@ -343,12 +390,15 @@ static int train_backward(const mval_train_op* ops, int n_ops, int n_images, flo
   MvalLanes* L = n_lanes > 1 ? mval_device_lanes() : nullptr;
   if (n_lanes > 1) MVAL_REQUIRE(L != nullptr, "mval_train_backward: could not create the side streams");
   MvalLaneWalk walk(L, mval_stream(stream0));
+  SlotOrder order;
   for (int i = n_ops - 1; i >= 0; i--) {
     g_tt_op = g_tt_base + i;
     const mval_train_op& t = ops[i];
     const mval_op& op = t.op;
     const int lane = lane_of(t, MVAL_TRAIN_LANE_BWD, n_lanes);
     hipStream_t s = walk.stream_for(op.phase, lane);
+    const bool ord = n_lanes > 1 && (t.p2_flags & MVAL_TRAIN_LANE_ORD);
+    if (ord) order.enter(op.phase);
     void* stream = reinterpret_cast<void*>(s);
     float* gz = gz0 + (int64_t)lane * gz_stride;
     float* wsf = wsf0 + (int64_t)lane * wsf_stride;
@@ -359,9 +409,11 @@ static int train_backward(const mval_train_op* ops, int n_ops, int n_images, flo
     MVAL_REQUIRE(t.gout_off >= 0, "mval_train_backward: op %d has no output gradient slot", i);
     if (op.kind == MVAL_OP_MAXPOOL) {
       if (t.gin_off >= 0) {
+        if (ord) order.before(t.gin_off, s);
         int rc = mval_maxpool_bwd(garena + t.gout_off, arena + op.in_off, garena + t.gin_off, n_images, op.hin, op.win,
                                   op.cin, op.hout, op.wout, op.k, op.stride, op.pad, !(t.first_touch & 1), stream);
         if (rc) return rc;
+        if (ord) order.after(t.gin_off, s);
       }
       continue;
     }
@@ -372,6 +424,10 @@ static int train_backward(const mval_train_op* ops, int n_ops, int n_images, flo
     int rc;
     // (p2_flags bit 2) the data gradient on the P2 kernels: the BatchNorm backward also leaves dz as P2 planes
     const bool dz_p2 = (t.p2_flags & 4) && t.gz_p2_off > 0 && t.gin_off >= 0 && bwd_fused && t.has_bn && op.up == 0;
+    if (ord) {  // (the BatchNorm backward scatters the residual gradients)
+      order.before(t.gres1_off, s);
+      order.before(t.gres2_off, s);
+    }
     {
     TtScope tt(TT_BN_BWD, s);
     if (bwd_fused && t.has_bn && op.up == 0 && (op.cout & 3) == 0)
@@ -390,6 +446,10 @@ static int train_backward(const mval_train_op* ops, int n_ops, int n_images, flo
                               op.hout, op.wout, op.cout, op.up, op.relu, t.has_bn, t.first_touch >> 1, gz_row, stream);
     }
     if (rc) return rc;
+    if (ord) {
+      order.after(t.gres1_off, s);
+      order.after(t.gres2_off, s);
+    }
     if (dz_p2 && g_probe && g_tt_base + i < g_probe_n) {
       rc = mval_p2_plane_stats(arena + t.gz_p2_off, reinterpret_cast<const uint32_t*>(arena + t.gz_p2_rows_off), n_images, op.cout,
                                op.hout * op.wout, g_probe + (int64_t)(g_tt_base + i) * 8 + 4, stream);
@@ -422,8 +482,10 @@ static int train_backward(const mval_train_op* ops, int n_ops, int n_images, flo
         a.out = garena + t.gin_off;
         a.res1 = (t.first_touch & 1) ? nullptr : a.out;
         a.res2 = nullptr;
+        if (ord) order.before(t.gin_off, s);
         rc = run_conv(a, MVAL_ALGO_MFMA, s, "mval_train_backward/deconv dgrad");
         if (rc) return rc;
+        if (ord) order.after(t.gin_off, s);
       }
       continue;
     }
@@ -442,6 +504,7 @@ static int train_backward(const mval_train_op* ops, int n_ops, int n_images, flo
     if (rc) return rc;
     if (t.gin_off >= 0) {
       MVAL_REQUIRE(t.dgrad_algo != MVAL_ALGO_MFMA_H2 || gz_row, "mval_train_backward: op %d: fp16-split data gradient without dz's magnitude row", i);
+      if (ord) order.before(t.gin_off, s);
       TtScope tt(TT_DGRAD, s);
       if (dz_p2) {
         // dx (+)= conv(dz, flip(W)^T) on conv_p2.hip: dz planes in, fp32 NHWC gradient slot out (accumulated in place unless first writer)
@@ -471,6 +534,7 @@ static int train_backward(const mval_train_op* ops, int n_ops, int n_images, flo
                                   op.hin, op.win, op.cin, op.hout, op.wout, op.cout, op.k, op.stride, op.pad, t.dgrad_algo,
                                   gz_row, stream);
       if (rc) return rc;
+      if (ord) order.after(t.gin_off, s);
     }
   }
   walk.finish();

@@ -69,7 +69,7 @@ SLACK_EVERY = int(os.environ.get("MVAL_TRAIN_SLACK_EVERY", "1024"))
 _SWITCHES = ("MVAL_TRAIN_P2", "MVAL_TRAIN_P2_WGRAD", "MVAL_TRAIN_P2_DGRAD", "MVAL_TRAIN_P2_RES", "MVAL_TRAIN_EPI_STATS", "MVAL_TRAIN_BWD_FUSED",
              "MVAL_TRAIN_RELU_MASK", "MVAL_TRAIN_DGRAD_PARITY", "MVAL_TRAIN_LANES")
 MAX_LANES = 4            # (csrc/conv_common.h MVAL_MAX_LANES)
-TRAIN_LANE_FWD, TRAIN_LANE_BWD = 256, 512  # (include/mval_hip.h MVAL_TRAIN_LANE_FWD / _BWD)
+TRAIN_LANE_FWD, TRAIN_LANE_BWD, TRAIN_LANE_ORD = 256, 512, 1024  # (include/mval_hip.h MVAL_TRAIN_LANE_FWD / _BWD / _ORD)
 
 
 def _switches():
@@ -467,7 +467,8 @@ class TrainPlan:
         MVAL_TRAIN_LANES=0.  What the ops of a lane share -- dz's magnitude row, the dz plane scratch, and the buffers the C call slices
         per lane -- exists once per lane."""
         self.n_lanes = 1
-        if os.environ.get("MVAL_TRAIN_LANES", "1") == "0" or not g.ops:
+        mode = os.environ.get("MVAL_TRAIN_LANES", "2")  # 0: one stream; 1: the phases without shared gradient slots only; 2: all phases
+        if mode == "0" or not g.ops:
             return
         nl = min(MAX_LANES, max(op.lane for op in g.ops) + 1)
         if nl <= 1:
@@ -483,10 +484,14 @@ class TrainPlan:
         scratch = {}
         for i, op in enumerate(g.ops):
             t = self.ops[i]
+            if op.phase in serial and mode != "1":
+                # lanes that share gradient slots (a fuse layer's chains, a transition): every op of the phase orders its slot writes
+                # behind the slot's previous writer (MVAL_TRAIN_LANE_ORD, csrc/net_train.hip) -- the one-stream store / accumulate order
+                t.p2_flags |= TRAIN_LANE_ORD
             if not (0 < op.lane < nl):
                 continue
             t.p2_flags |= TRAIN_LANE_FWD
-            if op.phase in serial:
+            if op.phase in serial and mode == "1":
                 continue
             t.p2_flags |= TRAIN_LANE_BWD
             if t.gz_amax_off > 0:

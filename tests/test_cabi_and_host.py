@@ -438,6 +438,7 @@ def test_python_constants_match_the_header():
     from multi_view_active_learning_amd import engine_train
 
     assert define("MVAL_TRAIN_LANE_FWD") == engine_train.TRAIN_LANE_FWD and define("MVAL_TRAIN_LANE_BWD") == engine_train.TRAIN_LANE_BWD
+    assert define("MVAL_TRAIN_LANE_ORD") == engine_train.TRAIN_LANE_ORD
     csrc = open(os.path.join(os.path.dirname(__file__), "..", "multi_view_active_learning_amd", "csrc", "conv_common.h")).read()
     assert int(re.search(r"#define\s+MVAL_MAX_LANES\s+(\d+)", csrc).group(1)) == engine_train.MAX_LANES
     for name, val in (("MVAL_OP_BNECK", engine.OP_BNECK), ("MVAL_OP_STEM_P2", engine.OP_STEM_P2), ("MVAL_OP_FUSE_UP", engine.OP_FUSE_UP),

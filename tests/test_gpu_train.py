@@ -561,7 +561,7 @@ def test_training_lanes_are_bit_identical_to_the_serial_passes(dev, case, monkey
         plan = next(iter(m1._train_plans.values()))
         assert plan.n_lanes == 4
         assert sum(int(t.p2_flags & engine_train.TRAIN_LANE_BWD != 0) for t in plan.ops) > 100
-        assert sum(int(t.p2_flags & engine_train.TRAIN_LANE_FWD != 0) for t in plan.ops) > sum(int(t.p2_flags & engine_train.TRAIN_LANE_BWD != 0) for t in plan.ops)
+        assert sum(int(t.p2_flags & engine_train.TRAIN_LANE_ORD != 0) for t in plan.ops) > 40  # (the fuse layers' and transitions' ops)
         runs.append((hm1.detach().clone(), l1.detach().clone(), {k: p.grad.detach().clone() for k, p in m1.named_parameters()},
                      {k: b.detach().clone() for k, b in m1.named_buffers() if "running" in k}))
     monkeypatch.setenv("MVAL_TRAIN_LANES", "0")
