@@ -537,6 +537,9 @@ int mval_train_backward(const mval_train_op* ops, int n_ops, int n_images, float
  * of that phase -- lane 0 included -- carries MVAL_TRAIN_LANE_ORD: each kernel that writes a gradient slot then waits for the slot's
  * previous writer of the phase (list order) through an event, so the slot's store / accumulate order stays the one-stream order. */
 #define MVAL_TRAIN_LANE_ORD 1024
+/* MVAL_TRAIN_LANE_FREE on every op of a backward call: the lanes do not join at phase changes; they fork once and join once per call,
+ * and every op also waits for the last writer of the gradient slot it READS (its own output's gradient).  Same results. */
+#define MVAL_TRAIN_LANE_FREE 2048
 int mval_train_forward_lanes(const mval_train_op* ops, int n_ops, int n_images, float* arena, const float* params,
                              int64_t ones_off, int64_t zeros_off, const float* input_nchw, float* output_nchw,
                              double* ws, int64_t ws_doubles_per_lane, int n_lanes, float momentum, float eps, void* stream);

@@ -196,8 +196,9 @@ struct SlotOrder {
     (void)hipGetDevice(&dev);
     return p[dev & 15];
   }
+  bool keep = false;  // (free-running lanes: the events carry the dependencies across phases)
   void enter(int ph) {
-    if (ph != phase) {  // (phases join on the caller's stream: everything before is ordered)
+    if (ph != phase && !keep) {  // (phases join on the caller's stream: everything before is ordered)
       last.clear();
       phase = ph;
     }
@@ -227,6 +228,38 @@ struct SlotOrder {
   }
 };
 
+// MVAL_TRAIN_LANE_FREE (backward, on every op of the call): no join at the phase changes at all -- the side streams fork once from the
+// caller's stream and join once at the end; EVERY dependency travels through the slot events: an op waits for the last writer of the
+// gradient slot it reads (its own output's gradient; the writers of a slot are chained, so the last one implies them all) and orders its
+// own slot writes as under MVAL_TRAIN_LANE_ORD.  A short lane (the 8 x 8 branch) then runs ahead into the next fuse layer's chain while
+// the 64 x 64 branch is still in its blocks.
+struct LanesFree {
+  MvalLanes* L;
+  hipStream_t main_s;
+  bool used[MVAL_MAX_LANES] = {false, false, false, false};
+  LanesFree(MvalLanes* lanes, hipStream_t s) : L(lanes), main_s(s) {
+    if (L) (void)hipEventRecord(L->fork_ev, main_s);
+  }
+  hipStream_t stream_for(int lane) {
+    if (!L || lane <= 0 || lane >= MVAL_MAX_LANES) return main_s;
+    if (!used[lane]) {
+      (void)hipStreamWaitEvent(L->side[lane], L->fork_ev, 0);
+      used[lane] = true;
+    }
+    return L->side[lane];
+  }
+  void finish() {
+    if (!L) return;
+    for (int l = 1; l < MVAL_MAX_LANES; l++)
+      if (used[l]) {
+        (void)hipEventRecord(L->join_ev[l], L->side[l]);
+        (void)hipStreamWaitEvent(main_s, L->join_ev[l], 0);
+        used[l] = false;
+      }
+  }
+  ~LanesFree() { finish(); }
+};
+
 static int lane_of(const mval_train_op& t, int bit, int n_lanes) {
   return (n_lanes > 1 && (t.p2_flags & bit) && t.op.lane > 0 && t.op.lane < n_lanes) ? t.op.lane : 0;
 }
@@ -238,6 +271,8 @@ static int train_forward(const mval_train_op* ops, int n_ops, int n_images, floa
   if (g_tt_out) n_lanes = 1;  // (measurement mode times every launch group on its own: one stream)
   MvalLanes* L = n_lanes > 1 ? mval_device_lanes() : nullptr;
   if (n_lanes > 1) MVAL_REQUIRE(L != nullptr, "mval_train_forward: could not create the side streams");
+  // (A forward without joins at the phase changes -- every op behind the events of its producers, as the backward's MVAL_TRAIN_LANE_FREE --
+  // measured the same or slower: C3 61.3-61.6 ms against 61.0-61.3 with the joins, profiles/r05/train_lanes_free2.log.)
   MvalLaneWalk walk(L, mval_stream(stream0));
   for (int i = 0; i < n_ops; i++) {
     g_tt_op = i;
@@ -389,16 +424,20 @@ static int train_backward(const mval_train_op* ops, int n_ops, int n_images, flo
   if (g_tt_out) n_lanes = 1;
   MvalLanes* L = n_lanes > 1 ? mval_device_lanes() : nullptr;
   if (n_lanes > 1) MVAL_REQUIRE(L != nullptr, "mval_train_backward: could not create the side streams");
-  MvalLaneWalk walk(L, mval_stream(stream0));
+  const bool free_run = n_lanes > 1 && (ops[n_ops - 1].p2_flags & MVAL_TRAIN_LANE_FREE);
+  MvalLaneWalk walk(free_run ? nullptr : L, mval_stream(stream0));
+  LanesFree lanes_free(free_run ? L : nullptr, mval_stream(stream0));
   SlotOrder order;
+  order.keep = free_run;
   for (int i = n_ops - 1; i >= 0; i--) {
     g_tt_op = g_tt_base + i;
     const mval_train_op& t = ops[i];
     const mval_op& op = t.op;
     const int lane = lane_of(t, MVAL_TRAIN_LANE_BWD, n_lanes);
-    hipStream_t s = walk.stream_for(op.phase, lane);
-    const bool ord = n_lanes > 1 && (t.p2_flags & MVAL_TRAIN_LANE_ORD);
+    hipStream_t s = free_run ? lanes_free.stream_for(lane) : walk.stream_for(op.phase, lane);
+    const bool ord = n_lanes > 1 && (free_run || (t.p2_flags & MVAL_TRAIN_LANE_ORD));
     if (ord) order.enter(op.phase);
+    if (free_run) order.before(t.gout_off, s);  // (the op reads its output's gradient: behind the slot's last writer)
     void* stream = reinterpret_cast<void*>(s);
     float* gz = gz0 + (int64_t)lane * gz_stride;
     float* wsf = wsf0 + (int64_t)lane * wsf_stride;
@@ -538,6 +577,7 @@ static int train_backward(const mval_train_op* ops, int n_ops, int n_images, flo
     }
   }
   walk.finish();
+  lanes_free.finish();
   tt_flush();
   return 0;
 }

@@ -69,7 +69,7 @@ SLACK_EVERY = int(os.environ.get("MVAL_TRAIN_SLACK_EVERY", "1024"))
 _SWITCHES = ("MVAL_TRAIN_P2", "MVAL_TRAIN_P2_WGRAD", "MVAL_TRAIN_P2_DGRAD", "MVAL_TRAIN_P2_RES", "MVAL_TRAIN_EPI_STATS", "MVAL_TRAIN_BWD_FUSED",
              "MVAL_TRAIN_RELU_MASK", "MVAL_TRAIN_DGRAD_PARITY", "MVAL_TRAIN_LANES")
 MAX_LANES = 4            # (csrc/conv_common.h MVAL_MAX_LANES)
-TRAIN_LANE_FWD, TRAIN_LANE_BWD, TRAIN_LANE_ORD = 256, 512, 1024  # (include/mval_hip.h MVAL_TRAIN_LANE_FWD / _BWD / _ORD)
+TRAIN_LANE_FWD, TRAIN_LANE_BWD, TRAIN_LANE_ORD, TRAIN_LANE_FREE = 256, 512, 1024, 2048  # (include/mval_hip.h MVAL_TRAIN_LANE_*)
 
 
 def _switches():
@@ -467,7 +467,9 @@ class TrainPlan:
         MVAL_TRAIN_LANES=0.  What the ops of a lane share -- dz's magnitude row, the dz plane scratch, and the buffers the C call slices
         per lane -- exists once per lane."""
         self.n_lanes = 1
-        mode = os.environ.get("MVAL_TRAIN_LANES", "2")  # 0: one stream; 1: the phases without shared gradient slots only; 2: all phases
+        # 0: one stream; 1: lanes in the phases without shared gradient slots only; 2: in all phases; 3 (default): and the backward without
+        # joins at the phase changes -- every dependency through the slot events
+        mode = os.environ.get("MVAL_TRAIN_LANES", "3")
         if mode == "0" or not g.ops:
             return
         nl = min(MAX_LANES, max(op.lane for op in g.ops) + 1)
@@ -509,6 +511,9 @@ class TrainPlan:
             self.p2_rows.append((rows, n * P2_ROW + 512 + 64))
             for i in idx:
                 self.ops[i].gz_p2_off, self.ops[i].gz_p2_rows_off = planes, rows
+        if mode == "3":  # (backward without joins at the phase changes: every dependency through the slot events)
+            for t in self.ops:
+                t.p2_flags |= TRAIN_LANE_FREE
         self.n_lanes = nl
 
     def _build_pack_table(self, holders, base):

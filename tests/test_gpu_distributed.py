@@ -154,6 +154,10 @@ def test_rccl_world_1_training_step_under_ddp():
     import subprocess
     import sys
 
+    import gc
+
+    gc.collect()
+    torch.cuda.empty_cache()  # (the child needs ~60 GB: give back what earlier tests of THIS process left in torch's caching allocator)
     env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29643")
     r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--workload", "c3", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
                         "--rccl-world-1"], capture_output=True, text=True, env=env, timeout=900)

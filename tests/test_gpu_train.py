@@ -548,9 +548,9 @@ def test_round4_training_paths_against_their_switches(dev, off, monkeypatch):
 
 @pytest.mark.parametrize("case", [cases.train_cases()["w32_train"], dict(arch="hrnet_w48", seed=9, n=2, h=192, w=288, j=5)], ids=lambda c: c["arch"])
 def test_training_lanes_are_bit_identical_to_the_serial_passes(dev, case, monkeypatch):
-    """Round 5: the training passes run HRNet's branches (hrnet.py:199-287) on separate streams (mval_train_*_lanes: forward every op of
-    a lane, backward the phases whose gradient slots each have one writing lane).  No arithmetic and no accumulation order changes, so one
-    step -- heat-maps, loss, EVERY parameter gradient, the BatchNorm running statistics -- equals the single-stream step
+    """Round 5: the training passes run HRNet's branches (hrnet.py:199-287) on separate streams (mval_train_*_lanes; by default without a
+    join at the phase changes: an op waits for the producers of what it reads and for the previous writer of every gradient slot it writes).
+    No arithmetic and no accumulation order changes, so one step -- heat-maps, loss, EVERY parameter gradient, the BatchNorm running statistics -- equals the single-stream step
     (MVAL_TRAIN_LANES=0) bit for bit, twice in a row (the side streams leave nothing behind)."""
     from multi_view_active_learning_amd import engine_train
 
@@ -569,6 +569,12 @@ def test_training_lanes_are_bit_identical_to_the_serial_passes(dev, case, monkey
     assert next(iter(m0._train_plans.values())).n_lanes == 1
     g0 = {k: p.grad for k, p in m0.named_parameters()}
     r0 = {k: b for k, b in m0.named_buffers() if "running" in k}
+    for mode in ("1", "2"):  # (lanes in the slot-disjoint phases only; in all phases, with joins at the phase changes)
+        monkeypatch.setenv("MVAL_TRAIN_LANES", mode)
+        mm, _, hmm, lm, _ = _train_once(c, dev)
+        assert next(iter(mm._train_plans.values())).n_lanes == 4
+        runs.append((hmm.detach().clone(), lm.detach().clone(), {k: p.grad.detach().clone() for k, p in mm.named_parameters()},
+                     {k: b.detach().clone() for k, b in mm.named_buffers() if "running" in k}))
     for hm1, l1, g1, r1 in runs:
         assert torch.equal(hm1, hm0) and torch.equal(l1, l0)
         bad = [k for k in g0 if not torch.equal(g0[k], g1[k])]
