@@ -648,13 +648,18 @@ class InferencePlan:
         return torch.empty((self.n, _lib.ARGMAX_SLOTS, self.out_channels), dtype=torch.int64, device=self.device) if self._keys_wanted() else None
 
     def _graph_wanted(self):
-        """The reference's default batches are 2 frames (config.py:67,87): ~300 launches of a few microseconds
-        of work each, i.e. launch-bound.  Small plans therefore replay a captured hipGraph (MVAL_GRAPH=0
-        disables, MVAL_GRAPH=1 forces it for every size)."""
+        """Small plans and every multi-stream plan replay a captured hipGraph of their forward (MVAL_GRAPH=0: eager launches, =1: replay
+        always).  The reference's default batches are 2
+        frames (config.py:67,87): ~300 launches of a few microseconds of work each, i.e. launch-bound -- rounds 1-4 replayed plans of up
+        to 32 images only.  Round 5 measured the large ones as well: the multi-stream forward's ~240 launches and its fork / join events
+        cost the device less as graph nodes than as host-enqueued packets, also at 128 images -- C2 10.22 -> 10.03 ms, C4 18.14 -> 17.77
+        ms per step, twice each on one box (profiles/r05/graph_replay.log), the copy of the batch into the graph's input buffer and of
+        the heat-maps out of its output buffer included."""
         mode = os.environ.get("MVAL_GRAPH", "auto")
         if mode == "0" or self._graph_failed:
             return False
-        return mode == "1" or self.n * self.h * self.w <= 32 * 256 * 256
+        # (single-stream plans -- PoseResNet -- gain nothing from the replay at large batches: C1 x 16 6.32 eager vs 6.36 ms replayed)
+        return mode == "1" or self.n * self.h * self.w <= 32 * 256 * 256 or any(int(o.lane) > 0 for o in self.ops)
 
     def _capture(self, x):
         self._gx = torch.empty_like(x)
