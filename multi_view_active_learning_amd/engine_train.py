@@ -77,6 +77,33 @@ def _switches():
     return tuple(os.environ.get(k, "1") for k in _SWITCHES)
 
 
+def lane_flags(g, nl, mode):
+    """MVAL_TRAIN_LANE_* bits of every op of graph ``g`` on ``nl`` lanes (pure host logic: TrainPlan._assign_lanes applies them).
+    A phase is SHARED if some activation's gradient is written -- data gradient into op.src, residual gradients into op.res1 / op.res2 -- by
+    ops of that phase on more than one lane.  FWD: every op on a lane > 0.  BWD: the same ops, in mode "1" only outside shared phases.
+    ORD (modes 2, 3): EVERY op of a shared phase, lane 0 included -- its slot writes wait for the slot's previous writer.  FREE (mode 3):
+    every op -- the backward joins once per call and an op also waits for the last writer of the slot it reads."""
+    writers = {}  # (phase, activation) -> lanes of the ops whose backward writes that activation's gradient
+    for op in g.ops:
+        for a in (None if op.src == g.input else op.src, op.res1, op.res2):
+            if a is not None:
+                writers.setdefault((op.phase, a), set()).add(op.lane if op.lane < nl else 0)
+    shared = {ph for (ph, _a), lanes in writers.items() if len(lanes) > 1}
+    out = []
+    for op in g.ops:
+        f = 0
+        if op.phase in shared and mode != "1":
+            f |= TRAIN_LANE_ORD
+        if 0 < op.lane < nl:
+            f |= TRAIN_LANE_FWD
+            if not (op.phase in shared and mode == "1"):
+                f |= TRAIN_LANE_BWD
+        if mode == "3":
+            f |= TRAIN_LANE_FREE
+        out.append(f)
+    return out
+
+
 class TrainPlan:
     def __init__(self, model, n, h, w, device, p2=True):
         g = model._graph
@@ -476,26 +503,14 @@ class TrainPlan:
         if nl <= 1:
             return
         from .engine import P2_ROW
-        writers = {}  # (phase, activation) -> lanes of the ops whose backward writes that activation's gradient
-        for op in g.ops:
-            for a in (None if op.src == g.input else op.src, op.res1, op.res2):
-                if a is not None:
-                    writers.setdefault((op.phase, a), set()).add(op.lane if op.lane < nl else 0)
-        serial = {ph for (ph, _a), lanes in writers.items() if len(lanes) > 1}
+        flags = lane_flags(g, nl, mode)
         row = {0: self.gz_amax_off}
         scratch = {}
         for i, op in enumerate(g.ops):
             t = self.ops[i]
-            if op.phase in serial and mode != "1":
-                # lanes that share gradient slots (a fuse layer's chains, a transition): every op of the phase orders its slot writes
-                # behind the slot's previous writer (MVAL_TRAIN_LANE_ORD, csrc/net_train.hip) -- the one-stream store / accumulate order
-                t.p2_flags |= TRAIN_LANE_ORD
-            if not (0 < op.lane < nl):
+            t.p2_flags |= flags[i]
+            if not (flags[i] & TRAIN_LANE_BWD):
                 continue
-            t.p2_flags |= TRAIN_LANE_FWD
-            if op.phase in serial and mode == "1":
-                continue
-            t.p2_flags |= TRAIN_LANE_BWD
             if t.gz_amax_off > 0:
                 if op.lane not in row:
                     row[op.lane] = self._row_top
@@ -511,9 +526,6 @@ class TrainPlan:
             self.p2_rows.append((rows, n * P2_ROW + 512 + 64))
             for i in idx:
                 self.ops[i].gz_p2_off, self.ops[i].gz_p2_rows_off = planes, rows
-        if mode == "3":  # (backward without joins at the phase changes: every dependency through the slot events)
-            for t in self.ops:
-                t.p2_flags |= TRAIN_LANE_FREE
         self.n_lanes = nl
 
     def _build_pack_table(self, holders, base):

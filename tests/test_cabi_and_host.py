@@ -446,6 +446,47 @@ def test_python_constants_match_the_header():
         assert enum(name) == val, name
 
 
+def test_training_lane_flags_keep_every_gradient_slot_on_one_ordered_chain():
+    """engine_train.lane_flags (host logic behind mval_train_*_lanes, hrnet.py:199-287): on HRNet-W32 / -W48 graphs, in every mode --
+    an op runs its backward on a side lane UNORDERED only in phases where each gradient slot it writes has all its writers on that lane;
+    in a phase whose lanes share a slot EVERY op (lane 0 included) carries the ordering bit (modes 2, 3) or the side lanes stay on the
+    caller's stream (mode 1); the join-less mode marks every op; PoseResNet (one lane) gets no lane bit."""
+    from multi_view_active_learning_amd import engine_train as et
+    from multi_view_active_learning_amd.pose_estimators import PoseHighResolutionNet, PoseResNet, hrnet_w48
+
+    for model in (PoseHighResolutionNet(19), PoseHighResolutionNet(5, hrnet_cfg=hrnet_w48())):
+        g = model._graph
+        nl = min(et.MAX_LANES, max(op.lane for op in g.ops) + 1)
+        assert nl == 4
+        for mode in ("1", "2", "3"):
+            fl = et.lane_flags(g, nl, mode)
+            assert len(fl) == len(g.ops)
+            by_phase = {}
+            for op, f in zip(g.ops, fl):
+                by_phase.setdefault(op.phase, []).append((op, f))
+            n_free_lane, n_ord = 0, 0
+            for ph, ops in by_phase.items():
+                slot_lanes = {}
+                for op, f in ops:
+                    lane = op.lane if (f & et.TRAIN_LANE_BWD) else 0  # the stream its backward runs on
+                    for a in (None if op.src == g.input else op.src, op.res1, op.res2):
+                        if a is not None:
+                            slot_lanes.setdefault(a, set()).add(lane)
+                shared = any(len(v) > 1 for v in slot_lanes.values())
+                for op, f in ops:
+                    assert bool(f & et.TRAIN_LANE_FWD) == (0 < op.lane < nl)
+                    assert bool(f & et.TRAIN_LANE_FREE) == (mode == "3")
+                    if shared:  # slots written from several streams: every writer of the phase must be ordered
+                        assert f & et.TRAIN_LANE_ORD, (mode, ph)
+                    n_ord += bool(f & et.TRAIN_LANE_ORD)
+                    n_free_lane += bool((f & et.TRAIN_LANE_BWD) and not (f & et.TRAIN_LANE_ORD))
+                if mode == "1":
+                    assert not shared  # (shared phases keep their side lanes on the caller's stream)
+            assert n_free_lane > 100 and (n_ord > 40) == (mode != "1")
+    g = PoseResNet(19)._graph
+    assert max(op.lane for op in g.ops) == 0 and not any(et.lane_flags(g, 1, "3")[i] & (et.TRAIN_LANE_FWD | et.TRAIN_LANE_BWD) for i in range(len(g.ops)))
+
+
 def test_adam_mirror_is_torch_adam_off_the_device():
     """multi_view_active_learning_amd.optim.Adam (strategy.py:405-407, :479): on CPU tensors -- and for every configuration the kernel
     does not implement -- it IS torch.optim.Adam: same updates bit for bit, same state_dict layout, StepLR drives it."""
