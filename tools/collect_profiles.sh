@@ -14,6 +14,7 @@ python3 bench.py --workload c3 --steps 20 2>/dev/null | tail -1 > $out/bench_c3_
 python3 bench.py 2>/dev/null | tail -1 > $out/bench_c2_$tag.json                            # (the driver's command: headline + exact_modes + companions)
 export MVAL_STREAMS=1
 export MVAL_TRAIN_LANES=0   # (likewise the training passes: one stream, so that a kernel's traced duration is its own)
+export MVAL_GRAPH=0         # (eager launches under the profiler: the traces and counter passes of rounds 1-5 were all taken that way)
 export MVAL_TRAIN_SLACK_CHECK=0   # (the training plan's one-off bound-slack probe -- 481 measurement launches on step 0 -- stays out of the traces)
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_c2 -o c2 -- python3 bench.py --no-cpu-baseline --no-exact-modes --no-companions --steps 30 2>/dev/null | tail -1 > $out/bench_c2_${tag}_under_rocprof.json
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_c3 -o c3 -- python3 bench.py --workload c3 --no-cpu-baseline --no-exact-modes --no-companions --no-rooflines --steps 5 2>/dev/null | tail -1 > $out/bench_c3_${tag}_under_rocprof.json
