@@ -939,6 +939,14 @@ def main():
             "roofline": roof,
             "parity_unpinned": PARITY_UNPINNED,
         }
+        if not train:
+            try:  # (how the timed steps enqueued the network: engine.InferencePlan._graph_wanted)
+                ip = _plan_for(model, images)
+                out["config"]["network_launch"] = ("captured hipGraph replayed per batch (multi-stream plan; the batch is copied into the graph's input "
+                                                   "tensor and the heat-maps out of its output tensor inside the timed region)" if getattr(ip, "_graph", None) is not None
+                                                   else "eager launches")
+            except Exception:
+                pass
         if train:
             tp = next(iter(model._train_plans.values()), None)
             out["p2_bound_slack"] = None if tp is None else tp.p2_slack
