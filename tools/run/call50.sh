@@ -1,0 +1,13 @@
+#!/bin/bash
+export TMPDIR=/tmp
+mkdir -p gpurun_out
+L=gpurun_out/ns4_nt2.log
+rm -f $L
+MVAL_LIB_TAG=ns4 timeout 600 python -m pytest tests/test_gpu_p2.py -q -m gpu -x -k "conv_vs_float64 or batch" 2>&1 | grep -a -E "passed|failed" >> $L
+MVAL_LIB_TAG=ns4 timeout 600 python -m pytest tests/test_gpu_models.py -q -m gpu -k "golden and w32" 2>&1 | grep -a -E "passed|failed" >> $L
+for r in 1 2 3; do
+for t in "" ns4; do
+  MVAL_LIB_TAG=$t python bench.py --no-cpu-baseline --no-exact-modes --no-companions --no-rooflines --steps 100 2>/dev/null | grep -a '^{' | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('variant \"$t\" c2', d['ms_per_step'])" >> $L 2>&1
+done
+done
+cat $L
