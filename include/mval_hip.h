@@ -129,7 +129,8 @@ typedef struct mval_view_desc {
   const uint8_t* img;               /* decoded RGB image [h0][w0][3] (device) */
   int32_t h0, w0;
   int32_t left, top, right, bottom; /* square / scaled box (utils/triangulation.py:96-134); may leave the image */
-  int64_t tmp_off;                  /* byte offset of this view's [bottom-top][in_w][3] slab in the workspace */
+  int64_t tmp_off;                  /* byte offset of this view's [bottom-top][in_w][3] slab in the workspace's temp part (slabs back to back:
+                                     * multiples of in_w * 3; the vertical pass reads 4 bytes at a time where the slab is 4-byte aligned) */
 } mval_view_desc;
 /* ws >= mval_prepare_views_workspace_bytes(n_views, sum of the views' crop heights, in_w, in_h). */
 size_t mval_prepare_views_workspace_bytes(int n_views, int64_t total_crop_rows, int in_w, int in_h);
