@@ -367,6 +367,37 @@ def test_parameter_replaced_by_assignment_repacks(dev):
     assert (y2 - want2).abs().max() < 2e-4 * want2.abs().max()
 
 
+def test_multi_stream_plans_replay_a_graph_at_every_batch_size(dev, monkeypatch):
+    """Round 5: every multi-stream plan replays its captured hipGraph, not only plans of up to 32 images (engine.InferencePlan._graph_wanted);
+    one-stream plans (PoseResNet) above 32 images stay eager.  The replay and the eager launches of the SAME plan give the same bits, and
+    the arg-max keys of the heat-map layer travel with the replayed output."""
+    from multi_view_active_learning_amd import _lib, engine
+    from multi_view_active_learning_amd.pose_estimators import PoseHighResolutionNet, PoseResNet
+
+    torch.manual_seed(3)
+    x = torch.randn(40, 3, 128, 96, device=dev)
+    with torch.no_grad():
+        m = PoseHighResolutionNet(19).to(dev).eval()
+        a = m(x)
+        plan = engine._plan_for(m, x)
+        assert plan._graph is not None and any(int(o.lane) > 0 for o in plan.ops)
+        b = m(x)  # (the replay proper: the first call captured)
+        ka = _lib.argmax_keys_of(b)
+        monkeypatch.setenv("MVAL_GRAPH", "0")
+        c = m(x)
+        assert engine._plan_for(m, x) is plan
+        assert torch.equal(a, c) and torch.equal(b, c)
+        kc = _lib.argmax_keys_of(c)
+        assert (ka is None) == (kc is None) and (ka is None or torch.equal(ka, kc))
+        monkeypatch.delenv("MVAL_GRAPH")
+        r = PoseResNet(19).to(dev).eval()
+        xb = torch.randn(48, 3, 256, 192, device=dev)  # (more pixels than 32 images of 256 x 256)
+        r(xb)
+        assert engine._plan_for(r, xb)._graph is None  # one stream, large: eager
+        r(x[:8])
+        assert engine._plan_for(r, x[:8])._graph is not None
+
+
 def test_reference_shape_tests(dev):
     """The reference's own model tests (tests/test_hrnet.py:14-22, test_pose_resnet.py:14-22):
     default-initialised model, (2,3,256,256) -> [2,19,64,64]."""
