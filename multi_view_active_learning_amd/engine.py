@@ -672,7 +672,9 @@ class InferencePlan:
             self._launch(self._gx, self._gout, self._gkeys)
         torch.cuda.current_stream(self.device).wait_stream(side)
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        # (thread-local capture mode: under torch.distributed the RCCL watchdog thread of the process queries its events while this
+        # thread captures -- in the default global mode any such call from another thread can invalidate the capture)
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
             self._launch(self._gx, self._gout, self._gkeys)
         self._graph = graph
 
