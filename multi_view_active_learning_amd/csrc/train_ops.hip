@@ -364,7 +364,10 @@ __global__ __launch_bounds__(TR_APPLY_THREADS) __attribute__((amdgpu_waves_per_e
       const int Y = pin / Wo, X = pin - Y * Wo;
       const int64_t zi = (((int64_t)n * H + (Y >> up)) * W + (X >> up)) * C + q * 4;
       const int64_t o = pix * C + q * 4;
-      const f32x4 zv = *reinterpret_cast<const f32x4*>(z + zi);
+            // (z is not needed again before the backward pass: a non-temporal load leaves the caches to the planes the next conv reads;
+      // with the same hint on the backward apply's LAST reads of the output gradient, z and the mask bytes: C3 61.28 -> 60.81 ms, three
+      // runs each on one box, profiles/r05/bn_nt_z.log)
+      const f32x4 zv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(z + zi));
       const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + q * 4);
       const f32x4 is = *reinterpret_cast<const f32x4*>(invstd + q * 4);
       const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + q * 4);
@@ -938,10 +941,11 @@ __global__ __launch_bounds__(TR_APPLY_THREADS) __attribute__((amdgpu_waves_per_e
       n = (int)(pix / HW);
       pin = (int)(pix - (int64_t)n * HW);
       const int64_t o = pix * C + q * 4;
-      const f32x4 gv0 = *reinterpret_cast<const f32x4*>(gsrc + o);
-      const f32x4 zv = *reinterpret_cast<const f32x4*>(z + o);
+      // (the LAST reads of the output gradient, of z and of the mask bytes: non-temporal, see bn_apply_fwd_p2_kernel)
+      const f32x4 gv0 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(gsrc + o));
+      const f32x4 zv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(z + o));
       f32x4 ov = MM == 1 ? *reinterpret_cast<const f32x4*>(out + o) : zero;
-      if (MM == 3) ov.x = __uint_as_float((unsigned)relu_mask[o >> 2]);
+      if (MM == 3) ov.x = __uint_as_float((unsigned)__builtin_nontemporal_load(relu_mask + (o >> 2)));
       const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + q * 4);
       const f32x4 is = *reinterpret_cast<const f32x4*>(invstd + q * 4);
       const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + q * 4);
