@@ -38,6 +38,10 @@
 #endif
 #endif
 
+#ifndef P2_RES_AUX
+#define P2_RES_AUX 2  // cache policy of the FIRST residual's loads: non-temporal (nt) -- the residual of a BasicBlock is its input's last use, that of a
+                      // fuse chain the partial sum's -- C2 10.08 -> 10.02 ms, C1x16 6.35 -> 6.31, C4 17.82 -> 17.78 (profiles/r05/p2_nt_res*.log); 0 = default policy
+#endif
 #ifndef P2_VALU_PRIO
 #define P2_VALU_PRIO 2
 #endif
@@ -521,7 +525,7 @@ __device__ __forceinline__ void conv_p2_body(const P2Args& a, const int by, cons
 #pragma unroll
         for (int nt = 0; nt < NT; nt++)
 #pragma unroll
-          for (int ms = 0; ms < MS; ms++) R1[ms][nt] = __builtin_amdgcn_raw_buffer_load_b128(r1r, voff(nt, ms), soff(ms), 0);
+          for (int ms = 0; ms < MS; ms++) R1[ms][nt] = __builtin_amdgcn_raw_buffer_load_b128(r1r, voff(nt, ms), soff(ms), P2_RES_AUX);
       }
       __builtin_amdgcn_sched_barrier(SB);
       mfma_stage(std::integral_constant<bool, K48>{}, buf, nst - 1, have_next, 0);
@@ -594,7 +598,7 @@ __device__ __forceinline__ void conv_p2_body(const P2Args& a, const int by, cons
           if constexpr (!pre_res) {
 #pragma unroll
             for (int ms = 0; ms < MS; ms++) {
-              if constexpr (decltype(has_r1)::value) q1[ms] = __builtin_amdgcn_raw_buffer_load_b128(r1r, voff(nt, ms), soff(ms), 0);
+              if constexpr (decltype(has_r1)::value) q1[ms] = __builtin_amdgcn_raw_buffer_load_b128(r1r, voff(nt, ms), soff(ms), P2_RES_AUX);
               if constexpr (decltype(has_r2)::value) q2[ms] = __builtin_amdgcn_raw_buffer_load_b128(r2r, voff(nt, ms), soff(ms), 0);
             }
           }
@@ -725,7 +729,7 @@ __device__ __forceinline__ void conv_p2_body(const P2Args& a, const int by, cons
               for (int u = 0; u < 4; u++) {
                 const int dy = (i0 + u) >> a.up, dx = (i0 + u) & (rep - 1);
                 vo[u] = ok ? vo0 + (unsigned)(dy * Wo + dx) * 16u : 0x80000000u;
-                if (a.res1) g1[u] = __builtin_amdgcn_raw_buffer_load_b128(r1r, vo[u], 0, 0);
+                if (a.res1) g1[u] = __builtin_amdgcn_raw_buffer_load_b128(r1r, vo[u], 0, P2_RES_AUX);
                 if (a.res2) g2[u] = __builtin_amdgcn_raw_buffer_load_b128(r2r, vo[u], 0, 0);
               }
 #pragma unroll

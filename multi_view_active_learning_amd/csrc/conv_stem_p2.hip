@@ -25,6 +25,9 @@
 #include <stdlib.h>
 
 #include "conv_p2.h"
+#ifndef P2_STEM_AUX
+#define P2_STEM_AUX 2  // cache policy of the image loads: non-temporal (every image is read by this launch only); with P2_RES_AUX: C2 10.08 -> 10.01 ms
+#endif
 
 #ifndef P2_VALU_PRIO
 #define P2_VALU_PRIO 2
@@ -153,7 +156,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
       const int py = r / IW, px = r - py * IW;
       const int iy = 4 * oy0 - 3 + py, ix = 4 * ox0 - 3 + px;
       const bool ok = e < 3 * IH * IW && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-      pre[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, ok ? (unsigned)(((n * 3 + c) * a.H + iy) * a.W + ix) * 4u : 0x80000000u, 0, 0));
+      pre[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, ok ? (unsigned)(((n * 3 + c) * a.H + iy) * a.W + ix) * 4u : 0x80000000u, 0, P2_STEM_AUX));
     }
   };
 #ifdef ST_MFMA1
