@@ -1,0 +1,13 @@
+#!/bin/bash
+export TMPDIR=/tmp
+mkdir -p gpurun_out
+L=gpurun_out/p2_nt_res3.log
+rm -f $L
+MVAL_LIB_TAG=bf timeout 600 python -m pytest tests/test_gpu_models.py -q -m gpu -k "golden and (w32 or w48 or r50)" 2>&1 | grep -a -E "passed|failed" >> $L
+for r in 1 2 3; do
+for t in "" bf; do
+  MVAL_LIB_TAG=$t python bench.py --no-cpu-baseline --no-exact-modes --no-companions --no-rooflines --steps 100 2>/dev/null | grep -a '^{' | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('variant \"$t\" c2', d['ms_per_step'])" >> $L 2>&1
+  MVAL_LIB_TAG=$t python bench.py --workload c4 --no-cpu-baseline --no-exact-modes --no-companions --no-rooflines --steps 100 2>/dev/null | grep -a '^{' | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('variant \"$t\" c4', d['ms_per_step'])" >> $L 2>&1
+done
+done
+cat $L
