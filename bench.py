@@ -56,6 +56,16 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0  # same guide: dense bf16 / fp16 MFMA (the 5 PF h
 SPLIT_PRODUCTS = {"p2": 3, "h2": 3, "bf3": 6}  # MFMA products per algorithmic product of the 16-bit splits
 PARITY_UNPINNED = ["soft_argmax (kornia absent)", "MPE / BSB peak_local_max: pinned on scikit-image 0.18.3 vectors except the order among equal intensities "
                    "(numpy's unstable argsort)"]
+# `dtype` of the line = the arithmetic the convs compute in (a label, <= 120 characters); the long form goes to the detail record
+DTYPE_LABEL = {"fp32": "f32 (exact-fp32 MFMA)",
+               "bf3": "f32 (convs: exact 3-way bf16 split, 6 bf16 MFMA products per fp32 product, fp32 accumulate)",
+               "h2": "f32 (convs: scaled 2-way fp16 split, 3 fp16 MFMA products per fp32 product, fp32 accumulate)",
+               "p2": "f32 (fp16 (h,l)-pair activations+weights: 3 fp16 MFMA products per fp32 product, fp32 accumulate)"}
+DTYPE_NOTE = {"fp32": "v_mfma_f32_16x16x4_f32 everywhere",
+              "bf3": "fp32 values as exact 3-way bf16 splits on the bf16 MFMA, fp32 accumulate",
+              "h2": "fp32 values as scaled 2-way fp16 splits on the fp16 MFMA, fp32 accumulate; measured at the exact-fp32 MFMA chain's error",
+              "p2": "activations held as scaled fp16 (h, l) pairs = 22-bit significands, weights likewise; convs: 3 fp16 MFMA products per fp32 "
+                    "product, lo x lo dropped, fp32 accumulate; measured below the exact-fp32 MFMA chain's error"}
 FLOP_PER_IMAGE = {"hrnet_w32_256": 20.387e9}  # conv FLOPs (2*MAC) per frame x view
 
 WORKLOADS = {
@@ -147,9 +157,9 @@ def cpu_baseline(wl, sd_np, seconds_target=20.0):
         _check=dict(images=imgs, proj=proj, **first),
         value=done * v / el, unit="frames*views/s", cores=torch.get_num_threads(), kind="port", host_cpu=host_cpu_model(),
         host_logical_cpus=os.cpu_count(),
-        sample=f"{done} frames x {v} views ({done * v} images) of the same workload, {el:.1f} s, "
-               f"stock torch fp32 {wl['arch']} + numpy RANSAC-DLT (oracle/), {torch.get_num_threads()} threads "
-               f"(best of {sorted(tried)}; {frames_per_call * v} images per call)",
+        sample=f"{done} frames x {v} views of the same workload, {el:.1f} s, torch-CPU fp32 net + numpy RANSAC-DLT",
+        sample_note=f"{done * v} images, stock torch fp32 {wl['arch']} + numpy RANSAC-DLT (oracle/), {torch.get_num_threads()} threads "
+                    f"(best of {sorted(tried)}; {frames_per_call * v} images per call)",
         threads_tried={str(k): round(frames_per_call * v / t, 2) for k, t in tried.items()},
         threads_tried_note="frames*views/s of the network alone per thread count, same images per call as `value` (which adds the "
                            "numpy RANSAC-DLT)",
@@ -196,8 +206,9 @@ def cpu_baseline_train(wl, sd_np, seconds_target=20.0):
             break
     return dict(_check=check, value=done * v / el, unit="frames*views/s", cores=best, kind="port", host_cpu=host_cpu_model(),
                 host_logical_cpus=os.cpu_count(),
-                sample=f"{done} frames x {v} views of the same shapes, {el:.1f} s, stock torch fp32 train-mode forward + masked MSE + "
-                       f"autograd backward (oracle/), {best} threads (best of {sorted(tried)}); no optimizer step",
+                sample=f"{done} frames x {v} views of the same shapes, {el:.1f} s, torch-CPU fp32 fwd + MSE + autograd bwd",
+                sample_note=f"stock torch fp32 train-mode forward + masked MSE + autograd backward (oracle/), {best} threads "
+                            f"(best of {sorted(tried)}); no optimizer step",
                 threads_tried={str(k): round(frames_per_call * v / t, 2) for k, t in tried.items()})
 
 
@@ -344,6 +355,127 @@ def train_rooflines(model, step, frames, v, mode):
     return top
 
 
+LINE_LIMIT = 4096  # the driver keeps an 8 000-character tail of stdout: the line it parses stays well inside it
+
+
+def _short(s, n):
+    """A label for the line: the text before the first explanatory parenthesis, at most n characters."""
+    if s is None:
+        return None
+    s = str(s).split(" (")[0].split("; ")[0].strip()
+    return s if len(s) <= n else s[: n - 1].rstrip() + "~"
+
+
+def _num(x, nd=4):
+    if isinstance(x, bool) or x is None:
+        return x
+    if isinstance(x, (int, np.integer)):
+        return int(x)
+    if isinstance(x, (float, np.floating)):
+        x = float(x)
+        if x != x or x in (float("inf"), float("-inf")):
+            return None
+        return round(x, nd) if abs(x) >= 1e-3 or x == 0 else float(f"{x:.3e}")
+    return x
+
+
+_ROOF_KEYS = ("bound", "achieved", "peak", "unit", "frac", "traffic", "seconds_in_kernel_per_step")
+
+
+def _roof_line(roof):
+    if not roof:
+        return None
+    r = {"kernel": _short(roof.get("kernel"), 60)}
+    r.update({k: _num(roof.get(k)) for k in _ROOF_KEYS})
+    r["seconds_in_kernel_per_step"] = _num(roof.get("seconds_in_kernel_per_step"), 6)
+    for k in ("launches_per_step", "avg_launch_us"):
+        if roof.get(k) is not None:
+            r[k] = _num(roof[k], 2)
+    return r
+
+
+def compact_line(out, detail_path=None):
+    """The ONE line of stdout: the driver's contract fields, the dominant kernel's roofline, the CPU baseline with its parity
+    sample, the bit-strict companions' times and one {ms_per_step, value, frac} triple per companion workload -- flat, numbers
+    and short labels only, at most LINE_LIMIT characters, strict JSON (no NaN / Infinity).  Everything else the run measured
+    (other kernels, pass counts, notes, per-rank attribution) is the detail record (--detail-out)."""
+    cfg = out.get("config") or {}
+    line = {k: _num(out.get(k)) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "timed_repeats",
+                                          "higher_is_better", "scaling", "vs_baseline")}
+    line["dtype"] = str(out.get("dtype"))[:120]
+    line["data"] = _short(out.get("data"), 40)
+    c = {"workload": str(cfg.get("workload", ""))[:160]}
+    for k in ("frames_per_step_per_gpu", "views", "images_per_step_per_gpu", "pool_frames", "frames_per_batch"):
+        if k in cfg:
+            c[k] = cfg[k]
+    if "parallelism" in cfg:
+        c["parallelism"] = _short(cfg["parallelism"], 60)
+    line["config"] = c
+    line["roofline"] = _roof_line(out.get("roofline"))
+    cpu = out.get("cpu_baseline")
+    if cpu:
+        cb = {k: _num(cpu.get(k), 3) for k in ("value", "unit", "cores", "kind")}
+        cb["host_cpu"] = _short(cpu.get("host_cpu"), 48)
+        cb["sample"] = str(cpu.get("sample"))[:110]
+        ps = cpu.get("parity_sample")
+        if ps:
+            flat = {}
+            for k, v_ in ps.items():
+                if isinstance(v_, dict):  # (the training sample's three gradient errors: the worst one)
+                    vals = [x for x in v_.values() if isinstance(x, (int, float))]
+                    if vals:
+                        flat[k + "_max"] = _num(max(vals))
+                elif isinstance(v_, (int, float, bool)):
+                    flat[k] = _num(v_)
+            cb["parity_sample"] = flat
+        line["cpu_baseline"] = cb
+    em = out.get("exact_modes")
+    if em:
+        line["exact_modes"] = {k: (_num(v_, 3) if isinstance(v_, (int, float)) else "failed") for k, v_ in em.items() if k != "note"}
+    comp = out.get("companions")
+    if comp:
+        cc = {}
+        for name, d in comp.items():
+            if not isinstance(d, dict):
+                continue
+            if "error" in d:
+                cc[name] = {"error": str(d["error"])[:80]}
+            else:
+                rf = d.get("roofline") or {}
+                cc[name] = {"ms_per_step": _num(d.get("ms_per_step"), 3), "value": _num(d.get("value"), 1),
+                            "kernel": _short(rf.get("kernel"), 40), "bound": rf.get("bound"), "frac": _num(rf.get("frac"))}
+                if rf.get("whole_step_tflops_3x_forward") is not None:  # (training: 3 x forward conv FLOPs / step time, SURVEY 8d)
+                    cc[name]["step_tflops_3x_fwd"] = _num(rf["whole_step_tflops_3x_forward"], 1)
+                if isinstance(d.get("cpu_baseline"), dict):
+                    cc[name]["cpu_value"] = _num(d["cpu_baseline"].get("value"), 2)
+        line["companions"] = cc
+    att = out.get("attribution")
+    if att:
+        a = {}
+        pr = att.get("per_rank_s") or {}
+        a["per_rank_s"] = {k: pr.get(k) for k in ("min", "mean", "max") if k in pr}
+        if len(pr.get("all", [])) <= 8:
+            a["per_rank_s"]["all"] = pr.get("all")
+        for k in ("compute_s", "gather_s", "select_s", "allreduce_exposed_s"):
+            if k in att:
+                a[k] = att[k]
+        line["attribution"] = a
+    if out.get("input_inclusive"):
+        line["input_inclusive"] = {"host_to_device_GBps": out["input_inclusive"].get("host_to_device_GBps")}
+    if out.get("picks_crc") is not None:
+        line["picks_crc"] = out["picks_crc"]
+    if detail_path:
+        line["detail"] = detail_path
+    # the limit is a contract, not a hope: drop the optional groups, least important first, until the line fits
+    for drop in (None, "input_inclusive", "attribution", "companions", "exact_modes", "detail"):
+        if drop:
+            line.pop(drop, None)
+        s = json.dumps(line, allow_nan=False, separators=(", ", ": "))
+        if len(s) <= LINE_LIMIT:
+            return s
+    raise RuntimeError(f"bench line is {len(s)} characters with every optional group dropped")
+
+
 def host_cpu_model():
     try:
         with open("/proc/cpuinfo") as f:
@@ -458,6 +590,13 @@ def main():
                     help="the K-step region is repeated until it is at least this long (counter passes use 0: K steps exactly)")
     ap.add_argument("--no-companions", action="store_true",
                     help="default c2 run: skip the C3 / C4 companion lines (child processes after the headline)")
+    ap.add_argument("--shared-device", action="store_true",
+                    help="TEST ONLY (tests/test_gpu_distributed.py): the N ranks all use cuda:0 and talk over gloo -- the rehearsal of this "
+                         "script's N > 1 code (self-launch, barriers, rank reductions, attribution, DDP) on a one-GPU box.  RCCL refuses two "
+                         "ranks on one device; the collectives' payloads are the same device tensors.  Not a measurement: the line says so")
+    ap.add_argument("--detail-out", default=os.path.join(ROOT, "bench_detail.json"),
+                    help="file for the run's full record (every kernel family, notes, pass counts, per-rank attribution, the companions' own "
+                         "records); stdout carries only the compact line (<= 4 KB).  '' = do not write it")
     args = ap.parse_args()
     pool_pass = args.pool is not None or WORKLOADS[args.workload].get("pool") is not None
     if args.steps is None:
@@ -472,7 +611,7 @@ def main():
         import subprocess
 
         have = torch.cuda.device_count()
-        if have < args.gpus:
+        if have < (1 if args.shared_device else args.gpus):
             sys.exit(f"bench.py --gpus {args.gpus}: needs {args.gpus} devices, this node has {have}")
         with socket.socket() as sk:
             sk.bind(("127.0.0.1", 0))
@@ -482,7 +621,7 @@ def main():
         sys.exit(subprocess.run(cmd).returncode)
 
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = 0 if args.shared_device else int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         sys.exit(f"bench.py --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus} "
@@ -496,7 +635,10 @@ def main():
             os.environ["MVAL_DIST_NO_SHORTCUT"] = "1"
             os.environ.setdefault("RANK", "0")
             os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.shared_device:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -516,8 +658,11 @@ def main():
         wl["frames"] = args.frames_per_batch
     v, h, w, j, frames = wl["v"], wl["h"], wl["w"], wl["j"], wl["frames"]
     model, sd_np = build_model(wl["arch"], j, dev)
-    images = torch.from_numpy(synth.images(1000 + rank, frames, v, h, w)).to(dev).reshape(frames * v, 3, h, w)
-    proj = torch.from_numpy(np.stack([synth.ring_cameras(v, h, w, seed=rank * 1000 + s) for s in range(frames)])).to(dev)
+    # (--shared-device: every rank holds the SAME resident batch, so that a pool pass's content -- the batch repeated -- does not depend on
+    # the number of ranks and the picks of an N-rank rehearsal can be compared with the one-rank run)
+    crank = 0 if args.shared_device else rank
+    images = torch.from_numpy(synth.images(1000 + crank, frames, v, h, w)).to(dev).reshape(frames * v, 3, h, w)
+    proj = torch.from_numpy(np.stack([synth.ring_cameras(v, h, w, seed=crank * 1000 + s) for s in range(frames)])).to(dev)
     valid = torch.ones(frames, j, dtype=torch.uint8, device=dev)
 
     train = wl["train"]
@@ -921,11 +1066,8 @@ def main():
             "higher_is_better": True,
             "scaling": "strong" if wl.get("pool") else "weak",
             "vs_baseline": None,
-            "dtype": {"fp32": "f32", "bf3": "f32 (convs: fp32 values as exact 3-way bf16 splits on the bf16 MFMA, fp32 accumulate)",
-                      "h2": "f32 (convs: fp32 values as scaled 2-way fp16 splits on the fp16 MFMA, fp32 accumulate; "
-                            "measured at the exact-fp32 MFMA chain's error)",
-                      "p2": "f32 (activations held as scaled fp16 (h, l) pairs = 22-bit significands, weights likewise; convs: 3 fp16 MFMA "
-                            "products per fp32 product, lo x lo dropped, fp32 accumulate; measured below the exact-fp32 MFMA chain's error)"}[_conv_mode()],
+            "dtype": DTYPE_LABEL[_conv_mode()],
+            "dtype_note": DTYPE_NOTE[_conv_mode()],
             "data": "synthetic (random variance-preserving weights, N(0,1) frames, ring cameras)",
             "config": ({"workload": wl["desc"].replace("256-frame pool", f"{wl['pool']}-frame pool")
                                    + ("" if wl.get("picks") else f"; one step = one pass over a {wl['pool']}-frame pool sharded over the ranks"),
@@ -939,6 +1081,14 @@ def main():
             "roofline": roof,
             "parity_unpinned": PARITY_UNPINNED,
         }
+        if args.shared_device:
+            out["config"]["parallelism"] = f"REHEARSAL: {world} ranks share cuda:0 over gloo; " + out["config"]["parallelism"]
+        if wl.get("pool") and r is not None and "picks" in r:
+            import zlib
+
+            pk = r["picks"]
+            pk = pk.cpu().tolist() if torch.is_tensor(pk) else [x if isinstance(x, (int, str)) else int(x) for x in pk]
+            out["picks_crc"] = zlib.crc32(json.dumps(pk).encode())  # (the selection of the last pass: equal across rank counts on equal content)
         if not train:
             try:  # (how the timed steps enqueued the network: engine.InferencePlan._graph_wanted)
                 ip = _plan_for(model, images)
@@ -1047,22 +1197,29 @@ def main():
             # BASELINE configs[2] / [3] under the same (driver) clock: child processes of this command, run after the headline's
             # timed region and measurements; each times >= 2 s of its own step.  A failure is recorded, not raised.
             import subprocess
+            import tempfile
 
             comp = {}
             _CK = ("kernel", "bound", "achieved", "peak", "unit", "frac", "seconds_in_kernel_per_step", "traffic", "traffic_source", "bytes_per_step",
-                   "flops_per_step", "passes", "bytes_round3_count", "frac_round3_count", "launches_per_step", "avg_launch_us")
+                   "flops_per_step", "passes", "bytes_round3_count", "frac_round3_count", "launches_per_step", "avg_launch_us",
+                   "whole_step_tflops_3x_forward")
             for name, extra in (("c3", ["--steps", "20", "--warmup", "3", "--cpu-seconds", str(min(args.cpu_seconds, 12.0))]),
                                 ("c4", ["--steps", "100", "--warmup", "3", "--no-cpu-baseline"]),
                                 # the headline's workload from uint8 crops in pinned host memory (H->D copy + device input pipeline in the step): never `value`
                                 ("c2_with_input", ["--steps", "100", "--warmup", "5", "--no-cpu-baseline", "--with-input", "--no-rooflines"])):
-                cmd = [sys.executable, os.path.abspath(__file__), "--workload", name.split("_")[0], "--no-companions", "--no-exact-modes"] + extra
+                fd, child_detail = tempfile.mkstemp(prefix=f"mval_bench_{name}_", suffix=".json")
+                os.close(fd)
+                cmd = [sys.executable, os.path.abspath(__file__), "--workload", name.split("_")[0], "--no-companions", "--no-exact-modes",
+                       "--detail-out", child_detail] + extra
                 if args.no_cpu_baseline and "--no-cpu-baseline" not in cmd:
                     cmd.append("--no-cpu-baseline")
                 t0 = time.perf_counter()
                 try:
                     pr = subprocess.run(cmd, capture_output=True, text=True, timeout=240)
-                    line = [ln for ln in pr.stdout.splitlines() if ln.startswith("{")]
-                    d = json.loads(line[-1]) if line else None
+                    d = None
+                    if pr.returncode == 0 and os.path.getsize(child_detail) > 0:  # the child's full record (its stdout holds the compact line only)
+                        with open(child_detail) as f:
+                            d = json.load(f)
                     if d is None:
                         comp[name] = {"error": f"rc {pr.returncode}: {pr.stderr[-300:]}"}
                     else:
@@ -1080,6 +1237,11 @@ def main():
                             comp[name]["cpu_baseline"] = {k: v_ for k, v_ in d["cpu_baseline"].items() if k != "threads_tried_note"}
                 except Exception as e:  # noqa: BLE001
                     comp[name] = {"error": f"{type(e).__name__}: {e}"}
+                finally:
+                    try:
+                        os.unlink(child_detail)
+                    except OSError:
+                        pass
                 comp[name]["wall_s"] = round(time.perf_counter() - t0, 1)
             comp["note"] = ("BASELINE configs[2] (C3 training step) and configs[3]'s per-GPU slice (C4: HRNet-W48, 8 views, 384x288, 8 frames + MPE "
                             "scoring) run by this command as child processes after the headline: same box, same driver clock; c2_with_input = the "
@@ -1097,7 +1259,15 @@ def main():
             ctypes.CDLL(None).fflush(None)
         except OSError:
             pass
-        print(json.dumps(out), flush=True)
+        detail_path = None
+        if args.detail_out:
+            try:
+                with open(args.detail_out, "w") as f:
+                    json.dump(out, f, indent=1)
+                detail_path = os.path.relpath(args.detail_out, ROOT) if os.path.abspath(args.detail_out).startswith(ROOT + os.sep) else args.detail_out
+            except OSError as e:  # (a read-only checkout must not cost the line)
+                print(f"bench.py: could not write {args.detail_out}: {e}", file=sys.stderr)
+        print(compact_line(out, detail_path), flush=True)
 
 
 if __name__ == "__main__":

@@ -977,10 +977,11 @@ int mval_launch_conv_p2(const P2Args& a0, hipStream_t s) {
     if (a.Wout < 4 || a.Hout < 4) return 1;
     // (four taps per 32-channel chunk: two chunks per stage -- twice the MFMA work per barrier -- from 64 input channels on)
     // (12-wide maps: 8 x 12-pixel tiles, one chunk per stage -- with two the six sub-tiles spill; 24-wide maps: three 8-wide tiles per row)
+    // (the scattered output's byte offsets are 32-bit: every parity form is refused above 2^29 elements, the 12- and 6-wide ones included)
+    if ((((int64_t)a.N * a.Hout * a.Wout * a.Cout) << (2 * a.os)) >= (int64_t)1 << 29) return 1;
     if (a.Wout == 12 && a.Hout % 8 == 0 && a.NS_total > 2) return launch_p2<2, 1, 1, 4, 1, 1, 6, 8, false, 12>(a, s);
     if (a.Wout == 6 && a.Hout % 8 == 0 && a.NS_total > 2)
       return a.Cin >= 64 ? launch_p2<2, 1, 2, 4, 1, 1, 3, 8, false, 6>(a, s) : launch_p2<2, 1, 1, 4, 1, 1, 3, 8, false, 6>(a, s);
-    if ((((int64_t)a.N * a.Hout * a.Wout * a.Cout) << (2 * a.os)) >= (int64_t)1 << 29) return 1;
     if (a.Wout >= 16 && a.Wout % 16 == 0) {
       if (a.NS_total <= 2) return launch_p2<2, 1, 1, 2, 2, 1, 2, 16>(a, s);
       return launch_p2<2, 1, 1, 4, 1, 1, 4, 16>(a, s);

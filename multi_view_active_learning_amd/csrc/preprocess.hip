@@ -133,9 +133,35 @@ __global__ __launch_bounds__(256) void pp_horizontal_lds_kernel(const mval_view_
   __syncthreads();
   // the tile's source span: lo and lo + n do not decrease with the column
   const int last = min(63, in_w - 1 - (int)blockIdx.x * 64);
-  const int span_lo = lo_s[0], span = lo_s[last] + n_s[last] - span_lo;  // (<= PP_SPAN: the launcher checked)
+  const int span_lo = lo_s[0], span = lo_s[last] + n_s[last] - span_lo;
   const int my_off = (lo_s[tx] - span_lo) * 3;
   const int r_end = min(crop_h, ((int)blockIdx.y + 1) * PP_HROWS);
+  if (span > PP_SPAN) {
+    // The launcher sizes the staged row from the HOST's max_crop_w; the span comes from the view's DEVICE descriptor.  A view whose box is
+    // wider than the host said must not write past px_s: its tiles read their taps straight from the image (pp_horizontal_kernel's loop:
+    // same integer sums, same bytes out).  Uniform per workgroup (span is a function of shared values), so no barrier is skipped.
+    for (int r = blockIdx.y * PP_HROWS + ty; r < r_end; r += 4) {
+      if (!col_ok) continue;
+      const int y = r + d.top;
+      int s0 = 1 << (PP_BITS - 1), s1 = s0, s2 = s0;
+      if (y >= 0 && y < d.h0) {
+        const unsigned char* row = d.img + (int64_t)y * d.w0 * 3;
+        for (int t = 0; t < n; t++) {
+          const int x = lo_s[tx] + t + d.left;
+          if (x < 0 || x >= d.w0) continue;
+          const int k = k_s[t][tx];
+          s0 += row[x * 3] * k;
+          s1 += row[x * 3 + 1] * k;
+          s2 += row[x * 3 + 2] * k;
+        }
+      }
+      unsigned char* o = tmp + d.tmp_off + ((int64_t)r * in_w + xx) * 3;
+      o[0] = (unsigned char)pp_clip8(s0);
+      o[1] = (unsigned char)pp_clip8(s1);
+      o[2] = (unsigned char)pp_clip8(s2);
+    }
+    return;
+  }
   for (int r0 = blockIdx.y * PP_HROWS; r0 < r_end; r0 += 4) {
     const int r = r0 + ty, y = r + d.top;
     const bool row_ok = r < crop_h && y >= 0 && y < d.h0;

@@ -731,22 +731,43 @@ class InferencePlan:
             "mval_op_launch")
 
 
+# Every register_parameter / register_buffer / register_module in the process -- `m.bias = nn.Parameter(...)` on a bias that was None, a
+# buffer added later, a submodule swapped inside a holder: nn.Module.__setattr__ goes through the same hooks -- moves this epoch; the cached
+# (dict, key) slots of _param_signature are rebuilt when it has moved since they were taken (the slots never saw those).
+_REG_EPOCH = [0]
+
+
+def _bump_reg_epoch(*_a):
+    _REG_EPOCH[0] += 1
+    return None  # (keep the value being registered)
+
+
+for _reg in ("register_module_parameter_registration_hook", "register_module_buffer_registration_hook", "register_module_module_registration_hook"):
+    getattr(torch.nn.modules.module, _reg)(_bump_reg_epoch)
+
+
 def _param_signature(model):
     """(version counters of every parameter and buffer, data pointers of the parameters): what a plan's packed weights depend on.
     Evaluated on EVERY forward, so the walk over the module tree is done once (nn.Module.parameters() / .buffers() are generators over
     named_modules: 4 400 calls and ~2 ms of host time per HRNet forward -- a third of what a 64-image batch takes on the device) and
     kept as (owning dict, key) slots; a slot is read through its module's own dict, so a parameter REPLACED by assignment
-    (`conv.weight = nn.Parameter(...)`, `.to(device)`) is seen like one modified in place."""
+    (`conv.weight = nn.Parameter(...)`, `.to(device)`) is seen like one modified in place.  The slots are dropped when anything was
+    registered since (the epoch above), when an entry was deleted (KeyError) and when they belong to another model (a deepcopy)."""
     slots = model.__dict__.get("_sig_slots")
-    if slots is None:
-        ps, bs = [], []
-        for h in model._holders.values():
-            for m in h.modules():
-                ps += [(m._parameters, k) for k, v in m._parameters.items() if v is not None]
-                bs += [(m._buffers, k) for k, v in m._buffers.items() if v is not None]
-        slots = model.__dict__["_sig_slots"] = (ps, bs)
-    ps, bs = slots
-    return tuple(d[k]._version for d, k in ps) + tuple(d[k]._version for d, k in bs) + tuple(d[k].data_ptr() for d, k in ps)
+    for _ in range(2):
+        if slots is None or slots[2] != _REG_EPOCH[0] or slots[3] != id(model):
+            ps, bs = [], []
+            for h in model._holders.values():
+                for m in h.modules():
+                    ps += [(m._parameters, k) for k, v in m._parameters.items() if v is not None]
+                    bs += [(m._buffers, k) for k, v in m._buffers.items() if v is not None]
+            slots = model.__dict__["_sig_slots"] = (ps, bs, _REG_EPOCH[0], id(model))
+        ps, bs = slots[0], slots[1]
+        try:
+            return tuple(d[k]._version for d, k in ps) + tuple(d[k]._version for d, k in bs) + tuple(d[k].data_ptr() for d, k in ps)
+        except (KeyError, AttributeError):  # (an entry deleted or set to None since the walk)
+            slots = None
+    raise RuntimeError("parameter signature: the module tree changed during the walk")
 
 
 # bound / actual maximum above which a P2 plan hands over to h2.  The pair (h, l) keeps all 22 significand bits of a value whose

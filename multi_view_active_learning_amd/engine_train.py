@@ -19,6 +19,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import weakref
 
 import torch
 
@@ -66,15 +67,18 @@ TRAIN_P2_MAX_SLACK_LOG2 = 15.0
 # Gaussian tensor crosses 0.5 at a slack of ~2^14; the BASELINE plan measures < 0.02 (tests/test_gpu_train.py).
 TRAIN_P2_MAX_SMALL_FRAC = 0.5
 SLACK_EVERY = int(os.environ.get("MVAL_TRAIN_SLACK_EVERY", "1024"))
-_SWITCHES = ("MVAL_TRAIN_P2", "MVAL_TRAIN_P2_WGRAD", "MVAL_TRAIN_P2_DGRAD", "MVAL_TRAIN_P2_RES", "MVAL_TRAIN_EPI_STATS", "MVAL_TRAIN_BWD_FUSED",
-             "MVAL_TRAIN_RELU_MASK", "MVAL_TRAIN_DGRAD_PARITY", "MVAL_TRAIN_LANES")
+# switch -> the value an unset variable stands for (the key must tell "unset" from every other setting: MVAL_TRAIN_LANES defaults to mode 3)
+_SWITCHES = {"MVAL_TRAIN_P2": "1", "MVAL_TRAIN_P2_WGRAD": "1", "MVAL_TRAIN_P2_DGRAD": "1", "MVAL_TRAIN_P2_RES": "1", "MVAL_TRAIN_EPI_STATS": "1",
+             "MVAL_TRAIN_BWD_FUSED": "1", "MVAL_TRAIN_RELU_MASK": "1", "MVAL_TRAIN_DGRAD_PARITY": "1", "MVAL_TRAIN_LANES": "3"}
 MAX_LANES = 4            # (csrc/conv_common.h MVAL_MAX_LANES)
 TRAIN_LANE_FWD, TRAIN_LANE_BWD, TRAIN_LANE_ORD, TRAIN_LANE_FREE = 256, 512, 1024, 2048  # (include/mval_hip.h MVAL_TRAIN_LANE_*)
+
+_ARMED = None  # weakref to the plan whose probe rows the library currently points at (one slot per process: csrc/net_train.hip g_probe)
 
 
 def _switches():
     """The A/B switches a training plan is built under (part of the plan-cache key: a plan never changes its paths after it is built)."""
-    return tuple(os.environ.get(k, "1") for k in _SWITCHES)
+    return tuple(os.environ.get(k, d) for k, d in _SWITCHES.items())
 
 
 def lane_flags(g, nl, mode):
@@ -108,7 +112,7 @@ class TrainPlan:
     def __init__(self, model, n, h, w, device, p2=True):
         g = model._graph
         self.model, self.graph, self.n, self.device = model, g, n, device
-        self.steps, self.p2_slack, self._probe = 0, None, None
+        self.steps, self.forwards, self.p2_slack, self._probe = 0, 0, None, None
         lib = _lib.lib()
         dims = {g.input: (h, w)}
         geo = []
@@ -496,7 +500,7 @@ class TrainPlan:
         self.n_lanes = 1
         # 0: one stream; 1: lanes in the phases without shared gradient slots only; 2: in all phases; 3 (default): and the backward without
         # joins at the phase changes -- every dependency through the slot events
-        mode = os.environ.get("MVAL_TRAIN_LANES", "3")
+        mode = os.environ.get("MVAL_TRAIN_LANES", _SWITCHES["MVAL_TRAIN_LANES"])
         if mode == "0" or not g.ops:
             return
         nl = min(MAX_LANES, max(op.lane for op in g.ops) + 1)
@@ -619,11 +623,32 @@ class TrainPlan:
     def _probe_due(self):
         if not self.uses_p2 or os.environ.get("MVAL_TRAIN_SLACK_CHECK", "1") == "0":
             return False
-        return self.steps == 0 or (SLACK_EVERY > 0 and self.steps % SLACK_EVERY == 0)
+        # counted in FORWARDS: a plan whose backward never runs (train-mode forwards under no_grad, NaN-skipped steps) probes once, not every time
+        return self.forwards == 0 or (SLACK_EVERY > 0 and self.forwards % SLACK_EVERY == 0)
 
     def _probe_arm(self):
+        global _ARMED
         self._probe = torch.zeros(len(self.ops) * 8, dtype=torch.int32, device=self.device)
         _lib._check(_lib.lib().mval_train_p2_probe(C.c_void_p(self._probe.data_ptr()), C.c_int(len(self.ops))), "mval_train_p2_probe")
+        _ARMED = weakref.ref(self)
+
+    def _probe_disarm(self):
+        """The library holds a raw pointer into ``self._probe`` while armed (csrc/net_train.hip g_probe): it is cleared before the tensor
+        can go away -- by the read-out, by this plan's next forward, and when the plan itself is dropped (``__del__``: cache.clear())."""
+        global _ARMED
+        if self._probe is not None:
+            if _ARMED is not None and _ARMED() is self:  # (another plan that armed after this one owns the slot now)
+                _lib._check(_lib.lib().mval_train_p2_probe(C.c_void_p(0), C.c_int(0)), "mval_train_p2_probe")
+                _ARMED = None
+            self._probe = None
+
+    def __del__(self):
+        try:
+            if self._probe is not None:
+                torch.cuda.synchronize(self.device)  # (launches of the armed forward may still be writing the rows)
+                self._probe_disarm()
+        except Exception:  # noqa: BLE001  (interpreter shutdown)
+            pass
 
     def _probe_read(self):
         """Disarm and turn the measured rows into ``self.p2_slack``: per kind ("act" = output planes of the BatchNorm applies, "dz" = the
@@ -631,9 +656,8 @@ class TrainPlan:
         largest fraction of a tensor's non-zero values that sit below 2^-3 scaled (fewer than 22 bits kept)."""
         import numpy as np
 
-        _lib._check(_lib.lib().mval_train_p2_probe(C.c_void_p(0), C.c_int(0)), "mval_train_p2_probe")
-        raw = self._probe.cpu().numpy().reshape(len(self.ops), 2, 4)
-        self._probe = None
+        raw = self._probe.cpu().numpy().reshape(len(self.ops), 2, 4)  # (synchronises: the armed step's launches are done)
+        self._probe_disarm()
         res = {"step": self.steps}
         for kind, col in (("act", 0), ("dz", 1)):
             r = raw[:, col]
@@ -665,10 +689,11 @@ class TrainPlan:
     def forward(self, x):
         self._refresh()
         if self._probe is not None:  # (an armed step whose backward never ran)
-            _lib._check(_lib.lib().mval_train_p2_probe(C.c_void_p(0), C.c_int(0)), "mval_train_p2_probe")
-            self._probe = None
+            torch.cuda.current_stream(self.device).synchronize()
+            self._probe_disarm()
         if self._probe_due():
             self._probe_arm()
+        self.forwards += 1
         # the arena, z buffers and batch statistics of THIS forward are what backward reads: a second train-mode
         # forward of the same plan overwrites them, so backward checks that it pairs with the latest forward
         self.generation = getattr(self, "generation", 0) + 1

@@ -515,3 +515,32 @@ def test_adam_mirror_is_torch_adam_off_the_device():
         assert da["state"][k].keys() == db["state"][k].keys()
         for n in da["state"][k]:
             assert torch.equal(da["state"][k][n], db["state"][k][n])
+
+
+def test_param_signature_sees_registrations_after_the_first_walk():
+    """engine._param_signature caches (dict, key) slots per model; a parameter or buffer registered later, a bias set from None and a
+    swapped submodule must still be seen -- the slots are rebuilt when nn.Module's registration hooks have fired."""
+    import copy
+
+    import torch
+
+    from multi_view_active_learning_amd import engine
+    from multi_view_active_learning_amd.pose_estimators import PoseResNet
+
+    m = PoseResNet(19, 50)
+    s0 = engine._param_signature(m)
+    assert engine._param_signature(m) == s0
+    holder = next(h for h in m._holders.values() if hasattr(h, "bias") and h.bias is None)  # a conv without bias
+    holder.bias = torch.nn.Parameter(torch.zeros(holder.weight.shape[0]))  # bias set from None
+    s1 = engine._param_signature(m)
+    assert len(s1) == len(s0) + 2  # one more version counter, one more data pointer
+    holder.register_buffer("extra_stat", torch.zeros(3))
+    s2 = engine._param_signature(m)
+    assert len(s2) == len(s1) + 1
+    del holder._buffers["extra_stat"]  # (no hook fires on deletion: the KeyError path rebuilds)
+    assert len(engine._param_signature(m)) == len(s1)
+    m2 = copy.deepcopy(m)
+    with torch.no_grad():
+        next(m2.parameters()).add_(1.0)
+    assert engine._param_signature(m2) != engine._param_signature(m)  # the copy's slots are its own
+    assert engine._param_signature(m) == s1

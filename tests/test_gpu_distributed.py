@@ -166,3 +166,142 @@ def test_rccl_world_1_training_step_under_ddp():
     assert line["n_gpus"] == 1 and line["value"] > 0 and line["ms_per_step"] < 200
     at = line["attribution"]
     assert at["per_rank_s"]["max"] > 0 and "allreduce_exposed_s" in at and abs(at["allreduce_exposed_s"]) < 0.05
+
+
+def _ddp_train_worker(rank, world, path, out, c, lanes):
+    import sys
+
+    for p in (REPO, os.path.join(REPO, "tests", "golden")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    if lanes is not None:
+        os.environ["MVAL_TRAIN_LANES"] = lanes
+    from multi_view_active_learning_amd.pose_estimators import Pose2DMeanSquaredError
+
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda:0")
+    dist.init_process_group("gloo", rank=rank, world_size=world, init_method="file://" + path)
+    x, gt, valid = cases.train_input(c)
+    sd = {k: torch.from_numpy(v) for k, v in cases.model_state_dict(c).items()}
+    m = cases.product_model(c)
+    m.load_state_dict(sd, strict=True)
+    m = m.to(dev).train()
+    if rank == 1:  # broadcast_buffers / the constructor's parameter broadcast must overwrite these with rank 0's
+        with torch.no_grad():
+            for b in m.buffers():
+                if b.dtype.is_floating_point:
+                    b.add_(1.0)
+    net = torch.nn.parallel.DistributedDataParallel(m, device_ids=[0], broadcast_buffers=True)  # workflow.py:133-138
+    sl = slice(rank, None, world)  # DistributedSampler: indices[rank::world]
+    xs, gs, vs = (torch.from_numpy(a[sl]).to(dev) for a in (x, gt, valid.reshape(c["n"], -1, 1, 1)))
+    loss = Pose2DMeanSquaredError().pose_2d_mse(net(xs), gs, vs)
+    loss.backward()
+    grads = {k: p.grad.detach().cpu().clone() for k, p in m.named_parameters()}
+    with torch.no_grad():
+        net(xs)  # second forward: starts with the broadcast of rank 0's buffers (as every reference step does)
+    torch.cuda.synchronize()
+    torch.save({"loss": float(loss), "grads": grads, "buffers": {k: b.detach().cpu().clone() for k, b in m.named_buffers()}}, out + ".%d" % rank)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("lanes", [None, "0"], ids=["lanes-default", "lanes-off"])
+def test_two_rank_ddp_training_step_averages_shard_gradients(tmp_path, lanes, monkeypatch):
+    """workflow.py:133-138 + strategy.py:460-487 at world size 2 (two processes on cuda:0 over gloo): one training step of the
+    product model under DistributedDataParallel(broadcast_buffers=True).  Every rank's gradients == the mean of the two
+    single-rank shard gradients (BatchNorm statistics stay per rank: no SyncBN in the reference), and the BatchNorm buffers
+    after the next forward are rank 0's (broadcast at the start of the forward) advanced by the rank's own shard -- with the
+    training lanes (branches on separate streams, join-less backward) at their default and switched off."""
+    from multi_view_active_learning_amd.pose_estimators import Pose2DMeanSquaredError
+
+    assert torch.cuda.is_available()
+    if lanes is not None:
+        monkeypatch.setenv("MVAL_TRAIN_LANES", lanes)
+    dev = torch.device("cuda:0")
+    c = dict(arch="hrnet_w32", seed=12, n=8, h=64, w=64, j=19)
+    sync, out = str(tmp_path / "sync"), str(tmp_path / "out")
+    mp.spawn(_ddp_train_worker, args=(2, sync, out, c, lanes), nprocs=2, join=True)
+    got = [torch.load(out + ".%d" % r, weights_only=False) for r in range(2)]
+
+    x, gt, valid = cases.train_input(c)
+    sd = {k: torch.from_numpy(v) for k, v in cases.model_state_dict(c).items()}
+    single = []
+    for r in range(2):
+        m = cases.product_model(c)
+        m.load_state_dict(sd, strict=True)
+        m = m.to(dev).train()
+        sl = slice(r, None, 2)
+        xs, gs, vs = (torch.from_numpy(a[sl]).to(dev) for a in (x, gt, valid.reshape(c["n"], -1, 1, 1)))
+        loss = Pose2DMeanSquaredError().pose_2d_mse(m(xs), gs, vs)
+        loss.backward()
+        single.append(dict(loss=float(loss), grads={k: p.grad.detach().cpu().clone() for k, p in m.named_parameters()},
+                           buffers={k: b.detach().cpu().clone() for k, b in m.named_buffers()}, model=m, xs=xs))
+    for r in range(2):
+        assert got[r]["loss"] == single[r]["loss"]  # the forward is the rank's own shard
+    worst = 0.0
+    for k in single[0]["grads"]:
+        want = (single[0]["grads"][k] + single[1]["grads"][k]) / 2  # (x / 2 is exact: sum-then-halve == halve-then-sum)
+        for r in range(2):
+            g = got[r]["grads"][k]
+            assert torch.equal(got[0]["grads"][k], g), k  # every rank holds the same averaged gradient
+            if not torch.equal(g, want):  # <= 1 ulp where the all-reduce rounds differently from the host sum
+                ulp = torch.finfo(torch.float32).eps * want.abs().clamp_min(1e-30)
+                worst = max(worst, float(((g - want).abs() / ulp).max()))
+    assert worst <= 1.0, worst
+    # buffers after the second forward: rank 0's buffers after step 1, advanced by one train-mode forward of the rank's own shard
+    for r in range(2):
+        m = single[r]["model"]
+        m.load_state_dict({**{k: v for k, v in m.state_dict().items()}, **{k: v.to(dev) for k, v in single[0]["buffers"].items()}}, strict=True)
+        with torch.no_grad():
+            m(single[r]["xs"])
+        for k, b in m.named_buffers():
+            assert torch.equal(b.cpu(), got[r]["buffers"][k]), (r, k)
+
+
+def _bench_line(args, env_extra=None, timeout=900):
+    import json
+    import subprocess
+    import sys
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env.update(env_extra or {})
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py")] + args, capture_output=True, text=True, env=env, timeout=timeout)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and len(lines[0]) <= 4096  # ONE line from rank 0, inside the driver's tail
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("workload", ["c5", "c4"])
+def test_bench_two_rank_rehearsal_pool_passes(tmp_path, workload):
+    """bench.py's own N > 1 code on a one-GPU box (--shared-device: both ranks on cuda:0 over gloo): the self-launch as a child
+    torchrun BEFORE any GPU call, the barriers, the rank reductions of `repeats` / the elapsed time, per-rank attribution -- and
+    the picks of the two-rank pass equal the one-rank pass over the same pool content."""
+    import gc
+
+    gc.collect()
+    torch.cuda.empty_cache()
+    common = ["--workload", workload, "--pool", "64", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-rooflines", "--shared-device"]
+    two = _bench_line(["--gpus", "2"] + common + ["--detail-out", str(tmp_path / "d2.json")])
+    one = _bench_line(["--gpus", "1"] + common + ["--detail-out", str(tmp_path / "d1.json")])
+    assert two["n_gpus"] == 2 and one["n_gpus"] == 1 and two["value"] > 0 and two["scaling"] == "strong"
+    assert two["config"]["pool_frames"] == 64 and "REHEARSAL" in two["config"]["parallelism"]
+    at = two["attribution"]
+    assert len(at["per_rank_s"]["all"]) == 2 and at["compute_s"]["max"] > 0 and at["gather_s"] > 0 and at["select_s"] > 0
+    assert two["picks_crc"] == one["picks_crc"]
+
+
+def test_bench_two_rank_rehearsal_training_step(tmp_path):
+    """The C3 line at two ranks on one GPU: DistributedDataParallel over gloo, `repeats` agreed by all_reduce, the exposed
+    all-reduce measurement (step vs the same step under no_sync) in the line."""
+    import gc
+
+    gc.collect()
+    torch.cuda.empty_cache()
+    d = _bench_line(["--gpus", "2", "--workload", "c3", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-rooflines", "--shared-device",
+                     "--min-timed-seconds", "0", "--detail-out", str(tmp_path / "d.json")])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["config"]["images_per_step_per_gpu"] == 128
+    at = d["attribution"]
+    assert len(at["per_rank_s"]["all"]) == 2 and "allreduce_exposed_s" in at

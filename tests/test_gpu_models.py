@@ -442,8 +442,14 @@ def test_c2_full_size_properties(dev):
     safe = (top2[..., 1] - top2[..., 0]) > 2 * tol  # maps whose arg-max cannot flip within tolerance
     k2 = r["keypoints_2d"][0].cpu().numpy()
     assert np.array_equal(k2[safe], o["keypoints_2d"][safe])
-    if safe.all():  # MPJPE target: 3-D keypoints within 1e-3 mm of the reference path
-        np.testing.assert_allclose(r["keypoints_3d"][0].cpu().numpy(), o["keypoints_3d"], rtol=1e-9, atol=1e-3)
+    # MPJPE target (BASELINE.json: within 1e-3 mm of the reference path), UNCONDITIONAL on every joint all of whose views are safe
+    # (RANSAC-DLT runs per joint: a joint's 3-D point depends on its own V key-points only); the safe share is asserted and printed
+    safe_frac = float(safe.mean())
+    joints = np.flatnonzero(safe.all(axis=0))
+    print(f"[c2 full size] safe maps {safe_frac:.4f}, joints compared in 3-D {len(joints)}/19")
+    assert safe_frac >= 0.9 and len(joints) >= 10
+    np.testing.assert_allclose(r["keypoints_3d"][0].cpu().numpy()[joints], o["keypoints_3d"][joints], rtol=1e-9, atol=1e-3)
+    if safe.all():  # (the frame's metric averages over all joints)
         assert abs(float(r["metric"][0]) - o["metric"]) <= 1e-9 * abs(o["metric"])
     # every frame triangulated, finite, sane inlier counts
     assert torch.isfinite(r["keypoints_3d"]).all() and int(r["inlier_count"].min()) >= 2

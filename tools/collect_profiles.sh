@@ -8,10 +8,10 @@ out=gpurun_out/prof_$tag
 mkdir -p $out
 export TMPDIR=/tmp
 for w in c1 c1x16 c4 c5; do
-  python3 bench.py --workload $w --no-cpu-baseline --steps 20 2>/dev/null | tail -1 > $out/bench_${w}_$tag.json
+  python3 bench.py --workload $w --no-cpu-baseline --steps 20 --detail-out $out/bench_${w}_${tag}_detail.json 2>/dev/null | tail -1 > $out/bench_${w}_$tag.json
 done
-python3 bench.py --workload c3 --steps 20 2>/dev/null | tail -1 > $out/bench_c3_$tag.json   # (with its cpu_baseline)
-python3 bench.py 2>/dev/null | tail -1 > $out/bench_c2_$tag.json                            # (the driver's command: headline + exact_modes + companions)
+python3 bench.py --workload c3 --steps 20 --detail-out $out/bench_c3_${tag}_detail.json 2>/dev/null | tail -1 > $out/bench_c3_$tag.json   # (with its cpu_baseline)
+python3 bench.py --detail-out $out/bench_c2_${tag}_detail.json 2>/dev/null | tail -1 > $out/bench_c2_$tag.json                            # (the driver's command: headline + exact_modes + companions)
 export MVAL_STREAMS=1
 export MVAL_TRAIN_LANES=0   # (likewise the training passes: one stream, so that a kernel's traced duration is its own)
 export MVAL_GRAPH=0         # (eager launches under the profiler: the traces and counter passes of rounds 1-5 were all taken that way)
@@ -48,7 +48,7 @@ if [ "${PMC_C34:-1}" != "0" ]; then   # the same three counter passes for the tr
 fi
 rm -rf $out/kt_c3 $out/kt_c4
 if [ -n "$POOL50K" ]; then   # the BASELINE-size pool passes (about 140 s each): unedited bench lines
-  python3 bench.py --workload c4 --pool 50000 --no-cpu-baseline --warmup 0 2>/dev/null | tail -1 > $out/bench_c4_pool50000.json
-  python3 bench.py --workload c5 --pool 50000 --no-cpu-baseline --warmup 0 2>/dev/null | tail -1 > $out/bench_c5_pool50000.json
+  python3 bench.py --workload c4 --pool 50000 --no-cpu-baseline --warmup 0 --detail-out $out/bench_c4_pool50000_detail.json 2>/dev/null | tail -1 > $out/bench_c4_pool50000.json
+  python3 bench.py --workload c5 --pool 50000 --no-cpu-baseline --warmup 0 --detail-out $out/bench_c5_pool50000_detail.json 2>/dev/null | tail -1 > $out/bench_c5_pool50000.json
 fi
 ls -la $out
