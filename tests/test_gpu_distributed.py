@@ -288,7 +288,7 @@ def test_bench_two_rank_rehearsal_pool_passes(tmp_path, workload):
     assert two["n_gpus"] == 2 and one["n_gpus"] == 1 and two["value"] > 0 and two["scaling"] == "strong"
     assert two["config"]["pool_frames"] == 64 and "REHEARSAL" in two["config"]["parallelism"]
     at = two["attribution"]
-    assert len(at["per_rank_s"]["all"]) == 2 and at["compute_s"]["max"] > 0 and at["gather_s"] > 0 and at["select_s"] > 0
+    assert len(at["per_rank_s"]["all"]) == 2 and at["compute_s"]["max"] > 0 and at["gather_s"] >= 0 and at["select_s"] >= 0
     assert two["picks_crc"] == one["picks_crc"]
 
 

@@ -26,8 +26,15 @@ constexpr int NO_X = 1;      // x fragments read once per stage (no LDS fragment
 constexpr int NO_W = 2;      // weight fragments fetched once per kernel (no weight stream)
 constexpr int NO_STAGE = 4;  // no global -> LDS staging of the next patch (the barrier stays)
 constexpr int NO_MFMA = 8;   // everything but the MFMAs
+// round 6: issue-order / prefetch-depth variants of the product form (MODE 0).  Loads return IN ORDER (one vmcnt counter): a wait for a weight
+// fragment also waits for every load issued before it -- in the product's order that is the next stage's patch granules, straight from HBM / MALL.
+constexpr int OPT_WFIRST = 1;  // request the next column's weights BEFORE the next stage's patch granules (the column-1 wait then leaves them in flight)
+constexpr int OPT_X2 = 2;      // x fragments two steps ahead (three register pairs) instead of one
+constexpr int OPT_W2 = 4;      // weight fragments two columns ahead (three register sets) instead of one
+constexpr int OPT_PRIO = 8;    // s_setprio 1 around each step's MFMA group
+constexpr int OPT_LATE = 16;   // patch granules requested at the start of column 1 (behind column 2's weights) instead of the stage's start
 
-template <int MODE, int ABL, int WMX = 2>
+template <int MODE, int ABL, int WMX = 2, int OPT = 0>
 __global__ __launch_bounds__(MODE ? 256 * WMX : 256) __attribute__((amdgpu_waves_per_eu(MODE ? WMX : 2, MODE ? WMX : 2))) void loop_kernel(const u32x4* __restrict__ W,
                                                                                                          const u32x4* __restrict__ X,
                                                                                                          float* __restrict__ out, int stages,
@@ -47,7 +54,8 @@ __global__ __launch_bounds__(MODE ? 256 * WMX : 256) __attribute__((amdgpu_waves
   f32x4 acc[MS];
 #pragma unroll
   for (int ms = 0; ms < MS; ms++) acc[ms] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  u32x4 B[2][3][2];
+  constexpr bool W2 = (OPT & OPT_W2) && !MODE, X2 = (OPT & OPT_X2) != 0;
+  u32x4 B[W2 ? 3 : 2][3][2];
   u32x4 stage[NE], wst[MODE ? 9 : 1];
   const unsigned g0 = (unsigned)((blockIdx.y * gridDim.x + blockIdx.x) * 8 * PPX);
   auto load_stage = [&](int s) {
@@ -90,45 +98,59 @@ __global__ __launch_bounds__(MODE ? 256 * WMX : 256) __attribute__((amdgpu_waves
   store_x(0);
   __syncthreads();
   wload(0, 0, 0);
+  if (W2) wload(1, 0, 1);
   int buf = 0;
   for (int s = 0; s < stages; s++) {
-    load_stage(s + 1);
+    if (!(OPT & (OPT_WFIRST | OPT_LATE))) load_stage(s + 1);
     const char* xs = smem + buf * buf_bytes + xb;
-    constexpr int Q = 3 * (MS + 2);
-    u32x4 Xf[2][2];
+    constexpr int Q = 3 * (MS + 2), XD = X2 ? 3 : 2;
+    u32x4 Xf[XD][2];
     Xf[0][0] = *reinterpret_cast<const u32x4*>(xs);
     Xf[0][1] = *reinterpret_cast<const u32x4*>(xs + plane_b);
+    if (X2) {
+      Xf[1][0] = *reinterpret_cast<const u32x4*>(xs + PW * 16);
+      Xf[1][1] = *reinterpret_cast<const u32x4*>(xs + PW * 16 + plane_b);
+    }
 #pragma unroll
     for (int q = 0; q < Q; q++) {
       const int kx = q / (MS + 2), pr = q % (MS + 2);
       if (pr == 0 && !(ABL & NO_W)) {
-        if (kx + 1 < 3) wload((kx + 1) & 1, s & 7, kx + 1);
-        else if (!MODE) wload(1, (s + 1) & 7, 0);  // (MODE 1: the next stage's weights are not in LDS yet: fetched after the barrier)
+        if (W2) {  // column kx lives in set kx; request column kx + 2 (the next stage's kx - 1 for kx >= 1) into the set column kx - 1 left
+          if (kx == 0) wload(2, s & 7, 2);
+          else wload(kx - 1, (s + 1) & 7, kx - 1);
+        } else {
+          if (kx + 1 < 3) wload((kx + 1) & 1, s & 7, kx + 1);
+          else if (!MODE) wload(1, (s + 1) & 7, 0);  // (MODE 1: the next stage's weights are not in LDS yet: fetched after the barrier)
+        }
       }
-      if (q + 1 < Q && !(ABL & NO_X)) {
-        const int kx1 = (q + 1) / (MS + 2), pr1 = (q + 1) % (MS + 2);
+      if ((OPT & OPT_WFIRST) && q == 0) load_stage(s + 1);
+      if ((OPT & OPT_LATE) && q == MS + 2) load_stage(s + 1);
+      if (q + (XD - 1) < Q && !(ABL & NO_X)) {
+        const int kx1 = (q + XD - 1) / (MS + 2), pr1 = (q + XD - 1) % (MS + 2);
         const char* ap = xs + (pr1 * PW + kx1) * 16;
-        Xf[(q + 1) & 1][0] = *reinterpret_cast<const u32x4*>(ap);
-        Xf[(q + 1) & 1][1] = *reinterpret_cast<const u32x4*>(ap + plane_b);
+        Xf[(q + XD - 1) % XD][0] = *reinterpret_cast<const u32x4*>(ap);
+        Xf[(q + XD - 1) % XD][1] = *reinterpret_cast<const u32x4*>(ap + plane_b);
       }
       __builtin_amdgcn_sched_barrier(0);
-      const u32x4 xh = Xf[(ABL & NO_X) ? 0 : (q & 1)][0], xl = Xf[(ABL & NO_X) ? 0 : (q & 1)][1];
+      const u32x4 xh = Xf[(ABL & NO_X) ? 0 : (q % XD)][0], xl = Xf[(ABL & NO_X) ? 0 : (q % XD)][1];
       if (!(ABL & NO_MFMA)) {
+        if (OPT & OPT_PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int t3 = 0; t3 < 3; t3++)
 #pragma unroll
           for (int ky = 0; ky < 3; ky++) {
             const int ms = pr - ky;
             if (ms < 0 || ms >= MS) continue;
-            const u32x4* wv = B[(ABL & NO_W) ? 0 : (kx & 1)][ky];
+            const u32x4* wv = B[(ABL & NO_W) ? 0 : W2 ? kx : (kx & 1)][ky];
             acc[ms] = t3 == 0 ? mfma(wv[1], xh, acc[ms]) : t3 == 1 ? mfma(wv[0], xl, acc[ms]) : mfma(wv[0], xh, acc[ms]);
           }
+        if (OPT & OPT_PRIO) __builtin_amdgcn_s_setprio(0);
       } else {
-        acc[0] += __builtin_bit_cast(f32x4, xh) + __builtin_bit_cast(f32x4, xl) + __builtin_bit_cast(f32x4, B[kx & 1][pr % 3][0]);
+        acc[0] += __builtin_bit_cast(f32x4, xh) + __builtin_bit_cast(f32x4, xl) + __builtin_bit_cast(f32x4, B[W2 ? kx : (kx & 1)][pr % 3][0]);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
-    if (!MODE && !(ABL & NO_W)) {  // the next stage starts on parity 0
+    if (!MODE && !(ABL & NO_W) && !W2) {  // the next stage starts on parity 0
 #pragma unroll
       for (int ky = 0; ky < 3; ky++)
 #pragma unroll
@@ -147,12 +169,12 @@ __global__ __launch_bounds__(MODE ? 256 * WMX : 256) __attribute__((amdgpu_waves
   out[(blockIdx.y * gridDim.x + blockIdx.x) * NTH + tid] = r.x + r.y + r.z + r.w;
 }
 
-template <int MODE, int ABL, int WMX = 2>
+template <int MODE, int ABL, int WMX = 2, int OPT = 0>
 static void run(const char* name, const u32x4* W, const u32x4* X, float* out, int stages, unsigned xmask) {
   constexpr int WM = MODE ? WMX : 1;
   constexpr int PH = 4 * WM + 2, PPX = (PH * PW + 15) & ~15;
   const size_t smem = 2 * 8 * PPX * 16 + (MODE ? 9 * 8192 : 0);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(loop_kernel<MODE, ABL, WMX>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(loop_kernel<MODE, ABL, WMX, OPT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   hipDeviceProp_t pr;
   (void)hipGetDeviceProperties(&pr, 0);
   const int cus = pr.multiProcessorCount;
@@ -164,7 +186,7 @@ static void run(const char* name, const u32x4* W, const u32x4* X, float* out, in
   float best = 1e9f;
   for (int rep = 0; rep < 4; rep++) {
     (void)hipEventRecord(e0);
-    hipLaunchKernelGGL((loop_kernel<MODE, ABL, WMX>), grid, dim3(MODE ? 256 * WMX : 256), smem, 0, W, X, out, stages, xmask);
+    hipLaunchKernelGGL((loop_kernel<MODE, ABL, WMX, OPT>), grid, dim3(MODE ? 256 * WMX : 256), smem, 0, W, X, out, stages, xmask);
     (void)hipEventRecord(e1);
     (void)hipEventSynchronize(e1);
     float ms;
@@ -327,6 +349,21 @@ int main(int argc, char** argv) {
   const unsigned xmask = (unsigned)(((size_t)1 << xlog) - 1);
   printf("p2_loop: %d stages of 108 MFMAs per wave; weights %.2f MB; staging window %.0f MB\n", stages, wq * 16 / 1e6, ((size_t)1 << xlog) * 16 / 1e6);
   run<0, 0>("product form (2 x 4 waves per CU, weights per wave from L2)", W, X, out, stages, xmask);
+  if (argc > 3) {  // round 6: the issue-order / prefetch-depth variants only
+    run<0, 0, 2, OPT_WFIRST>("  weights requested before the patch granules", W, X, out, stages, xmask);
+    run<0, 0, 2, OPT_LATE>("  patch granules requested at the start of column 1", W, X, out, stages, xmask);
+    run<0, 0, 2, OPT_X2>("  x fragments two steps ahead", W, X, out, stages, xmask);
+    run<0, 0, 2, OPT_W2>("  weights two columns ahead", W, X, out, stages, xmask);
+    run<0, 0, 2, OPT_PRIO>("  s_setprio 1 around the MFMA groups", W, X, out, stages, xmask);
+    run<0, 0, 2, OPT_WFIRST | OPT_X2>("  weights first + x two ahead", W, X, out, stages, xmask);
+    run<0, 0, 2, OPT_WFIRST | OPT_W2>("  weights first + weights two columns ahead", W, X, out, stages, xmask);
+    run<0, 0, 2, OPT_WFIRST | OPT_X2 | OPT_W2>("  weights first + x two ahead + weights two ahead", W, X, out, stages, xmask);
+    run<0, 0, 2, OPT_LATE | OPT_X2 | OPT_W2>("  granules at column 1 + x two ahead + weights two ahead", W, X, out, stages, xmask);
+    run<0, 0, 2, OPT_WFIRST | OPT_X2 | OPT_W2 | OPT_PRIO>("  all four", W, X, out, stages, xmask);
+    run<0, NO_STAGE, 2, OPT_X2 | OPT_W2>("  (x + weights two ahead, no patch staging)", W, X, out, stages, xmask);
+    run<0, NO_W | NO_X | NO_STAGE>("  (MFMAs + barrier only)", W, X, out, stages, xmask);
+    return 0;
+  }
   run<0, NO_STAGE>("  - without the patch staging (loads + LDS stores)", W, X, out, stages, xmask);
   run<0, NO_W>("  - without the weight stream", W, X, out, stages, xmask);
   run<0, NO_X>("  - without the x fragment reads", W, X, out, stages, xmask);
