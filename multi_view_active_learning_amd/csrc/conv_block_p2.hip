@@ -28,6 +28,12 @@
 #ifndef P2_VALU_PRIO
 #define P2_VALU_PRIO 2
 #endif
+#ifndef BP_ORDER
+#define BP_ORDER 1      // 0: the next tile's patch granules / the scale row requested at the start of the tile (rounds 3-5); 1: behind weight requests
+#endif
+#ifndef BP_MFMA_PRIO
+#define BP_MFMA_PRIO 1  // s_setprio around every step's MFMA group (conv_p2.hip P2_MFMA_PRIO)
+#endif
 
 typedef p2_f32x4 f32x4;
 typedef p2_f16x8 f16x8;
@@ -212,9 +218,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
     const int next_tile = tile + wgx;
     const bool have_next = next_tile < tile_end;
     if (have_next) decode(next_tile, tn, toy, tox);
-    if (!OVERLAY && have_next) load_patch(tn, toy, tox);  // C = 32: the next patch travels during conv1
+    // (round 6, conv_p2.hip P2_ORDER: loads return in order, so the patch granules -- HBM / MALL latency -- requested HERE sat in front of
+    // conv1's weight ring and its third step waited for them.  BP_ORDER 1: they are requested behind conv2's first weight column at the end
+    // of conv1, travel during the BN1 phase and conv2's first column, and are stored into X at the end of the tile)
+    if (BP_ORDER == 0 && !OVERLAY && have_next) load_patch(tn, toy, tox);  // C = 32: the next patch travels during conv1
     P2RowRegs row_in;
-    p2_row_request(a.in_row, n, row_in);
+    if (BP_ORDER == 0) p2_row_request(a.in_row, n, row_in);
 
     // ---- 1. conv1: step = (tap, chunk) in packed order chunk-minor; x fragments three sub-tiles ahead -------------------
     f32x4 acc1[MS1];
@@ -243,12 +252,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
             const int s2 = step + 2;
             B1[s2 % 3][0] = w1f(s2 / NCH, s2 % NCH, 0);
             B1[s2 % 3][1] = w1f(s2 / NCH, s2 % NCH, 1);
+            if (BP_ORDER != 0 && step == 0) p2_row_request(a.in_row, n, row_in);  // (read after conv1: behind the ring's first request)
           } else if (step + 2 == STEPS) {  // the first column of conv2's weights behind the last steps of conv1
 #pragma unroll
             for (int ky = 0; ky < 3; ky++) {
               B2[0][ky][0] = w2f(ky * 3, 0, 0);
               B2[0][ky][1] = w2f(ky * 3, 0, 1);
             }
+            if (BP_ORDER != 0 && !OVERLAY && have_next) load_patch(tn, toy, tox);
           }
         }
         if (q + RD - 1 < Q) {
@@ -257,10 +268,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
           Xf[q1 % RD][1] = *reinterpret_cast<const u32x4*>(smem + xb1[q1 % MS1] + xoff(q1) + XPL);
         }
         __builtin_amdgcn_sched_barrier(SB);
+        if (BP_MFMA_PRIO) __builtin_amdgcn_s_setprio(BP_MFMA_PRIO);
         f32x4 c = acc1[ms];
         c = bp_mfma(B1[step % 3][1], Xf[q % RD][0], c);
         c = bp_mfma(B1[step % 3][0], Xf[q % RD][1], c);
         acc1[ms] = bp_mfma(B1[step % 3][0], Xf[q % RD][0], c);
+        if (BP_MFMA_PRIO) __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(SB);
       }
     }
@@ -309,7 +322,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
     BP_ACC(1);
     __syncthreads();  // M is complete (C = 32: and every wave is done with X)
     BP_ACC(2);
-    if (!OVERLAY && have_next) store_patch();
+    if (BP_ORDER == 0 && !OVERLAY && have_next) store_patch();
 
     __builtin_amdgcn_s_setprio(0);
     // ---- 3. conv2 with row sharing over M -------------------------------------------------------------------------------------
@@ -349,6 +362,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
         }
         __builtin_amdgcn_sched_barrier(SB);
         const u32x4 xh = Xf[q & 1][0], xl = Xf[q & 1][1];
+        if (BP_MFMA_PRIO) __builtin_amdgcn_s_setprio(BP_MFMA_PRIO);
 #pragma unroll
         for (int t3 = 0; t3 < 3; t3++) {
 #pragma unroll
@@ -359,6 +373,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
             acc2[ms] = t3 == 0 ? bp_mfma(wv[1], xh, acc2[ms]) : t3 == 1 ? bp_mfma(wv[0], xl, acc2[ms]) : bp_mfma(wv[0], xh, acc2[ms]);
           }
         }
+        if (BP_MFMA_PRIO) __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(SB);
       }
     }
@@ -409,7 +424,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
     BP_ACC(4);
     __builtin_amdgcn_s_setprio(0);
     if (!have_next) break;
-    __syncthreads();  // every wave is done with M (C = 64: X may be written)
+    if (BP_ORDER != 0 && !OVERLAY) store_patch();  // (X has been free since the barrier behind the BN1 phase)
+    __syncthreads();  // every wave is done with M (C = 64: X may be written; C = 32: the next patch is in X)
     if (OVERLAY) {  // C = 64: 60 staging registers do not fit beside conv2: the next patch is fetched here (the
       load_patch(tn, toy, tox);  // other workgroup of the CU computes meanwhile)
       store_patch();

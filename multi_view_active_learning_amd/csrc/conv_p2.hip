@@ -45,6 +45,28 @@
 #ifndef P2_VALU_PRIO
 #define P2_VALU_PRIO 2
 #endif
+// ---- round 6: issue order and prefetch depth of the main loop (tools/micro/p2_loop.hip, profiles/r06/p2_loop_order_prefetch.log) --------
+// Vector-memory loads return IN ORDER (one vmcnt counter): the wait for a weight fragment also waits for every load issued before it.  Rounds
+// 3-5 requested the next stage's patch granules (and, in a tile's last stage, the epilogue's residual granules and factor rows: HBM / MALL
+// latency) at the START of a stage, in front of the next column's weight fragments (L2) -- so the first weight wait of every stage also
+// waited for them.  In the loop's skeleton: 2.98-3.09 us per stage -> 2.77 (weights first) / 2.51-2.58 (weights two columns ahead) /
+// 2.65 (x fragments two steps ahead) / 2.57-2.62 (s_setprio 1 around the MFMA groups) -> 2.41-2.44 together.
+#ifndef P2_ORDER
+#define P2_ORDER 1      // 0: patch granules / epilogue operands requested before the stage's MFMA loop (rounds 3-5); 1: behind the first weight
+                        // request of the stage; 2: at the start of the stage's second column / step
+#endif
+#ifndef P2_XD
+#define P2_XD 3         // x fragment ring: 2 = one step ahead (rounds 3-5), 3 = two steps ahead (light instantiations only: 8 more registers)
+#endif
+#ifndef P2_WD_RS
+#define P2_WD_RS 3      // row-sharing 3x3 kernels: weight columns in flight + in use: 2 = one column ahead, 3 = two (NT = 1 only: 24 more registers)
+#endif
+#ifndef P2_WD
+#define P2_WD 4         // the other kernels: weight steps in the ring (2 = one step ahead; a step is only MS x NT x 3 MFMAs: 192 cycles at MS x NT = 4)
+#endif
+#ifndef P2_MFMA_PRIO
+#define P2_MFMA_PRIO 1  // s_setprio around every step's MFMA group (0 = off)
+#endif
 
 typedef p2_f32x4 f32x4;
 typedef p2_f16x8 f16x8;
@@ -311,7 +333,16 @@ __device__ __forceinline__ void conv_p2_body(const P2Args& a, const int by, cons
   constexpr int SB = 0;  // sched_barrier mask: nothing crosses.  Left to itself the compiler sinks every weight load and
                          // LDS fragment read next to its first use (buffer_load; s_waitcnt vmcnt(1); v_mfma).
   constexpr int STEPS = G * TAPS;
-  u32x4 B[2][RS ? 3 : 1][NT][2];  // weight fragments [parity][row tap (RS)][cout sub-tile][plane]
+  // register budget of the deeper rings: the light instantiations (<= 4 accumulator tiles per wave) have room, the others keep rounds 3-5's depth
+  constexpr bool LIGHT = MS * NT <= 4;
+  // (by the register tables, tools/kernel_resources.py: two pixel waves stage 6 granules per thread -- x ring only; the stride-2 patch is four
+  // times the tile -- one more weight step, no x ring)
+  constexpr int XD = (LIGHT && S == 1 && P2_XD >= 3) ? 3 : 2;                                   // x fragment ring
+  constexpr int WDR = (RS && NT == 1 && MS <= 4 && WM == 1 && !K48 && P2_WD_RS >= 3) ? 3 : 2;   // row-sharing: weight column ring
+  constexpr int WDN_ = LIGHT ? (P2_WD < 2 ? 2 : S == 2 && P2_WD > 3 ? 3 : P2_WD) : 2;
+  constexpr int WDN = WDN_ > STEPS + 1 ? STEPS + 1 : WDN_;                            // other kernels: weight step ring
+  constexpr int WD = RS ? WDR : WDN;
+  u32x4 B[WD][RS ? 3 : 1][NT][2];  // weight fragments [ring slot][row tap (RS)][cout sub-tile][plane]
   // RS: a "column" = the three row taps of column tap kx; else a "step" = one (chunk of the stage, tap) block
   auto wload = [&](int par, int stg, int u) {
     if constexpr (RS) {
@@ -346,9 +377,11 @@ __device__ __forceinline__ void conv_p2_body(const P2Args& a, const int by, cons
     return g * chunk_b + (S == 1 ? ky * PW + kx : ((kx & 1) * PH + ky) * PWh + (kx >> 1)) * 16;
   };
 
-  // One stage's MFMAs from LDS buffer `buf`; `pre` != 0: request the first weight blocks of stage `nst_next` at the end.
-  auto mfma_stage = [&](auto rem_tag, int buf, int st, bool pre, int st_next) {
+  // One stage's MFMAs from LDS buffer `buf`; `pre` != 0: request the first weight blocks of stage `st_next` at the end.  `early()` issues the
+  // stage's other loads (the next stage's patch granules; in a tile's last stage also the epilogue's operands) at the point P2_ORDER names.
+  auto mfma_stage = [&](auto rem_tag, int buf, int st, bool pre, int st_next, auto&& early) {
     constexpr bool REM = decltype(rem_tag)::value;  // (K48) the remainder stage: two column steps
+    if constexpr (P2_ORDER == 0) early();
     if constexpr (RS) {
       const char* xs = smem + buf * buf_bytes + xb[0];
       const char* xsp = smem + buf * buf_bytes + xb_pair;
@@ -359,24 +392,34 @@ __device__ __forceinline__ void conv_p2_body(const P2Args& a, const int by, cons
         if constexpr (REM) return c == 0 ? xsp + (pr * PW) * 16 : xs + (pr * PW + 2) * 16;
         else return xs + (pr * PW + c) * 16;
       };
-      u32x4 Xf[2][2];
-      Xf[0][0] = *reinterpret_cast<const u32x4*>(frag_at(0, 0));
-      Xf[0][1] = *reinterpret_cast<const u32x4*>(frag_at(0, 0) + plane_b);
+      u32x4 Xf[XD][2];
 #pragma unroll
-      for (int q = 0; q < Q; q++) {
+      for (int q0 = 0; q0 < XD - 1; q0++) {
+        Xf[q0][0] = *reinterpret_cast<const u32x4*>(frag_at(q0 / (MS + 2), q0 % (MS + 2)));
+        Xf[q0][1] = *reinterpret_cast<const u32x4*>(frag_at(q0 / (MS + 2), q0 % (MS + 2)) + plane_b);
+      }
+      auto body = [&](const int q) {
         const int kx = q / (MS + 2), pr = q % (MS + 2);
-        if (pr == 0) {  // request the next column's weights (last column: the first column of the next stage, into parity NC & 1)
-          if (kx + 1 < NC) wload((kx + 1) & 1, st, kx + 1);
-          else if (pre) wload(NC & 1, st_next, 0);
+        if (pr == 0) {
+          if constexpr (WDR == 3) {
+            // column kx lives in slot kx; request column kx + 2 (kx >= 1: the next stage's column kx - 1) into the slot column kx - 1 left
+            if (kx == 0) wload(2, st, 2);
+            else if (pre) wload(kx - 1, st_next, kx - 1);
+          } else {
+            // request the next column's weights (last column: the first column of the next stage, into parity NC & 1)
+            if (kx + 1 < NC) wload((kx + 1) & 1, st, kx + 1);
+            else if (pre) wload(NC & 1, st_next, 0);
+          }
         }
-        if (q + 1 < Q) {
-          const int kx1 = (q + 1) / (MS + 2), pr1 = (q + 1) % (MS + 2);
+        if (q + XD - 1 < Q) {
+          const int kx1 = (q + XD - 1) / (MS + 2), pr1 = (q + XD - 1) % (MS + 2);
           const char* ap = frag_at(kx1, pr1);
-          Xf[(q + 1) & 1][0] = *reinterpret_cast<const u32x4*>(ap);
-          Xf[(q + 1) & 1][1] = *reinterpret_cast<const u32x4*>(ap + plane_b);
+          Xf[(q + XD - 1) % XD][0] = *reinterpret_cast<const u32x4*>(ap);
+          Xf[(q + XD - 1) % XD][1] = *reinterpret_cast<const u32x4*>(ap + plane_b);
         }
         __builtin_amdgcn_sched_barrier(SB);
-        const u32x4 xh = Xf[q & 1][0], xl = Xf[q & 1][1];
+        const u32x4 xh = Xf[q % XD][0], xl = Xf[q % XD][1];
+        if (P2_MFMA_PRIO) __builtin_amdgcn_s_setprio(P2_MFMA_PRIO);
 #pragma unroll
         for (int nt = 0; nt < NT; nt++) {
 #pragma unroll
@@ -385,14 +428,22 @@ __device__ __forceinline__ void conv_p2_body(const P2Args& a, const int by, cons
             for (int ky = 0; ky < 3; ky++) {
               const int ms = pr - ky;
               if (ms < 0 || ms >= MS) continue;
-              const u32x4* wv = B[kx & 1][ky][nt];
+              const u32x4* wv = B[WDR == 3 ? kx : (kx & 1)][ky][nt];
               acc[ms][nt] = t3 == 0 ? p2_mfma(wv[1], xh, acc[ms][nt]) : t3 == 1 ? p2_mfma(wv[0], xl, acc[ms][nt]) : p2_mfma(wv[0], xh, acc[ms][nt]);
             }
           }
         }
+        if (P2_MFMA_PRIO) __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(SB);
-      }
-      if (pre && (NC & 1)) {  // the next stage starts on parity 0
+      };
+      // the stage's other loads go out between two steps (a call inside ONE unrolled loop left loops of `early` rolled: arrays in scratch)
+      constexpr int QE = P2_ORDER == 1 ? 1 : P2_ORDER == 2 ? MS + 2 : 0;
+#pragma unroll
+      for (int q = 0; q < QE; q++) body(q);
+      if constexpr (P2_ORDER != 0) early();
+#pragma unroll
+      for (int q = QE; q < Q; q++) body(q);
+      if (WDR == 2 && pre && (NC & 1)) {  // the next stage starts on parity 0
 #pragma unroll
         for (int ky = 0; ky < 3; ky++)
 #pragma unroll
@@ -403,40 +454,60 @@ __device__ __forceinline__ void conv_p2_body(const P2Args& a, const int by, cons
     } else {
       const char* xs = smem + buf * buf_bytes;
       constexpr int Q = STEPS * MS;
-      u32x4 Xf[2][2];
-      Xf[0][0] = *reinterpret_cast<const u32x4*>(xs + xb[0] + toff_of(0));
-      Xf[0][1] = *reinterpret_cast<const u32x4*>(xs + xb[0] + toff_of(0) + plane_b);
+      u32x4 Xf[XD][2];
 #pragma unroll
-      for (int q = 0; q < Q; q++) {
+      for (int q0 = 0; q0 < XD - 1 && q0 < Q; q0++) {
+        Xf[q0][0] = *reinterpret_cast<const u32x4*>(xs + xb[q0 % MS] + toff_of(q0 / MS));
+        Xf[q0][1] = *reinterpret_cast<const u32x4*>(xs + xb[q0 % MS] + toff_of(q0 / MS) + plane_b);
+      }
+      auto body = [&](const int q) {
         const int step = q / MS, ms = q % MS;
-        if (ms == 0) {
-          if (step + 1 < STEPS) wload((step + 1) & 1, st, step + 1);
-          else if (pre) wload(STEPS & 1, st_next, 0);
+        if (ms == 0) {  // step u of a stage sits in ring slot u % WDN (the ring is rotated at the end of a stage); request step u + WDN - 1
+          const int u = step + WDN - 1;
+          if (u < STEPS) wload(u % WDN, st, u);
+          else if (pre) wload(u % WDN, st_next, u - STEPS);
         }
-        if (q + 1 < Q) {
-          const int s1 = (q + 1) / MS, m1 = (q + 1) % MS;
+        if (q + XD - 1 < Q) {
+          const int s1 = (q + XD - 1) / MS, m1 = (q + XD - 1) % MS;
           const char* ap = xs + xb[m1] + toff_of(s1);
-          Xf[(q + 1) & 1][0] = *reinterpret_cast<const u32x4*>(ap);
-          Xf[(q + 1) & 1][1] = *reinterpret_cast<const u32x4*>(ap + plane_b);
+          Xf[(q + XD - 1) % XD][0] = *reinterpret_cast<const u32x4*>(ap);
+          Xf[(q + XD - 1) % XD][1] = *reinterpret_cast<const u32x4*>(ap + plane_b);
         }
         __builtin_amdgcn_sched_barrier(SB);
         if (G == 1 || st * G + step / TAPS < nchunks) {  // (chunk count not a multiple of G: the tail stage is short)
-          const u32x4 xh = Xf[q & 1][0], xl = Xf[q & 1][1];
+          const u32x4 xh = Xf[q % XD][0], xl = Xf[q % XD][1];
+          if (P2_MFMA_PRIO) __builtin_amdgcn_s_setprio(P2_MFMA_PRIO);
 #pragma unroll
           for (int nt = 0; nt < NT; nt++) {
             f32x4 c = acc[ms][nt];
-            c = p2_mfma(B[step & 1][0][nt][1], xh, c);
-            c = p2_mfma(B[step & 1][0][nt][0], xl, c);
-            acc[ms][nt] = p2_mfma(B[step & 1][0][nt][0], xh, c);
+            c = p2_mfma(B[step % WDN][0][nt][1], xh, c);
+            c = p2_mfma(B[step % WDN][0][nt][0], xl, c);
+            acc[ms][nt] = p2_mfma(B[step % WDN][0][nt][0], xh, c);
           }
+          if (P2_MFMA_PRIO) __builtin_amdgcn_s_setprio(0);
         }
         __builtin_amdgcn_sched_barrier(SB);
-      }
-      if (pre && (STEPS & 1)) {  // an odd number of steps: the next stage's first block sits in parity 1
+      };
+      constexpr int QE = P2_ORDER == 1 ? 1 : P2_ORDER == 2 ? (STEPS > 1 ? MS : 1) : 0;
 #pragma unroll
-        for (int nt = 0; nt < NT; nt++)
+      for (int q = 0; q < QE; q++) body(q);
+      if constexpr (P2_ORDER != 0) early();
 #pragma unroll
-          for (int p = 0; p < 2; p++) B[0][0][nt][p] = B[1][0][nt][p];
+      for (int q = QE; q < Q; q++) body(q);
+      if (pre && (STEPS % WDN) != 0) {  // the next stage's step u was requested into slot (STEPS + u) % WDN: rotate it to slot u
+        u32x4 T[WDN][NT][2];
+#pragma unroll
+        for (int i = 0; i < WDN - 1; i++)
+#pragma unroll
+          for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+            for (int p = 0; p < 2; p++) T[i][nt][p] = B[(STEPS + i) % WDN][0][nt][p];
+#pragma unroll
+        for (int i = 0; i < WDN - 1; i++)
+#pragma unroll
+          for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+            for (int p = 0; p < 2; p++) B[i][0][nt][p] = T[i][nt][p];
       }
     }
   };
@@ -447,7 +518,10 @@ __device__ __forceinline__ void conv_p2_body(const P2Args& a, const int by, cons
   P2_MARK(0);
   load_stage(0);
   if (tid == 0) wgred[0] = wgred[1] = 0u;
-  if (wave_active) wload(0, 0, 0);
+  if (wave_active) {  // the ring's first slots: the first stage's first WD - 1 columns / steps
+#pragma unroll
+    for (int u = 0; u < WD - 1; u++) wload(u, 0, u);
+  }
   store_stage(0);
   __syncthreads();
   P2_MARK(1);
@@ -460,8 +534,9 @@ __device__ __forceinline__ void conv_p2_body(const P2Args& a, const int by, cons
 #pragma unroll
       for (int nt = 0; nt < NT; nt++) acc[ms][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     for (int st = 0; st + 1 < nst; st++) {  // all but the tile's last stage
-      load_stage(st + 1);
-      if (wave_active) mfma_stage(std::false_type{}, buf, st, true, st + 1);
+      auto early = [&]() { load_stage(st + 1); };
+      if (wave_active) mfma_stage(std::false_type{}, buf, st, true, st + 1, early);
+      else early();
       P2_ACC(0);
       store_stage(buf ^ 1);
       __syncthreads();
@@ -475,7 +550,6 @@ __device__ __forceinline__ void conv_p2_body(const P2Args& a, const int by, cons
     if (have_next) {
       decode(next_tile, tn, toy, tox);
       plan(tn, toy, tox);
-      load_stage(0);
     }
     P2_ACC(2);
     P2RowRegs row_in, row_r1, row_r2;
@@ -503,33 +577,40 @@ __device__ __forceinline__ void conv_p2_body(const P2Args& a, const int by, cons
       else return (yl + sub_ty(ms) < a.Hout && xl + sub_tx(ms) < a.Wout) ? vb[nt] : 0x80000000u;
     };
     auto soff = [&](int ms) -> int { return OW ? 0 : (((sub_ty(ms) << osh) * Wo + (sub_tx(ms) << osh)) * 16); };
-    if (wave_active) {
-      p2_row_request(a.in_row, n, row_in);
-      if (a.res1) p2_row_request(a.res1_row, n, row_r1);
-      if (a.res2) p2_row_request(a.res2_row, n, row_r2);
+    // the last stage's other loads, issued where P2_ORDER says (round 6: behind the stage's first weight request -- residual granules and
+    // factor rows come from HBM / MALL and every later weight wait would wait for them too): the next tile's first patch granules (every
+    // wave), then what the epilogue reads
+    auto early_last = [&]() {
+      if (have_next) load_stage(0);
+      if (wave_active) {
+        p2_row_request(a.in_row, n, row_in);
+        if (a.res1) p2_row_request(a.res1_row, n, row_r1);
+        if (a.res2) p2_row_request(a.res2_row, n, row_r2);
 #pragma unroll
-      for (int nt = 0; nt < NT; nt++) {
-        const int c0 = (ns0 + nt) * 16 + cq;
-        if (c0 + 3 < a.Cout) {
-          sc[nt] = *reinterpret_cast<const f32x4*>(a.scale + c0);
-          sh[nt] = *reinterpret_cast<const f32x4*>(a.shift + c0);
-        } else {
+        for (int nt = 0; nt < NT; nt++) {
+          const int c0 = (ns0 + nt) * 16 + cq;
+          if (c0 + 3 < a.Cout) {
+            sc[nt] = *reinterpret_cast<const f32x4*>(a.scale + c0);
+            sh[nt] = *reinterpret_cast<const f32x4*>(a.shift + c0);
+          } else {
 #pragma unroll
-          for (int j = 0; j < 4; j++) {
-            sc[nt][j] = c0 + j < a.Cout ? a.scale[c0 + j] : 0.f;
-            sh[nt][j] = c0 + j < a.Cout ? a.shift[c0 + j] : 0.f;
+            for (int j = 0; j < 4; j++) {
+              sc[nt][j] = c0 + j < a.Cout ? a.scale[c0 + j] : 0.f;
+              sh[nt][j] = c0 + j < a.Cout ? a.shift[c0 + j] : 0.f;
+            }
           }
         }
-      }
-      if (pre_res && a.res1) {
+        if (pre_res && a.res1) {
 #pragma unroll
-        for (int nt = 0; nt < NT; nt++)
+          for (int nt = 0; nt < NT; nt++)
 #pragma unroll
-          for (int ms = 0; ms < MS; ms++) R1[ms][nt] = __builtin_amdgcn_raw_buffer_load_b128(r1r, voff(nt, ms), soff(ms), P2_RES_AUX);
+            for (int ms = 0; ms < MS; ms++) R1[ms][nt] = __builtin_amdgcn_raw_buffer_load_b128(r1r, voff(nt, ms), soff(ms), P2_RES_AUX);
+        }
+        __builtin_amdgcn_sched_barrier(SB);
       }
-      __builtin_amdgcn_sched_barrier(SB);
-      mfma_stage(std::integral_constant<bool, K48>{}, buf, nst - 1, have_next, 0);
-    }
+    };
+    if (wave_active) mfma_stage(std::integral_constant<bool, K48>{}, buf, nst - 1, have_next, 0, early_last);
+    else early_last();
     P2_ACC(3);
 
     // ---- epilogue in registers: lane = (pixel lane & 15 of the sub-tile, couts cq .. cq + 3 of the sub-tile) -------------
