@@ -29,6 +29,11 @@
 
 #include "conv_p2.h"
 
+#ifndef BN_ORDER
+#define BN_ORDER 1  // 0: conv1's patch chunk requested before the next chunk's weights (rounds 4-5)
+#endif
+
+
 #ifndef P2_VALU_PRIO
 #define P2_VALU_PRIO 2
 #endif
@@ -257,14 +262,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
         // chunk k: requested at iteration k - 4 into set k & 1, stored at k - 2, multiplied at k (chunks 0 .. 2 of a tile
         // come from the previous tile's phase 3, chunk 3 is requested here)
         if (ch + 2 < NCH1) store_x(region(ch + 2), ch & 1);
-        if (ch == 0 && 3 < NCH1) load_x(3, 1);
-        if (ch + 4 < NCH1) load_x(ch + 4, ch & 1);
+        // (round 6, BN_ORDER 1: loads return in order -- the next chunk's weight fragments (L2) are requested BEFORE the patch chunk four
+        // ahead (HBM / MALL), so the wait for them at the next chunk does not include that chunk's round trip; conv_p2.hip P2_ORDER)
+        if (BN_ORDER == 0) {
+          if (ch == 0 && 3 < NCH1) load_x(3, 1);
+          if (ch + 4 < NCH1) load_x(ch + 4, ch & 1);
+        }
         if (ch + 1 < NCH1) {
 #pragma unroll
           for (int nt = 0; nt < 2; nt++) { W1[(ch + 1) & 1][nt][0] = wld(wv + nt * 2048, (ch + 1) * (4 * 2048)); W1[(ch + 1) & 1][nt][1] = wld(wv + nt * 2048 + 1024, (ch + 1) * (4 * 2048)); }
         } else {  // the first column of conv2's weights behind the last chunk
 #pragma unroll
           for (int ky = 0; ky < 3; ky++) { B2[0][ky][0] = wld(wv2, (ky * 3 * 2) * (4 * 2048)); B2[0][ky][1] = wld(wv2 + 1024, (ky * 3 * 2) * (4 * 2048)); }
+        }
+        if (BN_ORDER != 0) {
+          if (ch == 0 && 3 < NCH1) load_x(3, 1);
+          if (ch + 4 < NCH1) load_x(ch + 4, ch & 1);
         }
         const int xb = xb1 + region(ch);
         u32x4 Xf[2][2];

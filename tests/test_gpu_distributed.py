@@ -305,3 +305,78 @@ def test_bench_two_rank_rehearsal_training_step(tmp_path):
     assert d["config"]["images_per_step_per_gpu"] == 128
     at = d["attribution"]
     assert len(at["per_rank_s"]["all"]) == 2 and "allreduce_exposed_s" in at
+
+
+def test_pool_pass_issues_no_host_copy_on_the_side_stream(monkeypatch):
+    """The PRODUCT's pool loop (strategy.py:1004-1147 -> ActiveLearningStrategy._compute_sal_dict), fed what the reference's DataLoader
+    yields -- HOST tensors -- over 64 frames of 8 views with 96 x 72 heat-maps (the C4 shapes): everything a batch's side-stream body
+    (parallel.PostStream: decode + MPE + RANSAC-DLT + the table row) reads was staged on the caller's stream beforehand, so inside the
+    body there is NO host -> device copy and NO device -> host read (either one blocks the host until the side stream drains and the
+    next batch's network could not be enqueued meanwhile).  Timing-free: the transfers are counted, not clocked."""
+    from multi_view_active_learning_amd import parallel, synth
+    from multi_view_active_learning_amd.config import get_default_configs
+    from multi_view_active_learning_amd.strategy import ActiveLearningStrategy
+
+    assert torch.cuda.is_available()
+    dev = torch.device("cuda:0")
+    b, v, j, hh, wh, nb = 8, 8, 19, 96, 72, 8
+    cfg = get_default_configs()
+    cfg.AL.STRATEGY = "MPE"
+    cfg.POSE_ESTIMATOR.STRIDE = 4
+    st = ActiveLearningStrategy(cfg)
+    rng = np.random.default_rng(3)
+    loader = []
+    for i in range(nb):  # host tensors, pageable, as a DataLoader's collate yields them (dataset/dataset.py:158-220)
+        loader.append({
+            "images": torch.zeros(b, v, 3, 8, 8),
+            "proj_matrices": torch.from_numpy(np.stack([synth.ring_cameras(v, hh * 4, wh * 4, seed=i * b + s) for s in range(b)])),
+            "joint_valid": torch.ones(b, j, dtype=torch.uint8),
+            "3d_keypoints": torch.from_numpy(rng.standard_normal((b, 3, j)) * 300.0),
+            "pose": torch.full((b,), 7, dtype=torch.int64),
+            "frame_id": torch.arange(i * b, (i + 1) * b, dtype=torch.int64),
+        })
+    g = torch.Generator(device=dev).manual_seed(5)
+    maps = [torch.rand(b * v, j, hh, wh, device=dev, generator=g) for _ in range(nb)]
+    it = iter(maps)
+
+    inside = {"depth": 0, "bodies": 0}
+    events = []
+    real_enter, real_exit = parallel.PostStream._Ctx.__enter__, parallel.PostStream._Ctx.__exit__
+
+    def enter(self):
+        r = real_enter(self)
+        inside["depth"] += 1
+        inside["bodies"] += 1
+        return r
+
+    def exit_(self, *exc):
+        inside["depth"] -= 1
+        return real_exit(self, *exc)
+
+    monkeypatch.setattr(parallel.PostStream._Ctx, "__enter__", enter)
+    monkeypatch.setattr(parallel.PostStream._Ctx, "__exit__", exit_)
+
+    def watch(name, kind):
+        real = getattr(torch.Tensor, name)
+
+        def f(self, *a, **k):
+            if inside["depth"] > 0:
+                if kind == "d2h" and self.is_cuda:
+                    events.append((name, tuple(self.shape)))
+                if kind == "to" and not self.is_cuda:
+                    tgt = [x for x in list(a) + list(k.values()) if isinstance(x, (torch.device, str)) or (torch.is_tensor(x) and x.is_cuda)]
+                    if name == "cuda" or any("cuda" in str(getattr(x, "device", x)) for x in tgt):
+                        events.append((name + " host->device", tuple(self.shape)))
+            return real(self, *a, **k)
+
+        monkeypatch.setattr(torch.Tensor, name, f)
+
+    for nm in ("cpu", "item", "tolist", "numpy"):
+        watch(nm, "d2h")
+    for nm in ("to", "cuda"):
+        watch(nm, "to")
+
+    sal = st._compute_sal_dict(loader, lambda images: next(it))
+    assert inside["bodies"] == nb and inside["depth"] == 0
+    assert events == [], events
+    assert len(sal["al_metric"]) == nb * b and list(sal["al_metric"])[0] == "7-0"

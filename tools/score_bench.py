@@ -1,5 +1,49 @@
+"""Per-kernel times of the post-network stage (decode, scoring, RANSAC-DLT) at the bench workloads' sizes.
+   --product-loop [frames=512]: the PRODUCT's pool loop instead -- ActiveLearningStrategy._compute_sal_dict (strategy.py:1004-1147) over a
+   loader of HOST tensors (what the reference's DataLoader yields: pageable images (B, V, 3, 384, 288) fp32, float64 cameras), HRNet-W48,
+   8 views, 8 frames per batch, MPE scoring: frames x views / s of the loop a user of workflow.py runs, next to bench.py --workload c4
+   (which feeds device-resident frames)."""
 import sys, os, torch, numpy as np
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if "--product-loop" in sys.argv:
+    import json, time
+    from multi_view_active_learning_amd import synth
+    from multi_view_active_learning_amd.config import get_default_configs
+    from multi_view_active_learning_amd.pose_estimators import PoseHighResolutionNet, hrnet_w48
+    from multi_view_active_learning_amd.strategy import ActiveLearningStrategy
+    i = sys.argv.index("--product-loop")
+    frames = int(sys.argv[i + 1]) if len(sys.argv) > i + 1 else 512
+    b, v, j, h, w = 8, 8, 19, 384, 288
+    dev = torch.device("cuda:0")
+    m = PoseHighResolutionNet(j, hrnet_cfg=hrnet_w48())
+    m.load_state_dict({k: torch.from_numpy(a) for k, a in synth.synthetic_state_dict(m._graph.param_shapes(), 0).items()}, strict=True)
+    m = m.to(dev).eval()
+    cfg = get_default_configs()
+    cfg.AL.STRATEGY = "MPE"
+    cfg.POSE_ESTIMATOR.STRIDE = 4
+    st = ActiveLearningStrategy(cfg)
+    rng = np.random.default_rng(0)
+    base = torch.from_numpy(synth.images(5, b, v, h, w))
+    def loader(pinned):
+        for i0 in range(0, frames, b):
+            img = base.pin_memory() if pinned else base.clone()  # (a DataLoader hands over a fresh tensor per batch)
+            yield {"images": img, "proj_matrices": torch.from_numpy(np.stack([synth.ring_cameras(v, h, w, seed=i0 + s) for s in range(b)])),
+                   "joint_valid": torch.ones(b, j, dtype=torch.uint8), "3d_keypoints": torch.from_numpy(rng.standard_normal((b, 3, j)) * 300.0),
+                   "pose": torch.zeros(b, dtype=torch.int64), "frame_id": torch.arange(i0, i0 + b, dtype=torch.int64)}
+    out = {}
+    for pinned in (False, True):
+        batches = list(loader(pinned))  # (built before the clock: the reference's loader workers prepare batches ahead of the model)
+        st._compute_sal_dict(batches[:2], m)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        sal = st._compute_sal_dict(batches, m)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        assert len(sal["al_metric"]) == frames
+        out["pinned_host_images" if pinned else "pageable_host_images"] = {"frames_x_views_per_s": round(frames * v / el, 1), "ms_per_batch_of_64_images": round(el / (frames / b) * 1e3, 3)}
+    out["workload"] = f"_compute_sal_dict, HRNet-W48 8-view 384x288, MPE, {frames} frames in batches of {b}, host tensors in (21.2 MB of fp32 images per batch over PCIe)"
+    print(json.dumps(out))
+    sys.exit(0)
 from multi_view_active_learning_amd import _lib
 from multi_view_active_learning_amd import synth
 dev = torch.device("cuda:0")
