@@ -264,6 +264,11 @@ static int lane_of(const mval_train_op& t, int bit, int n_lanes) {
   return (n_lanes > 1 && (t.p2_flags & bit) && t.op.lane > 0 && t.op.lane < n_lanes) ? t.op.lane : 0;
 }
 
+#ifdef MVAL_TRAIN_ABLATE
+#include <stdio.h>
+extern int g_train_ablate;
+static int g_train_fwd_calls = 0, g_train_ablated = 0;
+#endif
 static int train_forward(const mval_train_op* ops, int n_ops, int n_images, float* arena, const float* params,
                          int64_t ones_off, int64_t zeros_off, const float* input_nchw, float* output_nchw,
                          double* ws0, int64_t ws_doubles, int n_lanes, float momentum, float eps, void* stream0) {
@@ -274,6 +279,15 @@ static int train_forward(const mval_train_op* ops, int n_ops, int n_images, floa
   // (A forward without joins at the phase changes -- every op behind the events of its producers, as the backward's MVAL_TRAIN_LANE_FREE --
   // measured the same or slower: C3 61.3-61.6 ms against 61.0-61.3 with the joins, profiles/r05/train_lanes_free2.log.)
   MvalLaneWalk walk(L, mval_stream(stream0));
+#ifdef MVAL_TRAIN_ABLATE
+  {
+    const char* e = getenv("MVAL_TRAIN_ABL");
+    g_train_ablate = e ? atoi(e) : 0;
+    g_train_fwd_calls++;
+    if (g_train_fwd_calls == 4 && g_train_ablate) fprintf(stderr, "[ablate %d] forward applies skipped per step: %d\n", g_train_ablate, g_train_ablated);
+    g_train_ablated = 0;
+  }
+#endif
   for (int i = 0; i < n_ops; i++) {
     g_tt_op = i;
     const mval_train_op& t = ops[i];
@@ -361,6 +375,14 @@ static int train_forward(const mval_train_op* ops, int n_ops, int n_images, floa
       }
       if (rc) return rc;
       TtScope tt(TT_BN_APPLY, s);
+#ifdef MVAL_TRAIN_ABLATE
+      // measurement build only (profiles/r06: the step-level UPPER BOUND of BatchNorm-apply-in-the-consumer's-staging): from the third
+      // forward on, the apply of every residual-free ReLU op whose output exists as planes only is skipped -- its consumers read stale planes
+      if ((g_train_ablate & 1) && g_train_fwd_calls > 2 && t.out_p2_off > 0 && (t.p2_flags & 2) && op.res1_off < 0 && op.res2_off < 0 && op.relu && op.up == 0) {
+        g_train_ablated++;
+        continue;
+      }
+#endif
       if (t.out_p2_off > 0) {
         // (p2_flags bit 4 / 5) a residual that exists as planes only is read from those
         const bool r1p = (t.p2_flags & 16) && op.res1_off >= 0 && t.res1_p2_off > 0, r2p = (t.p2_flags & 32) && op.res2_off >= 0 && t.res2_p2_off > 0;

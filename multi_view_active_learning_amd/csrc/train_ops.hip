@@ -392,6 +392,9 @@ __global__ __launch_bounds__(TR_APPLY_THREADS) __attribute__((amdgpu_waves_per_e
   if (amax_row) tr_amax_store(amax_row, amax);
 }
 
+#ifdef MVAL_TRAIN_ABLATE
+int g_train_ablate = 0;  // bit 0: skip the forward apply of residual-free P2-only ops (net_train.hip); bit 1: skip the backward reduction of residual-free ops
+#endif
 extern "C" int mval_bn_apply_fwd_p2_res(const float* z, const float* mean, const float* invstd, const float* gamma, const float* beta,
                                         const float* res1, const float* res2, float* out, void* p2_planes, uint32_t* p2_rows, int N, int H,
                                         int W, int C, int up, int relu, uint32_t* amax_row, uint8_t* relu_mask, const uint32_t* res1_row,
@@ -1009,6 +1012,9 @@ extern "C" int mval_bn_bwd_fused_p2(const float* gout, const float* out, const u
   const size_t sh = (size_t)rows * lanes * 4 * 2 * sizeof(double);
   hipStream_t s = mval_stream(stream);
   const int mask_mode = !relu ? 0 : (gres1 || gres2) ? (relu_mask ? 3 : 1) : 2;
+#ifdef MVAL_TRAIN_ABLATE  // (measurement build only: the upper bound of "the backward reduction in the producer dgrad's epilogue" -- the sums stay stale)
+  if (!(g_train_ablate & 2) || gres1 || gres2)
+#endif
   hipLaunchKernelGGL(bn_bwd_reduce2_kernel, dim3(nb), dim3(256), sh, s, gout, out, z, mean, invstd, gamma, beta, gres1, gres2, ws,
                      (int)M, C, mask_mode, overwrite, relu_mask, p2 ? gmax_ws : nullptr, p2 ? bound_slot : nullptr);
   MVAL_CHECK_LAUNCH("mval_bn_bwd_fused/reduce");
