@@ -450,6 +450,8 @@ int mval_conv_dgrad(const float* dz, const float* w_packed, const float* ones, c
 int mval_conv_wgrad_p2_covers(int cin, int cout, int k, int stride);
 /* 1 when the split weight-gradient kernel covers the conv at all (it can then read dz as P2 planes when cout % 8 == 0). */
 int mval_conv_wgrad_split_covers(int cin, int cout, int k, int stride);
+/* 1 when the training forward's P2 conv can apply its producer's BatchNorm + ReLU while staging (3x3 stride 1; mval_train_op.zin_rel). */
+int mval_conv_p2_inz_supported(int cin, int cout, int h, int w, int n);
 int mval_conv_dgrad_parity_supported(int N, int hin, int win, int cin, int hout, int wout, int cout, int algo);
 int mval_conv_dgrad_parity(const float* dz, const float* w_packed, const float* ones, const float* zeros, float* dx,
                            int accumulate, int N, int hin, int win, int cin, int hout, int wout, int cout, int algo,
@@ -510,6 +512,12 @@ typedef struct mval_train_op {
   /* p2_flags bit 4 / bit 5: the forward apply reads res1 / res2 from that activation's P2 planes at res1_p2_off / res2_p2_off (rows at
    * res*_p2_rows_off) -- the residual's producer then writes no fp32 copy when its other readers take the planes too. */
   int64_t res1_p2_off, res1_p2_rows_off, res2_p2_off, res2_p2_rows_off;
+  /* Round 6: BatchNorm apply inside the consumer.  z_out != 0: this op's forward apply is NOT run -- its output (ReLU, no residual, no
+   * upsample, planes only) has exactly one reader, the 3x3 stride-1 P2 conv `zin_rel` ops away, whose forward staging and whose weight
+   * gradient's staging compute relu(BatchNorm(z)) from this op's raw z, batch statistics and affine parameters on the way into LDS
+   * (csrc/conv_p2.h P2Args::in_z, conv_wgrad_bf3.hip XZ: the same arithmetic, scale and split as the apply pass -- bit-identical operands).
+   * zin_rel != 0 (the reader): ops[i + zin_rel] is that producer (zin_rel < 0: it precedes the reader in the list). */
+  int32_t zin_rel, z_out;
 } mval_train_op;
 
 /* ones_off / zeros_off: params offsets of >= max(cout) floats of 1.0 / 0.0.

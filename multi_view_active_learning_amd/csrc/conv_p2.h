@@ -193,12 +193,21 @@ struct P2Args {
   unsigned tiles_img_magic, tiles_x_magic;  // 2^32 / d + 1: tile index -> (image, tile row) without a divide
   int tiles_total, wgs_x;  // persistent tile walk: tiles_x * tiles_y * N tiles over wgs_x workgroups per cout group
   unsigned long long* dbg;  // diagnostic builds (-DP2_STAMP): per-wave phase time stamps; nullptr otherwise
+  // (round 6, training forward, EPI 3, 3x3 stride 1) in_z != nullptr: the input activation does not exist as planes -- it is
+  // relu(BatchNorm(in_z)) of the producer's RAW conv output in_z (fp32 NHWC, N x Hin x Win x Cin) with the producer's batch statistics and
+  // affine parameters, and the staging applies it while it copies: the same alpha = invstd * gamma, beta' = fma(-mean, alpha, beta),
+  // r = fma(z, alpha, beta'), ReLU, scale 2^s from Samuelson's bound max_c(|gamma| sqrt(M - 1) + |beta|), split into (h, l) as the separate
+  // apply pass (train_ops.hip bn_apply_fwd_p2_kernel) writes -- the LDS image is bit-identical to the one staged from its planes.
+  const float* in_z;
+  const float* zin_mean; const float* zin_invstd; const float* zin_gamma; const float* zin_beta;
+  float zin_sqrt_m1;
 };
 
 int mval_launch_conv_p2(const P2Args& a, hipStream_t s);  // conv_p2.hip; 1 = unsupported (dry != 0: no launch)
 int mval_launch_nhwc_to_p2(const float* x, const unsigned* rows_in, _Float16* planes, unsigned* rows, int n_images, int HW, int C,
                             hipStream_t s);
 int mval_conv_p2_supported(int k, int stride, int cin, int cout, int hin, int win, int up, int out_nchw, int n);
+int mval_conv_p2_inz_supported(int cin, int cout, int h, int w, int n);  // the in_z form above (3x3 stride 1, raw fp32 NHWC out)
 int mval_conv_p2_parity_supported(int cin, int cout, int h, int w, int n, int nhwc_out);  // one parity conv (k 2) over an h x w grid
 
 // conv_block_p2.hip: a whole BasicBlock over P2 activations in one launch; 1 = unsupported

@@ -138,9 +138,10 @@ __device__ __forceinline__ f32x4 p2_mfma(const u32x4 a, const u32x4 b, const f32
 // The kernel body: `by` / `gy` = the workgroup's cout group and the number of cout groups (blockIdx.y / gridDim.y).  (Round 4 also ran the
 // two or three first-level stride-2 convs of a fuse layer as ONE launch through this body -- 112 us of launches less per forward back to
 // back, but slower as a step under the multi-stream forward, C2 10.17 vs 10.10 ms: removed in round 5)
-template <int KS, int S, int G, int WN, int WM, int NT, int MS, int TW, bool RS, int EPI, int OW = 0, bool K48 = false>
+template <int KS, int S, int G, int WN, int WM, int NT, int MS, int TW, bool RS, int EPI, int OW = 0, bool K48 = false, bool INZ = false>
 __device__ __forceinline__ void conv_p2_body(const P2Args& a, const int by, const int gy) {
   static_assert(!K48 || (RS && G == 1), "K48: the row-sharing 3x3 kernels");
+  static_assert(!INZ || (EPI == 3 && KS == 3 && S == 1 && OW == 0 && !K48), "INZ: the training forward's 3x3 stride-1 convs");
   constexpr int NTH = 64 * WN * WM, TAPS = KS * KS, SPN = 8 * G, SPN_LOG2 = G == 1 ? 3 : G == 2 ? 4 : 5;
   static_assert(KS == 1 || KS == 2 || KS == 3, "kernel size");
   static_assert(KS != 2 || (S == 1 && !RS && (EPI == 0 || EPI == 3)), "parity convs: stride 1, no row sharing, planes or fp32 NHWC out");
@@ -163,6 +164,8 @@ __device__ __forceinline__ void conv_p2_body(const P2Args& a, const int by, cons
   constexpr int NE = (PH * SPN * PW + NTH - 1) / NTH;  // staged granules per thread
   static_assert(PH * SPN * PW < 4096 && PH < 32 && PW < 127, "staging plan packing");
   unsigned* wgred = reinterpret_cast<unsigned*>(smem + 2 * buf_bytes);  // [max |x| of the tile, waves that added]
+  float* ztab = reinterpret_cast<float*>(smem + 2 * buf_bytes + 16);    // (INZ) [Cin][alpha * 2^s, beta' * 2^s]
+  constexpr int NEZ = INZ ? (PH * 4 * G * PW + NTH - 1) / NTH : 1;      // (INZ) staged items per thread: one (pixel, 8 channels) of z = 32 bytes
   const int ns0 = (by * WN + wn) * NT;
   const bool wave_active = ns0 < a.NS_total;
 
@@ -220,6 +223,7 @@ __device__ __forceinline__ void conv_p2_body(const P2Args& a, const int by, cons
   unsigned lp[NE];    // LDS byte offset << 16 | c8 << 12 | py << 7 | px   (px = 127: no granule)
   unsigned cb[NE];    // (plane * C8 + c8) * H * W * 16
   unsigned goff[NE];  // byte offset of the granule of the tile being staged, chunk 0 (0xffffffff: zero padding)
+  unsigned lpz[NEZ], goffz[NEZ];  // (INZ) the same two per staged item of z (below)
 #pragma unroll
   for (int i = 0; i < NE; i++) {
     const int e = tid + NTH * i;
@@ -235,6 +239,16 @@ __device__ __forceinline__ void conv_p2_body(const P2Args& a, const int by, cons
   const int isub = KS == 1 ? a.in_sub : 0;                                             // (KS 1: every 2^isub-th input pixel)
   auto plan = [&](int n, int oy0, int ox0) {
     const int iy0 = oy0 * S - pad_y, ix0 = ox0 * S - pad_x;
+    if constexpr (INZ) {
+#pragma unroll
+      for (int i = 0; i < NEZ; i++) {
+        const int px = lpz[i] & 127, py = (lpz[i] >> 7) & 31;
+        const int iy = iy0 + py, ix = ix0 + px;
+        const bool inb = px != 127 && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
+        goffz[i] = inb ? (unsigned)((n * a.Hin + iy) * a.Win + ix) * (unsigned)(a.Cin * 4) + ((lpz[i] >> 12) & 15) * 32u : 0xffffffffu;
+      }
+      return;
+    }
     const unsigned nbase = (unsigned)n * 2u * (unsigned)C8 * hw16;
 #pragma unroll
     for (int i = 0; i < NE; i++) {
@@ -246,19 +260,88 @@ __device__ __forceinline__ void conv_p2_body(const P2Args& a, const int by, cons
   };
   const int nchunks = (a.Cin + 31) >> 5;
   const int nst = (nchunks + G - 1) / G;  // stages per tile
-  u32x4 stage[NE];
+  u32x4 stage[INZ ? 1 : NE];
+  // ---- (INZ) the input is relu(BatchNorm(z)) of the producer's raw fp32 NHWC output: item e -> (patch row py, 8-channel block c8l of
+  // the stage, column px); two 16-byte loads of z per item, the affine + ReLU + scale + split on the way into LDS (P2Args::in_z) --------
+  float z_inv = 1.f;
+  u32x4 stagez[NEZ][2];
+  const __amdgpu_buffer_rsrc_t zinr = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(INZ ? a.in_z : nullptr), 0, INZ ? (unsigned)min((int64_t)0xffffffff, (int64_t)a.N * a.Hin * a.Win * a.Cin * 4) : 0u, 0x00020000);
+  if constexpr (INZ) {
+    float bnd = 0.f;
+    for (int c = lane; c < a.Cin; c += 64) bnd = fmaxf(bnd, __builtin_fmaf(fabsf(a.zin_gamma[c]), a.zin_sqrt_m1, fabsf(a.zin_beta[c])));
+    bnd = __uint_as_float(p2_wave_umax(__float_as_uint(bnd))) * (1.f + 1e-6f);
+    float z_mul;
+    p2_scale_of(bnd, z_mul, z_inv);
+    for (int c = tid; c < a.Cin; c += NTH) {
+      const float alpha = a.zin_invstd[c] * a.zin_gamma[c];
+      const float betap = __builtin_fmaf(-a.zin_mean[c], alpha, a.zin_beta[c]);
+      ztab[2 * c] = alpha * z_mul;      // (2^s: exact; fma(z, alpha 2^s, beta' 2^s) == 2^s fma(z, alpha, beta'))
+      ztab[2 * c + 1] = betap * z_mul;
+    }
+#pragma unroll
+    for (int i = 0; i < NEZ; i++) {
+      const int e = tid + NTH * i;
+      const int r = e / PW;
+      const int px = e - r * PW;
+      const int c8l = r & (4 * G - 1), py = r / (4 * G);
+      const int sp = (c8l >> 2) * 8 + (c8l & 3);  // plane h of chunk c8l / 4; plane l sits plane_b behind
+      lpz[i] = py < PH ? ((unsigned)((sp * PPX + py * PW + px) * 16) << 16) | (c8l << 12) | (py << 7) | px : 127u;
+    }
+    __syncthreads();
+  }
   auto load_stage = [&](int st) {
     const int c8b = st * 4 * G;
+    if constexpr (INZ) {
 #pragma unroll
-    for (int i = 0; i < NE; i++) {
-      const bool v = goff[i] != 0xffffffffu && c8b + (int)((lp[i] >> 12) & 15) < C8;
-      stage[i] = __builtin_amdgcn_raw_buffer_load_b128(xr, v ? goff[i] + (unsigned)c8b * hw16 : 0xffffffffu, 0, 0);
+      for (int i = 0; i < NEZ; i++) {
+        const bool v = goffz[i] != 0xffffffffu;
+        const unsigned o = goffz[i] + (unsigned)c8b * 32u;
+        stagez[i][0] = __builtin_amdgcn_raw_buffer_load_b128(zinr, v ? o : 0xffffffffu, 0, 0);
+        stagez[i][1] = __builtin_amdgcn_raw_buffer_load_b128(zinr, v ? o + 16u : 0xffffffffu, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NE; i++) {
+        const bool v = goff[i] != 0xffffffffu && c8b + (int)((lp[i] >> 12) & 15) < C8;
+        stage[i] = __builtin_amdgcn_raw_buffer_load_b128(xr, v ? goff[i] + (unsigned)c8b * hw16 : 0xffffffffu, 0, 0);
+      }
     }
   };
-  auto store_stage = [&](int buf) {
+  // (st: the stage the granules belong to -- INZ reads its channels' factors)
+  auto store_stage = [&](int buf, int st) {
+    if constexpr (INZ) {
+      const int c8b = st * 4 * G;
 #pragma unroll
-    for (int i = 0; i < NE; i++)
-      if ((lp[i] & 127) != 127) *reinterpret_cast<u32x4*>(smem + buf * buf_bytes + (lp[i] >> 16)) = stage[i];
+      for (int i = 0; i < NEZ; i++) {
+        if ((lpz[i] & 127) == 127) continue;
+        u32x4 gh = {0u, 0u, 0u, 0u}, gl = {0u, 0u, 0u, 0u};
+        if (goffz[i] != 0xffffffffu) {  // (outside the image: the conv's zero padding pads the ACTIVATION, not z)
+          const f32x4* t4 = reinterpret_cast<const f32x4*>(ztab + (c8b + (int)((lpz[i] >> 12) & 15)) * 16);
+          const f32x4 t0 = t4[0], t1 = t4[1], t2 = t4[2], t3 = t4[3];  // [a0 b0 a1 b1] [a2 b2 a3 b3] [a4 b4 a5 b5] [a6 b6 a7 b7]
+          const f32x4 z0 = __builtin_bit_cast(f32x4, stagez[i][0]), z1 = __builtin_bit_cast(f32x4, stagez[i][1]);
+          f32x4 y0, y1;
+          y0.x = mval_relu(__builtin_fmaf(z0.x, t0.x, t0.y)); y0.y = mval_relu(__builtin_fmaf(z0.y, t0.z, t0.w));
+          y0.z = mval_relu(__builtin_fmaf(z0.z, t1.x, t1.y)); y0.w = mval_relu(__builtin_fmaf(z0.w, t1.z, t1.w));
+          y1.x = mval_relu(__builtin_fmaf(z1.x, t2.x, t2.y)); y1.y = mval_relu(__builtin_fmaf(z1.y, t2.z, t2.w));
+          y1.z = mval_relu(__builtin_fmaf(z1.z, t3.x, t3.y)); y1.w = mval_relu(__builtin_fmaf(z1.w, t3.z, t3.w));
+          f16x4 h0, l0, h1, l1;
+          p2_split(y0, h0, l0);
+          p2_split(y1, h1, l1);
+          const u32x2 a0 = __builtin_bit_cast(u32x2, h0), a1 = __builtin_bit_cast(u32x2, h1);
+          const u32x2 b0 = __builtin_bit_cast(u32x2, l0), b1 = __builtin_bit_cast(u32x2, l1);
+          gh = (u32x4){a0.x, a0.y, a1.x, a1.y};
+          gl = (u32x4){b0.x, b0.y, b1.x, b1.y};
+        }
+        char* d = smem + buf * buf_bytes + (lpz[i] >> 16);
+        *reinterpret_cast<u32x4*>(d) = gh;
+        *reinterpret_cast<u32x4*>(d + 4 * PPX * 16) = gl;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NE; i++)
+        if ((lp[i] & 127) != 127) *reinterpret_cast<u32x4*>(smem + buf * buf_bytes + (lp[i] >> 16)) = stage[i];
+    }
   };
 
   // ---- fragment addressing ------------------------------------------------------------------------------------
@@ -522,7 +605,7 @@ __device__ __forceinline__ void conv_p2_body(const P2Args& a, const int by, cons
 #pragma unroll
     for (int u = 0; u < WD - 1; u++) wload(u, 0, u);
   }
-  store_stage(0);
+  store_stage(0, 0);
   __syncthreads();
   P2_MARK(1);
   P2_T0;
@@ -538,7 +621,7 @@ __device__ __forceinline__ void conv_p2_body(const P2Args& a, const int by, cons
       if (wave_active) mfma_stage(std::false_type{}, buf, st, true, st + 1, early);
       else early();
       P2_ACC(0);
-      store_stage(buf ^ 1);
+      store_stage(buf ^ 1, st + 1);
       __syncthreads();
       P2_ACC(1);
       buf ^= 1;
@@ -583,7 +666,7 @@ __device__ __forceinline__ void conv_p2_body(const P2Args& a, const int by, cons
     auto early_last = [&]() {
       if (have_next) load_stage(0);
       if (wave_active) {
-        p2_row_request(a.in_row, n, row_in);
+        if constexpr (!INZ) p2_row_request(a.in_row, n, row_in);
         if (a.res1) p2_row_request(a.res1_row, n, row_r1);
         if (a.res2) p2_row_request(a.res2_row, n, row_r2);
 #pragma unroll
@@ -617,7 +700,7 @@ __device__ __forceinline__ void conv_p2_body(const P2Args& a, const int by, cons
     __builtin_amdgcn_s_setprio(P2_VALU_PRIO);  // the vector phase wins issue arbitration against the partner wave's MFMA stream
     float amax = 0.f;
     if (wave_active) {
-      const float in_inv = __uint_as_float(row_in.inv);
+      const float in_inv = INZ ? z_inv : __uint_as_float(row_in.inv);
       float r1_inv = 0.f, r2_inv = 0.f, out_mul = 1.f, out_inv = 1.f;
       if constexpr (EPI < 2) {
         float bound = bound_a * p2_row_amax(row_in) + bound_b;
@@ -845,7 +928,7 @@ __device__ __forceinline__ void conv_p2_body(const P2Args& a, const int by, cons
     __builtin_amdgcn_s_setprio(0);
     P2_ACC(4);
     if (!have_next) break;
-    store_stage(buf ^ 1);
+    store_stage(buf ^ 1, 0);
     __syncthreads();
     P2_ACC(5);
     buf ^= 1;
@@ -857,22 +940,23 @@ __device__ __forceinline__ void conv_p2_body(const P2Args& a, const int by, cons
 }
 
 
-template <int KS, int S, int G, int WN, int WM, int NT, int MS, int TW, bool RS, int EPI, int OW = 0, bool K48 = false>
+template <int KS, int S, int G, int WN, int WM, int NT, int MS, int TW, bool RS, int EPI, int OW = 0, bool K48 = false, bool INZ = false>
 __global__ __launch_bounds__(64 * WN * WM) __attribute__((amdgpu_waves_per_eu(P2_WAVES(MS, NT, EPI), 8))) void conv_p2_kernel(P2Args a) {
-  conv_p2_body<KS, S, G, WN, WM, NT, MS, TW, RS, EPI, OW, K48>(a, (int)blockIdx.y, (int)gridDim.y);
+  conv_p2_body<KS, S, G, WN, WM, NT, MS, TW, RS, EPI, OW, K48, INZ>(a, (int)blockIdx.y, (int)gridDim.y);
 }
 
 static thread_local int g_p2_dry = 0;
 
-template <int KS, int S, int G, int WN, int WM, int NT, int MS, int TW, bool RS, int EPI, int OW = 0, bool K48 = false>
+template <int KS, int S, int G, int WN, int WM, int NT, int MS, int TW, bool RS, int EPI, int OW = 0, bool K48 = false, bool INZ = false>
 static int launch_p2e(P2Args a, hipStream_t s) {
   constexpr int TWE = OW ? OW : TW;
   constexpr int TH = 16 * MS * WM / TWE;
   constexpr int PH = (TH - 1) * S + KS, PW = (TWE - 1) * S + KS, PWh = (PW + 1) / 2;
   constexpr int slots = S == 1 ? PH * PW : 2 * PH * PWh;
   constexpr int PPX = (slots + 15) & ~15;
-  constexpr size_t smem = (size_t)2 * 8 * G * PPX * 16 + 16;
+  constexpr size_t smem = (size_t)2 * 8 * G * PPX * 16 + 16 + (INZ ? 512 * 8 : 0);  // (INZ: the affine table of <= 512 input channels)
   static_assert(smem <= 160 * 1024, "LDS");
+  if (INZ && (a.Cin > 512 || a.Cin % (32 * G) != 0)) return 1;
   constexpr int NTH = 64 * WN * WM;
   a.th = TH; a.tw = TWE;
   a.tiles_x = (a.Wout + TWE - 1) / TWE;
@@ -895,7 +979,7 @@ static int launch_p2e(P2Args a, hipStream_t s) {
   // registers), a multiple of 8 per cout group so that every XCD walks its own contiguous tile range; fewer tiles than
   // that: one tile each.  (No workgroup waits for another one: an optimistic answer only costs a second round.)
   static std::atomic<int> occ{0};
-  int per_cu = p2_resident_wgs(&conv_p2_kernel<KS, S, G, WN, WM, NT, MS, TW, RS, EPI, OW, K48>, occ, smem, NTH / 64);
+  int per_cu = p2_resident_wgs(&conv_p2_kernel<KS, S, G, WN, WM, NT, MS, TW, RS, EPI, OW, K48, INZ>, occ, smem, NTH / 64);
 #ifdef P2_TUNE
   const char* pe = getenv("MVAL_P2_WGS");  // measurement builds only: workgroups per CU
   if (pe && atoi(pe) > 0) per_cu = atoi(pe);
@@ -918,7 +1002,7 @@ static int launch_p2e(P2Args a, hipStream_t s) {
     if (a.bn_part && (int64_t)a.Cout * a.bn_slots * 2 > a.bn_part_cap) a.bn_part = nullptr;  // (no room: the caller runs the separate statistics pass)
     if (a.bn_part && a.bn_slots_host) *a.bn_slots_host = a.bn_slots;
   }
-  hipLaunchKernelGGL((conv_p2_kernel<KS, S, G, WN, WM, NT, MS, TW, RS, EPI, OW, K48>), grid, dim3(NTH), smem, s, a);
+  hipLaunchKernelGGL((conv_p2_kernel<KS, S, G, WN, WM, NT, MS, TW, RS, EPI, OW, K48, INZ>), grid, dim3(NTH), smem, s, a);
   return 0;
 }
 
@@ -965,6 +1049,16 @@ int mval_launch_conv_p2(const P2Args& a0, hipStream_t s) {
   int oms = 0, ont = 0, og = 0;
   p2_override(oms, ont, og);
   const int64_t px = (int64_t)a.N * a.Hout * a.Wout;
+  if (a.in_z) {  // (round 6) the training forward's 3x3 stride-1 conv that applies its producer's BatchNorm + ReLU while staging (P2Args::in_z)
+    if (a.k != 3 || a.stride != 1 || !a.out_nhwc || a.up || a.res1 || a.res2 || a.out_f32 || a.acc_nhwc || a.os) return 1;
+    if (!a.zin_mean || !a.zin_invstd || !a.zin_gamma || !a.zin_beta) return 1;
+    if (a.Wout >= 16 && a.Wout % 16 == 0 && a.Hout >= 4) {
+      if (a.NS_total <= 2) return launch_p2e<3, 1, 1, 2, 2, 1, 4, 16, true, 3, 0, false, true>(a, s);
+      return launch_p2e<3, 1, 1, 4, 1, 1, 4, 16, true, 3, 0, false, true>(a, s);
+    }
+    if (a.Wout == 8 && a.Hout == 8 && a.NS_total > 2 && a.Cin >= 64) return launch_p2e<3, 1, 2, 4, 1, 1, 4, 8, false, 3, 0, false, true>(a, s);
+    return 1;
+  }
   if (a.k == 3 && a.stride == 1) {
     // (round 3 also built the v_mfma_f32_32x32x16_f16 form of this conv -- half the MFMA issues, two thirds of the LDS fragment reads per
     // FLOP: 33.1 vs 31.5 us on 64 -> 64 at 32x32, 115 vs 112.5 at 64x64: equal or slower; removed in round 5)
@@ -1130,6 +1224,18 @@ int mval_conv_p2_supported(int k, int stride, int cin, int cout, int hin, int wi
   a.Wout = (win + 2 * pad - k) / stride + 1;
   a.up = up;
   a.out_f32 = out_nchw ? reinterpret_cast<float*>(1) : nullptr;
+  g_p2_dry = 1;
+  const int rc = mval_launch_conv_p2(a, nullptr);
+  g_p2_dry = 0;
+  return rc == 0;
+}
+
+int mval_conv_p2_inz_supported(int cin, int cout, int h, int w, int n) {
+  P2Args a = {};
+  a.k = 3; a.stride = 1;
+  a.Cin = cin; a.Cout = cout; a.Hin = a.Hout = h; a.Win = a.Wout = w; a.N = n;
+  a.out_nhwc = reinterpret_cast<float*>(1);
+  a.in_z = a.zin_mean = a.zin_invstd = a.zin_gamma = a.zin_beta = reinterpret_cast<const float*>(1);
   g_p2_dry = 1;
   const int rc = mval_launch_conv_p2(a, nullptr);
   g_p2_dry = 0;

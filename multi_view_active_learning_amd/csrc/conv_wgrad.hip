@@ -400,6 +400,7 @@ int mval_conv_wgrad_on(const float* x, const float* dz, float* dw, float* ws, in
   if (!x_nchw && pad == k / 2)  // split-bf16 kernel (conv_wgrad_bf3.hip); 0 = shape not covered
     PS = mval_launch_wgrad_bf3_p2(x, xp2, xp2_rows, dz, ws, N, Hin, Win, Cin, Hout, Wout, Cout, k, stride, wg_splits(Cin, Cout, 1024),
                                   x_amax_row, dz_amax_row, s, zp2, zp2_rows);
+  MVAL_REQUIRE(PS >= 0, "mval_conv_wgrad: x given as its producer's raw z (mval_conv_wgrad_set_z_x) needs the split kernel's 3x3 stride-1 form with dz as planes (k%d s%d cin%d cout%d)", k, stride, Cin, Cout);
   MVAL_REQUIRE(!(xp2 || zp2) || PS > 0, "mval_conv_wgrad: the P2 form of x needs the split kernel (k%d s%d cin%d cout%d) and dz's magnitude row", k, stride, Cin, Cout);
   if (PS > 0) {
     MVAL_CHECK_LAUNCH("mval_conv_wgrad/bf3");

@@ -54,6 +54,11 @@ struct WgradBf3Args {
   // ZP2: dz as P2 planes [n][plane][Cout/8][H][W][8] + rows (written by the BatchNorm backward for the P2 data-gradient conv)
   const _Float16* dz_p2;
   const unsigned* dz_p2_rows;
+  // XZ (round 6): x does not exist as a tensor -- it is relu(BatchNorm(x)) of the producer's raw conv output (a.x: fp32 NHWC z) with the
+  // producer's batch statistics and affine parameters; the staging applies it (conv_p2.h P2Args::in_z: same arithmetic, same scale, same
+  // split, so the LDS image equals the one staged from the producer's planes bit for bit)
+  const float* xz_mean; const float* xz_invstd; const float* xz_gamma; const float* xz_beta;
+  float xz_sqrt_m1;
 };
 
 __device__ __forceinline__ void wb_split_pair(const f32x2 x, unsigned& h, unsigned& m, unsigned& l) {
@@ -108,9 +113,10 @@ __device__ __forceinline__ void wb_scale(unsigned amax_bits, float& mul, float& 
 
 // KS x KS taps, stride S, tile TH x TW output pixels, NT cout tiles and MI cin tiles (of 16) per wave
 typedef unsigned wb_u32x4 __attribute__((ext_vector_type(4)));
-template <int PL, int KS, int S, int TH, int TW, int NT, int MI, bool XP2 = false, bool ZP2 = false>
+template <int PL, int KS, int S, int TH, int TW, int NT, int MI, bool XP2 = false, bool ZP2 = false, bool XZ = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((KS == 3 && S == 1 && TH == 8 && NT == 2) ? 2 : 1, 8))) void conv_wgrad_bf3_kernel(WgradBf3Args a) {
   static_assert(!(XP2 || ZP2) || PL == 2, "P2 activations are fp16 pairs");
+  static_assert(!XZ || (PL == 2 && !XP2 && ZP2), "XZ: x from the producer's z, dz from planes");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int T = KS * KS, MT = TH * TW;
   constexpr int PH = (TH - 1) * S + KS, PW = (TW - 1) * S + KS, PPX = PH * PW;
@@ -125,6 +131,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((KS == 3 &&
   if constexpr (PL == 2) {
     float xi, zi;
     if constexpr (XP2) xi = __uint_as_float(a.x_p2_rows[511]);  // (P2_INV_SLOT of row 0: one scale for the whole tensor in training)
+    else if constexpr (XZ) {
+      // the scale the producer's apply pass gives its planes: Samuelson's bound over ALL input channels into [2^13, 2^14) (conv_p2.h p2_scale_of)
+      float bnd = 0.f;
+      for (int c = threadIdx.x & 63; c < a.Cin; c += 64) bnd = fmaxf(bnd, __builtin_fmaf(fabsf(a.xz_gamma[c]), a.xz_sqrt_m1, fabsf(a.xz_beta[c])));
+      for (int o = 32; o > 0; o >>= 1) bnd = fmaxf(bnd, __shfl_xor(bnd, o));
+      bnd *= (1.f + 1e-6f);
+      const int e = (int)((__float_as_uint(bnd) >> 23) & 0xff);
+      int sft = (e == 0 || e == 255) ? 0 : 13 - (e - 127);
+      sft = max(-110, min(110, sft));
+      x_mul = __uint_as_float((unsigned)(127 + sft) << 23);
+      xi = __uint_as_float((unsigned)(127 - sft) << 23);
+    }
     else wb_scale(conv_amax_read(a.x_amax), x_mul, xi);
     if constexpr (ZP2) zi = __uint_as_float(a.dz_p2_rows[511]);
     else wb_scale(conv_amax_read(a.dz_amax), z_mul, zi);
@@ -169,6 +187,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((KS == 3 &&
   const bool cx_ok = ci0 + xq4 < a.Cin, cz_ok = co0 + zq4 < a.Cout;
 
   f32x4 xr[NEX], zr[NEZ];
+  // (XZ) the thread's four input channels' factors, pre-multiplied by 2^s (exact), and which of its staged pixels lie inside the image
+  // (the conv pads the ACTIVATION with zeros, not z)
+  f32x4 xz_a = (f32x4){0.f, 0.f, 0.f, 0.f}, xz_b = xz_a;
+  unsigned xz_ok = 0u;
+  if constexpr (XZ) {
+    if (cx_ok) {
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int c = ci0 + xq4 + k;
+        const float alpha = a.xz_invstd[c] * a.xz_gamma[c];
+        xz_a[k] = alpha * x_mul;
+        xz_b[k] = __builtin_fmaf(-a.xz_mean[c], alpha, a.xz_beta[c]) * x_mul;
+      }
+    }
+  }
   // XP2: item j = tid % XQ of a pixel -> plane j / (CI / 8), 8-channel block j % (CI / 8)  (XQ = CI / 4 = 2 planes x CI / 8 blocks)
   const int xp_plane = (tid % XQ) / (CI / 8), xp_c8 = (tid % XQ) % (CI / 8);
   const int zp_plane = (tid % ZQ) / (CO / 8), zp_c8 = (tid % ZQ) % (CO / 8);
@@ -190,6 +223,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((KS == 3 &&
       const bool ok = tid + 256 * i < PPX * XQ && cx_ok && (unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win;
       xr[i] = ok ? *reinterpret_cast<const f32x4*>(a.x + (((int64_t)n * a.Hin + iy) * a.Win + ix) * a.Cin + ci0 + xq4)
                  : (f32x4){0.f, 0.f, 0.f, 0.f};
+      if constexpr (XZ) xz_ok = (xz_ok & ~(1u << i)) | ((unsigned)ok << i);
       }
     }
 #pragma unroll
@@ -218,6 +252,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((KS == 3 &&
       const int e = tid + 256 * i;
       if (e < PPX * XQ) {
         if constexpr (XP2) *reinterpret_cast<wb_u32x4*>(xl + xp_plane * XPLANE + (e / XQ) * XROW + xp_c8 * 16) = __builtin_bit_cast(wb_u32x4, xr[i]);
+        else if constexpr (XZ) {
+          f32x4 y = (f32x4){0.f, 0.f, 0.f, 0.f};
+          if ((xz_ok >> i) & 1u) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) y[k] = __builtin_elementwise_maximum(__builtin_fmaf(xr[i][k], xz_a[k], xz_b[k]), 0.f);
+          }
+          wb_split_store2(y, 1.f, xl + (e / XQ) * XROW + (e % XQ) * 8, XPLANE);
+        }
         else if constexpr (PL == 3) wb_split_store(xr[i], xl + (e / XQ) * XROW + (e % XQ) * 8, XPLANE);
         else wb_split_store2(xr[i], x_mul, xl + (e / XQ) * XROW + (e % XQ) * 8, XPLANE);
       }
@@ -297,7 +339,10 @@ template <int KS, int S, int TH, int TW, int NT, int MI>
 static void wb_launch(const WgradBf3Args& a, dim3 grid, hipStream_t s) {
   constexpr int PPX = ((TH - 1) * S + KS) * ((TW - 1) * S + KS);
   constexpr size_t plane = (size_t)PPX * (64 * MI + 32) + (size_t)TH * TW * (64 * NT + 32);
-  if (a.x_p2 && a.dz_p2)
+  if (a.xz_mean && a.dz_p2) {
+    if constexpr (KS == 3 && S == 1)
+      hipLaunchKernelGGL((conv_wgrad_bf3_kernel<2, KS, S, TH, TW, NT, MI, false, true, true>), grid, dim3(256), 2 * plane, s, a);
+  } else if (a.x_p2 && a.dz_p2)
     hipLaunchKernelGGL((conv_wgrad_bf3_kernel<2, KS, S, TH, TW, NT, MI, true, true>), grid, dim3(256), 2 * plane, s, a);
   else if (a.dz_p2 && a.x_amax)
     hipLaunchKernelGGL((conv_wgrad_bf3_kernel<2, KS, S, TH, TW, NT, MI, false, true>), grid, dim3(256), 2 * plane, s, a);
@@ -329,24 +374,39 @@ int mval_launch_wgrad_bf3(const float* x, const float* dz, float* slabs, int N, 
   return mval_launch_wgrad_bf3_p2(x, nullptr, nullptr, dz, slabs, N, Hin, Win, Cin, Hout, Wout, Cout, k, stride, max_slabs, x_amax, dz_amax, s);
 }
 
+static thread_local const float* g_wb_xz[4] = {nullptr, nullptr, nullptr, nullptr};
+static thread_local float g_wb_xz_sqrt_m1 = 1.f;
+// The NEXT weight gradient's x is relu(BatchNorm(z)) of the tensor passed as x (WgradBf3Args, XZ)
+void mval_conv_wgrad_set_z_x(const float* mean, const float* invstd, const float* gamma, const float* beta, float sqrt_m1) {
+  g_wb_xz[0] = mean; g_wb_xz[1] = invstd; g_wb_xz[2] = gamma; g_wb_xz[3] = beta;
+  g_wb_xz_sqrt_m1 = sqrt_m1;
+}
+
 // x_p2 != nullptr: x as P2 planes (+ rows) instead of fp32 NHWC (needs dz_amax: the fp16 split; Cin % 8 == 0)
 int mval_launch_wgrad_bf3_p2(const float* x, const void* x_p2, const unsigned* x_p2_rows, const float* dz, float* slabs, int N, int Hin,
                              int Win, int Cin, int Hout, int Wout, int Cout, int k, int stride, int max_slabs, const unsigned* x_amax,
                              const unsigned* dz_amax, hipStream_t s, const void* dz_p2, const unsigned* dz_p2_rows) {
+  // (XZ: mval_conv_wgrad_set_z_x before the call -- x is then the producer's raw z; consumed by THIS call whatever it returns)
+  const float* xz[4] = {g_wb_xz[0], g_wb_xz[1], g_wb_xz[2], g_wb_xz[3]};
+  g_wb_xz[0] = g_wb_xz[1] = g_wb_xz[2] = g_wb_xz[3] = nullptr;
+  const int refuse = xz[0] ? -1 : 0;  // (no other kernel can stand in: x is not the activation)
   static int enabled = -1;
   if (enabled < 0) {
     const char* e = getenv("MVAL_CONV");
     enabled = (e && e[0] == 'f') ? 0 : 1;  // MVAL_CONV=fp32: exact-fp32 MFMA kernels everywhere
   }
-  if (!enabled || (Cin & 3) || (Cout & 3) || Cin < 16 || Cout < 16) return 0;
+  if (!enabled || (Cin & 3) || (Cout & 3) || Cin < 16 || Cout < 16) return refuse;
   const bool k3 = k == 3 && (stride == 1 || stride == 2);
   const bool k1 = k == 1 && stride == 1 && Cin >= 64 && Cout >= 64;
-  if (!k3 && !k1) return 0;
+  if (!k3 && !k1) return refuse;
   WgradBf3Args a;
   a.x = x; a.dz = dz; a.slabs = slabs;
   a.N = N; a.Hin = Hin; a.Win = Win; a.H = Hout; a.W = Wout; a.Cin = Cin; a.Cout = Cout;
   a.x_amax = x_amax; a.dz_amax = dz_amax;
-  a.dz_p2 = (dz_p2 && dz_p2_rows && (Cout & 7) == 0 && (x_p2 || x_amax)) ? reinterpret_cast<const _Float16*>(dz_p2) : nullptr;
+  a.xz_mean = xz[0]; a.xz_invstd = xz[1]; a.xz_gamma = xz[2]; a.xz_beta = xz[3];
+  a.xz_sqrt_m1 = g_wb_xz_sqrt_m1;
+  if (a.xz_mean && !(k == 3 && stride == 1 && dz_p2 && dz_p2_rows && (Cout & 7) == 0 && !x_p2)) return -1;  // (3x3 stride 1, dz as planes)
+  a.dz_p2 = (dz_p2 && dz_p2_rows && (Cout & 7) == 0 && (x_p2 || x_amax || a.xz_mean)) ? reinterpret_cast<const _Float16*>(dz_p2) : nullptr;
   a.dz_p2_rows = dz_p2_rows;
   if (dz_p2 && !a.dz_p2) return 0;
   a.x_p2 = (x_p2 && (dz_amax || a.dz_p2) && (Cin & 7) == 0) ? reinterpret_cast<const _Float16*>(x_p2) : nullptr;

@@ -47,6 +47,7 @@ int mval_conv_wgrad_on(const float* x, const float* dz, float* dw, float* ws, in
                        int k, int stride, int pad, int x_nchw, const uint32_t* x_amax_row, const uint32_t* dz_amax_row, hipStream_t s);
 void mval_conv_wgrad_set_p2_x(const void* planes, const unsigned* rows);  // conv_wgrad.hip: x as P2 planes for the next weight gradient
 void mval_conv_wgrad_set_p2_dz(const void* planes, const unsigned* rows);  // ... and dz
+void mval_conv_wgrad_set_z_x(const float* mean, const float* invstd, const float* gamma, const float* beta, float sqrt_m1);  // conv_wgrad_bf3.hip: x = relu(BatchNorm(z))
 // ---- measurement mode (bench.py, the c3 line's per-kernel roofline): hipEvents around every launch group of a
 // training step, summed per kernel family.  Off unless mval_train_timing() armed it; the events are resolved (one
 // stream synchronisation) at the end of each forward / backward call.
@@ -340,6 +341,16 @@ static int train_forward(const mval_train_op* ops, int n_ops, int n_images, floa
         P2Args p = {};
         p.in = reinterpret_cast<const _Float16*>(arena + t.in_p2_off);
         p.in_row = reinterpret_cast<const unsigned*>(arena + t.in_p2_rows_off);
+        if (t.zin_rel) {  // (round 6) the producer's apply was skipped: this conv applies its BatchNorm + ReLU while staging the raw z
+          const mval_train_op& pr = (&t)[t.zin_rel];
+          MVAL_REQUIRE(i + t.zin_rel >= 0 && t.zin_rel < 0 && pr.z_out && pr.has_bn && pr.op.cout == op.cin && pr.op.hout == op.hin && pr.op.wout == op.win,
+                       "mval_train_forward: op %d: zin_rel %d does not name its producer", i, t.zin_rel);
+          p.in = nullptr;
+          p.in_z = arena + pr.z_off;
+          p.zin_mean = pr.mean; p.zin_invstd = pr.invstd; p.zin_gamma = pr.gamma; p.zin_beta = pr.beta;
+          const double Mp = (double)n_images * pr.op.hout * pr.op.wout;
+          p.zin_sqrt_m1 = (float)sqrt(Mp > 1 ? Mp - 1.0 : 1.0);
+        }
         p.w = params + op.w_off;
         p.w_unscale = p.w + mval_packed_weight_floats(MVAL_PACK_MFMA16_H2, op.cout, op.cin, op.k) - 4;
         p.scale = params + ones_off;
@@ -374,6 +385,7 @@ static int train_forward(const mval_train_op* ops, int n_ops, int n_images, floa
                                    stream);
       }
       if (rc) return rc;
+      if (t.z_out) continue;  // (round 6) the one reader of this activation applies the BatchNorm itself (mval_train_op.z_out)
       TtScope tt(TT_BN_APPLY, s);
 #ifdef MVAL_TRAIN_ABLATE
       // measurement build only (profiles/r06: the step-level UPPER BOUND of BatchNorm-apply-in-the-consumer's-staging): from the third
@@ -557,10 +569,17 @@ static int train_backward(const mval_train_op* ops, int n_ops, int n_images, flo
     TtScope tt(TT_WGRAD, s);
     if (dz_p2 && (t.p2_flags & 8))
       mval_conv_wgrad_set_p2_dz(arena + t.gz_p2_off, reinterpret_cast<const unsigned*>(arena + t.gz_p2_rows_off));
-    if (t.fwd_p2 && (t.p2_flags & 1))  // (wgrad_p2: this op's input exists as P2 planes and its weight gradient reads those)
+    const float* xw = x;
+    if (t.zin_rel) {  // (round 6) x = relu(BatchNorm(z)) of the producer, applied by the weight gradient's staging
+      const mval_train_op& pr = (&t)[t.zin_rel];
+      MVAL_REQUIRE(dz_p2 && (t.p2_flags & 8), "mval_train_backward: op %d: zin_rel needs the weight gradient that reads dz from planes", i);
+      const double Mp = (double)n_images * pr.op.hout * pr.op.wout;
+      mval_conv_wgrad_set_z_x(pr.mean, pr.invstd, pr.gamma, pr.beta, (float)sqrt(Mp > 1 ? Mp - 1.0 : 1.0));
+      xw = arena + pr.z_off;
+    } else if (t.fwd_p2 && (t.p2_flags & 1))  // (wgrad_p2: this op's input exists as P2 planes and its weight gradient reads those)
       mval_conv_wgrad_set_p2_x(arena + t.in_p2_off, reinterpret_cast<const unsigned*>(arena + t.in_p2_rows_off));
-    rc = mval_conv_wgrad_on(x, gz, t.dweight, wsf, n_images, op.hin, op.win, op.cin, op.hout, op.wout, op.cout, op.k, op.stride, op.pad,
-                            op.in_nchw, x_row, x_row ? gz_row : nullptr, s);
+    rc = mval_conv_wgrad_on(xw, gz, t.dweight, wsf, n_images, op.hin, op.win, op.cin, op.hout, op.wout, op.cout, op.k, op.stride, op.pad,
+                            op.in_nchw, (x_row && !t.zin_rel) ? x_row : nullptr, (x_row && !t.zin_rel) ? gz_row : nullptr, s);
     }
     if (rc) return rc;
     if (t.gin_off >= 0) {

@@ -53,6 +53,7 @@ class MvalTrainOp(C.Structure):
         ("res1_amax_off", C.c_int64), ("res2_amax_off", C.c_int64),
         ("gz_p2_off", C.c_int64), ("gz_p2_rows_off", C.c_int64),
         ("res1_p2_off", C.c_int64), ("res1_p2_rows_off", C.c_int64), ("res2_p2_off", C.c_int64), ("res2_p2_rows_off", C.c_int64),
+        ("zin_rel", C.c_int32), ("z_out", C.c_int32),
     ]
 
 
@@ -69,7 +70,8 @@ TRAIN_P2_MAX_SMALL_FRAC = 0.5
 SLACK_EVERY = int(os.environ.get("MVAL_TRAIN_SLACK_EVERY", "1024"))
 # switch -> the value an unset variable stands for (the key must tell "unset" from every other setting: MVAL_TRAIN_LANES defaults to mode 3)
 _SWITCHES = {"MVAL_TRAIN_P2": "1", "MVAL_TRAIN_P2_WGRAD": "1", "MVAL_TRAIN_P2_DGRAD": "1", "MVAL_TRAIN_P2_RES": "1", "MVAL_TRAIN_EPI_STATS": "1",
-             "MVAL_TRAIN_BWD_FUSED": "1", "MVAL_TRAIN_RELU_MASK": "1", "MVAL_TRAIN_DGRAD_PARITY": "1", "MVAL_TRAIN_LANES": "3"}
+             "MVAL_TRAIN_BWD_FUSED": "1", "MVAL_TRAIN_RELU_MASK": "1", "MVAL_TRAIN_DGRAD_PARITY": "1", "MVAL_TRAIN_LANES": "3",
+             "MVAL_TRAIN_BN_IN_CONV": "1"}
 MAX_LANES = 4            # (csrc/conv_common.h MVAL_MAX_LANES)
 TRAIN_LANE_FWD, TRAIN_LANE_BWD, TRAIN_LANE_ORD, TRAIN_LANE_FREE = 256, 512, 1024, 2048  # (include/mval_hip.h MVAL_TRAIN_LANE_*)
 
@@ -375,6 +377,31 @@ class TrainPlan:
                                 and lib.mval_conv_wgrad_split_covers(C.c_int(op.cin), C.c_int(op.cout), C.c_int(op.k), C.c_int(op.stride))
                                 and ((self.ops[i].p2_flags & 1) or self.ops[i].op.in_amax_off > 0)):
                             self.ops[i].p2_flags |= 8
+            # Round 6: BatchNorm apply inside the consumer (include/mval_hip.h mval_train_op.z_out / zin_rel; hrnet.py:36-52: conv1 -> bn1 -> relu ->
+            # conv2 of every BasicBlock, the 3x3 of a Bottleneck).  A planes-only ReLU output without residual or upsample whose ONE reader is a
+            # 3x3 stride-1 P2 conv on the same lane, with the P2 weight gradient reading dz from planes, is never written: that conv's staging
+            # and its weight gradient's staging apply the BatchNorm from the producer's raw z.  MVAL_TRAIN_BN_IN_CONV=0: the separate apply pass.
+            self.n_bn_in_conv = 0
+            if os.environ.get("MVAL_TRAIN_BN_IN_CONV", "1") != "0":
+                lib.mval_conv_p2_inz_supported.restype = C.c_int
+                for a_ in p2_act:
+                    k = producer[a_]
+                    po, pt = g.ops[k], self.ops[k]
+                    cons = consumers.get(a_, [])
+                    if not ((pt.p2_flags & 2) and po.kind == "conv" and po.bn and po.relu and po.res1 is None and po.res2 is None and po.up == 0
+                            and len(cons) == 1 and not res_users.get(a_) and a_ != g.output):
+                        continue
+                    j = cons[0]
+                    co, ct = g.ops[j], self.ops[j]
+                    if not (co.kind == "conv" and co.k == 3 and co.stride == 1 and co.pad == 1 and ct.fwd_p2 and (ct.p2_flags & 1) and (ct.p2_flags & 8)
+                            and (co.phase, co.lane) == (po.phase, po.lane) and j > k):
+                        continue
+                    hin, win, _, _ = geo[j]
+                    if not lib.mval_conv_p2_inz_supported(C.c_int(co.cin), C.c_int(co.cout), C.c_int(hin), C.c_int(win), C.c_int(n)):
+                        continue
+                    pt.z_out = 1
+                    ct.zin_rel = k - j
+                    self.n_bn_in_conv += 1
         # the two BatchNorm A/B switches are the PLAN's decision and travel in p2_flags (bit 6: round 3's backward pair, bit 7: statistics by
         # the separate pass): net_train.hip does not read the environment
         bits = (0 if os.environ.get("MVAL_TRAIN_BWD_FUSED", "1") != "0" else 64) | (0 if os.environ.get("MVAL_TRAIN_EPI_STATS", "1") != "0" else 128)

@@ -582,6 +582,34 @@ def test_training_lanes_are_bit_identical_to_the_serial_passes(dev, case, monkey
         assert all(torch.equal(r0[k], r1[k]) for k in r0)
 
 
+@pytest.mark.parametrize("case", [cases.train_cases()["w32_train"], dict(arch="hrnet_w32", seed=4, n=4, h=256, w=256, j=19)], ids=["w32_train", "w32_256"])
+def test_bn_in_conv_is_bit_identical_to_the_separate_apply(dev, case, monkeypatch):
+    """Round 6 (hrnet.py:36-52, strategy.py:478): the BatchNorm apply of a residual-free ReLU layer whose one reader is a 3x3 stride-1 P2 conv
+    is not a pass of its own -- that conv's staging and its weight gradient's staging compute relu(BatchNorm(z)), scale and split from the
+    producer's raw z with the SAME arithmetic as the apply kernel.  So one training step (heat-maps, loss, every parameter gradient, the
+    running statistics) equals the step with the separate apply (MVAL_TRAIN_BN_IN_CONV=0) bit for bit, and the plan really fuses the
+    BasicBlocks' first convs."""
+    m1, _, hm1, l1, _ = _train_once(case, dev)
+    plan = next(iter(m1._train_plans.values()))
+    n_z = sum(int(t.z_out) for t in plan.ops)
+    assert n_z == plan.n_bn_in_conv == sum(int(t.zin_rel != 0) for t in plan.ops)
+    # (HRNet-W32: 104 BasicBlocks + layer1's Bottleneck 3x3s at 256 x 256; maps under 8 x 8 -- the deep branches of these small inputs -- keep the apply)
+    assert n_z >= (100 if case["h"] >= 256 else 80), n_z
+    for i, t in enumerate(plan.ops):
+        if t.zin_rel:
+            pr = plan.ops[i + t.zin_rel]
+            assert pr.z_out and pr.op.cout == t.op.cin and t.op.k == 3 and t.op.stride == 1
+    g1 = {k: p.grad.detach().clone() for k, p in m1.named_parameters()}
+    r1 = {k: b.detach().clone() for k, b in m1.named_buffers() if "running" in k}
+    monkeypatch.setenv("MVAL_TRAIN_BN_IN_CONV", "0")
+    m0, _, hm0, l0, _ = _train_once(case, dev)
+    assert sum(int(t.z_out) for t in next(iter(m0._train_plans.values())).ops) == 0
+    assert torch.equal(hm1, hm0) and torch.equal(l1, l0)
+    bad = [k for k, p in m0.named_parameters() if not torch.equal(p.grad, g1[k])]
+    assert not bad, (len(bad), bad[:5])
+    assert all(torch.equal(b, r1[k]) for k, b in m0.named_buffers() if "running" in k)
+
+
 @pytest.mark.parametrize("wd", [0.0, 0.01], ids=["plain", "weight_decay"])
 def test_adam_one_launch_vs_torch_adam(dev, wd):
     """optim.Adam (csrc/optim.hip: the update of every parameter in one launch; reference strategy.py:405-407, :479) against
