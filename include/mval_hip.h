@@ -452,6 +452,8 @@ int mval_conv_wgrad_p2_covers(int cin, int cout, int k, int stride);
 int mval_conv_wgrad_split_covers(int cin, int cout, int k, int stride);
 /* 1 when the training forward's P2 conv can apply its producer's BatchNorm + ReLU while staging (3x3 stride 1; mval_train_op.zin_rel). */
 int mval_conv_p2_inz_supported(int cin, int cout, int h, int w, int n);
+/* 1 when a 3x3 stride-1 data gradient (cin = the conv's cout, cout = its cin, h x w = its input map) can keep those sums. */
+int mval_conv_p2_bsum_supported(int cin, int cout, int h, int w, int n);
 int mval_conv_dgrad_parity_supported(int N, int hin, int win, int cin, int hout, int wout, int cout, int algo);
 int mval_conv_dgrad_parity(const float* dz, const float* w_packed, const float* ones, const float* zeros, float* dx,
                            int accumulate, int N, int hin, int win, int cin, int hout, int wout, int cout, int algo,
@@ -517,8 +519,11 @@ typedef struct mval_train_op {
    * gradient's staging compute relu(BatchNorm(z)) from this op's raw z, batch statistics and affine parameters on the way into LDS
    * (csrc/conv_p2.h P2Args::in_z, conv_wgrad_bf3.hip XZ: the same arithmetic, scale and split as the apply pass -- bit-identical operands).
    * zin_rel != 0 (the reader): ops[i + zin_rel] is that producer (zin_rel < 0: it precedes the reader in the list). */
-  int32_t zin_rel, z_out;
+  int32_t zin_rel, z_out;  /* p2_flags bit 12 (MVAL_TRAIN_BSUM, with zin_rel == -1): this op's data gradient -- the ONLY writer of its
+                            * producer's output gradient -- also keeps the BatchNorm backward reduction of what it writes (P2Args::bs_z), and the
+                            * producer's backward skips that pass */
 } mval_train_op;
+#define MVAL_TRAIN_BSUM 4096
 
 /* ones_off / zeros_off: params offsets of >= max(cout) floats of 1.0 / 0.0.
  * ws: ws_doubles >= 512*maxC*2 doubles.  With room for cout * (conv workgroups) * 2 doubles of an op (about

@@ -118,6 +118,14 @@ __device__ __forceinline__ float p2_row16_sum(float v) {
   v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, false));  // row_mirror
   return v;
 }
+// Maximum over each 16-lane row of the wave, in every lane of the row
+__device__ __forceinline__ float p2_row16_max(float v) {
+  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false)));
+  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false)));
+  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, false)));
+  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, false)));
+  return v;
+}
 // ... and their maximum (uniform over the wave)
 __device__ __forceinline__ float p2_row_amax(const P2RowRegs& r) {
   unsigned m = r.v[0];
@@ -201,6 +209,19 @@ struct P2Args {
   const float* in_z;
   const float* zin_mean; const float* zin_invstd; const float* zin_gamma; const float* zin_beta;
   float zin_sqrt_m1;
+  // (round 6, a data gradient, EPI 3) bs_z != nullptr: the tensor this launch writes is the gradient g of relu(BatchNorm(bs_z)) and this
+  // launch is its ONLY writer -- the epilogue also leaves what the BatchNorm backward's reduction pass would compute from a second read of
+  // it: per (workgroup, pixel wave) slot and channel the sums of m g and m g xhat (m = BatchNorm(z) > 0, xhat = (z - mean) invstd; float64
+  // bs_part[slot][Cout][2]) and max |m g| (float bs_gmax[slot][Cout], behind the sums); *bs_slots_host = the number of slots (0: no room
+  // in bs_cap doubles -- nothing kept).  bs_bound_slot: the dword the reduction pass zeroes for its finalize kernel.
+  const float* bs_z;
+  const float* bs_mean; const float* bs_invstd; const float* bs_gamma; const float* bs_beta;
+  double* bs_part;
+  float* bs_gmax;
+  int64_t bs_cap;
+  int* bs_slots_host;
+  int bs_slots;
+  unsigned* bs_bound_slot;
 };
 
 int mval_launch_conv_p2(const P2Args& a, hipStream_t s);  // conv_p2.hip; 1 = unsupported (dry != 0: no launch)
@@ -208,6 +229,7 @@ int mval_launch_nhwc_to_p2(const float* x, const unsigned* rows_in, _Float16* pl
                             hipStream_t s);
 int mval_conv_p2_supported(int k, int stride, int cin, int cout, int hin, int win, int up, int out_nchw, int n);
 int mval_conv_p2_inz_supported(int cin, int cout, int h, int w, int n);  // the in_z form above (3x3 stride 1, raw fp32 NHWC out)
+int mval_conv_p2_bsum_supported(int cin, int cout, int h, int w, int n);  // the bs_z form (3x3 stride-1 data gradient: cin = the conv's cout)
 int mval_conv_p2_parity_supported(int cin, int cout, int h, int w, int n, int nhwc_out);  // one parity conv (k 2) over an h x w grid
 
 // conv_block_p2.hip: a whole BasicBlock over P2 activations in one launch; 1 = unsupported

@@ -138,8 +138,9 @@ __device__ __forceinline__ f32x4 p2_mfma(const u32x4 a, const u32x4 b, const f32
 // The kernel body: `by` / `gy` = the workgroup's cout group and the number of cout groups (blockIdx.y / gridDim.y).  (Round 4 also ran the
 // two or three first-level stride-2 convs of a fuse layer as ONE launch through this body -- 112 us of launches less per forward back to
 // back, but slower as a step under the multi-stream forward, C2 10.17 vs 10.10 ms: removed in round 5)
-template <int KS, int S, int G, int WN, int WM, int NT, int MS, int TW, bool RS, int EPI, int OW = 0, bool K48 = false, bool INZ = false>
+template <int KS, int S, int G, int WN, int WM, int NT, int MS, int TW, bool RS, int EPI, int OW = 0, bool K48 = false, bool INZ = false, bool BSUM = false>
 __device__ __forceinline__ void conv_p2_body(const P2Args& a, const int by, const int gy) {
+  static_assert(!BSUM || (EPI == 3 && KS == 3 && S == 1 && OW == 0 && !K48 && !INZ), "BSUM: the 3x3 stride-1 data gradients");
   static_assert(!K48 || (RS && G == 1), "K48: the row-sharing 3x3 kernels");
   static_assert(!INZ || (EPI == 3 && KS == 3 && S == 1 && OW == 0 && !K48), "INZ: the training forward's 3x3 stride-1 convs");
   constexpr int NTH = 64 * WN * WM, TAPS = KS * KS, SPN = 8 * G, SPN_LOG2 = G == 1 ? 3 : G == 2 ? 4 : 5;
@@ -177,8 +178,25 @@ __device__ __forceinline__ void conv_p2_body(const P2Args& a, const int by, cons
   const int tile_end = min(a.tiles_total, (xg + 1) * per);
   // (EPI 3) batch-statistics sums of the lane's four output channels per cout sub-tile, over the workgroup's whole tile walk
   float bsum[EPI == 3 ? NT : 1][4], bsq[EPI == 3 ? NT : 1][4];
+  float bgmx[BSUM ? NT : 1][4];  // (BSUM) max |masked gradient| per channel
   auto stats_put = [&]() {
-    if constexpr (EPI == 3) {
+    if constexpr (BSUM) {
+      if (!a.bs_part || !wave_active) return;
+      const int cqs = ((lane >> 4) & 1) * 8 + (lane >> 5) * 4;
+#pragma unroll
+      for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const float s1 = p2_row16_sum(bsum[nt][j]), s2 = p2_row16_sum(bsq[nt][j]), mx = p2_row16_max(bgmx[nt][j]);
+          const int c = (ns0 + nt) * 16 + cqs + j;
+          if ((lane & 15) == 0 && c < a.Cout) {
+            const int64_t e = ((int64_t)blockIdx.x * WM + wm) * a.Cout + c;
+            a.bs_part[e * 2] = (double)s1;
+            a.bs_part[e * 2 + 1] = (double)s2;
+            a.bs_gmax[e] = mx;
+          }
+        }
+    } else if constexpr (EPI == 3) {
       if (!a.bn_part || !wave_active) return;
       const int cqs = ((lane >> 4) & 1) * 8 + (lane >> 5) * 4;
 #pragma unroll
@@ -200,6 +218,25 @@ __device__ __forceinline__ void conv_p2_body(const P2Args& a, const int by, cons
     for (int nt = 0; nt < NT; nt++)
 #pragma unroll
       for (int j = 0; j < 4; j++) bsum[nt][j] = bsq[nt][j] = 0.f;
+  }
+  // (BSUM) the lane's four output channels' BatchNorm factors per cout sub-tile: r = fma(z, alpha, beta') (train_ops.hip bn_affine),
+  // xhat = (z - mean) invstd
+  f32x4 bs_al[BSUM ? NT : 1], bs_bp[BSUM ? NT : 1], bs_mu[BSUM ? NT : 1], bs_is[BSUM ? NT : 1];
+  if constexpr (BSUM) {
+    if (a.bs_bound_slot && blockIdx.x == 0 && by == 0 && threadIdx.x == 0) *a.bs_bound_slot = 0u;
+    const int cqs = ((lane >> 4) & 1) * 8 + (lane >> 5) * 4;
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int c = min(((by * WN + wn) * NT + nt) * 16 + cqs + j, a.Cout - 1);
+        const float al = a.bs_invstd[c] * a.bs_gamma[c];
+        bs_al[nt][j] = al;
+        bs_bp[nt][j] = __builtin_fmaf(-a.bs_mean[c], al, a.bs_beta[c]);
+        bs_mu[nt][j] = a.bs_mean[c];
+        bs_is[nt][j] = a.bs_invstd[c];
+        bgmx[nt][j] = 0.f;
+      }
   }
   if (tile >= tile_end) {
     stats_put();  // (a workgroup without tiles still owns its slots of the partials)
@@ -792,6 +829,9 @@ __device__ __forceinline__ void conv_p2_body(const P2Args& a, const int by, cons
         // channel; a data gradient (acc_nhwc) adds to what the slot holds: those loads are all requested before the first store
         unsigned zo[MS][NT];
         f32x4 ex[MS][NT];
+        f32x4 zz[BSUM ? MS : 1][BSUM ? NT : 1];  // (BSUM) the producer's raw z at the lane's positions: same offsets as the store
+        const __amdgpu_buffer_rsrc_t bszr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(BSUM ? a.bs_z : nullptr), 0,
+            BSUM ? (unsigned)((int64_t)a.N * a.Hout * a.Wout * a.Cout * 4) : 0u, 0x00020000);
 #pragma unroll
         for (int nt = 0; nt < NT; nt++) {
           const int c0 = (ns0 + nt) * 16 + cq;
@@ -812,6 +852,7 @@ __device__ __forceinline__ void conv_p2_body(const P2Args& a, const int by, cons
             zo[ms][nt] = ok ? (unsigned)((((unsigned)n * (a.Hout << osh) + (y << osh) + (osh ? a.oy : 0)) * (a.Wout << osh) + (x << osh) + (osh ? a.ox : 0)) * a.Cout + c0) * 4u
                             : 0x80000000u;
             if (a.acc_nhwc) ex[ms][nt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(zr, zo[ms][nt], 0, 0));
+            if constexpr (BSUM) zz[ms][nt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(bszr, zo[ms][nt], 0, 0));
           }
         }
 #pragma unroll
@@ -823,10 +864,21 @@ __device__ __forceinline__ void conv_p2_body(const P2Args& a, const int by, cons
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), zr, zo[ms][nt], 0, 0);
             asm volatile("s_nop 1");
             if (zo[ms][nt] != 0x80000000u) {
+              if constexpr (BSUM) {
 #pragma unroll
-              for (int j = 0; j < 4; j++) {
-                bsum[nt][j] += v[j];
-                bsq[nt][j] = __builtin_fmaf(v[j], v[j], bsq[nt][j]);
+                for (int j = 0; j < 4; j++) {
+                  const float zj = zz[ms][nt][j];
+                  const float g = __builtin_fmaf(zj, bs_al[nt][j], bs_bp[nt][j]) > 0.f ? v[j] : 0.f;  // (bwd_mask mode 2, train_ops.hip)
+                  bsum[nt][j] += g;
+                  bsq[nt][j] = __builtin_fmaf(g, (zj - bs_mu[nt][j]) * bs_is[nt][j], bsq[nt][j]);
+                  bgmx[nt][j] = fmaxf(bgmx[nt][j], fabsf(g));
+                }
+              } else {
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                  bsum[nt][j] += v[j];
+                  bsq[nt][j] = __builtin_fmaf(v[j], v[j], bsq[nt][j]);
+                }
               }
             }
           }
@@ -940,14 +992,14 @@ __device__ __forceinline__ void conv_p2_body(const P2Args& a, const int by, cons
 }
 
 
-template <int KS, int S, int G, int WN, int WM, int NT, int MS, int TW, bool RS, int EPI, int OW = 0, bool K48 = false, bool INZ = false>
+template <int KS, int S, int G, int WN, int WM, int NT, int MS, int TW, bool RS, int EPI, int OW = 0, bool K48 = false, bool INZ = false, bool BSUM = false>
 __global__ __launch_bounds__(64 * WN * WM) __attribute__((amdgpu_waves_per_eu(P2_WAVES(MS, NT, EPI), 8))) void conv_p2_kernel(P2Args a) {
-  conv_p2_body<KS, S, G, WN, WM, NT, MS, TW, RS, EPI, OW, K48, INZ>(a, (int)blockIdx.y, (int)gridDim.y);
+  conv_p2_body<KS, S, G, WN, WM, NT, MS, TW, RS, EPI, OW, K48, INZ, BSUM>(a, (int)blockIdx.y, (int)gridDim.y);
 }
 
 static thread_local int g_p2_dry = 0;
 
-template <int KS, int S, int G, int WN, int WM, int NT, int MS, int TW, bool RS, int EPI, int OW = 0, bool K48 = false, bool INZ = false>
+template <int KS, int S, int G, int WN, int WM, int NT, int MS, int TW, bool RS, int EPI, int OW = 0, bool K48 = false, bool INZ = false, bool BSUM = false>
 static int launch_p2e(P2Args a, hipStream_t s) {
   constexpr int TWE = OW ? OW : TW;
   constexpr int TH = 16 * MS * WM / TWE;
@@ -979,7 +1031,7 @@ static int launch_p2e(P2Args a, hipStream_t s) {
   // registers), a multiple of 8 per cout group so that every XCD walks its own contiguous tile range; fewer tiles than
   // that: one tile each.  (No workgroup waits for another one: an optimistic answer only costs a second round.)
   static std::atomic<int> occ{0};
-  int per_cu = p2_resident_wgs(&conv_p2_kernel<KS, S, G, WN, WM, NT, MS, TW, RS, EPI, OW, K48, INZ>, occ, smem, NTH / 64);
+  int per_cu = p2_resident_wgs(&conv_p2_kernel<KS, S, G, WN, WM, NT, MS, TW, RS, EPI, OW, K48, INZ, BSUM>, occ, smem, NTH / 64);
 #ifdef P2_TUNE
   const char* pe = getenv("MVAL_P2_WGS");  // measurement builds only: workgroups per CU
   if (pe && atoi(pe) > 0) per_cu = atoi(pe);
@@ -1002,7 +1054,13 @@ static int launch_p2e(P2Args a, hipStream_t s) {
     if (a.bn_part && (int64_t)a.Cout * a.bn_slots * 2 > a.bn_part_cap) a.bn_part = nullptr;  // (no room: the caller runs the separate statistics pass)
     if (a.bn_part && a.bn_slots_host) *a.bn_slots_host = a.bn_slots;
   }
-  hipLaunchKernelGGL((conv_p2_kernel<KS, S, G, WN, WM, NT, MS, TW, RS, EPI, OW, K48, INZ>), grid, dim3(NTH), smem, s, a);
+  if constexpr (BSUM) {
+    a.bs_slots = wgs * WM;
+    if ((int64_t)a.Cout * a.bs_slots * 3 > a.bs_cap) return 2;  // (no room for the partials: the caller launches the plain form)
+    a.bs_gmax = reinterpret_cast<float*>(a.bs_part + (int64_t)a.Cout * a.bs_slots * 2);
+    if (a.bs_slots_host) *a.bs_slots_host = a.bs_slots;
+  }
+  hipLaunchKernelGGL((conv_p2_kernel<KS, S, G, WN, WM, NT, MS, TW, RS, EPI, OW, K48, INZ, BSUM>), grid, dim3(NTH), smem, s, a);
   return 0;
 }
 
@@ -1049,6 +1107,20 @@ int mval_launch_conv_p2(const P2Args& a0, hipStream_t s) {
   int oms = 0, ont = 0, og = 0;
   p2_override(oms, ont, og);
   const int64_t px = (int64_t)a.N * a.Hout * a.Wout;
+  if (a.bs_z) {  // (round 6) a 3x3 stride-1 data gradient that also keeps the BatchNorm backward's reduction of what it writes (P2Args::bs_z)
+    int rc = 1;
+    if (a.k == 3 && a.stride == 1 && a.out_nhwc && !a.up && !a.res1 && !a.res2 && !a.out_f32 && !a.acc_nhwc && !a.os && !a.bn_part && a.bs_part &&
+        a.bs_mean && a.bs_invstd && a.bs_gamma && a.bs_beta) {
+      if (a.Wout >= 16 && a.Wout % 16 == 0 && a.Hout >= 4)
+        rc = a.NS_total <= 2 ? launch_p2e<3, 1, 1, 2, 2, 1, 4, 16, true, 3, 0, false, false, true>(a, s)
+                             : launch_p2e<3, 1, 1, 4, 1, 1, 4, 16, true, 3, 0, false, false, true>(a, s);
+      else if (a.Wout == 8 && a.Hout == 8 && a.NS_total > 2 && a.Cin >= 64)
+        rc = launch_p2e<3, 1, 2, 4, 1, 1, 4, 8, false, 3, 0, false, false, true>(a, s);
+    }
+    if (rc == 0) return 0;
+    if (a.bs_slots_host) *a.bs_slots_host = 0;
+    a.bs_z = nullptr;  // (shape not covered, or no room for the partials: the plain data gradient; the caller runs the reduction pass)
+  }
   if (a.in_z) {  // (round 6) the training forward's 3x3 stride-1 conv that applies its producer's BatchNorm + ReLU while staging (P2Args::in_z)
     if (a.k != 3 || a.stride != 1 || !a.out_nhwc || a.up || a.res1 || a.res2 || a.out_f32 || a.acc_nhwc || a.os) return 1;
     if (!a.zin_mean || !a.zin_invstd || !a.zin_gamma || !a.zin_beta) return 1;
@@ -1228,6 +1300,14 @@ int mval_conv_p2_supported(int k, int stride, int cin, int cout, int hin, int wi
   const int rc = mval_launch_conv_p2(a, nullptr);
   g_p2_dry = 0;
   return rc == 0;
+}
+
+int mval_conv_p2_bsum_supported(int cin, int cout, int h, int w, int n) {
+  // (the same three tile forms as the in_z conv; room for the partials is decided at launch)
+  const int ns = (cout + 15) / 16;
+  if ((cin & 7) || (cout & 3) || (int64_t)n * h * w * cin >= ((int64_t)1 << 29) || (int64_t)n * h * w * cout >= ((int64_t)1 << 29)) return 0;
+  if (w >= 16 && w % 16 == 0 && h >= 4) return 1;
+  return w == 8 && h == 8 && ns > 2 && cin >= 64;
 }
 
 int mval_conv_p2_inz_supported(int cin, int cout, int h, int w, int n) {

@@ -385,7 +385,9 @@ static int train_forward(const mval_train_op* ops, int n_ops, int n_images, floa
                                    stream);
       }
       if (rc) return rc;
-      if (t.z_out) continue;  // (round 6) the one reader of this activation applies the BatchNorm itself (mval_train_op.z_out)
+      // (round 6) the one reader of this activation applies the BatchNorm itself (mval_train_op.z_out) -- except on the plan's bound-slack
+      // probe steps (first step, then every 1 024th): the planes are written then so that the probe measures this tensor like every other
+      if (t.z_out && !(g_probe && i < g_probe_n)) continue;
       TtScope tt(TT_BN_APPLY, s);
 #ifdef MVAL_TRAIN_ABLATE
       // measurement build only (profiles/r06: the step-level UPPER BOUND of BatchNorm-apply-in-the-consumer's-staging): from the third

@@ -621,6 +621,44 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_bound_kernel(const double
   atomicMax(bound_slot, __float_as_uint(bd));
 }
 
+// The same from the partials a data-gradient conv's epilogue left (conv_p2.h P2Args::bs_z): sums as above, the maxima per (slot, channel)
+// -- the bound then uses the CHANNEL's own max |masked gradient| (at most the tensor's: still a bound, and a tighter one)
+__global__ __launch_bounds__(256) void bn_bwd_finalize_bound_c_kernel(const double* __restrict__ part, const float* __restrict__ gmaxc, int nslots, int C,
+                                                                      float* __restrict__ dbeta, float* __restrict__ dgamma,
+                                                                      float* __restrict__ sums, const float* __restrict__ gamma,
+                                                                      const float* __restrict__ invstd, float inv_m, float sqrt_m1,
+                                                                      unsigned* __restrict__ bound_slot) {
+  __shared__ double red[2][4];
+  __shared__ float redm[4];
+  const int c = blockIdx.x;
+  double a = 0, b = 0;
+  float gm = 0.f;
+  for (int k = threadIdx.x; k < nslots; k += 256) {
+    a += part[((int64_t)k * C + c) * 2];
+    b += part[((int64_t)k * C + c) * 2 + 1];
+    gm = fmaxf(gm, gmaxc[(int64_t)k * C + c]);
+  }
+  a = wave_sum(a);
+  b = wave_sum(b);
+  gm = wave_max(gm);
+  if ((threadIdx.x & 63) == 0) {
+    red[0][threadIdx.x >> 6] = a;
+    red[1][threadIdx.x >> 6] = b;
+    redm[threadIdx.x >> 6] = gm;
+  }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  a = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+  b = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+  gm = fmaxf(fmaxf(redm[0], redm[1]), fmaxf(redm[2], redm[3]));
+  dbeta[c] = (float)a;
+  dgamma[c] = (float)b;
+  sums[c] = (float)a;
+  sums[C + c] = (float)b;
+  const float bd = fabsf(gamma[c] * invstd[c]) * (gm + fabsf((float)a) * inv_m + sqrt_m1 * fabsf((float)b) * inv_m) * (1.f + 1e-5f);
+  atomicMax(bound_slot, __float_as_uint(bd));
+}
+
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __restrict__ part, int nblocks, int C,
                                                               float* __restrict__ dbeta, float* __restrict__ dgamma,
                                                               float* __restrict__ sums) {
@@ -990,6 +1028,17 @@ extern "C" int mval_bn_bwd_fused_mask(const float* gout, const float* out, const
 // data-gradient conv on the P2 kernels (round 4).  Its scale comes from a bound of |dz| built in the finalize step from max |masked
 // gradient| (kept by the reduction, gmax_ws >= 512 floats), dbeta, dgamma and Samuelson's |xhat| <= sqrt(M - 1); bound_slot: one dword of
 // scratch.  gz may be NULL then (no fp32 copy of dz).
+// (round 6) The NEXT mval_bn_bwd_fused_p2 call finds its reduction done: part[nslots][C][2] and gmaxc[nslots][C] were left by the epilogue
+// of the data-gradient conv that wrote gout (its only writer; ReLU, no residual), and that kernel zeroed bound_slot.
+static thread_local const double* g_presum_part = nullptr;
+static thread_local const float* g_presum_gmax = nullptr;
+static thread_local int g_presum_slots = 0;
+void mval_bn_bwd_set_presummed(const double* part, const float* gmaxc, int nslots) {
+  g_presum_part = part;
+  g_presum_gmax = gmaxc;
+  g_presum_slots = nslots;
+}
+
 extern "C" int mval_bn_bwd_fused_p2(const float* gout, const float* out, const uint8_t* relu_mask, const float* z, const float* mean,
                                     const float* invstd, const float* gamma, const float* beta, float* gres1, float* gres2, float* gz,
                                     float* dgamma, float* dbeta, double* ws, float* sums, int N, int H, int W, int C, int relu,
@@ -1012,6 +1061,18 @@ extern "C" int mval_bn_bwd_fused_p2(const float* gout, const float* out, const u
   const size_t sh = (size_t)rows * lanes * 4 * 2 * sizeof(double);
   hipStream_t s = mval_stream(stream);
   const int mask_mode = !relu ? 0 : (gres1 || gres2) ? (relu_mask ? 3 : 1) : 2;
+  const double* pre_part = g_presum_part;
+  const float* pre_gmax = g_presum_gmax;
+  const int pre_slots = g_presum_slots;
+  g_presum_part = nullptr;
+  g_presum_gmax = nullptr;
+  g_presum_slots = 0;
+  if (pre_part) {
+    MVAL_REQUIRE(p2 && mask_mode == 2 && pre_gmax && pre_slots > 0, "mval_bn_bwd_fused_p2: pre-summed partials need the P2 form of a ReLU op without residuals");
+    hipLaunchKernelGGL(bn_bwd_finalize_bound_c_kernel, dim3(C), dim3(256), 0, s, pre_part, pre_gmax, pre_slots, C, dbeta, dgamma, sums, gamma, invstd,
+                       1.0f / (float)M, (float)sqrt(M > 1 ? (double)M - 1.0 : 1.0), bound_slot);
+    MVAL_CHECK_LAUNCH("mval_bn_bwd_fused/finalize (pre-summed)");
+  } else {
 #ifdef MVAL_TRAIN_ABLATE  // (measurement build only: the upper bound of "the backward reduction in the producer dgrad's epilogue" -- the sums stay stale)
   if (!(g_train_ablate & 2) || gres1 || gres2)
 #endif
@@ -1024,6 +1085,7 @@ extern "C" int mval_bn_bwd_fused_p2(const float* gout, const float* out, const u
   else
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, s, ws, nb, C, dbeta, dgamma, sums);
   MVAL_CHECK_LAUNCH("mval_bn_bwd_fused/finalize");
+  }
   // the masked gradient again: from the residual slot this op was the first to write (it holds exactly that), else
   // from gout with the mask re-derived
   const float* gsrc = gout;
