@@ -48,6 +48,7 @@ int mval_conv_wgrad_on(const float* x, const float* dz, float* dw, float* ws, in
 void mval_conv_wgrad_set_p2_x(const void* planes, const unsigned* rows);  // conv_wgrad.hip: x as P2 planes for the next weight gradient
 void mval_conv_wgrad_set_p2_dz(const void* planes, const unsigned* rows);  // ... and dz
 void mval_conv_wgrad_set_z_x(const float* mean, const float* invstd, const float* gamma, const float* beta, float sqrt_m1);  // conv_wgrad_bf3.hip: x = relu(BatchNorm(z))
+void mval_bn_bwd_set_presummed(const double* part, const float* gmaxc, int nslots);  // train_ops.hip: the next fused BatchNorm backward finds its reduction done
 // ---- measurement mode (bench.py, the c3 line's per-kernel roofline): hipEvents around every launch group of a
 // training step, summed per kernel family.  Off unless mval_train_timing() armed it; the events are resolved (one
 // stream synchronisation) at the end of each forward / backward call.
@@ -465,6 +466,10 @@ static int train_backward(const mval_train_op* ops, int n_ops, int n_images, flo
   LanesFree lanes_free(free_run ? L : nullptr, mval_stream(stream0));
   SlotOrder order;
   order.keep = free_run;
+  // (round 6, MVAL_TRAIN_BSUM) per lane: the slots of reduction partials the last data gradient on that lane left in the lane's `ws` for
+  // the op `presum_for` -- the very next op of the list (zin_rel == -1), so nothing else touches that scratch in between
+  int presum_slots[MVAL_MAX_LANES] = {0, 0, 0, 0};
+  const mval_train_op* presum_for[MVAL_MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};
   for (int i = n_ops - 1; i >= 0; i--) {
     g_tt_op = g_tt_base + i;
     const mval_train_op& t = ops[i];
@@ -505,6 +510,10 @@ static int train_backward(const mval_train_op* ops, int n_ops, int n_images, flo
     }
     {
     TtScope tt(TT_BN_BWD, s);
+    if (presum_for[lane] == &t && presum_slots[lane] > 0 && bwd_fused && dz_p2)
+      mval_bn_bwd_set_presummed(ws, reinterpret_cast<const float*>(ws + (int64_t)op.cout * presum_slots[lane] * 2), presum_slots[lane]);
+    presum_for[lane] = nullptr;
+    presum_slots[lane] = 0;
     if (bwd_fused && t.has_bn && op.up == 0 && (op.cout & 3) == 0)
       rc = mval_bn_bwd_fused_p2(garena + t.gout_off, outp, t.mask_off > 0 ? reinterpret_cast<const uint8_t*>(arena + t.mask_off) : nullptr,
                              arena + t.z_off, t.mean, t.invstd, t.gamma, t.beta,
@@ -601,9 +610,27 @@ static int train_backward(const mval_train_op* ops, int n_ops, int n_images, flo
         p.acc_nhwc = !(t.first_touch & 1);
         p.N = n_images; p.Hin = op.hout; p.Win = op.wout; p.Cin = op.cout; p.Hout = op.hin; p.Wout = op.win; p.Cout = op.cin;
         p.k = op.k; p.stride = 1;
+        int slots = 0;
+        if ((t.p2_flags & MVAL_TRAIN_BSUM) && t.zin_rel == -1 && i > 0 && (t.first_touch & 1)) {
+          // this launch is the only writer of the producer's output gradient: it also keeps that op's BatchNorm backward reduction
+          const mval_train_op& pr = ops[i - 1];
+          if (pr.has_bn && pr.op.relu && pr.op.res1_off < 0 && pr.op.res2_off < 0 && pr.op.up == 0 && pr.gout_off == t.gin_off && pr.gz_p2_rows_off > 0 &&
+              lane_of(pr, MVAL_TRAIN_LANE_BWD, n_lanes) == lane) {
+            p.bs_z = arena + pr.z_off;
+            p.bs_mean = pr.mean; p.bs_invstd = pr.invstd; p.bs_gamma = pr.gamma; p.bs_beta = pr.beta;
+            p.bs_part = ws;
+            p.bs_cap = ws_stride;  // (doubles of this lane's scratch; mval_train_backward without lanes passes 0: the plain data gradient)
+            p.bs_slots_host = &slots;
+            p.bs_bound_slot = reinterpret_cast<unsigned*>(arena + pr.gz_p2_rows_off + (int64_t)n_images * P2_ROW + 512);
+          }
+        }
         if (mval_launch_conv_p2(p, s)) {
           mval_set_error("mval_train_backward: op %d: no P2 kernel for the data gradient (k%d cin%d cout%d)", i, op.k, op.cin, op.cout);
           return -1;
+        }
+        if (slots > 0) {
+          presum_slots[lane] = slots;
+          presum_for[lane] = &ops[i - 1];
         }
         rc = 0;
       } else if (t.dgrad_form == 1)  // (dgrad_form: the four-parity form of a stride-2 3x3 data gradient)

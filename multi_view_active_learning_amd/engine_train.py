@@ -71,9 +71,10 @@ SLACK_EVERY = int(os.environ.get("MVAL_TRAIN_SLACK_EVERY", "1024"))
 # switch -> the value an unset variable stands for (the key must tell "unset" from every other setting: MVAL_TRAIN_LANES defaults to mode 3)
 _SWITCHES = {"MVAL_TRAIN_P2": "1", "MVAL_TRAIN_P2_WGRAD": "1", "MVAL_TRAIN_P2_DGRAD": "1", "MVAL_TRAIN_P2_RES": "1", "MVAL_TRAIN_EPI_STATS": "1",
              "MVAL_TRAIN_BWD_FUSED": "1", "MVAL_TRAIN_RELU_MASK": "1", "MVAL_TRAIN_DGRAD_PARITY": "1", "MVAL_TRAIN_LANES": "3",
-             "MVAL_TRAIN_BN_IN_CONV": "1"}
+             "MVAL_TRAIN_BN_IN_CONV": "1", "MVAL_TRAIN_BN_BWD_IN_DGRAD": "1"}
 MAX_LANES = 4            # (csrc/conv_common.h MVAL_MAX_LANES)
 TRAIN_LANE_FWD, TRAIN_LANE_BWD, TRAIN_LANE_ORD, TRAIN_LANE_FREE = 256, 512, 1024, 2048  # (include/mval_hip.h MVAL_TRAIN_LANE_*)
+TRAIN_BSUM = 4096  # (MVAL_TRAIN_BSUM)
 
 _ARMED = None  # weakref to the plan whose probe rows the library currently points at (one slot per process: csrc/net_train.hip g_probe)
 
@@ -402,6 +403,13 @@ class TrainPlan:
                     pt.z_out = 1
                     ct.zin_rel = k - j
                     self.n_bn_in_conv += 1
+                    # ... and the other direction: that conv's data gradient is the ONLY writer of the producer's output gradient, so its
+                    # epilogue keeps the sums the producer's BatchNorm backward would get from a second read of it (P2Args::bs_z;
+                    # MVAL_TRAIN_BN_BWD_IN_DGRAD=0: the reduction pass).  The library checks the rest at launch (first touch, same lane, room).
+                    lib.mval_conv_p2_bsum_supported.restype = C.c_int
+                    if (os.environ.get("MVAL_TRAIN_BN_BWD_IN_DGRAD", "1") != "0" and k == j - 1 and (ct.p2_flags & 4) and (pt.p2_flags & 4) and fused_bwd
+                            and lib.mval_conv_p2_bsum_supported(C.c_int(co.cout), C.c_int(co.cin), C.c_int(hin), C.c_int(win), C.c_int(n))):
+                        ct.p2_flags |= TRAIN_BSUM
         # the two BatchNorm A/B switches are the PLAN's decision and travel in p2_flags (bit 6: round 3's backward pair, bit 7: statistics by
         # the separate pass): net_train.hip does not read the environment
         bits = (0 if os.environ.get("MVAL_TRAIN_BWD_FUSED", "1") != "0" else 64) | (0 if os.environ.get("MVAL_TRAIN_EPI_STATS", "1") != "0" else 128)
@@ -456,7 +464,9 @@ class TrainPlan:
         # float64 scratch of the BatchNorm reductions; sized so that the forward conv epilogues' per-workgroup statistics
         # partials fit (cout x workgroups x 2, workgroups <= pixels / 32 for every tile the large layers use)
         epi = max((op.cout * ((n * geo[i][2] * geo[i][3] + 31) // 32 + 64) * 2 for i, op in enumerate(g.ops) if op.bn), default=0)
-        self.ws_lane = _align(max(512 * maxc * 2, epi) + 64)
+        # (round 6: ... and the data gradients' reduction partials, cout x slots x 3 with slots = persistent workgroups x pixel waves <= 2 304)
+        bsum = max((g.ops[i - 1].cout * 2304 * 3 for i, t in enumerate(self.ops) if t.p2_flags & TRAIN_BSUM), default=0)
+        self.ws_lane = _align(max(512 * maxc * 2, epi, bsum) + 64)
         self.ws = torch.empty(self.ws_lane * self.n_lanes, dtype=torch.float64, device=device)
         self.sums_lane = _align(2 * maxc + 64)
         self.sums = torch.empty(self.sums_lane * self.n_lanes, **f32)

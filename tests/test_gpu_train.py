@@ -599,15 +599,31 @@ def test_bn_in_conv_is_bit_identical_to_the_separate_apply(dev, case, monkeypatc
         if t.zin_rel:
             pr = plan.ops[i + t.zin_rel]
             assert pr.z_out and pr.op.cout == t.op.cin and t.op.k == 3 and t.op.stride == 1
-    g1 = {k: p.grad.detach().clone() for k, p in m1.named_parameters()}
-    r1 = {k: b.detach().clone() for k, b in m1.named_buffers() if "running" in k}
+    from multi_view_active_learning_amd import engine_train
+
+    n_bs = sum(int(t.p2_flags & engine_train.TRAIN_BSUM != 0) for t in plan.ops)
+    assert n_bs >= 0.9 * n_z, (n_bs, n_z)  # (the BasicBlocks' pairs are adjacent in the list: their data gradients keep the reduction)
+    # the forward half alone (the data gradients' epilogue sums off): bit-identical to the separate apply
+    monkeypatch.setenv("MVAL_TRAIN_BN_BWD_IN_DGRAD", "0")
+    mf, _, hmf, lf, _ = _train_once(case, dev)
+    assert sum(int(t.p2_flags & engine_train.TRAIN_BSUM != 0) for t in next(iter(mf._train_plans.values())).ops) == 0
+    gf = {k: p.grad.detach().clone() for k, p in mf.named_parameters()}
+    rf = {k: b.detach().clone() for k, b in mf.named_buffers() if "running" in k}
     monkeypatch.setenv("MVAL_TRAIN_BN_IN_CONV", "0")
     m0, _, hm0, l0, _ = _train_once(case, dev)
     assert sum(int(t.z_out) for t in next(iter(m0._train_plans.values())).ops) == 0
-    assert torch.equal(hm1, hm0) and torch.equal(l1, l0)
-    bad = [k for k, p in m0.named_parameters() if not torch.equal(p.grad, g1[k])]
+    assert torch.equal(hmf, hm0) and torch.equal(lf, l0)
+    bad = [k for k, p in m0.named_parameters() if not torch.equal(p.grad, gf[k])]
     assert not bad, (len(bad), bad[:5])
-    assert all(torch.equal(b, r1[k]) for k, b in m0.named_buffers() if "running" in k)
+    assert all(torch.equal(b, rf[k]) for k, b in m0.named_buffers() if "running" in k)
+    # both halves (the default): the forward is the same bits; the backward's reduction sums are accumulated in another order (fp32 per
+    # lane over the workgroup's tile walk, then float64) and the dz scale comes from the channel's own maximum, so the gradients agree to
+    # the noise level the switch tests hold (median 5e-3, worst 5e-2 relative L2: test_round4_training_paths_against_their_switches)
+    assert torch.equal(hm1, hm0) and torch.equal(l1, l0)
+    errs = sorted(_rel(p.grad.cpu().numpy(), m0_p.grad.cpu().numpy()) for (_, p), (_, m0_p) in zip(m1.named_parameters(), m0.named_parameters()))
+    print(f"[bn bwd in dgrad] gradient rel-L2 vs the reduction pass: median {errs[len(errs) // 2]:.2e} worst {errs[-1]:.2e}")
+    assert errs[-1] < 5e-2 and errs[len(errs) // 2] < 5e-3, (errs[-1], errs[len(errs) // 2])
+    assert all(torch.equal(b, rf[k]) for k, b in m1.named_buffers() if "running" in k)
 
 
 @pytest.mark.parametrize("wd", [0.0, 0.01], ids=["plain", "weight_decay"])
