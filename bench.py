@@ -222,7 +222,10 @@ def train_bn_bytes(plan, n):
     bp = dict(reduce_read_gout=0, reduce_read_z=0, reduce_read_out_or_mask=0, reduce_rw_res_grads=0, apply_read_g=0, apply_read_z=0,
               apply_read_out_or_mask=0, apply_write_fp32=0, apply_write_planes=0)
     n_bn = 0
-    for o in plan.ops:
+    # (round 6) ops whose apply runs inside their reader's staging (z_out) move no apply bytes; ops whose backward reduction was kept by their
+    # reader's data-gradient epilogue (the op in front of one with MVAL_TRAIN_BSUM) move no reduction bytes
+    presummed = {i - 1 for i, o in enumerate(plan.ops) if o.p2_flags & 4096}
+    for idx, o in enumerate(plan.ops):
         if not o.has_bn:
             continue
         n_bn += 1
@@ -234,9 +237,10 @@ def train_bn_bytes(plan, n):
         o_el += oe * (1 + nres)
         # forward apply
         p2_only = bool(o.p2_flags & 2)
-        apply_b += 4 * ze + 4 * oe * nres + (0 if p2_only else 4 * oe) + (4 * oe if o.out_p2_off > 0 else 0) + (oe / 4 if o.mask_off > 0 else 0)
-        ap["read_z"] += 1; ap["read_res"] += nres; ap["write_fp32"] += int(not p2_only); ap["write_planes"] += int(o.out_p2_off > 0)
-        ap["write_mask"] += int(o.mask_off > 0)
+        if not o.z_out:
+            apply_b += 4 * ze + 4 * oe * nres + (0 if p2_only else 4 * oe) + (4 * oe if o.out_p2_off > 0 else 0) + (oe / 4 if o.mask_off > 0 else 0)
+            ap["read_z"] += 1; ap["read_res"] += nres; ap["write_fp32"] += int(not p2_only); ap["write_planes"] += int(o.out_p2_off > 0)
+            ap["write_mask"] += int(o.mask_off > 0)
         # backward
         fused = not (o.p2_flags & 64) and op.up == 0 and op.cout % 4 == 0
         first = o.first_touch >> 1
@@ -248,9 +252,11 @@ def train_bn_bytes(plan, n):
             from_slot = st_res > 0 and bool(first & 3)  # apply re-reads the residual slot this op stored the masked gradient in: no mask
             dz_p2 = bool(o.p2_flags & 4) and o.gin_off >= 0
             w32 = not (dz_p2 and (o.p2_flags & 8))
-            bwd_b += 4 * oe + 4 * ze + mask_b + 4 * oe * (acc_res + st_res) + 4 * oe + 4 * ze + (0 if from_slot else mask_b) + (4 * ze if w32 else 0) + (4 * ze if dz_p2 else 0)
-            bp["reduce_read_gout"] += 1; bp["reduce_read_z"] += 1; bp["reduce_read_out_or_mask"] += mask_b / (4 * oe)
-            bp["reduce_rw_res_grads"] += acc_res + st_res
+            red = 0.0 if idx in presummed else 4 * oe + 4 * ze + mask_b + 4 * oe * (acc_res + st_res)
+            bwd_b += red + 4 * oe + 4 * ze + (0 if from_slot else mask_b) + (4 * ze if w32 else 0) + (4 * ze if dz_p2 else 0)
+            if idx not in presummed:
+                bp["reduce_read_gout"] += 1; bp["reduce_read_z"] += 1; bp["reduce_read_out_or_mask"] += mask_b / (4 * oe)
+                bp["reduce_rw_res_grads"] += acc_res + st_res
             bp["apply_read_g"] += 1; bp["apply_read_z"] += 1; bp["apply_read_out_or_mask"] += 0 if from_slot else mask_b / (4 * oe)
             bp["apply_write_fp32"] += int(w32); bp["apply_write_planes"] += int(dz_p2)
         else:  # round-3 pair: reduce (gout at the upsampled size [, out], z, residual gradients, masked / window-summed copy to gz), apply in place
@@ -264,6 +270,7 @@ def train_bn_bytes(plan, n):
             stats_b += 4.0 * n * o.op.hout * o.op.wout * o.op.cout
     rnd = lambda d: {k_: round(float(v_), 1) for k_, v_ in d.items()}
     return dict(apply=apply_b, bwd=bwd_b, stats=stats_b, apply_passes=rnd(ap), bwd_passes=rnd(bp), n_bn=n_bn,
+                applies_in_reader=sum(int(o.z_out) for o in plan.ops), reductions_in_reader_dgrad=len(presummed),
                 apply_r3=4.0 * (z_el + o_el), bwd_r3=2.0 * 4.0 * o_el + 4.0 * 4.0 * z_el)
 
 
@@ -297,7 +304,7 @@ def train_rooflines(model, step, frames, v, mode):
     # HBM bytes per step by kernel from the committed rocprofv3 counter passes of THIS workload (tools/collect_profiles.sh: separate
     # --pmc FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE x2 gfx950 correction; Infinity-Cache hits are counted by those counters)
     pmc, pmc_src = {}, None
-    for r_ in ("r05", "r04"):
+    for r_ in ("r06", "r05", "r04"):
         p_ = os.path.join(ROOT, "profiles", r_, f"bench_c3_{r_.replace('0', '')}_summary.json")
         if os.path.exists(p_):
             try:
@@ -1019,8 +1026,8 @@ def main():
         # HBM bytes per launch of the dominant kernel: PMC counters cannot be read from inside
         # the process, so this is the committed rocprofv3 measurement of THIS command (separate
         # --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE x2 gfx950 correction; tools/pmc_summary.py)
-        summary = next((p_ for p_ in (os.path.join("profiles", r_, f"bench_c2_{_conv_mode()}_summary.json") for r_ in ("r05", "r04", "r03"))
-                        if os.path.exists(os.path.join(ROOT, p_))), os.path.join("profiles", "r05", f"bench_c2_{_conv_mode()}_summary.json"))
+        summary = next((p_ for p_ in (os.path.join("profiles", r_, f"bench_c2_{_conv_mode()}_summary.json") for r_ in ("r06", "r05", "r04", "r03"))
+                        if os.path.exists(os.path.join(ROOT, p_))), os.path.join("profiles", "r06", f"bench_c2_{_conv_mode()}_summary.json"))
         try:
             with open(os.path.join(ROOT, summary)) as f:
                 pre = (roof["kernel"].split(" ...>")[0],) + (("conv_block_kernel",) if "conv_block_kernel" in roof["kernel"] else ()) + \
@@ -1106,8 +1113,11 @@ def main():
                                           "run the h2 training kernels")
             out["config"]["training_passes"] = (
                 "one stream" if tp is None or tp.n_lanes <= 1 else
-                f"{tp.n_lanes} lanes (HRNet's branches on separate streams: forward every op of a lane, backward the phases whose gradient slots each have "
-                "one writing lane; bit-identical to the one-stream step, MVAL_TRAIN_LANES=0; the per-kernel rooflines below are timed on one stream)")
+                f"{tp.n_lanes} lanes (MVAL_TRAIN_LANES mode {os.environ.get('MVAL_TRAIN_LANES', '3')}: HRNet's branches on separate streams; mode 3 = no joins at the "
+                "backward's phase changes; bit-identical to one stream; per-kernel rooflines are timed on one stream)")
+            if tp is not None:
+                out["config"]["bn_in_conv"] = {"applies_in_reader_staging": int(sum(int(t.z_out) for t in tp.ops)),
+                                               "reductions_in_reader_dgrad_epilogue": int(sum(int(t.p2_flags & 4096 != 0) for t in tp.ops))}
             out["config"]["optimizer"] = {"mval": "multi_view_active_learning_amd.optim.Adam (torch.optim.Adam subclass, step = one mval_adam_step launch)",
                                           "torch": "torch.optim.Adam (foreach)", "fused": "torch.optim.Adam(fused=True)"}[adam_kind]
         if feed is not None:

@@ -22,6 +22,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_c4 -o c4 -- pyth
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -o c2 -- python3 bench.py --no-cpu-baseline --no-exact-modes --no-companions --steps 5 > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -o c2 -- python3 bench.py --no-cpu-baseline --no-exact-modes --no-companions --steps 5 > /dev/null 2>&1
 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS --output-format csv -d $out/pmc_sq -o c2 -- python3 bench.py --no-cpu-baseline --no-exact-modes --no-companions --steps 3 > /dev/null 2>&1
+rocprofv3 --pmc TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum --output-format csv -d $out/pmc_l2 -o c2 -- python3 bench.py --no-cpu-baseline --no-exact-modes --no-companions --steps 3 > /dev/null 2>&1
 ks=$(find $out/kt_c2 -name '*kernel_stats.csv' | head -1)
 k3=$(find $out/kt_c3 -name '*kernel_stats.csv' | head -1)
 fe=$(find $out/pmc_fetch -name '*counter_collection.csv' | head -1)
@@ -31,8 +32,9 @@ cp $ks $out/bench_c2_kernel_stats_$tag.csv
 cp $k3 $out/bench_c3_kernel_stats_$tag.csv
 k4=$(find $out/kt_c4 -name '*kernel_stats.csv' | head -1)
 cp $k4 $out/bench_c4_kernel_stats_$tag.csv
-python3 tools/pmc_summary.py $ks $fe $wr $sq > $out/bench_c2_${tag}_summary.json
-rm -rf $out/kt_c2 $out/pmc_fetch $out/pmc_write $out/pmc_sq
+l2=$(find $out/pmc_l2 -name '*counter_collection.csv' | head -1)
+python3 tools/pmc_summary.py $ks $fe $wr $sq $l2 > $out/bench_c2_${tag}_summary.json
+rm -rf $out/kt_c2 $out/pmc_fetch $out/pmc_write $out/pmc_sq $out/pmc_l2
 if [ "${PMC_C34:-1}" != "0" ]; then   # the same three counter passes for the training step and the HRNet-W48 slice (every kernel >= 0.3 % of the trace)
   SQC="GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS"
   for w in c3 c4; do
