@@ -252,7 +252,10 @@ def train_bn_bytes(plan, n):
             from_slot = st_res > 0 and bool(first & 3)  # apply re-reads the residual slot this op stored the masked gradient in: no mask
             dz_p2 = bool(o.p2_flags & 4) and o.gin_off >= 0
             w32 = not (dz_p2 and (o.p2_flags & 8))
-            red = 0.0 if idx in presummed else 4 * oe + 4 * ze + mask_b + 4 * oe * (acc_res + st_res)
+            # (a pre-summed op with residuals: the apply pass masks from the kept bits and scatters the residual gradients itself)
+            red = 4 * oe * (acc_res + st_res) if idx in presummed else 4 * oe + 4 * ze + mask_b + 4 * oe * (acc_res + st_res)
+            if idx in presummed:
+                from_slot = False
             bwd_b += red + 4 * oe + 4 * ze + (0 if from_slot else mask_b) + (4 * ze if w32 else 0) + (4 * ze if dz_p2 else 0)
             if idx not in presummed:
                 bp["reduce_read_gout"] += 1; bp["reduce_read_z"] += 1; bp["reduce_read_out_or_mask"] += mask_b / (4 * oe)

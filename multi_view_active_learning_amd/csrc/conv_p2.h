@@ -215,6 +215,8 @@ struct P2Args {
   // bs_part[slot][Cout][2]) and max |m g| (float bs_gmax[slot][Cout], behind the sums); *bs_slots_host = the number of slots (0: no room
   // in bs_cap doubles -- nothing kept).  bs_bound_slot: the dword the reduction pass zeroes for its finalize kernel.
   const float* bs_z;
+  const unsigned char* bs_mask;  // != nullptr: m comes from the (out > 0) bits the producer's forward apply kept (one byte per float4: a ReLU behind
+                                 // residual adds, train_ops.hip mask mode 3) and this launch may ACCUMULATE (acc_nhwc): it is the slot's LAST writer
   const float* bs_mean; const float* bs_invstd; const float* bs_gamma; const float* bs_beta;
   double* bs_part;
   float* bs_gmax;

@@ -830,6 +830,7 @@ __device__ __forceinline__ void conv_p2_body(const P2Args& a, const int by, cons
         unsigned zo[MS][NT];
         f32x4 ex[MS][NT];
         f32x4 zz[BSUM ? MS : 1][BSUM ? NT : 1];  // (BSUM) the producer's raw z at the lane's positions: same offsets as the store
+        unsigned mk[BSUM ? MS : 1][BSUM ? NT : 1];  // ... and, for a producer with residuals, the ReLU mask byte of that float4
         const __amdgpu_buffer_rsrc_t bszr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(BSUM ? a.bs_z : nullptr), 0,
             BSUM ? (unsigned)((int64_t)a.N * a.Hout * a.Wout * a.Cout * 4) : 0u, 0x00020000);
 #pragma unroll
@@ -852,7 +853,10 @@ __device__ __forceinline__ void conv_p2_body(const P2Args& a, const int by, cons
             zo[ms][nt] = ok ? (unsigned)((((unsigned)n * (a.Hout << osh) + (y << osh) + (osh ? a.oy : 0)) * (a.Wout << osh) + (x << osh) + (osh ? a.ox : 0)) * a.Cout + c0) * 4u
                             : 0x80000000u;
             if (a.acc_nhwc) ex[ms][nt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(zr, zo[ms][nt], 0, 0));
-            if constexpr (BSUM) zz[ms][nt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(bszr, zo[ms][nt], 0, 0));
+            if constexpr (BSUM) {
+              zz[ms][nt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(bszr, zo[ms][nt], 0, 0));
+              mk[ms][nt] = (a.bs_mask && zo[ms][nt] != 0x80000000u) ? (unsigned)a.bs_mask[zo[ms][nt] >> 4] : 0u;  // (byte of the float4 at element zo / 4)
+            }
           }
         }
 #pragma unroll
@@ -868,7 +872,9 @@ __device__ __forceinline__ void conv_p2_body(const P2Args& a, const int by, cons
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                   const float zj = zz[ms][nt][j];
-                  const float g = __builtin_fmaf(zj, bs_al[nt][j], bs_bp[nt][j]) > 0.f ? v[j] : 0.f;  // (bwd_mask mode 2, train_ops.hip)
+                  // (bwd_mask, train_ops.hip: mode 2 = BatchNorm(z) > 0, mode 3 = the kept bits)
+                  const bool on = a.bs_mask ? ((mk[ms][nt] >> j) & 1u) != 0u : __builtin_fmaf(zj, bs_al[nt][j], bs_bp[nt][j]) > 0.f;
+                  const float g = on ? v[j] : 0.f;
                   bsum[nt][j] += g;
                   bsq[nt][j] = __builtin_fmaf(g, (zj - bs_mu[nt][j]) * bs_is[nt][j], bsq[nt][j]);
                   bgmx[nt][j] = fmaxf(bgmx[nt][j], fabsf(g));
@@ -1109,7 +1115,7 @@ int mval_launch_conv_p2(const P2Args& a0, hipStream_t s) {
   const int64_t px = (int64_t)a.N * a.Hout * a.Wout;
   if (a.bs_z) {  // (round 6) a 3x3 stride-1 data gradient that also keeps the BatchNorm backward's reduction of what it writes (P2Args::bs_z)
     int rc = 1;
-    if (a.k == 3 && a.stride == 1 && a.out_nhwc && !a.up && !a.res1 && !a.res2 && !a.out_f32 && !a.acc_nhwc && !a.os && !a.bn_part && a.bs_part &&
+    if (a.k == 3 && a.stride == 1 && a.out_nhwc && !a.up && !a.res1 && !a.res2 && !a.out_f32 && !a.os && !a.bn_part && a.bs_part &&
         a.bs_mean && a.bs_invstd && a.bs_gamma && a.bs_beta) {
       if (a.Wout >= 16 && a.Wout % 16 == 0 && a.Hout >= 4)
         rc = a.NS_total <= 2 ? launch_p2e<3, 1, 1, 2, 2, 1, 4, 16, true, 3, 0, false, false, true>(a, s)

@@ -611,12 +611,17 @@ static int train_backward(const mval_train_op* ops, int n_ops, int n_images, flo
         p.N = n_images; p.Hin = op.hout; p.Win = op.wout; p.Cin = op.cout; p.Hout = op.hin; p.Wout = op.win; p.Cout = op.cin;
         p.k = op.k; p.stride = 1;
         int slots = 0;
-        if ((t.p2_flags & MVAL_TRAIN_BSUM) && t.zin_rel == -1 && i > 0 && (t.first_touch & 1)) {
-          // this launch is the only writer of the producer's output gradient: it also keeps that op's BatchNorm backward reduction
+        if ((t.p2_flags & MVAL_TRAIN_BSUM) && i > 0) {
+          // this launch is the LAST writer of the producer's output gradient (the producer is the op in front of this one, so every other
+          // reader of its output sits behind this op in the list and has written already; under lanes `order` keeps that sequence): it also
+          // keeps that op's BatchNorm backward reduction.  Without residuals the ReLU mask comes from z; with residuals from the kept bits.
           const mval_train_op& pr = ops[i - 1];
-          if (pr.has_bn && pr.op.relu && pr.op.res1_off < 0 && pr.op.res2_off < 0 && pr.op.up == 0 && pr.gout_off == t.gin_off && pr.gz_p2_rows_off > 0 &&
+          const bool has_res = pr.op.res1_off >= 0 || pr.op.res2_off >= 0;
+          if (pr.has_bn && pr.op.relu && (!has_res || pr.mask_off > 0) && pr.op.up == 0 && pr.gout_off == t.gin_off && pr.gz_p2_rows_off > 0 &&
+              !(pr.p2_flags & 64) && (pr.p2_flags & 4) && pr.gz_p2_off > 0 && pr.gin_off >= 0 && (pr.op.cout & 3) == 0 &&
               lane_of(pr, MVAL_TRAIN_LANE_BWD, n_lanes) == lane) {
             p.bs_z = arena + pr.z_off;
+            p.bs_mask = has_res ? reinterpret_cast<const unsigned char*>(arena + pr.mask_off) : nullptr;
             p.bs_mean = pr.mean; p.bs_invstd = pr.invstd; p.bs_gamma = pr.gamma; p.bs_beta = pr.beta;
             p.bs_part = ws;
             p.bs_cap = ws_stride;  // (doubles of this lane's scratch; mval_train_backward without lanes passes 0: the plain data gradient)

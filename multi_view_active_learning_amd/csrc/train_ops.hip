@@ -948,12 +948,15 @@ __global__ __launch_bounds__(TR_APPLY_THREADS) void bn_bwd_apply2_kernel(const f
 // NHWC order, the granules through LDS (as bn_apply_fwd_p2_kernel); the scale from the bound the finalize step left in *bound_slot.
 // (MM = the mask mode as a template parameter and 8 waves per SIMD: with the mode at run time the kernel held 70 VGPRs -- 7 waves per
 // SIMD, i.e. ONE 1024-thread block per CU with 12 of 28 wave slots empty; bn_apply_fwd_p2_kernel likewise: 36.4 -> 31.9 us per launch)
-template <int MM>
-__global__ __launch_bounds__(TR_APPLY_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void bn_bwd_apply2_p2_kernel(
+// SC (round 6, pre-summed reductions of an op WITH residuals): the pass also scatters the masked gradient into the residual slots -- what
+// the reduction pass, which did not run, does otherwise (sc_ow bit 0 / 1: store instead of accumulate: first writer of that slot)
+template <int MM, bool SC = false>
+__global__ __launch_bounds__(TR_APPLY_THREADS) __attribute__((amdgpu_waves_per_eu(SC ? 6 : 8, 8))) void bn_bwd_apply2_p2_kernel(
     const float* __restrict__ gsrc, const float* __restrict__ out, const float* __restrict__ z, const float* __restrict__ mean,
     const float* __restrict__ invstd, const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ sums,
     float* __restrict__ gz, _Float16* __restrict__ planes, unsigned* __restrict__ p2_rows, const unsigned* __restrict__ bound_slot, int N,
-    int HW, int C, int, unsigned* __restrict__ amax_row, const unsigned char* __restrict__ relu_mask) {
+    int HW, int C, int, unsigned* __restrict__ amax_row, const unsigned char* __restrict__ relu_mask, float* __restrict__ sc_g1 = nullptr,
+    float* __restrict__ sc_g2 = nullptr, int sc_ow = 0) {
   const int C8 = C >> 3;
   const int64_t npx = (int64_t)N * HW;
   const float invM = 1.0f / (float)npx;
@@ -994,6 +997,10 @@ __global__ __launch_bounds__(TR_APPLY_THREADS) __attribute__((amdgpu_waves_per_e
       const f32x4 db = *reinterpret_cast<const f32x4*>(sums + q * 4);
       const f32x4 dg = *reinterpret_cast<const f32x4*>(sums + C + q * 4);
       const f32x4 gv = bwd_mask(gv0, MM, ov, zv, mu, is, g, bt);
+      if constexpr (SC) {
+        if (sc_g1) *reinterpret_cast<f32x4*>(sc_g1 + o) = (sc_ow & 1) ? gv : *reinterpret_cast<const f32x4*>(sc_g1 + o) + gv;
+        if (sc_g2) *reinterpret_cast<f32x4*>(sc_g2 + o) = (sc_ow & 2) ? gv : *reinterpret_cast<const f32x4*>(sc_g2 + o) + gv;
+      }
       const f32x4 xh = (zv - mu) * is;
       r = (g * is) * (gv - db * invM - xh * (dg * invM));
       if (gz) *reinterpret_cast<f32x4*>(gz + o) = r;
@@ -1068,7 +1075,8 @@ extern "C" int mval_bn_bwd_fused_p2(const float* gout, const float* out, const u
   g_presum_gmax = nullptr;
   g_presum_slots = 0;
   if (pre_part) {
-    MVAL_REQUIRE(p2 && mask_mode == 2 && pre_gmax && pre_slots > 0, "mval_bn_bwd_fused_p2: pre-summed partials need the P2 form of a ReLU op without residuals");
+    MVAL_REQUIRE(p2 && (mask_mode == 2 || mask_mode == 3) && pre_gmax && pre_slots > 0,
+                 "mval_bn_bwd_fused_p2: pre-summed partials need the P2 form of a ReLU op (mask from z, or from the kept bits with residuals)");
     hipLaunchKernelGGL(bn_bwd_finalize_bound_c_kernel, dim3(C), dim3(256), 0, s, pre_part, pre_gmax, pre_slots, C, dbeta, dgamma, sums, gamma, invstd,
                        1.0f / (float)M, (float)sqrt(M > 1 ? (double)M - 1.0 : 1.0), bound_slot);
     MVAL_CHECK_LAUNCH("mval_bn_bwd_fused/finalize (pre-summed)");
@@ -1090,11 +1098,20 @@ extern "C" int mval_bn_bwd_fused_p2(const float* gout, const float* out, const u
   // from gout with the mask re-derived
   const float* gsrc = gout;
   int apply_mask = mask_mode;
-  if (gres1 && (overwrite & 1)) { gsrc = gres1; apply_mask = 0; }
-  else if (gres2 && (overwrite & 2)) { gsrc = gres2; apply_mask = 0; }
+  if (!pre_part) {
+    if (gres1 && (overwrite & 1)) { gsrc = gres1; apply_mask = 0; }
+    else if (gres2 && (overwrite & 2)) { gsrc = gres2; apply_mask = 0; }
+  }
   const int64_t total = M * c4n;
   int nb2 = (int)((total + TR_APPLY_THREADS - 1) / TR_APPLY_THREADS);
   if (nb2 > TR_APPLY_BLOCKS) nb2 = TR_APPLY_BLOCKS;
+  if (p2 && pre_part && (gres1 || gres2)) {
+    // (round 6) the reduction pass did not run: this pass masks from the kept bits AND scatters the residual gradients
+    hipLaunchKernelGGL((bn_bwd_apply2_p2_kernel<3, true>), dim3(nb2), dim3(TR_APPLY_THREADS), 0, s, gout, out, z, mean, invstd, gamma, beta, sums, gz,
+                       reinterpret_cast<_Float16*>(dz_planes), dz_rows, bound_slot, N, H * W, C, 3, gz_amax_row, relu_mask, gres1, gres2, overwrite);
+    MVAL_CHECK_LAUNCH("mval_bn_bwd_fused/apply p2 + scatter");
+    return 0;
+  }
   if (p2) {
 #define BWD_P2_LAUNCH(MM_)                                                                                                              \
   hipLaunchKernelGGL(bn_bwd_apply2_p2_kernel<MM_>, dim3(nb2), dim3(TR_APPLY_THREADS), 0, s, gsrc, out, z, mean, invstd, gamma, beta, sums, gz, \

@@ -403,13 +403,7 @@ class TrainPlan:
                     pt.z_out = 1
                     ct.zin_rel = k - j
                     self.n_bn_in_conv += 1
-                    # ... and the other direction: that conv's data gradient is the ONLY writer of the producer's output gradient, so its
-                    # epilogue keeps the sums the producer's BatchNorm backward would get from a second read of it (P2Args::bs_z;
-                    # MVAL_TRAIN_BN_BWD_IN_DGRAD=0: the reduction pass).  The library checks the rest at launch (first touch, same lane, room).
-                    lib.mval_conv_p2_bsum_supported.restype = C.c_int
-                    if (os.environ.get("MVAL_TRAIN_BN_BWD_IN_DGRAD", "1") != "0" and k == j - 1 and (ct.p2_flags & 4) and (pt.p2_flags & 4) and fused_bwd
-                            and lib.mval_conv_p2_bsum_supported(C.c_int(co.cout), C.c_int(co.cin), C.c_int(hin), C.c_int(win), C.c_int(n))):
-                        ct.p2_flags |= TRAIN_BSUM
+
         # the two BatchNorm A/B switches are the PLAN's decision and travel in p2_flags (bit 6: round 3's backward pair, bit 7: statistics by
         # the separate pass): net_train.hip does not read the environment
         bits = (0 if os.environ.get("MVAL_TRAIN_BWD_FUSED", "1") != "0" else 64) | (0 if os.environ.get("MVAL_TRAIN_EPI_STATS", "1") != "0" else 128)
@@ -424,6 +418,27 @@ class TrainPlan:
                 if op.bn and op.relu and op.up == 0 and (op.res1 is not None or op.res2 is not None) and op.cout % 4 == 0:
                     self.ops[i].mask_off = self._row_top
                     self._row_top += _align((n * geo[i][2] * geo[i][3] * op.cout // 4 + 3) // 4)
+        # Round 6, the other direction (MVAL_TRAIN_BSUM; MVAL_TRAIN_BN_BWD_IN_DGRAD=0: the reduction pass): the data gradient of a 3x3 stride-1
+        # P2 conv whose input's producer is the op right in front of it in the list is the LAST writer of that producer's output gradient
+        # (every other reader sits behind it in the list and writes earlier in the backward), so its epilogue keeps the sums the producer's
+        # BatchNorm backward would take from a second read of it (P2Args::bs_z): ReLU producers without residual (mask from z: conv1 of a
+        # BasicBlock) and with residuals (mask from the kept bits: conv2 of a block followed by another block; the apply pass then also
+        # scatters the residual gradients).  The library checks the rest at launch (same lane, room for the partials).
+        self.n_bn_bwd_in_dgrad = 0
+        if self.uses_p2 and os.environ.get("MVAL_TRAIN_BN_BWD_IN_DGRAD", "1") != "0" and os.environ.get("MVAL_TRAIN_BWD_FUSED", "1") != "0":
+            lib.mval_conv_p2_bsum_supported.restype = C.c_int
+            for j in range(1, len(g.ops)):
+                co, ct, po, pt = g.ops[j], self.ops[j], g.ops[j - 1], self.ops[j - 1]
+                if not (co.kind == "conv" and co.k == 3 and co.stride == 1 and co.pad == 1 and co.src == po.dst and (ct.p2_flags & 4) and ct.gin_off >= 0
+                        and po.kind == "conv" and po.bn and po.relu and po.up == 0 and (pt.p2_flags & 4) and pt.gin_off >= 0 and pt.gz_p2_off > 0
+                        and (co.phase, co.lane) == (po.phase, po.lane)):
+                    continue
+                if (po.res1 is not None or po.res2 is not None) and not pt.mask_off > 0:
+                    continue
+                hin, win, _, _ = geo[j]
+                if lib.mval_conv_p2_bsum_supported(C.c_int(co.cout), C.c_int(co.cin), C.c_int(hin), C.c_int(win), C.c_int(n)):
+                    ct.p2_flags |= TRAIN_BSUM
+                    self.n_bn_bwd_in_dgrad += 1
         if g.input in amax_row:
             raise _lib.MvalError("the network input cannot feed an fp16-split conv")
         self._assign_lanes(g, n, geo)
