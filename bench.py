@@ -15,25 +15,22 @@ RANSAC-DLT triangulation + reprojection metric.  Random synthetic weights / fram
 One step = one pass of the hot path over one batch.  Frames are independent, so ranks shard
 frames with NO data-path collective (weak scaling: per-GPU work is fixed).
 
-Prints ONE JSON line on rank 0 with the driver's contract fields plus
-  roofline     dominant kernel family (by time) = the fused 3x3 stride-1 convs on the fp16 matrix cores
-               (conv_p2_kernel<3, 1, ...> and the fused BasicBlocks conv_block_p2_kernel<C>; MVAL_CONV=h2 / bf3 / fp32
-               select round 2's kernel families): algorithmic conv FLOPs of its launches in one step / time spent in them
-               (hipEvents around every launch on the launch stream, mval_net_forward_timed) against the peak of the
-               split in use (three fp16 MFMA products per fp32 product: 2500 / 3 = 833 TFLOP/s); the other kernels of
-               the step under "other_kernels", each against its own bound (stride-2 convs: the same matrix-core peak;
-               1x1 channel GEMMs and the stem: algorithmic bytes / time against HBM); HBM bytes per launch from the
-               committed rocprofv3 PMC passes (profiles/r05);
-  exact_modes  ms per step of the same workload with the bit-faithful conv kernels (MVAL_CONV=bf3: exact 3-way bf16
-               split, six MFMA products; fp32: v_mfma_f32_16x16x4_f32) and with round 2's fp32-activation fp16 split
-               (h2), 20 steps each, outside the headline's timed region;
-  companions   (default c2 run at one GPU only) BASELINE configs[2] and [3] under the same driver clock: the C3 training step and
-               the C4 scoring slice, each run by a child process of this command after the headline (>= 2 s timed each), with
-               their own rooflines (and C3's cpu_baseline);
-  cpu_baseline the CPU oracle (stock torch fp32 HRNet-W32 + numpy RANSAC-DLT restatement,
-               oracle/) timed on the host on a bounded sample of the same workload; its "parity_sample" compares
-               the HIP path with the oracle on that sample's first frames (the metric's "MPJPE vs ref": heat-map max
-               error, 2-D keypoint equality, MPJPE and worst-joint delta in mm) -- outside every timed region.
+Prints ONE JSON line on rank 0 -- at most 4 096 characters (compact_line; round 5's 21.9 KB line fell out of the driver's stdout tail) -- with the
+driver's contract fields plus
+  roofline     the dominant kernel family by time: {kernel (a label), bound, achieved, peak, unit, frac, traffic, seconds_in_kernel_per_step}.
+               For C2 the fused 3x3 stride-1 convs on the fp16 matrix cores: algorithmic conv FLOPs of its launches in one step / the time
+               spent in them (hipEvents around every launch on the launch stream, mval_net_forward_timed) against the peak of the split
+               in use (three fp16 MFMA products per fp32 product: 2500 / 3 = 833 TFLOP/s); traffic = HBM bytes per launch from the committed
+               rocprofv3 counter passes of this command (profiles/r06);
+  exact_modes  ms per step of the same workload with the bit-faithful conv kernels (bf3: exact 3-way bf16 split; fp32: exact-fp32 MFMA) and
+               with the fp32-activation fp16 split (h2), 20 steps each, outside the headline's timed region;
+  companions   (default c2 run at one GPU only) {ms_per_step, value, kernel, bound, frac} of BASELINE configs[2] (C3 training step), configs[3]'s
+               slice (C4) and C2 from uint8 host crops, each run by a child process of this command after the headline (>= 2 s timed each);
+  cpu_baseline the CPU oracle (stock torch fp32 HRNet-W32 + numpy RANSAC-DLT restatement, oracle/) timed on the host on a bounded sample of
+               the same workload; "parity_sample" compares the HIP path with the oracle on that sample's first frames (heat-map max error,
+               2-D key-point equality, MPJPE and worst-joint delta in mm) -- outside every timed region.
+Everything else the run measured -- the other kernel families each against its own bound, pass counts, notes, per-rank attribution, the
+companions' own records -- goes to the detail record (--detail-out, default bench_detail.json beside this script).
 """
 from __future__ import annotations
 
@@ -327,19 +324,19 @@ def train_rooflines(model, step, frames, v, mode):
 
     def mf(name, f, tt, prefixes=()):
         return dict(bound="mfma", achieved=round(f / tt / 1e12, 2), peak=round(peak, 1), unit="TFLOP/s", frac=round(f / tt / 1e12 / peak, 4),
-                    traffic=traffic_of(prefixes) if prefixes else None, kernel=name, peak_note=note, seconds_in_kernel_per_step=round(tt, 6), flops_per_step=f)
+                    traffic=traffic_of(prefixes) if prefixes else None, peak_note=note, seconds_in_kernel_per_step=round(tt, 6), flops_per_step=f, **_kn(name))
 
     def hb(name, b, tt, prefixes=(), **extra):
         return dict(bound="hbm", achieved=round(b / tt / 1e9, 1), peak=PEAK_HBM_GBPS, unit="GB/s", frac=round(b / tt / 1e9 / PEAK_HBM_GBPS, 4),
-                    traffic=traffic_of(prefixes) if prefixes else None, traffic_source=pmc_src, kernel=name,
+                    traffic=traffic_of(prefixes) if prefixes else None, traffic_source=pmc_src, **_kn(name),
                     peak_note="HBM3E ~8 TB/s (guide); ~6.3 TB/s achievable", seconds_in_kernel_per_step=round(tt, 6), bytes_per_step=b, **extra)
 
     fams = [
         mf("conv forward (conv_p2_kernel<..., EPI 3> over fp16-pair activations -- raw fp32 NHWC z + the batch-statistics sums of "
            "its persistent workgroups; conv_split_kernel / conv_mfma_kernel for the shapes P2 does not cover)", fl_fwd, t[0]),
         dict(bound="latency", achieved=None, peak=None, unit=None, frac=None, traffic=None,
-             kernel="BatchNorm statistics (finalize of the conv epilogues' float64 partials -> mean / invstd / running stats: no pass over z; "
-                    "ops whose conv keeps no partials -- the stem -- run bn_stats_partial over z)",
+             **_kn("BatchNorm statistics (finalize of the conv epilogues' float64 partials -> mean / invstd / running stats: no pass over z; "
+                   "ops whose conv keeps no partials -- the stem -- run bn_stats_partial over z)"),
              peak_note="launch- / latency-bound: one small dependent launch per BatchNorm", launches_per_step=bn["n_bn"],
              seconds_in_kernel_per_step=round(t[1], 6), bytes_per_step=bn["stats"]),
         hb("BatchNorm apply (bn_apply_fwd[_p2]: z [+ residuals] -> normalise + residuals + ReLU (+ upsample) -> out as P2 planes and / or fp32 "
@@ -390,6 +387,24 @@ def _num(x, nd=4):
 
 
 _ROOF_KEYS = ("bound", "achieved", "peak", "unit", "frac", "traffic", "seconds_in_kernel_per_step")
+
+
+def _kn(desc):
+    """A kernel family's description -> {"kernel": its name (what stands before the first parenthesis), "kernel_note": the prose}: JSON values
+    stay labels, the explanation travels beside them in the detail record."""
+    desc = str(desc)
+    i = desc.find(" (")
+    if i < 0:
+        return {"kernel": desc}
+    note = desc[i + 1:].strip()
+    depth, closes_at = 0, -1
+    for k, ch in enumerate(note):  # strip the outer parentheses only when ONE group spans the whole note
+        depth += ch == "("
+        depth -= ch == ")"
+        if depth == 0:
+            closes_at = k
+            break
+    return {"kernel": desc[:i].strip(), "kernel_note": note[1:-1] if closes_at == len(note) - 1 else note}
 
 
 def _roof_line(roof):
@@ -516,7 +531,7 @@ def path_kernels(dev, frames, v, j, hh, wh):
 
     def hbm(name, t, nbytes, note):
         return dict(bound="hbm", achieved=round(nbytes / t / 1e9, 1), peak=PEAK_HBM_GBPS, unit="GB/s",
-                    frac=round(nbytes / t / 1e9 / PEAK_HBM_GBPS, 4), traffic=None, kernel=name, peak_note=note,
+                    frac=round(nbytes / t / 1e9 / PEAK_HBM_GBPS, 4), traffic=None, peak_note=note, **_kn(name),
                     launches_per_step=1, avg_launch_us=round(t * 1e6, 2), bytes_per_step=nbytes,
                     seconds_in_kernel_per_step=round(t, 7))
 
@@ -548,7 +563,7 @@ def path_kernels(dev, frames, v, j, hh, wh):
     kp = _lib.score_decode_maps(_lib.SCORE_HP, hm, valid, frames, v, j, hh, wh, 4, hh)[2]
     t = timed(lambda: _lib.triangulate_ransac(kp, proj, valid, frames, v, j, 4.0))
     out.append(dict(bound="latency", achieved=round(frames * j / t), peak=None, unit="problems/s", frac=None, traffic=None,
-                    kernel="ransac_dlt_kernel (pairwise RANSAC + DLT + reprojection error, float64)",
+                    **_kn("ransac_dlt_kernel (pairwise RANSAC + DLT + reprojection error, float64)"),
                     peak_note=f"{frames * j} (frame, joint) problems x {v * (v - 1) // 2} pairs per launch: "
                               "a few waves per CU, latency-bound; bytes are negligible",
                     launches_per_step=1, avg_launch_us=round(t * 1e6, 2), seconds_in_kernel_per_step=round(t, 7)))
@@ -953,7 +968,7 @@ def main():
             t = float(ms[mask].sum()) * 1e-3
             f = float(flops[mask].sum())
             return dict(bound="mfma", achieved=round(f / t / 1e12, 2), peak=peak, unit="TFLOP/s",
-                        frac=round(f / t / 1e12 / peak, 4), traffic=None, kernel=name, peak_note=peak_note,
+                        frac=round(f / t / 1e12 / peak, 4), traffic=None, peak_note=peak_note, **_kn(name),
                         launches_per_step=n, avg_launch_us=round(t / n * 1e6, 2), flops_per_step=f,
                         seconds_in_kernel_per_step=round(t, 6))
 
@@ -973,7 +988,7 @@ def main():
                     # (a fused Bottleneck whose residual is its own input reads that tensor once, algorithmically)
                     b += 4.0 * nimg * (o.hin * o.win * o.cin + outp * (1 + (o.res1_off >= 0 and o.res1_off != o.in_off) + (o.res2_off >= 0)))
             return dict(bound="hbm", achieved=round(b / t / 1e9, 1), peak=PEAK_HBM_GBPS, unit="GB/s",
-                        frac=round(b / t / 1e9 / PEAK_HBM_GBPS, 4), traffic=None, kernel=name,
+                        frac=round(b / t / 1e9 / PEAK_HBM_GBPS, 4), traffic=None, **_kn(name),
                         peak_note="HBM3E ~8 TB/s (guide); ~6.3 TB/s achievable",
                         launches_per_step=n, avg_launch_us=round(t / n * 1e6, 2), bytes_per_step=b,
                         seconds_in_kernel_per_step=round(t, 6))
