@@ -1051,6 +1051,13 @@ extern "C" int mval_bn_bwd_fused_p2(const float* gout, const float* out, const u
                                     float* dgamma, float* dbeta, double* ws, float* sums, int N, int H, int W, int C, int relu,
                                     int overwrite, uint32_t* gz_amax_row, void* dz_planes, uint32_t* dz_rows, float* gmax_ws,
                                     uint32_t* bound_slot, void* stream) {
+  // (pre-summed partials are consumed by THIS call, whatever it returns: a failed call must not leave them for the next one)
+  const double* pre_part = g_presum_part;
+  const float* pre_gmax = g_presum_gmax;
+  const int pre_slots = g_presum_slots;
+  g_presum_part = nullptr;
+  g_presum_gmax = nullptr;
+  g_presum_slots = 0;
   const bool p2 = dz_planes != nullptr;
   MVAL_REQUIRE(!p2 || (dz_rows && gmax_ws && bound_slot && (C & 7) == 0 && dgamma && dbeta), "mval_bn_bwd_fused_p2: the P2 form needs rows, scratch and C % 8 == 0");
   MVAL_REQUIRE(p2 || gz, "mval_bn_bwd_fused: no output for dz");
@@ -1068,12 +1075,6 @@ extern "C" int mval_bn_bwd_fused_p2(const float* gout, const float* out, const u
   const size_t sh = (size_t)rows * lanes * 4 * 2 * sizeof(double);
   hipStream_t s = mval_stream(stream);
   const int mask_mode = !relu ? 0 : (gres1 || gres2) ? (relu_mask ? 3 : 1) : 2;
-  const double* pre_part = g_presum_part;
-  const float* pre_gmax = g_presum_gmax;
-  const int pre_slots = g_presum_slots;
-  g_presum_part = nullptr;
-  g_presum_gmax = nullptr;
-  g_presum_slots = 0;
   if (pre_part) {
     MVAL_REQUIRE(p2 && (mask_mode == 2 || mask_mode == 3) && pre_gmax && pre_slots > 0,
                  "mval_bn_bwd_fused_p2: pre-summed partials need the P2 form of a ReLU op (mask from z, or from the kept bits with residuals)");
