@@ -25,7 +25,13 @@
 //     global -> registers during the MFMA loop.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "conv_common.h"
+
+#ifndef WB_PF
+#define WB_PF 2  // register sets of staged operands: 1 = the next tile requested during this tile's MFMA phase (rounds 2-5), 2 = two tiles ahead
+#endif
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -186,11 +192,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((KS == 3 &&
   const int xq4 = (tid % XQ) * 4, zq4 = (tid % ZQ) * 4;  // 256 % XQ == 0 == 256 % ZQ
   const bool cx_ok = ci0 + xq4 < a.Cin, cz_ok = co0 + zq4 < a.Cout;
 
-  f32x4 xr[NEX], zr[NEZ];
+  // (round 6, WB_PF 2) TWO register sets: the operands of tile t + 2 PS are requested while tile t is multiplied, so a load has a whole
+  // iteration -- not only one MFMA phase -- before its LDS store waits for it (the loop was: barrier, store what was requested one MFMA
+  // phase ago, barrier, request, multiply: every iteration waited out the rest of an HBM round trip with the matrix pipe idle)
+  f32x4 xr[WB_PF][NEX], zr[WB_PF][NEZ];
   // (XZ) the thread's four input channels' factors, pre-multiplied by 2^s (exact), and which of its staged pixels lie inside the image
   // (the conv pads the ACTIVATION with zeros, not z)
   f32x4 xz_a = (f32x4){0.f, 0.f, 0.f, 0.f}, xz_b = xz_a;
-  unsigned xz_ok = 0u;
+  unsigned xz_ok[WB_PF] = {};
   if constexpr (XZ) {
     if (cx_ok) {
 #pragma unroll
@@ -207,7 +216,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((KS == 3 &&
   const int zp_plane = (tid % ZQ) / (CO / 8), zp_c8 = (tid % ZQ) % (CO / 8);
   const int C8x = a.Cin >> 3;
   const int64_t xp_hw = (int64_t)a.Hin * a.Win;
-  auto load_tile = [&](int t) {
+  auto load_tile = [&](int t, auto set_) {
+    constexpr int B = decltype(set_)::value;
     const int txi = t % a.tiles_x;
     t /= a.tiles_x;
     const int oy0 = (t % a.tiles_y) * TH, ox0 = txi * TW, n = t / a.tiles_y;
@@ -218,12 +228,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((KS == 3 &&
         const bool ok = tid + 256 * i < PPX * XQ && ci0 + xp_c8 * 8 < a.Cin && (unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win;
         const wb_u32x4 g = ok ? *reinterpret_cast<const wb_u32x4*>(a.x_p2 + ((((int64_t)n * 2 + xp_plane) * C8x + (ci0 >> 3) + xp_c8) * xp_hw + (int64_t)iy * a.Win + ix) * 8)
                               : (wb_u32x4){0u, 0u, 0u, 0u};
-        xr[i] = __builtin_bit_cast(f32x4, g);
+        xr[B][i] = __builtin_bit_cast(f32x4, g);
       } else {
       const bool ok = tid + 256 * i < PPX * XQ && cx_ok && (unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win;
-      xr[i] = ok ? *reinterpret_cast<const f32x4*>(a.x + (((int64_t)n * a.Hin + iy) * a.Win + ix) * a.Cin + ci0 + xq4)
-                 : (f32x4){0.f, 0.f, 0.f, 0.f};
-      if constexpr (XZ) xz_ok = (xz_ok & ~(1u << i)) | ((unsigned)ok << i);
+      xr[B][i] = ok ? *reinterpret_cast<const f32x4*>(a.x + (((int64_t)n * a.Hin + iy) * a.Win + ix) * a.Cin + ci0 + xq4)
+                    : (f32x4){0.f, 0.f, 0.f, 0.f};
+      if constexpr (XZ) xz_ok[B] = (xz_ok[B] & ~(1u << i)) | ((unsigned)ok << i);
       }
     }
 #pragma unroll
@@ -234,47 +244,61 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((KS == 3 &&
         const bool ok = tid + 256 * i < MT * ZQ && co0 + zp_c8 * 8 < a.Cout && y < a.H && x < a.W;
         const wb_u32x4 g = ok ? *reinterpret_cast<const wb_u32x4*>(a.dz_p2 + ((((int64_t)n * 2 + zp_plane) * (a.Cout >> 3) + (co0 >> 3) + zp_c8) * ((int64_t)a.H * a.W) + (int64_t)y * a.W + x) * 8)
                               : (wb_u32x4){0u, 0u, 0u, 0u};
-        zr[i] = __builtin_bit_cast(f32x4, g);
+        zr[B][i] = __builtin_bit_cast(f32x4, g);
       } else {
-      zr[i] = (tid + 256 * i < MT * ZQ && cz_ok && y < a.H && x < a.W)
+      zr[B][i] = (tid + 256 * i < MT * ZQ && cz_ok && y < a.H && x < a.W)
                   ? *reinterpret_cast<const f32x4*>(a.dz + (((int64_t)n * a.H + y) * a.W + x) * a.Cout + co0 + zq4)
                   : (f32x4){0.f, 0.f, 0.f, 0.f};
       }
     }
   };
 
+  using I0_ = std::integral_constant<int, 0>;
+  using I1_ = std::integral_constant<int, WB_PF - 1>;
   int tile = blockIdx.x;
-  if (tile < a.ntiles) load_tile(tile);
+  if (tile < a.ntiles) load_tile(tile, I0_{});
+  if (WB_PF > 1 && tile + a.PS < a.ntiles) load_tile(tile + a.PS, I1_{});
   for (; tile < a.ntiles; tile += a.PS) {
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < NEX; i++) {
       const int e = tid + 256 * i;
       if (e < PPX * XQ) {
-        if constexpr (XP2) *reinterpret_cast<wb_u32x4*>(xl + xp_plane * XPLANE + (e / XQ) * XROW + xp_c8 * 16) = __builtin_bit_cast(wb_u32x4, xr[i]);
+        if constexpr (XP2) *reinterpret_cast<wb_u32x4*>(xl + xp_plane * XPLANE + (e / XQ) * XROW + xp_c8 * 16) = __builtin_bit_cast(wb_u32x4, xr[0][i]);
         else if constexpr (XZ) {
           f32x4 y = (f32x4){0.f, 0.f, 0.f, 0.f};
-          if ((xz_ok >> i) & 1u) {
+          if ((xz_ok[0] >> i) & 1u) {
 #pragma unroll
-            for (int k = 0; k < 4; k++) y[k] = __builtin_elementwise_maximum(__builtin_fmaf(xr[i][k], xz_a[k], xz_b[k]), 0.f);
+            for (int k = 0; k < 4; k++) y[k] = __builtin_elementwise_maximum(__builtin_fmaf(xr[0][i][k], xz_a[k], xz_b[k]), 0.f);
           }
           wb_split_store2(y, 1.f, xl + (e / XQ) * XROW + (e % XQ) * 8, XPLANE);
         }
-        else if constexpr (PL == 3) wb_split_store(xr[i], xl + (e / XQ) * XROW + (e % XQ) * 8, XPLANE);
-        else wb_split_store2(xr[i], x_mul, xl + (e / XQ) * XROW + (e % XQ) * 8, XPLANE);
+        else if constexpr (PL == 3) wb_split_store(xr[0][i], xl + (e / XQ) * XROW + (e % XQ) * 8, XPLANE);
+        else wb_split_store2(xr[0][i], x_mul, xl + (e / XQ) * XROW + (e % XQ) * 8, XPLANE);
       }
     }
 #pragma unroll
     for (int i = 0; i < NEZ; i++) {
       const int e = tid + 256 * i;
       if (e < MT * ZQ) {
-        if constexpr (ZP2) *reinterpret_cast<wb_u32x4*>(zl + zp_plane * ZPLANE + (e / ZQ) * ZROW + zp_c8 * 16) = __builtin_bit_cast(wb_u32x4, zr[i]);
-        else if constexpr (PL == 3) wb_split_store(zr[i], zl + (e / ZQ) * ZROW + (e % ZQ) * 8, ZPLANE);
-        else wb_split_store2(zr[i], z_mul, zl + (e / ZQ) * ZROW + (e % ZQ) * 8, ZPLANE);
+        if constexpr (ZP2) *reinterpret_cast<wb_u32x4*>(zl + zp_plane * ZPLANE + (e / ZQ) * ZROW + zp_c8 * 16) = __builtin_bit_cast(wb_u32x4, zr[0][i]);
+        else if constexpr (PL == 3) wb_split_store(zr[0][i], zl + (e / ZQ) * ZROW + (e % ZQ) * 8, ZPLANE);
+        else wb_split_store2(zr[0][i], z_mul, zl + (e / ZQ) * ZROW + (e % ZQ) * 8, ZPLANE);
       }
     }
     __syncthreads();
-    if (tile + a.PS < a.ntiles) load_tile(tile + a.PS);
+    if constexpr (WB_PF > 1) {
+      // set 1 (requested one whole iteration ago) becomes set 0; the tile two strides ahead is requested into set 1.  (One loop body:
+      // alternating the sets in two copies of the body doubled its registers.)
+#pragma unroll
+      for (int i = 0; i < NEX; i++) xr[0][i] = xr[WB_PF - 1][i];
+#pragma unroll
+      for (int i = 0; i < NEZ; i++) zr[0][i] = zr[WB_PF - 1][i];
+      xz_ok[0] = xz_ok[WB_PF - 1];
+      if (tile + 2 * a.PS < a.ntiles) load_tile(tile + 2 * a.PS, I1_{});
+    } else {
+      if (tile + a.PS < a.ntiles) load_tile(tile + a.PS, I0_{});
+    }
 #pragma unroll
     for (int ks = 0; ks < TH / KROWS; ks++) {
       // dz fragments of this k-step: [cout tile][plane]
