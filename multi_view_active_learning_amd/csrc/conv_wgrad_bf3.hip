@@ -30,7 +30,11 @@
 #include "conv_common.h"
 
 #ifndef WB_PF
-#define WB_PF 2  // register sets of staged operands: 1 = the next tile requested during this tile's MFMA phase (rounds 2-5), 2 = two tiles ahead
+// register sets of staged operands: 1 = the next tile requested during this tile's MFMA phase; 2 = two tiles ahead (round 6 measurement knob:
+// SLOWER -- weight-gradient family 15.29 -> 15.76 ms per C3 step, 256 -> 256 @8x8 48.3 -> 56.0 us, step 58.8 -> 58.5-59.3 ms
+// (profiles/r06/wgrad_prefetch2_ab.log): three resident workgroups per CU already cover one another's load latency, and the second set costs
+// 30-60 registers)
+#define WB_PF 1
 #endif
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -192,9 +196,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((KS == 3 &&
   const int xq4 = (tid % XQ) * 4, zq4 = (tid % ZQ) * 4;  // 256 % XQ == 0 == 256 % ZQ
   const bool cx_ok = ci0 + xq4 < a.Cin, cz_ok = co0 + zq4 < a.Cout;
 
-  // (round 6, WB_PF 2) TWO register sets: the operands of tile t + 2 PS are requested while tile t is multiplied, so a load has a whole
-  // iteration -- not only one MFMA phase -- before its LDS store waits for it (the loop was: barrier, store what was requested one MFMA
-  // phase ago, barrier, request, multiply: every iteration waited out the rest of an HBM round trip with the matrix pipe idle)
+  // (WB_PF 2, measurement: TWO register sets -- the operands of tile t + 2 PS requested while tile t is multiplied, so a load has a whole
+  // iteration before its LDS store waits for it; measured slower, see WB_PF above)
   f32x4 xr[WB_PF][NEX], zr[WB_PF][NEZ];
   // (XZ) the thread's four input channels' factors, pre-multiplied by 2^s (exact), and which of its staged pixels lie inside the image
   // (the conv pads the ACTIVATION with zeros, not z)
