@@ -535,6 +535,8 @@ int mval_train_forward(const mval_train_op* ops, int n_ops, int n_images, float*
 /* gz: scratch >= max over ops of N*hout*wout*cout floats; wsf: >= max wgrad workspace;
  * sums: >= 2*maxC floats.  The gradient w.r.t. the network output must already be in garena at
  * the last op's gout_off (NHWC). */
+/* Measurement only (profiles/r06 item 2b): wsf of the next backward calls holds k regions of region_floats per lane, walked op by op. */
+int mval_train_slab_rotation(int k, int64_t region_floats);
 int mval_train_backward(const mval_train_op* ops, int n_ops, int n_images, float* arena, float* garena,
                         const float* params, int64_t ones_off, int64_t zeros_off, const float* input_nchw,
                         float* gz, float* wsf, double* ws, float* sums, void* stream);

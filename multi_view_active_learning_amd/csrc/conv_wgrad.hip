@@ -472,6 +472,10 @@ int mval_conv_wgrad_on(const float* x, const float* dz, float* dw, float* ws, in
   }
   int parts = PS / 8;  // >= 8 slabs per lane
   parts = parts < 1 ? 1 : parts > 16 ? 16 : parts;
+#ifdef MVAL_TRAIN_ABLATE  // (measurement build: MVAL_TRAIN_ABL bit 2 -- no slab reductions at all: the upper bound of batching them; gradients are garbage)
+  extern int g_train_ablate;
+  if (!(g_train_ablate & 4))
+#endif
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n_out + 63) / 64)), dim3(64 * parts), 0, s, ws, PS, T, Cin, Cout, dw);
   MVAL_CHECK_LAUNCH("mval_conv_wgrad/reduce");
   return 0;

@@ -452,6 +452,15 @@ extern "C" int mval_train_forward_lanes(const mval_train_op* ops, int n_ops, int
                        eps, stream);
 }
 
+// (measurement only: MVAL_WGRAD_SLAB_ROT, engine_train.py -- the weight gradients' slab workspace of a lane as K regions walked op by op)
+static int g_slab_rot = 1;
+static int64_t g_slab_region = 0;
+extern "C" int mval_train_slab_rotation(int k, int64_t region_floats) {
+  g_slab_rot = k > 1 ? k : 1;
+  g_slab_region = region_floats;
+  return 0;
+}
+
 static int train_backward(const mval_train_op* ops, int n_ops, int n_images, float* arena, float* garena,
                           const float* params, int64_t ones_off, int64_t zeros_off, const float* input_nchw,
                           float* gz0, float* wsf0, double* ws0, float* sums0, int n_lanes, int64_t gz_stride, int64_t wsf_stride,
@@ -481,7 +490,7 @@ static int train_backward(const mval_train_op* ops, int n_ops, int n_images, flo
     if (free_run) order.before(t.gout_off, s);  // (the op reads its output's gradient: behind the slot's last writer)
     void* stream = reinterpret_cast<void*>(s);
     float* gz = gz0 + (int64_t)lane * gz_stride;
-    float* wsf = wsf0 + (int64_t)lane * wsf_stride;
+    float* wsf = wsf0 + (int64_t)lane * wsf_stride + (g_slab_rot > 1 ? (int64_t)((g_tt_base + i) % g_slab_rot) * g_slab_region : 0);
     double* ws = ws0 + (int64_t)lane * ws_stride;
     float* sums = sums0 + (int64_t)lane * sums_stride;
     const bool bwd_fused = !(t.p2_flags & 64);  // (bit 6: round 3's backward pair -- the plan's decision, MVAL_TRAIN_BWD_FUSED=0; it reads `out`)

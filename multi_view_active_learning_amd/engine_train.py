@@ -71,7 +71,7 @@ SLACK_EVERY = int(os.environ.get("MVAL_TRAIN_SLACK_EVERY", "1024"))
 # switch -> the value an unset variable stands for (the key must tell "unset" from every other setting: MVAL_TRAIN_LANES defaults to mode 3)
 _SWITCHES = {"MVAL_TRAIN_P2": "1", "MVAL_TRAIN_P2_WGRAD": "1", "MVAL_TRAIN_P2_DGRAD": "1", "MVAL_TRAIN_P2_RES": "1", "MVAL_TRAIN_EPI_STATS": "1",
              "MVAL_TRAIN_BWD_FUSED": "1", "MVAL_TRAIN_RELU_MASK": "1", "MVAL_TRAIN_DGRAD_PARITY": "1", "MVAL_TRAIN_LANES": "3",
-             "MVAL_TRAIN_BN_IN_CONV": "1", "MVAL_TRAIN_BN_BWD_IN_DGRAD": "1"}
+             "MVAL_TRAIN_BN_IN_CONV": "1", "MVAL_TRAIN_BN_BWD_IN_DGRAD": "1", "MVAL_WGRAD_SLAB_ROT": "1"}
 MAX_LANES = 4            # (csrc/conv_common.h MVAL_MAX_LANES)
 TRAIN_LANE_FWD, TRAIN_LANE_BWD, TRAIN_LANE_ORD, TRAIN_LANE_FREE = 256, 512, 1024, 2048  # (include/mval_hip.h MVAL_TRAIN_LANE_*)
 TRAIN_BSUM = 4096  # (MVAL_TRAIN_BSUM)
@@ -474,6 +474,11 @@ class TrainPlan:
         self.stats = torch.zeros(max(stat_top, 64), **f32)
         # (lanes: one slice of every scratch buffer per lane, mval_train_*_lanes)
         self.gz_lane, self.wsf_lane = _align(max(gz_max, 64)), _align(max(wsf_max, 64))
+        # (measurement only, profiles/r06 item 2b: MVAL_WGRAD_SLAB_ROT=K gives every lane K slab regions and the library walks them op by op, so an op's
+        # slab reduction reads from HBM instead of the Infinity Cache -- what a reduction deferred to the end of a backward segment would do)
+        self.slab_rot = max(1, int(os.environ.get("MVAL_WGRAD_SLAB_ROT", "1")))
+        self.wsf_region = self.wsf_lane
+        self.wsf_lane *= self.slab_rot
         self.gz = torch.empty(self.gz_lane * self.n_lanes, **f32)
         self.wsf = torch.empty(self.wsf_lane * self.n_lanes, **f32)
         # float64 scratch of the BatchNorm reductions; sized so that the forward conv epilogues' per-workgroup statistics
@@ -794,6 +799,8 @@ class TrainPlan:
         lo, hi = self.segments[k]
         grads = self._grads
         sub = (MvalTrainOp * (hi - lo)).from_address(C.addressof(self.ops) + lo * C.sizeof(MvalTrainOp))
+        if self.slab_rot > 1:
+            _lib.lib().mval_train_slab_rotation(C.c_int(self.slab_rot), C.c_int64(self.wsf_region))
         _lib.lib().mval_train_timing_base(C.c_int(lo))  # (measurement mode's per-operator breakdown)
         _lib._check(
             _lib.lib().mval_train_backward_lanes(

@@ -582,7 +582,8 @@ def test_training_lanes_are_bit_identical_to_the_serial_passes(dev, case, monkey
         assert all(torch.equal(r0[k], r1[k]) for k in r0)
 
 
-@pytest.mark.parametrize("case", [cases.train_cases()["w32_train"], dict(arch="hrnet_w32", seed=4, n=4, h=256, w=256, j=19)], ids=["w32_train", "w32_256"])
+@pytest.mark.parametrize("case", [cases.train_cases()["w32_train"], dict(arch="hrnet_w32", seed=4, n=4, h=256, w=256, j=19),
+                                  dict(arch="hrnet_w32", seed=5, n=3, h=192, w=128, j=19)], ids=["w32_train", "w32_256", "w32_192x128_n3"])
 def test_bn_in_conv_is_bit_identical_to_the_separate_apply(dev, case, monkeypatch):
     """Round 6 (hrnet.py:36-52, strategy.py:478): the BatchNorm apply of a residual-free ReLU layer whose one reader is a 3x3 stride-1 P2 conv
     is not a pass of its own -- that conv's staging and its weight gradient's staging compute relu(BatchNorm(z)), scale and split from the
@@ -594,7 +595,8 @@ def test_bn_in_conv_is_bit_identical_to_the_separate_apply(dev, case, monkeypatc
     n_z = sum(int(t.z_out) for t in plan.ops)
     assert n_z == plan.n_bn_in_conv == sum(int(t.zin_rel != 0) for t in plan.ops)
     # (HRNet-W32: 104 BasicBlocks + layer1's Bottleneck 3x3s at 256 x 256; maps under 8 x 8 -- the deep branches of these small inputs -- keep the apply)
-    assert n_z >= (100 if case["h"] >= 256 else 80), n_z
+    # (the non-square odd-batch case: 48 x 32 and 24 x 16 maps take the fused path, the 12 x 8 / 6 x 4 maps of the deep branches fall back)
+    assert n_z >= (100 if case["h"] >= 256 else 50 if case["w"] != case["h"] else 80), n_z
     for i, t in enumerate(plan.ops):
         if t.zin_rel:
             pr = plan.ops[i + t.zin_rel]
