@@ -524,6 +524,10 @@ typedef struct mval_train_op {
                             * producer's backward skips that pass */
 } mval_train_op;
 #define MVAL_TRAIN_BSUM 4096
+/* p2_flags bit 13 on every op of a backward call (the library looks at the call's last op): the weight gradients' slab reductions of the call run
+ * as ONE launch per 64 ops when its lanes have joined; wsf is then one arena of n_lanes * wsf_floats_per_lane floats that must hold the sum of
+ * mval_conv_wgrad_workspace_floats (rounded up to 64) over the call's ops. */
+#define MVAL_TRAIN_WGRAD_DEFER 8192
 
 /* ones_off / zeros_off: params offsets of >= max(cout) floats of 1.0 / 0.0.
  * ws: ws_doubles >= 512*maxC*2 doubles.  With room for cout * (conv workgroups) * 2 doubles of an op (about

@@ -376,10 +376,84 @@ extern "C" int mval_conv_wgrad_scaled(const float* x, const float* dz, float* dw
   return mval_conv_wgrad_on(x, dz, dw, ws, N, Hin, Win, Cin, Hout, Wout, Cout, k, stride, pad, x_nchw, x_amax_row, dz_amax_row, mval_stream(stream));
 }
 
+// ---- (round 6) the slab reductions of a whole backward call in ONE launch ------------------------------------------------------------
+// Every op of a call writes its slabs into its own region of the workspace; mval_conv_wgrad_defer(&job) makes the NEXT
+// mval_conv_wgrad_on record its reduction there instead of launching it; mval_wgrad_reduce_jobs runs up to 64 recorded reductions as one
+// kernel (a job's outputs are walked by the same `parts` lanes per output, in the same order, as its own launch would: same bits).
+struct WgradReduceJob {
+  const float* slabs;
+  float* dw;
+  int PS, T, Cin, Cout, parts;
+};
+struct WgradReduceJobs {
+  int n;
+  int blk0[65];  // first block of job j; blk0[n] = total
+  WgradReduceJob j[64];
+};
+static thread_local WgradReduceJob* g_wgrad_defer = nullptr;
+void mval_conv_wgrad_defer(WgradReduceJob* out) { g_wgrad_defer = out; }
+
+__global__ __launch_bounds__(1024) void wgrad_reduce_jobs_kernel(const WgradReduceJobs J) {
+  __shared__ double red[1024];
+  int jn = 0;
+  while (jn + 1 < J.n && (int)blockIdx.x >= J.blk0[jn + 1]) jn++;  // (uniform: <= 63 scalar steps)
+  const WgradReduceJob job = J.j[jn];
+  const int64_t n = (int64_t)job.T * job.Cin * job.Cout;
+  const int64_t i = (int64_t)((int)blockIdx.x - J.blk0[jn]) * 64 + (threadIdx.x & 63);
+  const int part = threadIdx.x >> 6, parts = job.parts, PS = job.PS;
+  const float* __restrict__ slabs = job.slabs;
+  double s = 0;
+  if (i < n && part < parts) {
+    int p = part;
+    for (; p + 7 * parts < PS; p += 8 * parts) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) v[u] = slabs[(int64_t)(p + u * parts) * n + i];
+      s += (((double)v[0] + (double)v[1]) + ((double)v[2] + (double)v[3])) + (((double)v[4] + (double)v[5]) + ((double)v[6] + (double)v[7]));
+    }
+    for (; p + 3 * parts < PS; p += 4 * parts) {
+      const float v0 = slabs[(int64_t)p * n + i], v1 = slabs[(int64_t)(p + parts) * n + i];
+      const float v2 = slabs[(int64_t)(p + 2 * parts) * n + i], v3 = slabs[(int64_t)(p + 3 * parts) * n + i];
+      s += ((double)v0 + (double)v1) + ((double)v2 + (double)v3);
+    }
+    for (; p < PS; p += parts) s += (double)slabs[(int64_t)p * n + i];
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (part == 0 && i < n) {
+    s = 0;
+    for (int k = 0; k < parts; k++) s += red[k * 64 + threadIdx.x];
+    const int co = (int)(i % job.Cout);
+    const int ci = (int)((i / job.Cout) % job.Cin);
+    const int t = (int)(i / ((int64_t)job.Cout * job.Cin));
+    job.dw[((int64_t)co * job.Cin + ci) * job.T + t] = (float)s;
+  }
+}
+
+// jobs[0 .. n): recorded by mval_conv_wgrad_defer; launched in chunks of 64 on `s`
+int mval_wgrad_reduce_jobs(const WgradReduceJob* jobs, int n, hipStream_t s) {
+  for (int j0 = 0; j0 < n; j0 += 64) {
+    WgradReduceJobs J;
+    J.n = n - j0 < 64 ? n - j0 : 64;
+    int b = 0;
+    for (int j = 0; j < J.n; j++) {
+      J.j[j] = jobs[j0 + j];
+      J.blk0[j] = b;
+      b += (int)(((int64_t)J.j[j].T * J.j[j].Cin * J.j[j].Cout + 63) / 64);
+    }
+    J.blk0[J.n] = b;
+    hipLaunchKernelGGL(wgrad_reduce_jobs_kernel, dim3((unsigned)b), dim3(1024), 0, s, J);
+    MVAL_CHECK_LAUNCH("mval_wgrad_reduce_jobs");
+  }
+  return 0;
+}
+
 // (net_train.hip's entry: the HIP stream as such.  Round 4 also ran the slab reduction on a side stream beside the op's data gradient:
 // two event hand-overs per operator cost more than the 7 us reduction they hid, C3 79.9 vs 77.7 ms -- removed in round 5.)
 int mval_conv_wgrad_on(const float* x, const float* dz, float* dw, float* ws, int N, int Hin, int Win, int Cin, int Hout, int Wout, int Cout,
                        int k, int stride, int pad, int x_nchw, const uint32_t* x_amax_row, const uint32_t* dz_amax_row, hipStream_t s) {
+  WgradReduceJob* defer = g_wgrad_defer;  // (consumed by THIS call, whatever it returns)
+  g_wgrad_defer = nullptr;
   MVAL_REQUIRE(N > 0 && Cin > 0 && Cout > 0 && k > 0 && stride > 0, "mval_conv_wgrad: bad dims");
   const int T = k * k;
   const int64_t n_out = (int64_t)T * Cin * Cout;
@@ -472,6 +546,10 @@ int mval_conv_wgrad_on(const float* x, const float* dz, float* dw, float* ws, in
   }
   int parts = PS / 8;  // >= 8 slabs per lane
   parts = parts < 1 ? 1 : parts > 16 ? 16 : parts;
+  if (defer) {  // the caller runs this reduction with the others of its backward call (mval_wgrad_reduce_jobs)
+    defer->slabs = ws; defer->dw = dw; defer->PS = PS; defer->T = T; defer->Cin = Cin; defer->Cout = Cout; defer->parts = parts;
+    return 0;
+  }
 #ifdef MVAL_TRAIN_ABLATE  // (measurement build: MVAL_TRAIN_ABL bit 2 -- no slab reductions at all: the upper bound of batching them; gradients are garbage)
   extern int g_train_ablate;
   if (!(g_train_ablate & 4))

@@ -48,6 +48,14 @@ int mval_conv_wgrad_on(const float* x, const float* dz, float* dw, float* ws, in
 void mval_conv_wgrad_set_p2_x(const void* planes, const unsigned* rows);  // conv_wgrad.hip: x as P2 planes for the next weight gradient
 void mval_conv_wgrad_set_p2_dz(const void* planes, const unsigned* rows);  // ... and dz
 void mval_conv_wgrad_set_z_x(const float* mean, const float* invstd, const float* gamma, const float* beta, float sqrt_m1);  // conv_wgrad_bf3.hip: x = relu(BatchNorm(z))
+struct WgradReduceJob {  // (conv_wgrad.hip)
+  const float* slabs;
+  float* dw;
+  int PS, T, Cin, Cout, parts;
+};
+void mval_conv_wgrad_defer(WgradReduceJob* out);  // the next mval_conv_wgrad_on records its slab reduction instead of launching it
+int mval_wgrad_reduce_jobs(const WgradReduceJob* jobs, int n, hipStream_t s);
+extern "C" size_t mval_conv_wgrad_workspace_floats(int cin, int cout, int k);
 void mval_bn_bwd_set_presummed(const double* part, const float* gmaxc, int nslots);  // train_ops.hip: the next fused BatchNorm backward finds its reduction done
 // ---- measurement mode (bench.py, the c3 line's per-kernel roofline): hipEvents around every launch group of a
 // training step, summed per kernel family.  Off unless mval_train_timing() armed it; the events are resolved (one
@@ -467,6 +475,7 @@ static int train_backward(const mval_train_op* ops, int n_ops, int n_images, flo
                           int64_t ws_stride, int64_t sums_stride, void* stream0) {
   MVAL_REQUIRE(ops && n_ops > 0 && n_images > 0 && garena && gz0 && wsf0 && ws0 && sums0 && n_lanes >= 1 && n_lanes <= MVAL_MAX_LANES,
                "mval_train_backward: bad arguments");
+  const int n_lanes_arg = n_lanes;  // (the workspace holds this many slices whatever the measurement mode does to n_lanes)
   if (g_tt_out) n_lanes = 1;
   MvalLanes* L = n_lanes > 1 ? mval_device_lanes() : nullptr;
   if (n_lanes > 1) MVAL_REQUIRE(L != nullptr, "mval_train_backward: could not create the side streams");
@@ -477,6 +486,14 @@ static int train_backward(const mval_train_op* ops, int n_ops, int n_images, flo
   order.keep = free_run;
   // (round 6, MVAL_TRAIN_BSUM) per lane: the slots of reduction partials the last data gradient on that lane left in the lane's `ws` for
   // the op `presum_for` -- the very next op of the list (zin_rel == -1), so nothing else touches that scratch in between
+  // (round 6, MVAL_TRAIN_WGRAD_DEFER on the call's last op) every op's weight-gradient slabs go to a region of their own inside the whole
+  // workspace (all lanes' slices as ONE arena, walked in list order) and the reductions run as one launch per 64 ops when the call's lanes
+  // have joined -- 293 seven-microsecond launches per step become one per backward segment
+  const bool defer_reduce = !g_tt_out && wsf_stride > 0 && (ops[n_ops - 1].p2_flags & MVAL_TRAIN_WGRAD_DEFER);
+  std::vector<WgradReduceJob> rjobs;
+  if (defer_reduce) rjobs.reserve(n_ops);
+  int64_t slab_off = 0;
+  const int64_t slab_cap = wsf_stride * (int64_t)n_lanes_arg;
   int presum_slots[MVAL_MAX_LANES] = {0, 0, 0, 0};
   const mval_train_op* presum_for[MVAL_MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};
   for (int i = n_ops - 1; i >= 0; i--) {
@@ -554,7 +571,16 @@ static int train_backward(const mval_train_op* ops, int n_ops, int n_images, flo
       // is the conv  x' = conv(y', W as [cout' = cin][cin' = cout], stride s, pad p), so
       //   dW = weight gradient of that conv with input dz (at the output resolution) and "dz" = x;
       //   dx = that conv applied to dz (plain stride-2 conv on the matrix cores).
-      rc = mval_conv_wgrad(gz, x, t.dweight, wsf, n_images, op.hout, op.wout, op.cout, op.hin, op.win, op.cin, op.k,
+      float* wsd = wsf;
+      if (defer_reduce) {
+        const int64_t need = ((int64_t)mval_conv_wgrad_workspace_floats(op.cout, op.cin, op.k) + 63) & ~(int64_t)63;
+        MVAL_REQUIRE(slab_off + need <= slab_cap, "mval_train_backward: op %d: the slab workspace does not hold this call's deferred reductions", i);
+        wsd = wsf0 + slab_off;
+        slab_off += need;
+        rjobs.emplace_back();
+        mval_conv_wgrad_defer(&rjobs.back());
+      }
+      rc = mval_conv_wgrad(gz, x, t.dweight, wsd, n_images, op.hout, op.wout, op.cout, op.hin, op.win, op.cin, op.k,
                            op.stride, op.pad, 0, stream);
       if (rc) return rc;
       if (t.gin_off >= 0) {
@@ -598,7 +624,17 @@ static int train_backward(const mval_train_op* ops, int n_ops, int n_images, flo
       xw = arena + pr.z_off;
     } else if (t.fwd_p2 && (t.p2_flags & 1))  // (wgrad_p2: this op's input exists as P2 planes and its weight gradient reads those)
       mval_conv_wgrad_set_p2_x(arena + t.in_p2_off, reinterpret_cast<const unsigned*>(arena + t.in_p2_rows_off));
-    rc = mval_conv_wgrad_on(xw, gz, t.dweight, wsf, n_images, op.hin, op.win, op.cin, op.hout, op.wout, op.cout, op.k, op.stride, op.pad,
+    float* wsl = wsf;
+    if (defer_reduce) {
+      const int64_t need = ((int64_t)mval_conv_wgrad_workspace_floats(op.cin, op.cout, op.k) + 63) & ~(int64_t)63;
+      MVAL_REQUIRE(slab_off + need <= slab_cap, "mval_train_backward: op %d: the slab workspace (%lld floats) does not hold this call's deferred reductions", i,
+                   (long long)slab_cap);
+      wsl = wsf0 + slab_off;
+      slab_off += need;
+      rjobs.emplace_back();
+      mval_conv_wgrad_defer(&rjobs.back());
+    }
+    rc = mval_conv_wgrad_on(xw, gz, t.dweight, wsl, n_images, op.hin, op.win, op.cin, op.hout, op.wout, op.cout, op.k, op.stride, op.pad,
                             op.in_nchw, (x_row && !t.zin_rel) ? x_row : nullptr, (x_row && !t.zin_rel) ? gz_row : nullptr, s);
     }
     if (rc) return rc;
@@ -662,6 +698,10 @@ static int train_backward(const mval_train_op* ops, int n_ops, int n_images, flo
   }
   walk.finish();
   lanes_free.finish();
+  if (!rjobs.empty()) {  // (every lane has joined the caller's stream: the slabs are complete)
+    int rc = mval_wgrad_reduce_jobs(rjobs.data(), (int)rjobs.size(), mval_stream(stream0));
+    if (rc) return rc;
+  }
   tt_flush();
   return 0;
 }

@@ -71,10 +71,12 @@ SLACK_EVERY = int(os.environ.get("MVAL_TRAIN_SLACK_EVERY", "1024"))
 # switch -> the value an unset variable stands for (the key must tell "unset" from every other setting: MVAL_TRAIN_LANES defaults to mode 3)
 _SWITCHES = {"MVAL_TRAIN_P2": "1", "MVAL_TRAIN_P2_WGRAD": "1", "MVAL_TRAIN_P2_DGRAD": "1", "MVAL_TRAIN_P2_RES": "1", "MVAL_TRAIN_EPI_STATS": "1",
              "MVAL_TRAIN_BWD_FUSED": "1", "MVAL_TRAIN_RELU_MASK": "1", "MVAL_TRAIN_DGRAD_PARITY": "1", "MVAL_TRAIN_LANES": "3",
-             "MVAL_TRAIN_BN_IN_CONV": "1", "MVAL_TRAIN_BN_BWD_IN_DGRAD": "1", "MVAL_WGRAD_SLAB_ROT": "1"}
+             "MVAL_TRAIN_BN_IN_CONV": "1", "MVAL_TRAIN_BN_BWD_IN_DGRAD": "1", "MVAL_WGRAD_SLAB_ROT": "1",
+             "MVAL_TRAIN_WGRAD_BATCH": "1"}
 MAX_LANES = 4            # (csrc/conv_common.h MVAL_MAX_LANES)
 TRAIN_LANE_FWD, TRAIN_LANE_BWD, TRAIN_LANE_ORD, TRAIN_LANE_FREE = 256, 512, 1024, 2048  # (include/mval_hip.h MVAL_TRAIN_LANE_*)
 TRAIN_BSUM = 4096  # (MVAL_TRAIN_BSUM)
+TRAIN_WGRAD_DEFER = 8192  # (MVAL_TRAIN_WGRAD_DEFER)
 
 _ARMED = None  # weakref to the plan whose probe rows the library currently points at (one slot per process: csrc/net_train.hip g_probe)
 
@@ -529,6 +531,20 @@ class TrainPlan:
                 bounds.append(i)
         bounds.append(len(g.ops))
         self.segments = [(a, b) for a, b in zip(bounds, bounds[1:]) if b > a]
+        # Round 6 (MVAL_TRAIN_WGRAD_DEFER; MVAL_TRAIN_WGRAD_BATCH=0: one reduction launch per op): the weight gradients' slab reductions of a
+        # backward segment run as ONE launch per 64 ops at its end, so every op of a segment needs a slab region of its own: the workspace becomes
+        # one arena that holds the largest segment's regions (the library walks it in list order)
+        self.wgrad_batch = os.environ.get("MVAL_TRAIN_WGRAD_BATCH", "1") != "0" and self.slab_rot == 1
+        if self.wgrad_batch:
+            lib.mval_conv_wgrad_workspace_floats.restype = C.c_size_t
+            need = [0 if op.kind == "maxpool" else (int(lib.mval_conv_wgrad_workspace_floats(C.c_int(op.cin), C.c_int(op.cout), C.c_int(op.k))) + 63) // 64 * 64
+                    for op in g.ops]
+            total = max(sum(need[a:b]) for a, b in self.segments)
+            if total > self.wsf_lane * self.n_lanes:
+                self.wsf_lane = _align((total + self.n_lanes - 1) // self.n_lanes)
+                self.wsf = torch.empty(self.wsf_lane * self.n_lanes, dtype=torch.float32, device=device)
+            for t in self.ops:
+                t.p2_flags |= TRAIN_WGRAD_DEFER
         self.seg_params = []
         for lo, hi in self.segments:
             ps = []

@@ -438,7 +438,7 @@ def test_python_constants_match_the_header():
     from multi_view_active_learning_amd import engine_train
 
     assert define("MVAL_TRAIN_LANE_FWD") == engine_train.TRAIN_LANE_FWD and define("MVAL_TRAIN_LANE_BWD") == engine_train.TRAIN_LANE_BWD
-    assert define("MVAL_TRAIN_LANE_ORD") == engine_train.TRAIN_LANE_ORD and define("MVAL_TRAIN_BSUM") == engine_train.TRAIN_BSUM
+    assert define("MVAL_TRAIN_LANE_ORD") == engine_train.TRAIN_LANE_ORD and define("MVAL_TRAIN_BSUM") == engine_train.TRAIN_BSUM and define("MVAL_TRAIN_WGRAD_DEFER") == engine_train.TRAIN_WGRAD_DEFER
     # the ctypes mirror of mval_train_op ends with the round-6 fields and has the header's size (8-byte aligned, two int32 at the end)
     assert [f[0] for f in engine_train.MvalTrainOp._fields_][-2:] == ["zin_rel", "z_out"]
     csrc = open(os.path.join(os.path.dirname(__file__), "..", "multi_view_active_learning_amd", "csrc", "conv_common.h")).read()

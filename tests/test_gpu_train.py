@@ -628,6 +628,26 @@ def test_bn_in_conv_is_bit_identical_to_the_separate_apply(dev, case, monkeypatc
     assert all(torch.equal(b, rf[k]) for k, b in m1.named_buffers() if "running" in k)
 
 
+@pytest.mark.parametrize("case", [cases.train_cases()["w32_train"], cases.train_cases()["r50_train"]], ids=["w32_train", "r50_train"])
+def test_batched_slab_reductions_are_bit_identical_to_the_per_op_launches(dev, case, monkeypatch):
+    """Round 6 (MVAL_TRAIN_WGRAD_DEFER): the weight gradients' split-K slab reductions of a backward segment run as ONE launch per 64 ops at the
+    segment's end (every op's slabs in a region of their own) instead of one 7 us launch per op.  Every output is still summed by the same number
+    of lanes in the same order, so the gradients equal the per-op form (MVAL_TRAIN_WGRAD_BATCH=0) bit for bit -- HRNet-W32 and PoseResNet-50
+    (transposed convs: the roles-swapped weight gradient)."""
+    from multi_view_active_learning_amd import engine_train
+
+    m1, _, hm1, l1, _ = _train_once(case, dev)
+    plan = next(iter(m1._train_plans.values()))
+    assert plan.wgrad_batch and all(t.p2_flags & engine_train.TRAIN_WGRAD_DEFER for t in plan.ops)
+    g1 = {k: p.grad.detach().clone() for k, p in m1.named_parameters()}
+    monkeypatch.setenv("MVAL_TRAIN_WGRAD_BATCH", "0")
+    m0, _, hm0, l0, _ = _train_once(case, dev)
+    assert not next(iter(m0._train_plans.values())).wgrad_batch
+    assert torch.equal(hm1, hm0) and torch.equal(l1, l0)
+    bad = [k for k, p in m0.named_parameters() if not torch.equal(p.grad, g1[k])]
+    assert not bad, (len(bad), bad[:5])
+
+
 @pytest.mark.parametrize("wd", [0.0, 0.01], ids=["plain", "weight_decay"])
 def test_adam_one_launch_vs_torch_adam(dev, wd):
     """optim.Adam (csrc/optim.hip: the update of every parameter in one launch; reference strategy.py:405-407, :479) against
