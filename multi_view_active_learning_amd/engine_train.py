@@ -72,7 +72,7 @@ SLACK_EVERY = int(os.environ.get("MVAL_TRAIN_SLACK_EVERY", "1024"))
 _SWITCHES = {"MVAL_TRAIN_P2": "1", "MVAL_TRAIN_P2_WGRAD": "1", "MVAL_TRAIN_P2_DGRAD": "1", "MVAL_TRAIN_P2_RES": "1", "MVAL_TRAIN_EPI_STATS": "1",
              "MVAL_TRAIN_BWD_FUSED": "1", "MVAL_TRAIN_RELU_MASK": "1", "MVAL_TRAIN_DGRAD_PARITY": "1", "MVAL_TRAIN_LANES": "3",
              "MVAL_TRAIN_BN_IN_CONV": "1", "MVAL_TRAIN_BN_BWD_IN_DGRAD": "1", "MVAL_WGRAD_SLAB_ROT": "1",
-             "MVAL_TRAIN_WGRAD_BATCH": "1"}
+             "MVAL_TRAIN_WGRAD_BATCH": "0"}
 MAX_LANES = 4            # (csrc/conv_common.h MVAL_MAX_LANES)
 TRAIN_LANE_FWD, TRAIN_LANE_BWD, TRAIN_LANE_ORD, TRAIN_LANE_FREE = 256, 512, 1024, 2048  # (include/mval_hip.h MVAL_TRAIN_LANE_*)
 TRAIN_BSUM = 4096  # (MVAL_TRAIN_BSUM)
@@ -531,10 +531,12 @@ class TrainPlan:
                 bounds.append(i)
         bounds.append(len(g.ops))
         self.segments = [(a, b) for a, b in zip(bounds, bounds[1:]) if b > a]
-        # Round 6 (MVAL_TRAIN_WGRAD_DEFER; MVAL_TRAIN_WGRAD_BATCH=0: one reduction launch per op): the weight gradients' slab reductions of a
-        # backward segment run as ONE launch per 64 ops at its end, so every op of a segment needs a slab region of its own: the workspace becomes
-        # one arena that holds the largest segment's regions (the library walks it in list order)
-        self.wgrad_batch = os.environ.get("MVAL_TRAIN_WGRAD_BATCH", "1") != "0" and self.slab_rot == 1
+        # Round 6 (MVAL_TRAIN_WGRAD_DEFER; opt-in: MVAL_TRAIN_WGRAD_BATCH=1): the weight gradients' slab reductions of a backward segment as ONE
+        # launch per 64 ops at its end, every op's slabs in a region of its own (the workspace becomes one arena that holds the largest segment's
+        # regions).  Bit-identical and MEASURED SLOWER -- C3 57.7-58.3 -> 60.8 ms (profiles/r06/wgrad_reduce_batched_ab.log): the per-op reduction
+        # reads its 28-56 MB of slabs back from the Infinity Cache right after they were written, into a buffer the next op overwrites there; deferred,
+        # ~5 GB of slabs per step go out to HBM and come back (the 293 launches it saves are worth at most 1.5 ms: wgrad_reduce_bounds...log).
+        self.wgrad_batch = os.environ.get("MVAL_TRAIN_WGRAD_BATCH", "0") == "1" and self.slab_rot == 1
         if self.wgrad_batch:
             lib.mval_conv_wgrad_workspace_floats.restype = C.c_size_t
             need = [0 if op.kind == "maxpool" else (int(lib.mval_conv_wgrad_workspace_floats(C.c_int(op.cin), C.c_int(op.cout), C.c_int(op.k))) + 63) // 64 * 64

@@ -630,12 +630,13 @@ def test_bn_in_conv_is_bit_identical_to_the_separate_apply(dev, case, monkeypatc
 
 @pytest.mark.parametrize("case", [cases.train_cases()["w32_train"], cases.train_cases()["r50_train"]], ids=["w32_train", "r50_train"])
 def test_batched_slab_reductions_are_bit_identical_to_the_per_op_launches(dev, case, monkeypatch):
-    """Round 6 (MVAL_TRAIN_WGRAD_DEFER): the weight gradients' split-K slab reductions of a backward segment run as ONE launch per 64 ops at the
-    segment's end (every op's slabs in a region of their own) instead of one 7 us launch per op.  Every output is still summed by the same number
-    of lanes in the same order, so the gradients equal the per-op form (MVAL_TRAIN_WGRAD_BATCH=0) bit for bit -- HRNet-W32 and PoseResNet-50
-    (transposed convs: the roles-swapped weight gradient)."""
+    """Round 6 (MVAL_TRAIN_WGRAD_DEFER, opt-in MVAL_TRAIN_WGRAD_BATCH=1: measured slower, profiles/r06): the weight gradients' split-K slab
+    reductions of a backward segment as ONE launch per 64 ops at the segment's end (every op's slabs in a region of their own) instead of one
+    7 us launch per op.  Every output is still summed by the same number of lanes in the same order, so the gradients equal the per-op form
+    (the default) bit for bit -- HRNet-W32 and PoseResNet-50 (transposed convs: the roles-swapped weight gradient)."""
     from multi_view_active_learning_amd import engine_train
 
+    monkeypatch.setenv("MVAL_TRAIN_WGRAD_BATCH", "1")
     m1, _, hm1, l1, _ = _train_once(case, dev)
     plan = next(iter(m1._train_plans.values()))
     assert plan.wgrad_batch and all(t.p2_flags & engine_train.TRAIN_WGRAD_DEFER for t in plan.ops)
