@@ -280,6 +280,7 @@ class TrainPlan:
         P2_ROW = 512
         producer = {op.dst: k for k, op in enumerate(g.ops)}
         p2_act = {}
+        self.n_bn_in_conv = 0  # (round 6: ops whose BatchNorm apply runs inside their reader's staging; set below for P2 plans)
         self.p2_rows = []
         if h2 and p2 and os.environ.get("MVAL_TRAIN_P2", "1") != "0":
             for i, op in enumerate(g.ops):
