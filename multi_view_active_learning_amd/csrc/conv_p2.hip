@@ -64,6 +64,9 @@
 #ifndef P2_WD
 #define P2_WD 4         // the other kernels: weight steps in the ring (2 = one step ahead; a step is only MS x NT x 3 MFMAs: 192 cycles at MS x NT = 4)
 #endif
+#ifndef P2_INZ_MAP
+#define P2_INZ_MAP 1    // (INZ staging) 1: a pixel's channel blocks on consecutive lanes; 0: a block's pixels on consecutive lanes (measurement)
+#endif
 #ifndef P2_MFMA_PRIO
 #define P2_MFMA_PRIO 1  // s_setprio around every step's MFMA group (0 = off)
 #endif
@@ -318,10 +321,18 @@ __device__ __forceinline__ void conv_p2_body(const P2Args& a, const int by, cons
     }
 #pragma unroll
     for (int i = 0; i < NEZ; i++) {
+      // consecutive lanes = the 4 G channel blocks of ONE pixel (32 bytes each: 128 G contiguous bytes of its NHWC row), then the next pixel
+      // of the patch row: a wave's two load instructions use every byte of the lines they touch.  (P2_INZ_MAP 0, the first form: consecutive
+      // lanes = consecutive pixels of one block, 16 bytes at a 4 C-byte stride -- 64 sectors per instruction; conv forward +0.6 ms per C3 step)
       const int e = tid + NTH * i;
+#if P2_INZ_MAP
+      const int c8l = e & (4 * G - 1), t_ = e / (4 * G);
+      const int py = t_ / PW, px = t_ - py * PW;
+#else
       const int r = e / PW;
       const int px = e - r * PW;
       const int c8l = r & (4 * G - 1), py = r / (4 * G);
+#endif
       const int sp = (c8l >> 2) * 8 + (c8l & 3);  // plane h of chunk c8l / 4; plane l sits plane_b behind
       lpz[i] = py < PH ? ((unsigned)((sp * PPX + py * PW + px) * 16) << 16) | (c8l << 12) | (py << 7) | px : 127u;
     }
