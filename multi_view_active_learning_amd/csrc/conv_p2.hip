@@ -325,14 +325,20 @@ __device__ __forceinline__ void conv_p2_body(const P2Args& a, const int by, cons
       // of the patch row: a wave's two load instructions use every byte of the lines they touch.  (P2_INZ_MAP 0, the first form: consecutive
       // lanes = consecutive pixels of one block, 16 bytes at a 4 C-byte stride -- 64 sectors per instruction; conv forward +0.6 ms per C3 step)
       const int e = tid + NTH * i;
-#if P2_INZ_MAP
-      const int c8l = e & (4 * G - 1), t_ = e / (4 * G);
-      const int py = t_ / PW, px = t_ - py * PW;
-#else
-      const int r = e / PW;
-      const int px = e - r * PW;
-      const int c8l = r & (4 * G - 1), py = r / (4 * G);
-#endif
+      // (G = 2 -- the 8 x 8 maps' form -- keeps the first mapping: eight blocks of a pixel are eight LDS stores to one bank group;
+      // 256 -> 256 @8x8 measured 34.0 us with the first mapping, 36.3 with this one; profiles/r06/inz_lane_map_ab.log)
+      int c8l, py, px;
+      if constexpr (P2_INZ_MAP && G == 1) {
+        c8l = e & 3;
+        const int t_ = e >> 2;
+        py = t_ / PW;
+        px = t_ - py * PW;
+      } else {
+        const int r = e / PW;
+        px = e - r * PW;
+        c8l = r & (4 * G - 1);
+        py = r / (4 * G);
+      }
       const int sp = (c8l >> 2) * 8 + (c8l & 3);  // plane h of chunk c8l / 4; plane l sits plane_b behind
       lpz[i] = py < PH ? ((unsigned)((sp * PPX + py * PW + px) * 16) << 16) | (c8l << 12) | (py << 7) | px : 127u;
     }
